@@ -1,0 +1,42 @@
+"""Golden-fixture case table shared by tools/gen_golden.py (reference side) and the
+oracle / HIP parity tests.  Data only: sizes and flags of each case."""
+import zlib
+import numpy as np
+
+CH = {"rgb": 3, "flow": 10, "rgbdiff": 15, "sound": 1}
+
+CASES = {
+    # unimodal RGB ResNet-50 (config 1 shape at full resolution, eval) and a reduced train step
+    "resnet50_full": dict(kind="resnet", modality=["rgb"], groups=8, B=1, size=224, modes=["eval"]),
+    "resnet50_train": dict(kind="resnet", modality=["rgb"], groups=8, B=2, size=96, modes=["eval", "train"]),
+    "resnet50_avg": dict(kind="resnet", modality=["rgb"], groups=16, B=1, size=64, pooling="avg", modes=["train"]),
+    "resnet50_flow": dict(kind="resnet", modality=["flow"], groups=8, B=1, size=64, modes=["train"]),
+    "sound_mbv2": dict(kind="sound", modality=["sound"], B=2, sound_size=128, modes=["eval", "train"]),
+    # AdaMML RGB+Audio (config 2 shape, reduced B/S/resolution)
+    "adamml_rgb_sound": dict(kind="adamml", modality=["rgb", "sound"], groups=8, B=2, S=3, size=96, sound_size=96,
+                             modes=["eval", "train_main", "train_policy"]),
+    "adamml_rgb_sound_nolstm": dict(kind="adamml", modality=["rgb", "sound"], groups=8, B=2, S=2, size=64,
+                                    sound_size=64, causality=None, modes=["eval", "train_policy"]),
+    # config 4 / 5 modality sets
+    "adamml_rgb_flow_rgbdiff": dict(kind="adamml", modality=["rgb", "flow", "rgbdiff"], groups=8, B=1, S=2, size=64,
+                                    sound_size=64, modes=["eval", "train_main"]),
+    "adamml_4mod": dict(kind="adamml", modality=["rgb", "sound", "flow", "rgbdiff"], groups=8, B=1, S=2, size=64,
+                        sound_size=64, modes=["eval", "train_policy"]),
+}
+
+
+def _idx(name, n, k=4):
+    r = np.random.Generator(np.random.PCG64(zlib.crc32(name.encode())))
+    return r.integers(0, n, size=(k,))
+
+
+def grad_probe(name, g):
+    """[sum, l2-norm, 4 sampled elements] of a gradient tensor (float64 accumulate)."""
+    a = np.asarray(g.detach().cpu().double().numpy()).reshape(-1)
+    return np.concatenate([[a.sum(), np.sqrt((a * a).sum())], a[_idx(name, a.size)]])
+
+
+def stat_probe(t):
+    """[mean, abs-mean, l2-norm, first, last] of a tensor."""
+    a = np.asarray(t.detach().cpu().double().numpy()).reshape(-1)
+    return np.array([a.mean(), np.abs(a).mean(), np.sqrt((a * a).sum()), a[0], a[-1]])

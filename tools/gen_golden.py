@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the REAL reference (IBM/AdaMML, read-only at
+$ADAMML_REF, default /root/reference) on CPU fp32 in the build container.
+
+Only this script ever imports the reference.  Nothing from the reference is copied:
+weights / inputs / Gumbel draws come from adamml_amd.synth (name-keyed, torch-RNG
+independent), so fixtures hold *outputs only* and the GPU box regenerates identical
+inputs from the recipe.  Usage:  python tools/gen_golden.py [case ...]
+"""
+import os
+import sys
+import types
+import json
+import numpy as np
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("ADAMML_REF", "/root/reference")
+sys.path.insert(1, REF)
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+# shim: torchvision is absent but utils/utils.py imports it (SURVEY.md section 8c shim 2)
+tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+tvt.Compose = lambda ts: None
+tvt.CenterCrop = tvt.Resize = lambda *a, **k: None
+tv.transforms = tvt
+sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt})
+
+import models  # noqa: E402  (the reference package)
+import models.policy_net as pn  # noqa: E402
+from utils.utils import compute_policy_loss  # noqa: E402
+
+from adamml_amd import synth  # noqa: E402
+from tests.golden_cases import CASES, CH, grad_probe, stat_probe  # noqa: E402
+
+# shim 1: policy_net.py:221 always downloads ImageNet weights; serve a local 3-channel state_dict
+pn.model_zoo.load_url = lambda url, **kw: pn.MobileNetV2(1000, num_frames=1, input_channels=3).state_dict()
+
+_EXPO = {"q": None, "i": 0}
+_orig_gumbel = F.gumbel_softmax
+
+
+def _gumbel_softmax(logits, tau=1, hard=False, eps=1e-10, dim=-1):
+    """F.gumbel_softmax with the Exponential(1) draw replaced by supplied samples."""
+    e = _EXPO["q"]
+    if e.dim() == 3 and logits.shape[0] == e.shape[1]:
+        ex = e[_EXPO["i"]]
+        _EXPO["i"] += 1
+    else:
+        ex = e.reshape(-1, 2)
+    gumbels = -ex.log()
+    y_soft = ((logits + gumbels) / tau).softmax(dim)
+    index = y_soft.max(dim, keepdim=True)[1]
+    y_hard = torch.zeros_like(logits).scatter_(dim, index, 1.0)
+    return y_hard - y_soft.detach() + y_soft
+
+
+F.gumbel_softmax = _gumbel_softmax
+
+
+def build_adamml(c):
+    mod = c["modality"]
+    return models.adamml(groups=c["groups"], modality=mod, input_channels=[CH[m] for m in mod],
+                         num_segments=c["S"], rng_policy=False, rng_threshold=0.5,
+                         causality_modeling=c.get("causality", "lstm"), num_classes=31, depth=50,
+                         without_t_stride=False, dropout=c.get("dropout", 0.0),
+                         pooling_method=c.get("pooling", "max"), fusion_point="logits",
+                         unimodality_pretrained=[], learnable_lf_weights=True)
+
+
+def run_case(name, c):
+    torch.manual_seed(0)
+    out = {}
+    kind = c["kind"]
+    if kind == "resnet":
+        model = models.resnet(depth=50, num_classes=31, without_t_stride=False, groups=c["groups"], dropout=0.0,
+                              pooling_method=c.get("pooling", "max"), input_channels=CH[c["modality"][0]],
+                              imagenet_pretrained=False)
+    elif kind == "sound":
+        model = models.sound_mobilenet_v2(num_classes=31, input_channels=1, dropout=0.0, imagenet_pretrained=False)
+    else:
+        model = build_adamml(c)
+    sd = synth.synth_state_dict(model.state_dict(), seed=1234)
+    model.load_state_dict(sd)
+    B, S = c["B"], c.get("S", 1)
+    if kind == "adamml":
+        xs = synth.synth_inputs(c["modality"], B, S, c["groups"], c["size"], c["sound_size"], seed=42)
+    elif kind == "resnet":
+        xs = synth.synth_inputs(c["modality"], B, 1, c["groups"], c["size"], seed=42)[0]
+    else:
+        xs = synth.synth_inputs(["sound"], B, 1, sound_size=c["sound_size"], seed=42)[0]
+    target = synth.synth_labels(B, 31, seed=42)
+
+    for mode in c["modes"]:
+        model.load_state_dict(sd)
+        model.zero_grad()
+        if kind == "adamml":
+            M = model.num_modality
+            _EXPO["q"] = synth.synth_gumbel_exponential(S, M, B, seed=7)
+            _EXPO["i"] = 0
+            model.policy_net.set_temperature(c.get("tau", 5.0))
+            model.unfreeze_policy_net()
+            model.unfreeze_main_net()
+        if mode == "eval":
+            model.eval()
+            with torch.no_grad():
+                y = model(xs)
+        else:
+            model.train()
+            if kind == "adamml":
+                if mode == "train_main":
+                    model.freeze_policy_net()
+                elif mode == "train_policy":
+                    model.freeze_main_net()
+            y = model(xs)
+        if kind == "adamml":
+            logits, sel = y
+            out[mode + ".logits"] = logits.detach().numpy()
+            out[mode + ".decisions"] = sel.detach().numpy()
+            cw = torch.tensor(c.get("cost_weights", [1.0] * sel.shape[-1]))
+            gam = torch.tensor(10.0)
+            pl_b = compute_policy_loss("blockdrop", sel, cw, gam, logits, target)
+            pl_m = compute_policy_loss("mean", sel, cw, gam, logits, target)
+            out[mode + ".policy_loss_blockdrop"] = pl_b.detach().numpy()
+            out[mode + ".policy_loss_mean"] = pl_m.detach().numpy()
+        else:
+            logits = y
+            out[mode + ".logits"] = logits.detach().numpy()
+        ce = F.cross_entropy(logits, target)
+        out[mode + ".ce"] = ce.detach().numpy()
+        if mode != "eval":
+            loss = ce
+            if kind == "adamml" and model.update_policy_net:
+                loss = loss + pl_b
+            loss.backward()
+            gp = {k: grad_probe(k, p.grad) for k, p in model.named_parameters() if p.grad is not None}
+            out[mode + ".grad_names"] = np.array(sorted(gp.keys()))
+            out[mode + ".grad_probe"] = np.stack([gp[k] for k in sorted(gp.keys())])
+            st = {k: stat_probe(v) for k, v in model.state_dict().items()
+                  if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+            out[mode + ".stat_names"] = np.array(sorted(st.keys()))
+            out[mode + ".stat_probe"] = np.stack([st[k] for k in sorted(st.keys())])
+    if kind == "adamml":
+        # policy logits [S,M,B,2] in eval mode (for margin-aware decision checks)
+        model.load_state_dict(sd)
+        model.eval()
+        _EXPO["i"] = 0
+        with torch.no_grad():
+            p_x, m_x, _ = model.data_layer(xs, S)
+            dec, plog = model.policy_net(p_x)
+        out["eval.policy_logits"] = plog.numpy()
+        out["eval.p_x_probe"] = np.stack([stat_probe(t) for t in p_x])
+        out["eval.m_x_probe"] = np.stack([stat_probe(t) for t in m_x])
+    out["n_state"] = np.array(len(sd))
+    return out
+
+
+def main():
+    names = sys.argv[1:] or list(CASES.keys())
+    os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    for n in names:
+        o = run_case(n, CASES[n])
+        path = os.path.join(ROOT, "tests", "golden", n + ".npz")
+        np.savez_compressed(path, **o)
+        print(n, "->", path, os.path.getsize(path), "bytes", flush=True)
+    # state_dict name/shape manifest (the on-disk contract)
+    import gzip
+    man = {}
+    for n, c in CASES.items():
+        key = "%s:%s:%s" % (c["kind"], "+".join(c["modality"]), c.get("causality", "lstm"))
+        if key in man:
+            continue
+        if c["kind"] == "adamml":
+            m = build_adamml(c)
+        elif c["kind"] == "resnet":
+            m = models.resnet(depth=50, num_classes=31, without_t_stride=False, groups=8, dropout=0.0,
+                              pooling_method="max", input_channels=CH[c["modality"][0]], imagenet_pretrained=False)
+        else:
+            m = models.sound_mobilenet_v2(num_classes=31, input_channels=1, dropout=0.0, imagenet_pretrained=False)
+        man[key] = {k: [list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()}
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "state_manifest.json.gz"), "wt") as f:
+        json.dump(man, f)
+
+
+if __name__ == "__main__":
+    main()
