@@ -114,7 +114,7 @@ def compare_records(got, ref, rtol=1e-4, atol=1e-5, grad_rtol=2e-3, skip=()):
             assert list(g) == list(v), k
         elif k.endswith("grad_probe"):
             # columns: sum, l2, 4 samples -> compare l2 relatively, others against l2 scale
-            l2 = np.maximum(v[:, 1:2], 1e-12)
+            l2 = np.maximum(v[:, 1:2], 1e-5 * v[:, 1].max())   # analytically-zero grads are rounding noise
             err = np.abs(g - v) / l2
             # the 'sum' column cancels over many elements: allow 5x the bound there
             err[:, 0] /= 5.0
