@@ -1,0 +1,120 @@
+"""Shared machinery of the HIP backbones: parameter containers with reference-identical state_dict names,
+flat fp32 parameter / gradient buffers, weight re-packing, and the autograd bridge that runs one backbone
+call as a single node (forward = fused HIP launches, backward = the recorded tape in reverse)."""
+import torch
+import torch.nn as nn
+
+from . import hip
+from .runtime import NetRT, ConvState, Tape
+
+
+class FlatBuffers:
+    """Re-homes every parameter of `module` into one flat fp32 buffer and pre-assigns .grad as views of a
+    second flat buffer: one memset zeroes all gradients, one RCCL all-reduce synchronises them, and the fused
+    optimizer kernels update the whole sub-network in one launch."""
+
+    def __init__(self, module):
+        self.module = module
+        self.flat = None
+        self.flat_grad = None
+        self.params = []
+
+    def ensure(self, device):
+        params = [p for p in self.module.parameters()]
+        if self.flat is not None and self.flat.device == device and len(params) == len(self.params) and \
+                all(p.data_ptr() == v.data_ptr() for p, v in zip(params[:2], self.views[:2])):
+            return
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+        views = []
+        off = 0
+        for p in params:
+            n = p.numel()
+            v = flat[off:off + n].view(p.shape)
+            v.copy_(p.data.to(device=device, dtype=torch.float32))
+            p.data = v
+            views.append(v)
+            off += n
+        self.flat, self.views, self.params = flat, views, params
+        self.flat_grad = None
+
+    def ensure_grads(self):
+        """(Re)attach zeroed gradient views when the optimizer dropped them (zero_grad(set_to_none=True))."""
+        params = self.params
+        if self.flat_grad is None:
+            self.flat_grad = torch.zeros_like(self.flat)
+            attached = False
+        else:
+            attached = all((p.grad is not None) for p in params if p.requires_grad)
+        if attached:
+            return
+        self.flat_grad.zero_()
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.grad = self.flat_grad[off:off + n].view(p.shape) if p.requires_grad else None
+            off += n
+
+
+class _NetCall(torch.autograd.Function):
+    """One backbone invocation as one autograd node.  `anchor` only makes the node differentiable; parameter
+    gradients are accumulated straight into the flat gradient buffer by the HIP weight-grad kernels."""
+
+    @staticmethod
+    def forward(ctx, anchor, net, x, extra):
+        out, tape = net._run(x, extra, need_grad=anchor.requires_grad)
+        ctx.tape = tape
+        ctx.net = net
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        net = ctx.net
+        net.rt.bwd_arena.reset(g.device)
+        ctx.tape.grad_out = g.contiguous()
+        ctx.tape.backward()
+        return None, None, None, None
+
+
+class HipBackbone(nn.Module):
+    """Base of ResNet / MobileNetV2 backbones executed by libadamml_hip."""
+
+    def __init__(self):
+        super().__init__()
+        self.rt = NetRT()
+        self._conv_states = []
+        self._anchor = None
+        self._packed_version = None
+        self.flat_owner = None       # FlatBuffers managing this net's parameters (self or the enclosing sub-network)
+
+    # -- weight packs ------------------------------------------------------------------------------
+    def _register_conv(self, conv, depthwise=False):
+        cs = ConvState(conv.weight, conv.stride[0], conv.padding[0], depthwise)
+        self._conv_states.append(cs)
+        return cs
+
+    def mark_weights_dirty(self):
+        self._packed_version = None
+
+    def _repack(self, need_dgrad):
+        ver = tuple(cs.weight._version for cs in self._conv_states[:4]) + (self._conv_states[0].weight.data_ptr(), need_dgrad)
+        if self._packed_version == ver:
+            return
+        for cs in self._conv_states:
+            cs.repack(need_dgrad)
+        self._packed_version = ver
+
+    def _trainable(self):
+        return any(p.requires_grad for p in self.parameters())
+
+    def call(self, x, extra=None):
+        """x: NHWC bf16 frames tensor on the GPU.  Returns the fp32 head output."""
+        hip.require_gpu(x)
+        need_grad = torch.is_grad_enabled() and self._trainable()
+        if self._anchor is None or self._anchor.device != x.device:
+            self._anchor = torch.zeros(1, device=x.device)
+        anchor = self._anchor.detach().requires_grad_(need_grad)
+        return _NetCall.apply(anchor, self, x, extra)
+
+    def _run(self, x, extra, need_grad):
+        raise NotImplementedError

@@ -1,0 +1,24 @@
+// Error plumbing and version for the C ABI (include/adamml_hip.h).
+#include "common.h"
+#include "../../include/adamml_hip.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+int adamml_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int adamml_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return ADAMML_OK;
+}
+
+extern "C" int adamml_version(void) { return 100; }
+extern "C" const char* adamml_last_error_string(void) { return g_err; }

@@ -1,0 +1,62 @@
+// Shared device helpers for libadamml_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2 };
+
+#define ADAMML_OK 0
+#define ADAMML_EINVAL (-1)
+#define ADAMML_EUNSUPPORTED (-2)
+#define ADAMML_ELAUNCH (-3)
+
+// error plumbing (api.hip)
+int adamml_set_error(int code, const char* fmt, ...);
+int adamml_check_launch(const char* what);
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    return v;
+}
+// derivative mask of the activation evaluated at pre-activation value v
+__device__ __forceinline__ float act_mask(float v, int act) {
+    if (act == ACT_RELU) return v > 0.f ? 1.f : 0.f;
+    if (act == ACT_RELU6) return (v > 0.f && v < 6.f) ? 1.f : 0.f;
+    return 1.f;
+}
+
+__device__ __forceinline__ f32x8 bf8_to_f32(bf16x8 v) { return __builtin_convertvector(v, f32x8); }
+__device__ __forceinline__ bf16x8 f32_to_bf8(f32x8 v) { return __builtin_convertvector(v, bf16x8); }
+__device__ __forceinline__ f32x4 bf4_to_f32(bf16x4 v) { return __builtin_convertvector(v, f32x4); }
+__device__ __forceinline__ bf16x4 f32_to_bf4(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
+
+__device__ __forceinline__ f32x8 load_f32x8(const float* p) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    f32x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+
+// lazily-normalised activation read: a = act(scale*z + shift) (scale == nullptr -> identity)
+__device__ __forceinline__ f32x8 transform8(bf16x8 raw, const float* scale, const float* shift, int c, int act) {
+    f32x8 v = bf8_to_f32(raw);
+    if (scale) {
+        f32x8 s = load_f32x8(scale + c), t = load_f32x8(shift + c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = apply_act(fmaf(v[i], s[i], t[i]), act);
+    }
+    return v;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,320 @@
+// Depthwise 3x3 convolution (MobileNetV2 blocks: models/sound_mobilenet_v2.py:58, models/policy_net.py:66,80)
+// forward / data-grad / weight-grad as VALU kernels (K = 9 per channel: bandwidth work, not MFMA work), and the
+// fp32 strided GEMM used by the Linear / LSTMCell layers of the policy head and the classifier heads.
+#include "common.h"
+#include "../../include/adamml_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAXC = 2048;
+
+struct ChanMap {
+    int nchunk, rows_per_pass, chunk, rslot;
+    bool active;
+    __device__ ChanMap(int C, int tid) {
+        nchunk = C >> 3;
+        rows_per_pass = NT / nchunk;
+        if (rows_per_pass < 1) rows_per_pass = 1;
+        active = tid < rows_per_pass * nchunk;
+        chunk = tid % nchunk;
+        rslot = tid / nchunk;
+    }
+};
+
+struct DwP {
+    const bf16_t* x;
+    const float* w;       // [9][C]
+    const float* in_scale;
+    const float* in_shift;
+    bf16_t* y;
+    double* stats;
+    int N, H, W, C, OH, OW, stride, pad, act, accumulate;
+    size_t P, ppb;
+};
+
+__global__ __launch_bounds__(NT) void dwconv_fwd_kernel(DwP p) {
+    __shared__ float smem[2 * MAXC];
+    ChanMap m(p.C, threadIdx.x);
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+    const size_t pb = (size_t)blockIdx.x * p.ppb;
+    const size_t pe = pb + p.ppb < p.P ? pb + p.ppb : p.P;
+    if (m.active) {
+        const int c = m.chunk * 8;
+        f32x8 wt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = load_f32x8(p.w + (size_t)t * p.C + c);
+        for (size_t pp = pb + m.rslot; pp < pe; pp += m.rows_per_pass) {
+            const int ow = (int)(pp % p.OW);
+            size_t r = pp / p.OW;
+            const int oh = (int)(r % p.OH);
+            const int n = (int)(r / p.OH);
+            f32x8 acc;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+                    if (ih < 0 || iw < 0 || ih >= p.H || iw >= p.W) continue;
+                    f32x8 v = transform8(*reinterpret_cast<const bf16x8*>(p.x + (((size_t)n * p.H + ih) * p.W + iw) * p.C + c),
+                                         p.in_scale, p.in_shift, c, p.act);
+                    acc += v * wt[kh * 3 + kw];
+                }
+            bf16x8 o = f32_to_bf8(acc);
+            *reinterpret_cast<bf16x8*>(p.y + pp * p.C + c) = o;
+            f32x8 rv = bf8_to_f32(o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s[i] += rv[i]; q[i] += rv[i] * rv[i]; }
+        }
+    }
+    if (p.stats) {
+        for (int i = threadIdx.x; i < 2 * p.C; i += NT) smem[i] = 0.f;
+        __syncthreads();
+        if (m.active) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                atomicAdd(&smem[m.chunk * 8 + i], s[i]);
+                atomicAdd(&smem[p.C + m.chunk * 8 + i], q[i]);
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * p.C; i += NT) atomicAdd(&p.stats[i], (double)smem[i]);
+    }
+}
+
+// dx[n,ih,iw,c] = sum_{kh,kw} dz[n,(ih+pad-kh)/s,(iw+pad-kw)/s,c] * w[kh,kw,c]
+__global__ __launch_bounds__(NT) void dwconv_bwd_data_kernel(DwP p) {   // p.x = dz [N,OH,OW,C], p.y = dx [N,H,W,C]
+    ChanMap m(p.C, threadIdx.x);
+    if (!m.active) return;
+    const size_t pb = (size_t)blockIdx.x * p.ppb;
+    const size_t pe = pb + p.ppb < p.P ? pb + p.ppb : p.P;
+    const int c = m.chunk * 8;
+    f32x8 wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = load_f32x8(p.w + (size_t)t * p.C + c);
+    for (size_t pp = pb + m.rslot; pp < pe; pp += m.rows_per_pass) {
+        const int iw = (int)(pp % p.W);
+        size_t r = pp / p.W;
+        const int ih = (int)(r % p.H);
+        const int n = (int)(r / p.H);
+        f32x8 acc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        if (p.accumulate) acc = bf8_to_f32(*reinterpret_cast<const bf16x8*>(p.y + pp * p.C + c));
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                int vh = ih + p.pad - kh, vw = iw + p.pad - kw;
+                if (vh < 0 || vw < 0) continue;
+                if (p.stride == 2) {
+                    if ((vh | vw) & 1) continue;
+                    vh >>= 1; vw >>= 1;
+                }
+                if (vh >= p.OH || vw >= p.OW) continue;
+                f32x8 g = bf8_to_f32(*reinterpret_cast<const bf16x8*>(p.x + (((size_t)n * p.OH + vh) * p.OW + vw) * p.C + c));
+                acc += g * wt[kh * 3 + kw];
+            }
+        *reinterpret_cast<bf16x8*>(p.y + pp * p.C + c) = f32_to_bf8(acc);
+    }
+}
+
+struct DwWP {
+    const bf16_t* dz;
+    const bf16_t* x;
+    const float* in_scale;
+    const float* in_shift;
+    float* dw;            // [C][3][3] fp32
+    int N, H, W, C, OH, OW, stride, pad, act;
+    size_t P, ppb;
+};
+
+__global__ __launch_bounds__(NT) void dwconv_bwd_weight_kernel(DwWP p) {
+    extern __shared__ float dsm[];        // [9][C]
+    ChanMap m(p.C, threadIdx.x);
+    for (int i = threadIdx.x; i < 9 * p.C; i += NT) dsm[i] = 0.f;
+    __syncthreads();
+    const size_t pb = (size_t)blockIdx.x * p.ppb;
+    const size_t pe = pb + p.ppb < p.P ? pb + p.ppb : p.P;
+    if (m.active) {
+        const int c = m.chunk * 8;
+        f32x8 acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
+        for (size_t pp = pb + m.rslot; pp < pe; pp += m.rows_per_pass) {
+            const int ow = (int)(pp % p.OW);
+            size_t r = pp / p.OW;
+            const int oh = (int)(r % p.OH);
+            const int n = (int)(r / p.OH);
+            f32x8 g = bf8_to_f32(*reinterpret_cast<const bf16x8*>(p.dz + pp * p.C + c));
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+                    if (ih < 0 || iw < 0 || ih >= p.H || iw >= p.W) continue;
+                    f32x8 v = transform8(*reinterpret_cast<const bf16x8*>(p.x + (((size_t)n * p.H + ih) * p.W + iw) * p.C + c),
+                                         p.in_scale, p.in_shift, c, p.act);
+                    acc[kh * 3 + kw] += g * v;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) atomicAdd(&dsm[t * p.C + c + i], acc[t][i]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * p.C; i += NT) {
+        const int t = i / p.C, c = i - t * p.C;
+        atomicAdd(&p.dw[(size_t)c * 9 + t], dsm[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fp32 GEMM
+// C[m,n] (+)= act(sum_k A[m,k] * B[n,k] + bias[n]);  arbitrary element strides.  64x64x16 tiles, 4x4 per thread.
+struct GemmP {
+    const float* a; int64_t a_sm, a_sk;
+    const float* b; int64_t b_sn, b_sk;
+    float* c; int64_t c_sm, c_sn;
+    const float* bias;
+    int act, accumulate, M, N, K;
+};
+
+__global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmP p) {
+    __shared__ float As[16][64 + 4];
+    __shared__ float Bs[16][64 + 4];
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < p.K; k0 += 16) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const int e = tid + l * NT;      // 0..1023 -> (row 0..63, k 0..15)
+            const int kk = e & 15, rr = e >> 4;
+            const int k = k0 + kk;
+            float av = 0.f, bv = 0.f;
+            if (k < p.K) {
+                if (m0 + rr < p.M) av = p.a[(int64_t)(m0 + rr) * p.a_sm + (int64_t)k * p.a_sk];
+                if (n0 + rr < p.N) bv = p.b[(int64_t)(n0 + rr) * p.b_sn + (int64_t)k * p.b_sk];
+            }
+            As[kk][rr] = av;
+            Bs[kk][rr] = bv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a4[4], b4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a4[i] = As[kk][ty * 4 + i]; b4[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a4[i], b4[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int mm = m0 + ty * 4 + i;
+        if (mm >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nn = n0 + tx * 4 + j;
+            if (nn >= p.N) continue;
+            float v = acc[i][j];
+            if (p.bias) v += p.bias[nn];
+            v = apply_act(v, p.act);
+            float* dst = p.c + (int64_t)mm * p.c_sm + (int64_t)nn * p.c_sn;
+            if (p.accumulate) v += *dst;
+            *dst = v;
+        }
+    }
+}
+
+static int dw_blocks(size_t P, int C, size_t* ppb_out) {
+    const int rows = NT / (C / 8) > 0 ? NT / (C / 8) : 1;
+    size_t ppb = (size_t)rows * 8;
+    size_t nblk = (P + ppb - 1) / ppb;
+    if (nblk > 4096) { ppb = ((P + 4095) / 4096 + rows - 1) / rows * rows; nblk = (P + ppb - 1) / ppb; }
+    *ppb_out = ppb;
+    return (int)nblk;
+}
+
+}  // namespace
+
+static int check_dw(const adamml_conv_desc_t* d, const char* name) {
+    if (!d) return adamml_set_error(ADAMML_EINVAL, "%s: null desc", name);
+    if (d->KH != 3 || d->KW != 3 || d->Cin != d->Cout || d->Cin % 8 || d->Cin > MAXC || (d->stride != 1 && d->stride != 2))
+        return adamml_set_error(ADAMML_EUNSUPPORTED, "%s: depthwise kernel supports 3x3, stride 1/2, C%%8==0 (C=%d k=%d s=%d)", name,
+                                d->Cin, d->KH, d->stride);
+    return ADAMML_OK;
+}
+
+extern "C" int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, const float* w, const float* in_scale,
+                                 const float* in_shift, void* y, double* stats, hipStream_t stream) {
+    int rc = check_dw(d, "dwconv_fwd");
+    if (rc) return rc;
+    DwP p;
+    p.x = (const bf16_t*)x; p.w = w; p.in_scale = in_scale; p.in_shift = in_shift; p.y = (bf16_t*)y; p.stats = stats;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.pad = d->pad;
+    p.act = d->act; p.accumulate = 0;
+    p.P = (size_t)d->N * d->OH * d->OW;
+    if (!p.P) return ADAMML_OK;
+    int nblk = dw_blocks(p.P, p.C, &p.ppb);
+    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(nblk), dim3(NT), 0, stream, p);
+    return adamml_check_launch("dwconv_fwd");
+}
+
+extern "C" int adamml_dwconv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const float* w, void* dx, int accumulate,
+                                      hipStream_t stream) {
+    int rc = check_dw(d, "dwconv_bwd_data");
+    if (rc) return rc;
+    DwP p;
+    p.x = (const bf16_t*)dz; p.w = w; p.in_scale = nullptr; p.in_shift = nullptr; p.y = (bf16_t*)dx; p.stats = nullptr;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.pad = d->pad;
+    p.act = 0; p.accumulate = accumulate;
+    p.P = (size_t)d->N * d->H * d->W;
+    if (!p.P) return ADAMML_OK;
+    int nblk = dw_blocks(p.P, p.C, &p.ppb);
+    hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(nblk), dim3(NT), 0, stream, p);
+    return adamml_check_launch("dwconv_bwd_data");
+}
+
+extern "C" int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
+                                        const float* in_shift, float* dw, hipStream_t stream) {
+    int rc = check_dw(d, "dwconv_bwd_weight");
+    if (rc) return rc;
+    DwWP p;
+    p.dz = (const bf16_t*)dz; p.x = (const bf16_t*)x; p.in_scale = in_scale; p.in_shift = in_shift; p.dw = dw;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.pad = d->pad; p.act = d->act;
+    p.P = (size_t)d->N * d->OH * d->OW;
+    if (!p.P) return ADAMML_OK;
+    const int rows = NT / (p.C / 8) > 0 ? NT / (p.C / 8) : 1;
+    size_t ppb = (size_t)rows * 32;
+    size_t nblk = (p.P + ppb - 1) / ppb;
+    if (nblk > 1024) { ppb = ((p.P + 1023) / 1024 + rows - 1) / rows * rows; nblk = (p.P + ppb - 1) / ppb; }
+    p.ppb = ppb;
+    hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3((unsigned)nblk), dim3(NT), 9 * p.C * sizeof(float), stream, p);
+    return adamml_check_launch("dwconv_bwd_weight");
+}
+
+extern "C" int adamml_gemm_f32(const float* a, int64_t a_sm, int64_t a_sk, const float* b, int64_t b_sn, int64_t b_sk, float* c,
+                               int64_t c_sm, int64_t c_sn, const float* bias, int act, int accumulate, int M, int N, int K,
+                               hipStream_t stream) {
+    if (!a || !b || !c) return adamml_set_error(ADAMML_EINVAL, "gemm_f32: null argument");
+    if (M <= 0 || N <= 0) return ADAMML_OK;
+    GemmP p{a, a_sm, a_sk, b, b_sn, b_sk, c, c_sm, c_sn, bias, act, accumulate, M, N, K};
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(NT), 0, stream, p);
+    return adamml_check_launch("gemm_f32");
+}

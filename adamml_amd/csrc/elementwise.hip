@@ -1,0 +1,608 @@
+// HBM-bound kernels of the AdaMML hot path (gfx950): BatchNorm finalize / apply / backward, residual add,
+// pooling, global average pool, input re-layout, optimizer steps.  All activation traffic is 16 B per lane
+// (8 bf16 channels of one NHWC pixel), grid-stride, with per-channel reductions staged through LDS and
+// finished with fp64 global atomics.
+#include "common.h"
+#include "../../include/adamml_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAXC = 2048;
+
+__host__ __device__ inline int imin(int a, int b) { return a < b ? a : b; }
+
+static inline int grid_for(size_t work, int per_block = NT, int cap = 256 * 16) {
+    size_t g = (work + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > (size_t)cap) g = cap;
+    return (int)g;
+}
+
+// thread -> (pixel slot, channel chunk) mapping that keeps a thread's channel chunk fixed across its pixels
+struct ChanMap {
+    int nchunk, rows_per_pass, chunk, rslot;
+    bool active;
+    __device__ ChanMap(int C, int tid) {
+        nchunk = C >> 3;
+        rows_per_pass = NT / nchunk;
+        if (rows_per_pass < 1) rows_per_pass = 1;
+        active = tid < rows_per_pass * nchunk;
+        chunk = tid % nchunk;
+        rslot = tid / nchunk;
+    }
+};
+
+__device__ __forceinline__ void block_channel_publish(const float (&s)[8], const float (&q)[8], const ChanMap& m, float* smem,
+                                                      int C, double* out) {
+    for (int i = threadIdx.x; i < 2 * C; i += NT) smem[i] = 0.f;
+    __syncthreads();
+    if (m.active) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            atomicAdd(&smem[m.chunk * 8 + i], s[i]);
+            atomicAdd(&smem[C + m.chunk * 8 + i], q[i]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += NT) atomicAdd(&out[i], (double)smem[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ BN
+__global__ void bn_finalize_kernel(const double* stats, double count, const float* gamma, const float* beta, float* rm,
+                                   float* rv, float momentum, float eps, float* scale, float* shift, float* mean,
+                                   float* invstd, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mu = stats[c] / count;
+    double var = stats[C + c] / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    float is = (float)(1.0 / sqrt(var + (double)eps));
+    float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mu * sc;
+    mean[c] = (float)mu;
+    invstd[c] = is;
+    if (rm) {
+        double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mu;
+        rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      float* scale, float* shift, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+__global__ void bn_act_add_kernel(const bf16_t* z, const float* scale, const float* shift, int act, const bf16_t* idn,
+                                  const float* id_scale, const float* id_shift, bf16_t* out, size_t nchunks, int C) {
+    const int cpr = C >> 3;
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nchunks; e += (size_t)gridDim.x * NT) {
+        const int c = (int)(e % cpr) * 8;
+        f32x8 v = transform8(*reinterpret_cast<const bf16x8*>(z + e * 8), scale, shift, c, ACT_NONE);
+        if (idn) {
+            f32x8 w = transform8(*reinterpret_cast<const bf16x8*>(idn + e * 8), id_scale, id_shift, c, ACT_NONE);
+            v += w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i], act);
+        *reinterpret_cast<bf16x8*>(out + e * 8) = f32_to_bf8(v);
+    }
+}
+
+__global__ void act_bwd_from_output_kernel(const bf16_t* g_out, const bf16_t* out, int act, bf16_t* g, size_t nchunks) {
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nchunks; e += (size_t)gridDim.x * NT) {
+        f32x8 gv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(g_out + e * 8));
+        f32x8 ov = bf8_to_f32(*reinterpret_cast<const bf16x8*>(out + e * 8));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float m = 1.f;
+            if (act == ACT_RELU) m = ov[i] > 0.f ? 1.f : 0.f;
+            else if (act == ACT_RELU6) m = (ov[i] > 0.f && ov[i] < 6.f) ? 1.f : 0.f;
+            gv[i] *= m;
+        }
+        *reinterpret_cast<bf16x8*>(g + e * 8) = f32_to_bf8(gv);
+    }
+}
+
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const bf16_t* g, const bf16_t* z, const float* scale,
+                                                           const float* shift, const float* mean, const float* invstd,
+                                                           int act, double* sums, size_t P, int C, size_t ppb) {
+    __shared__ float smem[2 * MAXC];
+    ChanMap m(C, threadIdx.x);
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+    const size_t pb = (size_t)blockIdx.x * ppb;
+    const size_t pe = pb + ppb < P ? pb + ppb : P;
+    if (m.active) {
+        const int c = m.chunk * 8;
+        f32x8 sc = load_f32x8(scale + c), sh = load_f32x8(shift + c), mu = load_f32x8(mean + c), is = load_f32x8(invstd + c);
+        for (size_t p = pb + m.rslot; p < pe; p += m.rows_per_pass) {
+            f32x8 gv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(g + p * C + c));
+            f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(z + p * C + c));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float gp = gv[i] * act_mask(fmaf(zv[i], sc[i], sh[i]), act);
+                s[i] += gp;
+                q[i] += gp * (zv[i] - mu[i]) * is[i];
+            }
+        }
+    }
+    block_channel_publish(s, q, m, smem, C, sums);
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* sums, double count, const float* gamma, const float* invstd,
+                                       float* dgamma, float* dbeta, float* coef, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sg = sums[c], sgz = sums[C + c];
+    if (dgamma) dgamma[c] += (float)sgz;
+    if (dbeta) dbeta[c] += (float)sg;
+    coef[c] = gamma[c] * invstd[c];
+    coef[C + c] = (float)(sg / count);
+    coef[2 * C + c] = (float)(sgz / count);
+}
+
+__global__ void bn_bwd_apply_kernel(const bf16_t* g, const bf16_t* z, const float* scale, const float* shift,
+                                    const float* mean, const float* invstd, int act, const float* coef, bf16_t* dz,
+                                    size_t nchunks, int C) {
+    const int cpr = C >> 3;
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nchunks; e += (size_t)gridDim.x * NT) {
+        const int c = (int)(e % cpr) * 8;
+        f32x8 gv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(g + e * 8));
+        f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(z + e * 8));
+        f32x8 sc = load_f32x8(scale + c), sh = load_f32x8(shift + c), mu = load_f32x8(mean + c), is = load_f32x8(invstd + c);
+        f32x8 k0 = load_f32x8(coef + c), k1 = load_f32x8(coef + C + c), k2 = load_f32x8(coef + 2 * C + c);
+        f32x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float gp = gv[i] * act_mask(fmaf(zv[i], sc[i], sh[i]), act);
+            float zh = (zv[i] - mu[i]) * is[i];
+            o[i] = k0[i] * (gp - k1[i] - zh * k2[i]);
+        }
+        *reinterpret_cast<bf16x8*>(dz + e * 8) = f32_to_bf8(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pooling
+__global__ void maxpool_fwd_kernel(const bf16_t* x, const float* scale, const float* shift, int act, bf16_t* y,
+                                   uint8_t* idx, int N, int H, int W, int C, int OH, int OW) {
+    const int cpr = C >> 3;
+    const size_t total = (size_t)N * OH * OW * cpr;
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+        const int ch = (int)(e % cpr);
+        size_t pix = e / cpr;
+        const int ow = (int)(pix % OW);
+        pix /= OW;
+        const int oh = (int)(pix % OH);
+        const int n = (int)(pix / OH);
+        f32x8 best;
+        int bi[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bi[i] = 0; }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+                if (ih < 0 || iw < 0 || ih >= H || iw >= W) continue;
+                f32x8 v = transform8(*reinterpret_cast<const bf16x8*>(x + (((size_t)n * H + ih) * W + iw) * C + ch * 8), scale,
+                                     shift, ch * 8, act);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (v[i] > best[i]) { best[i] = v[i]; bi[i] = kh * 3 + kw; }
+            }
+        *reinterpret_cast<bf16x8*>(y + e * 8) = f32_to_bf8(best);
+        uint64_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) packed |= (uint64_t)bi[i] << (8 * i);
+        *reinterpret_cast<uint64_t*>(idx + e * 8) = packed;
+    }
+}
+
+__global__ void maxpool_bwd_kernel(const bf16_t* gy, const uint8_t* idx, bf16_t* gx, int N, int H, int W, int C, int OH,
+                                   int OW, int accumulate) {
+    const int cpr = C >> 3;
+    const size_t total = (size_t)N * H * W * cpr;
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+        const int ch = (int)(e % cpr);
+        size_t pix = e / cpr;
+        const int iw = (int)(pix % W);
+        pix /= W;
+        const int ih = (int)(pix % H);
+        const int n = (int)(pix / H);
+        f32x8 acc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        if (accumulate) acc = bf8_to_f32(*reinterpret_cast<const bf16x8*>(gx + e * 8));
+        const int oh_lo = ih >> 1, oh_hi = (ih + 1) >> 1;   // windows with oh*2-1 <= ih <= oh*2+1
+        const int ow_lo = iw >> 1, ow_hi = (iw + 1) >> 1;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            if (oh >= OH) continue;
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                if (ow >= OW) continue;
+                const int tap = (ih - (oh * 2 - 1)) * 3 + (iw - (ow * 2 - 1));
+                const size_t o = ((((size_t)n * OH + oh) * OW + ow) * cpr + ch) * 8;
+                const uint64_t packed = *reinterpret_cast<const uint64_t*>(idx + o);
+                f32x8 g = bf8_to_f32(*reinterpret_cast<const bf16x8*>(gy + o));
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if ((int)((packed >> (8 * i)) & 0xff) == tap) acc[i] += g[i];
+            }
+        }
+        *reinterpret_cast<bf16x8*>(gx + e * 8) = f32_to_bf8(acc);
+    }
+}
+
+// x: [NB, T, HWC] -> y: [NB, To, HWC], To = (T-1)/2+1
+__global__ void temporal_pool_fwd_kernel(const bf16_t* x, const float* scale, const float* shift, int act, bf16_t* y,
+                                         int NB, int T, int To, size_t hwc8, int C, int mode) {
+    const size_t total = (size_t)NB * To * hwc8;
+    const int cpr = C >> 3;
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+        const size_t in = e % hwc8;
+        size_t r = e / hwc8;
+        const int to = (int)(r % To);
+        const int nb = (int)(r / To);
+        const int c = (int)(in % cpr) * 8;
+        f32x8 accv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) accv[i] = mode == 0 ? -INFINITY : 0.f;
+#pragma unroll
+        for (int k = -1; k <= 1; ++k) {
+            const int t = 2 * to + k;
+            if (t < 0 || t >= T) continue;
+            f32x8 v = transform8(*reinterpret_cast<const bf16x8*>(x + (((size_t)nb * T + t) * hwc8 + in) * 8), scale, shift, c, act);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) accv[i] = mode == 0 ? fmaxf(accv[i], v[i]) : accv[i] + v[i];
+        }
+        if (mode == 1) accv *= (1.f / 3.f);
+        *reinterpret_cast<bf16x8*>(y + e * 8) = f32_to_bf8(accv);
+    }
+}
+
+// gradient w.r.t. the ACTIVATED input value (the lazy transform's own backward is the producer's business)
+__global__ void temporal_pool_bwd_kernel(const bf16_t* gy, const bf16_t* x, const float* scale, const float* shift, int act,
+                                         bf16_t* gx, int NB, int T, int To, size_t hwc8, int C, int mode) {
+    const size_t total = (size_t)NB * T * hwc8;
+    const int cpr = C >> 3;
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+        const size_t in = e % hwc8;
+        size_t r = e / hwc8;
+        const int t = (int)(r % T);
+        const int nb = (int)(r / T);
+        const int c = (int)(in % cpr) * 8;
+        f32x8 acc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        const int to_lo = t >> 1, to_hi = (t + 1) >> 1;
+        for (int to = to_lo; to <= to_hi; ++to) {
+            if (to >= To) continue;
+            f32x8 g = bf8_to_f32(*reinterpret_cast<const bf16x8*>(gy + (((size_t)nb * To + to) * hwc8 + in) * 8));
+            if (mode == 1) {
+                acc += g * (1.f / 3.f);
+                continue;
+            }
+            // recompute the window's first arg-max (scan order 2to-1, 2to, 2to+1, strict >)
+            f32x8 best;
+            int bt[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bt[i] = -1; }
+#pragma unroll
+            for (int k = -1; k <= 1; ++k) {
+                const int tt = 2 * to + k;
+                if (tt < 0 || tt >= T) continue;
+                f32x8 v = transform8(*reinterpret_cast<const bf16x8*>(x + (((size_t)nb * T + tt) * hwc8 + in) * 8), scale, shift, c, act);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (v[i] > best[i]) { best[i] = v[i]; bt[i] = tt; }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (bt[i] == t) acc[i] += g[i];
+        }
+        *reinterpret_cast<bf16x8*>(gx + e * 8) = f32_to_bf8(acc);
+    }
+}
+
+__global__ void gap_fwd_kernel(const bf16_t* x, const float* scale, const float* shift, int act, float* out, int N, int HW,
+                               int C) {
+    const int cpr = C >> 3;
+    const int total = N * cpr;
+    for (int e = blockIdx.x * NT + threadIdx.x; e < total; e += gridDim.x * NT) {
+        const int ch = e % cpr, n = e / cpr;
+        f32x8 acc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int p = 0; p < HW; ++p)
+            acc += transform8(*reinterpret_cast<const bf16x8*>(x + ((size_t)n * HW + p) * C + ch * 8), scale, shift, ch * 8, act);
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) out[(size_t)n * C + ch * 8 + i] = acc[i] * inv;
+    }
+}
+
+__global__ void gap_bwd_kernel(const float* g, bf16_t* gx, int N, int HW, int C) {
+    const int cpr = C >> 3;
+    const size_t total = (size_t)N * HW * cpr;
+    const float inv = 1.f / (float)HW;
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+        const int ch = (int)(e % cpr);
+        const int n = (int)(e / ((size_t)HW * cpr));
+        f32x8 v = load_f32x8(g + (size_t)n * C + ch * 8);
+        v *= inv;
+        *reinterpret_cast<bf16x8*>(gx + e * 8) = f32_to_bf8(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ input re-layout
+// x [B, S*F*C, H, W] fp32 -> y [S][B*Fk][OH][OW][c_pad] bf16; frames f = fk*frame_step; bilinear when OH != H.
+__global__ void clip_to_nhwc_kernel(const float* x, bf16_t* y, int B, int S, int F, int C, int H, int W, int OH, int OW,
+                                    int frame_step, int Fk, int c_pad) {
+    const size_t total = (size_t)S * B * Fk * OH * OW;
+    const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+    const bool resize = (OH != H) || (OW != W);
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+        size_t r = e;
+        const int ow = (int)(r % OW); r /= OW;
+        const int oh = (int)(r % OH); r /= OH;
+        const int fk = (int)(r % Fk); r /= Fk;
+        const int b = (int)(r % B);
+        const int s = (int)(r / B);
+        const int f = fk * frame_step;
+        const float* src = x + (((size_t)b * S + s) * F + f) * C * (size_t)H * W;
+        int h0 = oh, h1 = oh, w0 = ow, w1 = ow;
+        float lh1 = 0.f, lw1 = 0.f;
+        if (resize) {
+            float fh = fmaxf(sh * (oh + 0.5f) - 0.5f, 0.f), fw = fmaxf(sw * (ow + 0.5f) - 0.5f, 0.f);
+            h0 = (int)fh; w0 = (int)fw;
+            h1 = h0 + (h0 < H - 1 ? 1 : 0); w1 = w0 + (w0 < W - 1 ? 1 : 0);
+            lh1 = fh - h0; lw1 = fw - w0;
+        }
+        const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+        bf16_t* dst = y + e * c_pad;
+        for (int c8 = 0; c8 < c_pad; c8 += 8) {
+            f32x8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = c8 + i;
+                float val = 0.f;
+                if (c < C) {
+                    const float* pl = src + (size_t)c * H * W;
+                    if (resize)
+                        val = lh0 * (lw0 * pl[(size_t)h0 * W + w0] + lw1 * pl[(size_t)h0 * W + w1]) +
+                              lh1 * (lw0 * pl[(size_t)h1 * W + w0] + lw1 * pl[(size_t)h1 * W + w1]);
+                    else
+                        val = pl[(size_t)oh * W + ow];
+                }
+                v[i] = val;
+            }
+            *reinterpret_cast<bf16x8*>(dst + c8) = f32_to_bf8(v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+__global__ void pack_conv_weight_kernel(const float* w, void* out, int cout, int cin_true, int cin_pad, int kh, int kw, int mode) {
+    const int taps = kh * kw;
+    const size_t total = mode == 2 ? (size_t)taps * cout : (size_t)cout * taps * cin_pad;
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+        if (mode == 0) {            // [co][tap][ci]
+            const int ci = (int)(e % cin_pad);
+            const int tap = (int)((e / cin_pad) % taps);
+            const int co = (int)(e / ((size_t)cin_pad * taps));
+            float v = ci < cin_true ? w[((size_t)co * cin_true + ci) * taps + tap] : 0.f;
+            reinterpret_cast<__bf16*>(out)[e] = (__bf16)v;
+        } else if (mode == 1) {     // [ci][tap flipped][co]
+            const int co = (int)(e % cout);
+            const int tap = (int)((e / cout) % taps);
+            const int ci = (int)(e / ((size_t)cout * taps));
+            float v = ci < cin_true ? w[((size_t)co * cin_true + ci) * taps + (taps - 1 - tap)] : 0.f;
+            reinterpret_cast<__bf16*>(out)[e] = (__bf16)v;
+        } else {                    // depthwise [tap][c] fp32
+            const int c = (int)(e % cout);
+            const int tap = (int)(e / cout);
+            reinterpret_cast<float*>(out)[e] = w[(size_t)c * taps + tap];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ optimizers
+__global__ void sgd_step_kernel(float* p, const float* g, float* mom, size_t n, float lr, float momentum, float wd,
+                                int nesterov, int first) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        float d = g[i] + wd * p[i];
+        if (momentum != 0.f) {
+            float b = first ? d : momentum * mom[i] + d;
+            mom[i] = b;
+            d = nesterov ? d + momentum * b : b;
+        }
+        p[i] -= lr * d;
+    }
+}
+
+__global__ void adam_step_kernel(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
+                                 float eps, float wd, float bc1, float bc2) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        float d = g[i] + wd * p[i];
+        float mi = b1 * m[i] + (1.f - b1) * d;
+        float vi = b2 * v[i] + (1.f - b2) * d * d;
+        m[i] = mi;
+        v[i] = vi;
+        float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        p[i] -= (lr / bc1) * mi / denom;
+    }
+}
+
+}  // namespace
+
+#define CHECK_C(C, name)                                                                                     \
+    if ((C) % 8 != 0 || (C) > MAXC || (C) <= 0)                                                              \
+        return adamml_set_error(ADAMML_EINVAL, name ": C=%d must be a multiple of 8 in (0, %d]", (C), MAXC);
+
+extern "C" int adamml_bn_finalize(const double* stats, double count, const float* gamma, const float* beta, float* rm,
+                                  float* rv, float momentum, float eps, float* scale, float* shift, float* mean,
+                                  float* invstd, int C, hipStream_t stream) {
+    if (!stats || !gamma || !beta || !scale || !shift || !mean || !invstd) return adamml_set_error(ADAMML_EINVAL, "bn_finalize: null argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, stats, count, gamma, beta, rm, rv,
+                       momentum, eps, scale, shift, mean, invstd, C);
+    return adamml_check_launch("bn_finalize");
+}
+
+extern "C" int adamml_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                     float* scale, float* shift, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, gamma, beta, rm, rv, eps, scale, shift, C);
+    return adamml_check_launch("bn_eval_affine");
+}
+
+extern "C" int adamml_bn_act_add(const void* z, const float* scale, const float* shift, int act, const void* idn,
+                                 const float* id_scale, const float* id_shift, void* out, size_t P, int C, hipStream_t stream) {
+    CHECK_C(C, "bn_act_add");
+    const size_t n = P * (size_t)(C / 8);
+    if (!n) return ADAMML_OK;
+    hipLaunchKernelGGL(bn_act_add_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, (const bf16_t*)z, scale, shift, act,
+                       (const bf16_t*)idn, id_scale, id_shift, (bf16_t*)out, n, C);
+    return adamml_check_launch("bn_act_add");
+}
+
+extern "C" int adamml_act_bwd_from_output(const void* g_out, const void* out, int act, void* g, size_t n, hipStream_t stream) {
+    if (n % 8) return adamml_set_error(ADAMML_EINVAL, "act_bwd_from_output: n must be a multiple of 8");
+    if (!n) return ADAMML_OK;
+    hipLaunchKernelGGL(act_bwd_from_output_kernel, dim3(grid_for(n / 8)), dim3(NT), 0, stream, (const bf16_t*)g_out,
+                       (const bf16_t*)out, act, (bf16_t*)g, n / 8);
+    return adamml_check_launch("act_bwd_from_output");
+}
+
+extern "C" int adamml_bn_bwd_reduce(const void* g, const void* z, const float* scale, const float* shift, const float* mean,
+                                    const float* invstd, int act, double* sums, size_t P, int C, hipStream_t stream) {
+    CHECK_C(C, "bn_bwd_reduce");
+    if (!P) return ADAMML_OK;
+    const int rows = NT / (C / 8) > 0 ? NT / (C / 8) : 1;
+    size_t ppb = (size_t)rows * 16;
+    size_t nblk = (P + ppb - 1) / ppb;
+    if (nblk > 2048) { ppb = ((P + 2047) / 2048 + rows - 1) / rows * rows; nblk = (P + ppb - 1) / ppb; }
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)nblk), dim3(NT), 0, stream, (const bf16_t*)g, (const bf16_t*)z, scale,
+                       shift, mean, invstd, act, sums, P, C, ppb);
+    return adamml_check_launch("bn_bwd_reduce");
+}
+
+extern "C" int adamml_bn_bwd_finalize(const double* sums, double count, const float* gamma, const float* invstd, float* dgamma,
+                                      float* dbeta, float* coef, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, sums, count, gamma, invstd, dgamma,
+                       dbeta, coef, C);
+    return adamml_check_launch("bn_bwd_finalize");
+}
+
+extern "C" int adamml_bn_bwd_apply(const void* g, const void* z, const float* scale, const float* shift, const float* mean,
+                                   const float* invstd, int act, const float* coef, void* dz, size_t P, int C, hipStream_t stream) {
+    CHECK_C(C, "bn_bwd_apply");
+    const size_t n = P * (size_t)(C / 8);
+    if (!n) return ADAMML_OK;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, (const bf16_t*)g, (const bf16_t*)z, scale, shift,
+                       mean, invstd, act, coef, (bf16_t*)dz, n, C);
+    return adamml_check_launch("bn_bwd_apply");
+}
+
+extern "C" int adamml_maxpool2d_fwd(const void* x, const float* scale, const float* shift, int act, void* y, uint8_t* idx, int N,
+                                    int H, int W, int C, int OH, int OW, hipStream_t stream) {
+    CHECK_C(C, "maxpool2d_fwd");
+    const size_t n = (size_t)N * OH * OW * (C / 8);
+    if (!n) return ADAMML_OK;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, (const bf16_t*)x, scale, shift, act, (bf16_t*)y,
+                       idx, N, H, W, C, OH, OW);
+    return adamml_check_launch("maxpool2d_fwd");
+}
+
+extern "C" int adamml_maxpool2d_bwd(const void* g_y, const uint8_t* idx, void* g_x, int N, int H, int W, int C, int OH, int OW,
+                                    int accumulate, hipStream_t stream) {
+    CHECK_C(C, "maxpool2d_bwd");
+    const size_t n = (size_t)N * H * W * (C / 8);
+    if (!n) return ADAMML_OK;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, (const bf16_t*)g_y, idx, (bf16_t*)g_x, N, H, W, C,
+                       OH, OW, accumulate);
+    return adamml_check_launch("maxpool2d_bwd");
+}
+
+extern "C" int adamml_temporal_pool_fwd(const void* x, const float* scale, const float* shift, int act, void* y, int NB, int T,
+                                        size_t HWC, int C, int mode, hipStream_t stream) {
+    CHECK_C(C, "temporal_pool_fwd");
+    if (mode == 1 && T < 3)   // models/common.py:20 nn.AvgPool3d raises for T < kernel (torch: "input image smaller than kernel size")
+        return adamml_set_error(ADAMML_EINVAL, "temporal_pool_fwd: avg pooling needs T >= 3 (got %d), as in the reference", T);
+    const int To = (T - 1) / 2 + 1;
+    const size_t n = (size_t)NB * To * (HWC / 8);
+    if (!n) return ADAMML_OK;
+    hipLaunchKernelGGL(temporal_pool_fwd_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, (const bf16_t*)x, scale, shift, act,
+                       (bf16_t*)y, NB, T, To, HWC / 8, C, mode);
+    return adamml_check_launch("temporal_pool_fwd");
+}
+
+extern "C" int adamml_temporal_pool_bwd(const void* g_y, const void* x, const float* scale, const float* shift, int act, void* g_x,
+                                        int NB, int T, size_t HWC, int C, int mode, hipStream_t stream) {
+    CHECK_C(C, "temporal_pool_bwd");
+    const int To = (T - 1) / 2 + 1;
+    const size_t n = (size_t)NB * T * (HWC / 8);
+    if (!n) return ADAMML_OK;
+    hipLaunchKernelGGL(temporal_pool_bwd_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, (const bf16_t*)g_y, (const bf16_t*)x, scale,
+                       shift, act, (bf16_t*)g_x, NB, T, To, HWC / 8, C, mode);
+    return adamml_check_launch("temporal_pool_bwd");
+}
+
+extern "C" int adamml_gap_fwd(const void* x, const float* scale, const float* shift, int act, float* out, int N, int HW, int C,
+                              hipStream_t stream) {
+    CHECK_C(C, "gap_fwd");
+    const size_t n = (size_t)N * (C / 8);
+    if (!n) return ADAMML_OK;
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(grid_for(n, 64)), dim3(NT), 0, stream, (const bf16_t*)x, scale, shift, act, out, N, HW, C);
+    return adamml_check_launch("gap_fwd");
+}
+
+extern "C" int adamml_gap_bwd(const float* g, void* g_x, int N, int HW, int C, hipStream_t stream) {
+    CHECK_C(C, "gap_bwd");
+    const size_t n = (size_t)N * HW * (C / 8);
+    if (!n) return ADAMML_OK;
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, g, (bf16_t*)g_x, N, HW, C);
+    return adamml_check_launch("gap_bwd");
+}
+
+extern "C" int adamml_clip_to_nhwc(const float* x, void* y, int B, int S, int F, int C, int H, int W, int OH, int OW,
+                                   int frame_step, int c_pad, hipStream_t stream) {
+    if (c_pad % 8 || c_pad < C || frame_step < 1) return adamml_set_error(ADAMML_EINVAL, "clip_to_nhwc: bad c_pad/frame_step");
+    const int Fk = (F + frame_step - 1) / frame_step;
+    const size_t n = (size_t)S * B * Fk * OH * OW;
+    if (!n) return ADAMML_OK;
+    hipLaunchKernelGGL(clip_to_nhwc_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, x, (bf16_t*)y, B, S, F, C, H, W, OH, OW,
+                       frame_step, Fk, c_pad);
+    return adamml_check_launch("clip_to_nhwc");
+}
+
+extern "C" int adamml_pack_conv_weight(const float* w, void* out, int cout, int cin_true, int cin_pad, int kh, int kw, int mode,
+                                       hipStream_t stream) {
+    if (mode < 0 || mode > 2) return adamml_set_error(ADAMML_EINVAL, "pack_conv_weight: mode %d", mode);
+    const size_t n = mode == 2 ? (size_t)kh * kw * cout : (size_t)cout * kh * kw * cin_pad;
+    if (!n) return ADAMML_OK;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, w, out, cout, cin_true, cin_pad, kh, kw, mode);
+    return adamml_check_launch("pack_conv_weight");
+}
+
+extern "C" int adamml_sgd_step(float* p, const float* g, float* mom, size_t n, float lr, float momentum, float weight_decay,
+                               int nesterov, int first_step, hipStream_t stream) {
+    if (!n) return ADAMML_OK;
+    hipLaunchKernelGGL(sgd_step_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, p, g, mom, n, lr, momentum, weight_decay, nesterov,
+                       first_step);
+    return adamml_check_launch("sgd_step");
+}
+
+extern "C" int adamml_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, int step, hipStream_t stream) {
+    if (!n) return ADAMML_OK;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                       bc1, bc2);
+    return adamml_check_launch("adam_step");
+}

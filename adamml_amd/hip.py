@@ -1,0 +1,92 @@
+"""ctypes binding of libadamml_hip.so (include/adamml_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a launch fails the
+caller gets a RuntimeError -- never a silent CPU / eager path."""
+import ctypes
+import os
+from ctypes import c_void_p, c_int, c_int32, c_int64, c_float, c_double, c_size_t, c_char_p, POINTER, Structure, byref
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadamml_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int32) for n in ("N", "H", "W", "Cin", "OH", "OW", "Cout", "KH", "KW", "stride", "pad", "up", "act",
+                                      "accumulate")]
+
+
+_P, _I, _F, _D, _Z, _L = c_void_p, c_int, c_float, c_double, c_size_t, c_int64
+_DESC = POINTER(ConvDesc)
+
+# name -> argtypes (every entry point declared in include/adamml_hip.h, stream last)
+SIGNATURES = {
+    "adamml_conv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
+    "adamml_conv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
+    "adamml_conv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _I, _P],
+    "adamml_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "adamml_dwconv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
+    "adamml_dwconv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
+    "adamml_dwconv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _P],
+    "adamml_bn_finalize": [_P, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
+    "adamml_bn_eval_affine": [_P, _P, _P, _P, _F, _P, _P, _I, _P],
+    "adamml_bn_act_add": [_P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _P],
+    "adamml_act_bwd_from_output": [_P, _P, _I, _P, _Z, _P],
+    "adamml_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _I, _P, _Z, _I, _P],
+    "adamml_bn_bwd_finalize": [_P, _D, _P, _P, _P, _P, _P, _I, _P],
+    "adamml_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _I, _P],
+    "adamml_maxpool2d_fwd": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "adamml_maxpool2d_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adamml_temporal_pool_fwd": [_P, _P, _P, _I, _P, _I, _I, _Z, _I, _I, _P],
+    "adamml_temporal_pool_bwd": [_P, _P, _P, _P, _I, _P, _I, _I, _Z, _I, _I, _P],
+    "adamml_gap_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _P],
+    "adamml_gap_bwd": [_P, _P, _I, _I, _I, _P],
+    "adamml_clip_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adamml_gemm_f32": [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _I, _I, _P],
+    "adamml_sgd_step": [_P, _P, _P, _Z, _F, _F, _F, _I, _I, _P],
+    "adamml_adam_step": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _P],
+}
+
+_lib = None
+
+
+def load():
+    """Load libadamml_hip.so (built in-tree by __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("adamml_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+                           "there is no CPU fallback for the HIP hot path" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argt in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.argtypes = argt
+        fn.restype = c_int
+    lib.adamml_version.restype = c_int
+    lib.adamml_last_error_string.restype = c_char_p
+    _lib = lib
+    return lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args, _stream())
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.adamml_last_error_string().decode()))
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("adamml_amd: tensors must live on an MI355X (got device %s); there is no CPU path" % t.device)

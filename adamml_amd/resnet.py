@@ -1,0 +1,153 @@
+"""TSN-style 2-D ResNet-50/101/152 over N*T frames with temporal pooling between stages, executed by
+libadamml_hip (bf16 MFMA implicit-GEMM convs with fused BatchNorm statistics).
+
+Mirrors the interface and state_dict of models/resnet.py:116-259 (class ResNet, factory resnet()).
+"""
+import torch
+import torch.nn as nn
+
+from . import hip
+from .backbone import HipBackbone, FlatBuffers
+from .common import MeanStdMixin
+from .runtime import (Lazy, conv_bn, add_act, maxpool3x3s2, temporal_pool, gap, gemm_f32, clip_to_nhwc, pad8,
+                      ACT_NONE, ACT_RELU)
+
+__all__ = ['ResNet', 'resnet']
+
+_BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+
+
+class _Bottleneck(nn.Module):
+    """Parameter container with the names of models/resnet.py:77-92."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class ResNet(HipBackbone, MeanStdMixin):
+
+    def __init__(self, depth, num_frames, num_classes=1000, dropout=0.5, zero_init_residual=False,
+                 without_t_stride=False, pooling_method='max', input_channels=3):
+        super().__init__()
+        if depth not in _BLOCKS:
+            raise ValueError("adamml_amd.ResNet: the HIP path implements the Bottleneck depths 50/101/152 "
+                             "(the AdaMML hot path uses 50); got depth=%r" % (depth,))
+        layers = _BLOCKS[depth]
+        self.pooling_method = pooling_method.lower()
+        self.depth = depth
+        self.num_frames = num_frames
+        self.orig_num_frames = num_frames
+        self.num_classes = num_classes
+        self.without_t_stride = without_t_stride
+        self.input_channels = input_channels
+
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(input_channels, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], stride=2)
+        self.layer3 = self._make_layer(256, layers[2], stride=2)
+        self.layer4 = self._make_layer(512, layers[3], stride=2)
+        self.dropout_p = dropout
+        self.fc = nn.Linear(2048, num_classes)
+
+        self._stem = self._register_conv(self.conv1)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for b in layer:
+                b._cs1 = self._register_conv(b.conv1)
+                b._cs2 = self._register_conv(b.conv2)
+                b._cs3 = self._register_conv(b.conv3)
+                b._csd = self._register_conv(b.downsample[0]) if b.downsample is not None else None
+        self.flat_owner = FlatBuffers(self)
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride, bias=False),
+                                       nn.BatchNorm2d(planes * 4))
+        layers = [_Bottleneck(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(_Bottleneck(self.inplanes, planes, 1, None))
+        return nn.Sequential(*layers)
+
+    # ------------------------------------------------------------------------------------------
+    def _run(self, x, extra, need_grad):
+        """x: [N*T, H, W, pad8(C)] bf16 frames.  Returns fp32 logits [N, num_classes]."""
+        rt = self.rt
+        tape = rt.begin_forward(x.device, self.training, need_grad)
+        self._repack(need_grad)
+        frames = self.orig_num_frames
+        nt = x.shape[0]
+        n = nt // frames
+        h = Lazy(x, requires_grad=False)
+        h = conv_bn(rt, h, self._stem, self.bn1, ACT_RELU)
+        h = maxpool3x3s2(rt, h)
+        for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
+            for b in layer:
+                o = conv_bn(rt, h, b._cs1, b.bn1, ACT_RELU)
+                o = conv_bn(rt, o, b._cs2, b.bn2, ACT_RELU)
+                o = conv_bn(rt, o, b._cs3, b.bn3, ACT_NONE)
+                idn = conv_bn(rt, h, b._csd, b.downsample[1], ACT_NONE) if b._csd is not None else h
+                h = add_act(rt, o, idn, ACT_RELU)
+            if li < 3 and not self.without_t_stride:
+                h = temporal_pool(rt, h, frames, self.pooling_method)
+                frames = max(1, frames // 2)
+        feat, push = gap(rt, h)                       # [N*T', 2048] fp32
+        mask = None
+        if self.training and self.dropout_p > 0:
+            keep = 1.0 - self.dropout_p
+            mask = (torch.rand_like(feat) < keep).to(feat.dtype) / keep
+            feat = feat * mask
+        y = gemm_f32(feat, self.fc.weight, bias=self.fc.bias)          # [N*T', classes]
+        tprime = y.shape[0] // n
+        out = y.view(n, tprime, -1).mean(dim=1) if tprime > 1 else y.view(n, -1)
+        if need_grad:
+            fcw, fcb = self.fc.weight, self.fc.bias
+
+            def head_bwd():
+                g = tape.grad_out                                   # [N, classes]
+                gy = (g / tprime).unsqueeze(1).expand(n, tprime, g.shape[-1]).reshape(n * tprime, -1).contiguous()
+                if fcw.requires_grad:
+                    gemm_f32(gy, feat, out=fcw.grad, trans_a=True, trans_b=False, accumulate=True)   # dW += gy^T feat
+                    fcb.grad += gy.sum(0)
+                gf = gemm_f32(gy, fcw, trans_b=False)                # [N*T', 2048]
+                if mask is not None:
+                    gf = gf * mask
+                push(gf)
+            tape.record(head_bwd)
+        return out, tape
+
+    def forward(self, x):
+        """models/resnet.py:195-223 contract: x [N, T*C, H, W] fp32 -> logits [N, num_classes]."""
+        hip.require_gpu(x)
+        self.flat_owner.ensure(x.device)
+        if self.training and torch.is_grad_enabled():
+            self.flat_owner.ensure_grads()
+        n, c_t, hh, ww = x.shape
+        frames = self.orig_num_frames if c_t != 1 else 1
+        xs = clip_to_nhwc(x, 1, frames, c_t // frames)[0]
+        return self.call(xs)
+
+    def forward_nhwc(self, frames_nhwc):
+        return self.call(frames_nhwc)
+
+
+def resnet(depth, num_classes, without_t_stride, groups, dropout, pooling_method,
+           input_channels, imagenet_pretrained=True, **kwargs):
+    """Factory with the signature of models/resnet.py:244-259.  There is no network on the target systems:
+    imagenet_pretrained=True raises instead of downloading; load weights with load_state_dict."""
+    model = ResNet(depth, num_frames=groups, num_classes=num_classes, without_t_stride=without_t_stride,
+                   dropout=dropout, pooling_method=pooling_method, input_channels=input_channels)
+    if imagenet_pretrained and kwargs.get("allow_download", False):
+        raise RuntimeError("adamml_amd.resnet: ImageNet weights cannot be downloaded here; pass a state_dict")
+    return model

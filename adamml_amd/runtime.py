@@ -1,0 +1,365 @@
+"""Host-side executor of the HIP hot path: lazy-BatchNorm activation tensors, a reverse tape,
+and one Python call per fused device op (each a single C-ABI launch into libadamml_hip.so).
+
+Data layout in HBM: activations NHWC bf16 (channels padded to x8); every conv writes its
+RAW output once and accumulates the per-channel sum / sum-of-squares in its epilogue; the consumer applies
+the producer's BatchNorm scale/shift (+ReLU/ReLU6) while staging its input, so normalised activations are
+never materialised except at residual adds.  BatchNorm statistics, scale/shift and master weights are fp32.
+"""
+import math
+import torch
+import torch.distributed as dist
+
+from . import hip
+from .hip import ConvDesc, ACT_NONE, ACT_RELU, ACT_RELU6, call, ptr
+from ctypes import byref
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+class Lazy:
+    """Activation tensor [N,H,W,C] bf16 whose value is act(scale*data + shift) (scale None -> data)."""
+    __slots__ = ("data", "scale", "shift", "act", "grad", "requires_grad")
+
+    def __init__(self, data, scale=None, shift=None, act=ACT_NONE, requires_grad=True):
+        self.data, self.scale, self.shift, self.act = data, scale, shift, act
+        self.grad = None            # gradient w.r.t. the ACTIVATED value, bf16, same shape
+        self.requires_grad = requires_grad
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+
+class Tape:
+    """Reverse-mode tape for one backbone call; closures run in reverse order."""
+
+    def __init__(self, need_grad):
+        self.need_grad = need_grad
+        self.fns = []
+
+    def record(self, fn):
+        if self.need_grad:
+            self.fns.append(fn)
+
+    def backward(self):
+        fns, self.fns = self.fns, []
+        for fn in reversed(fns):
+            fn()
+
+
+class Arena:
+    """Bump allocator over one zero-initialised fp64 buffer (BatchNorm statistic accumulators):
+    one memset per backbone pass instead of one per layer."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+        self.high = 0
+
+    def reset(self, device):
+        need = max(self.high, 1)
+        if self.buf is None or self.buf.numel() < need or self.buf.device != device:
+            self.buf = torch.zeros(need, dtype=torch.float64, device=device)
+        else:
+            self.buf[:need].zero_()
+        self.off = 0
+
+    def take(self, n):
+        if self.buf is None or self.off + n > self.buf.numel():
+            # first pass (size unknown yet): grow by individual zeroed allocations, remember the total
+            t = torch.zeros(n, dtype=torch.float64, device=self.buf.device if self.buf is not None else "cuda")
+        else:
+            t = self.buf[self.off:self.off + n]
+        self.off += n
+        self.high = max(self.high, self.off)
+        return t
+
+
+class SyncCtx:
+    """SyncBatchNorm plumbing (train_adamml.py:126-127): statistic sums are all-reduced over RCCL."""
+
+    def __init__(self, group=None, enabled=False):
+        self.group = group
+        self.enabled = enabled and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.enabled else 1
+
+    def reduce(self, t):
+        if self.enabled:
+            dist.all_reduce(t, group=self.group)
+
+
+class NetRT:
+    """Per-backbone runtime state: arenas, sync context, mode flags."""
+
+    def __init__(self):
+        self.fwd_arena = Arena()
+        self.bwd_arena = Arena()
+        self.sync = SyncCtx()
+        self.training = False
+        self.tape = Tape(False)
+
+    def begin_forward(self, device, training, need_grad):
+        self.training = training
+        self.tape = Tape(need_grad)
+        if training:
+            self.fwd_arena.reset(device)
+        return self.tape
+
+
+# ------------------------------------------------------------------------------------------ conv state
+class ConvState:
+    """Device-side operands derived from one fp32 OIHW master weight: bf16 GEMM packs."""
+
+    def __init__(self, weight, stride, pad, depthwise=False):
+        self.weight = weight
+        self.cout, self.cin_true, self.kh, self.kw = weight.shape
+        self.stride, self.pad = stride, pad
+        self.depthwise = depthwise
+        if depthwise:
+            self.cin_true = self.cout
+        self.cin = pad8(self.cin_true)
+        self.w_fwd = None
+        self.w_dgrad = None
+        self.version = -1
+
+    def repack(self, need_dgrad):
+        w = self.weight
+        if self.depthwise:
+            if self.w_fwd is None:
+                self.w_fwd = torch.empty(self.kh * self.kw, self.cout, dtype=torch.float32, device=w.device)
+            call("adamml_pack_conv_weight", ptr(w), ptr(self.w_fwd), self.cout, 1, 1, self.kh, self.kw, 2)
+            return
+        if self.w_fwd is None:
+            self.w_fwd = torch.empty(self.cout, self.kh * self.kw * self.cin, dtype=torch.bfloat16, device=w.device)
+        call("adamml_pack_conv_weight", ptr(w), ptr(self.w_fwd), self.cout, self.cin_true, self.cin, self.kh, self.kw, 0)
+        if need_dgrad:
+            if self.w_dgrad is None:
+                self.w_dgrad = torch.empty(self.cin, self.kh * self.kw * self.cout, dtype=torch.bfloat16, device=w.device)
+            call("adamml_pack_conv_weight", ptr(w), ptr(self.w_dgrad), self.cout, self.cin_true, self.cin, self.kh, self.kw, 1)
+
+    def desc(self, x_shape, act):
+        n, h, w, c = x_shape
+        oh = (h + 2 * self.pad - self.kh) // self.stride + 1
+        ow = (w + 2 * self.pad - self.kw) // self.stride + 1
+        return ConvDesc(n, h, w, c, oh, ow, self.cout, self.kh, self.kw, self.stride, self.pad, 1, act, 0)
+
+
+def _bn_vectors(rt, bn, stats, count, C, device):
+    vec = torch.empty(4, C, dtype=torch.float32, device=device)
+    rt.sync.reduce(stats)
+    call("adamml_bn_finalize", ptr(stats), float(count * rt.sync.world), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+         ptr(bn.running_var), BN_MOMENTUM, BN_EPS, ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), C)
+    return vec
+
+
+def _bn_eval_vectors(bn, C, device):
+    vec = torch.empty(2, C, dtype=torch.float32, device=device)
+    call("adamml_bn_eval_affine", ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), BN_EPS,
+         ptr(vec[0]), ptr(vec[1]), C)
+    return vec
+
+
+def _bn_backward(rt, out, y, vec, bn, act, count):
+    """Turns out.grad (w.r.t. the activated value) into dz (w.r.t. the raw conv output); accumulates dgamma/dbeta."""
+    g = out.grad
+    out.grad = None
+    n, oh, ow, C = y.shape
+    P = n * oh * ow
+    sums = rt.bwd_arena.take(2 * C)
+    call("adamml_bn_bwd_reduce", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), act, ptr(sums), P, C)
+    rt.sync.reduce(sums)
+    coef = torch.empty(3, C, dtype=torch.float32, device=y.device)
+    train_bn = bn.weight.requires_grad
+    call("adamml_bn_bwd_finalize", ptr(sums), float(count * rt.sync.world), ptr(bn.weight), ptr(vec[3]),
+         ptr(bn.weight.grad) if train_bn else None, ptr(bn.bias.grad) if train_bn else None, ptr(coef), C)
+    dz = torch.empty_like(y)
+    call("adamml_bn_bwd_apply", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), act, ptr(coef), ptr(dz), P, C)
+    return dz
+
+
+def conv_bn(rt, x, cs, bn, act):
+    """conv (dense or depthwise) + train/eval BatchNorm + activation, as one lazy tensor."""
+    d = cs.desc(x.shape, x.act)
+    if x.shape[3] != cs.cin:
+        raise RuntimeError("conv_bn: input has %d channels, weight pack expects %d" % (x.shape[3], cs.cin))
+    dev = x.data.device
+    y = torch.empty(d.N, d.OH, d.OW, d.Cout, dtype=torch.bfloat16, device=dev)
+    C = d.Cout
+    count = d.N * d.OH * d.OW
+    fwd = "adamml_dwconv_fwd" if cs.depthwise else "adamml_conv_fwd"
+    if rt.training:
+        stats = rt.fwd_arena.take(2 * C)
+        call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), ptr(stats))
+        vec = _bn_vectors(rt, bn, stats, count, C, dev)
+    else:
+        call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), None)
+        vec = _bn_eval_vectors(bn, C, dev)
+    out = Lazy(y, vec[0], vec[1], act)
+    if rt.tape.need_grad:
+        def bwd():
+            if out.grad is None:
+                return
+            dz = _bn_backward(rt, out, y, vec, bn, act, count)
+            if cs.weight.requires_grad:
+                if cs.depthwise:
+                    call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(cs.weight.grad))
+                else:
+                    call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift),
+                         ptr(cs.weight.grad), cs.cin_true)
+            if x.requires_grad:
+                acc = 1
+                if x.grad is None:
+                    x.grad = torch.empty_like(x.data)
+                    acc = 0
+                if cs.depthwise:
+                    call("adamml_dwconv_bwd_data", byref(d), ptr(dz), ptr(cs.w_fwd), ptr(x.grad), acc)
+                else:
+                    call("adamml_conv_bwd_data", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc)
+        rt.tape.record(bwd)
+    return out
+
+
+def _accum_grad(t, g):
+    if not t.requires_grad:
+        return
+    if t.grad is None:
+        t.grad = g
+    else:
+        n = g.numel() // g.shape[-1]
+        call("adamml_bn_act_add", ptr(t.grad), None, None, ACT_NONE, ptr(g), None, None, ptr(t.grad), n, g.shape[-1])
+
+
+def add_act(rt, z, idn, act):
+    """out = act(value(z) + value(idn)); idn may be None (pure materialisation)."""
+    n, h, w, C = z.shape
+    if z.act != ACT_NONE or (idn is not None and idn.act != ACT_NONE):
+        raise RuntimeError("add_act: operands must be linear (no pending activation)")
+    out_t = torch.empty_like(z.data)
+    call("adamml_bn_act_add", ptr(z.data), ptr(z.scale), ptr(z.shift), act, ptr(idn.data) if idn is not None else None,
+         ptr(idn.scale) if idn is not None else None, ptr(idn.shift) if idn is not None else None, ptr(out_t), n * h * w, C)
+    out = Lazy(out_t)
+    if rt.tape.need_grad:
+        def bwd():
+            g = out.grad
+            out.grad = None
+            if g is None:
+                return
+            if act != ACT_NONE:
+                g2 = torch.empty_like(g)
+                call("adamml_act_bwd_from_output", ptr(g), ptr(out_t), act, ptr(g2), g.numel())
+            else:
+                g2 = g
+            _accum_grad(z, g2)
+            if idn is not None:
+                _accum_grad(idn, g2)
+        rt.tape.record(bwd)
+    return out
+
+
+def maxpool3x3s2(rt, x):
+    n, h, w, C = x.shape
+    oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    y = torch.empty(n, oh, ow, C, dtype=torch.bfloat16, device=x.data.device)
+    idx = torch.empty(n, oh, ow, C, dtype=torch.uint8, device=x.data.device)
+    call("adamml_maxpool2d_fwd", ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, ptr(y), ptr(idx), n, h, w, C, oh, ow)
+    out = Lazy(y)
+    if rt.tape.need_grad:
+        def bwd():
+            g = out.grad
+            out.grad = None
+            if g is None or not x.requires_grad:
+                return
+            acc = 1
+            if x.grad is None:
+                x.grad = torch.empty_like(x.data)
+                acc = 0
+            call("adamml_maxpool2d_bwd", ptr(g), ptr(idx), ptr(x.grad), n, h, w, C, oh, ow, acc)
+        rt.tape.record(bwd)
+    return out
+
+
+def temporal_pool(rt, x, frames, mode):
+    """models/common.py:4-33 on [N*T,H,W,C]; mode 'max' | 'avg'."""
+    nt, h, w, C = x.shape
+    nb = nt // frames
+    to = (frames - 1) // 2 + 1
+    m = {"max": 0, "avg": 1}.get(mode)
+    if m is None:
+        raise ValueError("only support avg or max")
+    y = torch.empty(nb * to, h, w, C, dtype=torch.bfloat16, device=x.data.device)
+    call("adamml_temporal_pool_fwd", ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, ptr(y), nb, frames, h * w * C, C, m)
+    out = Lazy(y)
+    if rt.tape.need_grad:
+        def bwd():
+            g = out.grad
+            out.grad = None
+            if g is None or not x.requires_grad:
+                return
+            gx = torch.empty_like(x.data)
+            call("adamml_temporal_pool_bwd", ptr(g), ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, ptr(gx), nb, frames,
+                 h * w * C, C, m)
+            _accum_grad(x, gx)
+        rt.tape.record(bwd)
+    return out
+
+
+def gap(rt, x):
+    """AdaptiveAvgPool2d(1): lazy [N,H,W,C] -> fp32 [N,C]; returns (tensor, grad_setter)."""
+    n, h, w, C = x.shape
+    f = torch.empty(n, C, dtype=torch.float32, device=x.data.device)
+    call("adamml_gap_fwd", ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, ptr(f), n, h * w, C)
+
+    def push_grad(gf):
+        if not x.requires_grad:
+            return
+        gx = torch.empty_like(x.data)
+        call("adamml_gap_bwd", ptr(gf), ptr(gx), n, h * w, C)
+        _accum_grad(x, gx)
+    return f, push_grad
+
+
+def gemm_f32(a, b, out=None, bias=None, act=ACT_NONE, trans_a=False, trans_b=True, accumulate=False):
+    """out[M,N] (+)= act(op(a) @ op(b)^T-ish + bias) on 2-D fp32 tensors via adamml_gemm_f32.
+    trans_a=False: a is [M,K]; True: a is [K,M].  trans_b=True: b is [N,K]; False: b is [K,N]."""
+    if trans_a:
+        K, M = a.shape
+        a_sm, a_sk = a.stride(1), a.stride(0)
+    else:
+        M, K = a.shape
+        a_sm, a_sk = a.stride(0), a.stride(1)
+    if trans_b:
+        N, K2 = b.shape
+        b_sn, b_sk = b.stride(0), b.stride(1)
+    else:
+        K2, N = b.shape
+        b_sn, b_sk = b.stride(1), b.stride(0)
+    if K != K2:
+        raise RuntimeError("gemm_f32: inner dimensions differ (%d vs %d)" % (K, K2))
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    call("adamml_gemm_f32", ptr(a), a_sm, a_sk, ptr(b), b_sn, b_sk, ptr(out), out.stride(0), out.stride(1), ptr(bias), act,
+         1 if accumulate else 0, M, N, K)
+    return out
+
+
+def clip_to_nhwc(x, num_segments, frames, channels, out_hw=None, frame_step=1):
+    """AdaMML.data_layer re-layout (models/adamml.py:53-65): [B, S*F*C, H, W] fp32 -> [S, B*Fk, OH, OW, pad8(C)] bf16."""
+    hip.require_gpu(x)
+    b, sfc, h, w = x.shape
+    if sfc != num_segments * frames * channels:
+        raise RuntimeError("clip_to_nhwc: channel dim %d != S*F*C = %d*%d*%d" % (sfc, num_segments, frames, channels))
+    oh, ow = out_hw if out_hw else (h, w)
+    fk = (frames + frame_step - 1) // frame_step
+    cp = pad8(channels)
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        x = x.float()
+    y = torch.empty(num_segments, b * fk, oh, ow, cp, dtype=torch.bfloat16, device=x.device)
+    call("adamml_clip_to_nhwc", ptr(x), ptr(y), b, num_segments, frames, channels, h, w, oh, ow, frame_step, cp)
+    return y

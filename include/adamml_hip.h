@@ -1,0 +1,122 @@
+/* libadamml_hip.so -- C ABI of the MI355X-native AdaMML hot path (gfx950 only).
+ *
+ * The reference (IBM/AdaMML) has no FFI: its hot path is a chain of torch operators invoked from
+ *   models/resnet.py:195-223, models/sound_mobilenet_v2.py:152-162, models/policy_net.py:142-149,312-373,
+ *   models/common.py:28-33, models/joint_resnet_mobilenetv2.py:84-128, models/adamml.py:42-91.
+ * Each entry point below names the operator call site(s) it replaces.  Conventions:
+ *   - plain C types; every pointer is a DEVICE pointer valid on the current HIP device unless noted;
+ *   - activations are NHWC bf16 with the channel count padded to a multiple of 8;
+ *   - a "lazy" activation is (raw, scale, shift, act): value = act(scale[c]*raw + shift[c]); scale==NULL -> raw;
+ *   - the caller owns all memory (no allocation inside); work is enqueued on `stream`, never synchronised;
+ *   - return 0 on success, negative ADAMML_E* otherwise; adamml_last_error_string() describes the failure.
+ */
+#ifndef ADAMML_HIP_H
+#define ADAMML_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+#define ADAMML_ACT_NONE 0
+#define ADAMML_ACT_RELU 1
+#define ADAMML_ACT_RELU6 2
+
+typedef struct {
+    int32_t N, H, W, Cin;       /* input  [N,H,W,Cin]  (Cin padded to x8)            */
+    int32_t OH, OW, Cout;       /* output [N,OH,OW,Cout]                              */
+    int32_t KH, KW, stride, pad;
+    int32_t up;                 /* internal: zero-upsampling of the input (dgrad); 1 for forward */
+    int32_t act;                /* activation of the lazy INPUT transform             */
+    int32_t accumulate;         /* epilogue adds into the existing output             */
+} adamml_conv_desc_t;
+
+int adamml_version(void);
+const char* adamml_last_error_string(void);
+
+/* nn.Conv2d(bias=False) forward (models/resnet.py:37-43,138; sound_mobilenet_v2.py:37,60; policy_net.py:40,48,76,84)
+ * fused with the PRODUCER's BatchNorm+ReLU/ReLU6 on load and with the per-channel sum / sum-of-squares of its own
+ * output (stats[0..C) = sum, stats[C..2C) = sumsq, fp64, caller zeroes) for this layer's train-mode BatchNorm. */
+int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
+                    const float* in_shift, void* y, double* stats, hipStream_t stream);
+/* autograd of the above w.r.t. its input (d = forward descriptor; w packed with mode 1) */
+int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
+                         int accumulate, hipStream_t stream);
+/* autograd w.r.t. the weight: dw (fp32 OIHW, cin_true input channels) += ...  (atomic accumulate) */
+int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
+                           const float* in_shift, float* dw, int cin_true, hipStream_t stream);
+/* fp32 OIHW master weight -> bf16 GEMM operand.  mode 0: [Cout][KH*KW][cin_pad] (forward);
+ * mode 1: [cin_pad][KH*KW flipped][Cout] (data gradient); mode 2: depthwise [KH*KW][C] fp32. */
+int adamml_pack_conv_weight(const float* w, void* out, int cout, int cin_true, int cin_pad, int kh, int kw, int mode,
+                            hipStream_t stream);
+
+/* depthwise 3x3 conv (groups == channels; sound_mobilenet_v2.py:58, policy_net.py:66,80) */
+int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, const float* w_tapmajor, const float* in_scale,
+                      const float* in_shift, void* y, double* stats, hipStream_t stream);
+int adamml_dwconv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const float* w_tapmajor, void* dx,
+                           int accumulate, hipStream_t stream);
+int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
+                             const float* in_shift, float* dw, hipStream_t stream);
+
+/* nn.BatchNorm2d: train-mode statistics -> (scale, shift) consumed lazily by the next op, saved mean / invstd,
+ * running-stat momentum update (unbiased variance).  count = elements per channel (global count under SyncBN). */
+int adamml_bn_finalize(const double* stats, double count, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
+                       float* invstd, int C, hipStream_t stream);
+/* eval-mode BatchNorm folded to (scale, shift) from the running statistics */
+int adamml_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                          float eps, float* scale, float* shift, int C, hipStream_t stream);
+/* out = act(scale*z + shift + identity) -- BN apply + residual add + ReLU of a bottleneck / inverted-residual block
+ * (models/resnet.py:104-111, sound_mobilenet_v2.py:66-67, policy_net.py:92-93).  identity may be lazy or NULL. */
+int adamml_bn_act_add(const void* z, const float* scale, const float* shift, int act, const void* idn,
+                      const float* id_scale, const float* id_shift, void* out, size_t P, int C, hipStream_t stream);
+/* g = g_out * act'(out) evaluated from the stored block output */
+int adamml_act_bwd_from_output(const void* g_out, const void* out, int act, void* g, size_t n, hipStream_t stream);
+/* BatchNorm backward: per-channel sums of g' = g*act'(scale*z+shift) and g'*zhat (sums fp64 [2C], caller zeroes) */
+int adamml_bn_bwd_reduce(const void* g, const void* z, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, int act, double* sums, size_t P, int C, hipStream_t stream);
+/* dgamma += sum(g' zhat); dbeta += sum(g'); coef[0..C) = gamma*invstd, [C..2C) = sum g'/count, [2C..3C) = sum g' zhat/count */
+int adamml_bn_bwd_finalize(const double* sums, double count, const float* gamma, const float* invstd, float* dgamma,
+                           float* dbeta, float* coef, int C, hipStream_t stream);
+/* dz = coef0 * (g' - coef1 - zhat*coef2) */
+int adamml_bn_bwd_apply(const void* g, const void* z, const float* scale, const float* shift, const float* mean,
+                        const float* invstd, int act, const float* coef, void* dz, size_t P, int C, hipStream_t stream);
+
+/* nn.MaxPool2d(3, 2, 1) on a lazy input (models/resnet.py:141,202); idx = argmax tap (uint8) for the backward */
+int adamml_maxpool2d_fwd(const void* x, const float* scale, const float* shift, int act, void* y, uint8_t* idx, int N,
+                         int H, int W, int C, int OH, int OW, hipStream_t stream);
+int adamml_maxpool2d_bwd(const void* g_y, const uint8_t* idx, void* g_x, int N, int H, int W, int C, int OH, int OW,
+                         int accumulate, hipStream_t stream);
+/* TemporalPooling (models/common.py:4-33): k3 s2 p1 over the frame axis; mode 0 = max, 1 = avg (zeros counted) */
+int adamml_temporal_pool_fwd(const void* x, const float* scale, const float* shift, int act, void* y, int NB, int T,
+                             size_t HWC, int C, int mode, hipStream_t stream);
+int adamml_temporal_pool_bwd(const void* g_y, const void* x, const float* scale, const float* shift, int act, void* g_x,
+                             int NB, int T, size_t HWC, int C, int mode, hipStream_t stream);
+/* AdaptiveAvgPool2d(1) on a lazy input -> fp32 [N,C] (resnet.py:212, sound_mobilenet_v2.py:157, policy_net.py:147) */
+int adamml_gap_fwd(const void* x, const float* scale, const float* shift, int act, float* out, int N, int HW, int C,
+                   hipStream_t stream);
+int adamml_gap_bwd(const float* g, void* g_x, int N, int HW, int C, hipStream_t stream);
+
+/* AdaMML.data_layer (models/adamml.py:42-67): NCHW fp32 clip tensor [B, S*F*C, H, W] -> per-segment NHWC bf16
+ * frames [S][B*Fk][OH][OW][c_pad] with optional bilinear resize (align_corners=False) and frame stride. */
+int adamml_clip_to_nhwc(const float* x, void* y, int B, int S, int F, int C, int H, int W, int OH, int OW,
+                        int frame_step, int c_pad, hipStream_t stream);
+
+/* y[M,N] = act(x[M,K] @ w[N,K]^T + bias) in fp32 with arbitrary strides (nn.Linear / LSTMCell gates and their
+ * gradients: policy_net.py:228-231,278-279,351-362; resnet.py:215; sound_mobilenet_v2.py:158) */
+int adamml_gemm_f32(const float* a, int64_t a_sm, int64_t a_sk, const float* b, int64_t b_sn, int64_t b_sk, float* c,
+                    int64_t c_sm, int64_t c_sn, const float* bias, int act, int accumulate, int M, int N, int K,
+                    hipStream_t stream);
+
+/* flat fused optimizer steps (train_adamml.py:251-257 SGD-momentum / Adam with weight decay) */
+int adamml_sgd_step(float* p, const float* g, float* mom, size_t n, float lr, float momentum, float weight_decay,
+                    int nesterov, int first_step, hipStream_t stream);
+int adamml_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,331 @@
+"""Per-kernel parity: every C-ABI entry point of libadamml_hip against the torch fp32 operator it replaces
+(computed on the same bf16-rounded operands).  Tolerances: bf16 output rounding (2^-8 relative) on top of
+fp32 accumulation -> rtol 1e-2 / atol scaled to the output magnitude."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from ctypes import byref
+
+pytestmark = pytest.mark.gpu
+
+from adamml_amd import hip  # noqa: E402
+from adamml_amd.hip import ConvDesc, call, ptr  # noqa: E402
+from adamml_amd.runtime import pad8, gemm_f32, clip_to_nhwc  # noqa: E402
+
+DEV = "cuda"
+
+
+def nhwc(x, cpad=None):
+    """NCHW fp32 -> NHWC bf16 (channel padded)."""
+    n, c, h, w = x.shape
+    cp = cpad or pad8(c)
+    y = torch.zeros(n, h, w, cp, dtype=torch.bfloat16, device=x.device)
+    y[..., :c] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    return y.contiguous()
+
+
+def nchw(y, c=None):
+    return y.float().permute(0, 3, 1, 2)[:, :c].contiguous()
+
+
+def rb(x):
+    return x.to(torch.bfloat16).float()
+
+
+def close(a, b, rtol=1e-2, atol_frac=1e-2, what=""):
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= atol_frac * scale + rtol * 0, "%s: max err %g vs scale %g" % (what, err, scale)
+    # element-wise too, with a floor
+    assert torch.allclose(a, b, rtol=rtol, atol=atol_frac * scale), what
+
+
+def pack(w, cin_pad, mode):
+    cout, cin, kh, kw = w.shape
+    if mode == 2:
+        out = torch.empty(kh * kw, cout, dtype=torch.float32, device=w.device)
+        call("adamml_pack_conv_weight", ptr(w), ptr(out), cout, 1, 1, kh, kw, 2)
+    elif mode == 0:
+        out = torch.empty(cout, kh * kw * cin_pad, dtype=torch.bfloat16, device=w.device)
+        call("adamml_pack_conv_weight", ptr(w), ptr(out), cout, cin, cin_pad, kh, kw, 0)
+    else:
+        out = torch.empty(cin_pad, kh * kw * cout, dtype=torch.bfloat16, device=w.device)
+        call("adamml_pack_conv_weight", ptr(w), ptr(out), cout, cin, cin_pad, kh, kw, 1)
+    return out
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (2, 56, 56, 64, 256, 1, 1, 0),
+    (2, 56, 56, 256, 64, 1, 1, 0),
+    (3, 28, 28, 64, 64, 3, 1, 1),
+    (2, 30, 30, 128, 128, 3, 2, 1),
+    (2, 28, 28, 256, 512, 1, 2, 0),
+    (2, 64, 64, 3, 64, 7, 2, 3),
+    (1, 32, 32, 10, 64, 7, 2, 3),
+    (2, 40, 40, 1, 32, 3, 2, 1),
+    (2, 20, 20, 16, 96, 1, 1, 0),
+    (2, 20, 20, 144, 24, 1, 1, 0),
+    (1, 7, 7, 512, 2048, 1, 1, 0),
+    (3, 7, 7, 512, 512, 3, 1, 1),
+    (1, 5, 5, 320, 1280, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("lazy", [False, True])
+def test_conv_fwd_bwd(case, lazy):
+    torch.manual_seed(0)
+    N, H, W, Cin, Cout, k, s, p = case
+    x = torch.randn(N, Cin, H, W, device=DEV)
+    w = torch.randn(Cout, Cin, k, k, device=DEV) * (2.0 / (Cin * k * k)) ** 0.5
+    cp = pad8(Cin)
+    xh = nhwc(x)
+    scale = shift = None
+    act = 0
+    xr = rb(x)
+    if lazy:
+        scale = torch.rand(cp, device=DEV) + 0.5
+        shift = torch.randn(cp, device=DEV) * 0.3
+        act = 1
+        xr = rb(F.relu(xr * scale[:Cin].view(1, -1, 1, 1) + shift[:Cin].view(1, -1, 1, 1)))
+    wr = rb(w)
+    xr.requires_grad_(True)
+    wr.requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=s, padding=p)
+    OH, OW = ref.shape[2:]
+    d = ConvDesc(N, H, W, cp, OH, OW, Cout, k, k, s, p, 1, act, 0)
+    y = torch.empty(N, OH, OW, Cout, dtype=torch.bfloat16, device=DEV)
+    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+    call("adamml_conv_fwd", byref(d), ptr(xh), ptr(pack(w, cp, 0)), ptr(scale), ptr(shift), ptr(y), ptr(stats))
+    got = nchw(y)
+    close(got, ref.detach(), what="conv fwd")
+    # statistics of the stored (rounded) output
+    yf = y.float().reshape(-1, Cout).double()
+    assert torch.allclose(stats[:Cout], yf.sum(0), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(stats[Cout:], (yf * yf).sum(0), rtol=1e-4, atol=1e-3)
+
+    # backward
+    gy = torch.randn_like(ref)
+    gyr = rb(gy)
+    ref.backward(gyr)
+    dz = nhwc(gy)
+    dx = torch.empty(N, H, W, cp, dtype=torch.bfloat16, device=DEV)
+    call("adamml_conv_bwd_data", byref(d), ptr(dz), ptr(pack(w, cp, 1)), ptr(dx), 0)
+    close(nchw(dx, Cin), xr.grad, what="conv dgrad")
+    if cp != Cin:
+        assert dx[..., Cin:].float().abs().max().item() == 0.0
+    # accumulate flag
+    call("adamml_conv_bwd_data", byref(d), ptr(dz), ptr(pack(w, cp, 1)), ptr(dx), 1)
+    close(nchw(dx, Cin), 2 * xr.grad, rtol=2e-2, atol_frac=2e-2, what="conv dgrad acc")
+    dw = torch.zeros_like(w)
+    call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(xh), ptr(scale), ptr(shift), ptr(dw), Cin)
+    close(dw, wr.grad, what="conv wgrad")
+
+
+@pytest.mark.parametrize("case", [(2, 40, 40, 32, 1), (2, 41, 41, 96, 2), (1, 20, 20, 144, 2), (2, 10, 10, 960, 1), (1, 16, 16, 576, 2)])
+def test_dwconv(case):
+    torch.manual_seed(1)
+    N, H, W, C, s = case
+    x = torch.randn(N, C, H, W, device=DEV)
+    w = torch.randn(C, 1, 3, 3, device=DEV) * 0.4
+    scale = torch.rand(C, device=DEV) + 0.5
+    shift = torch.randn(C, device=DEV) * 0.3
+    xr = rb(torch.clamp(rb(x) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1), 0, 6)).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=s, padding=1, groups=C)
+    OH, OW = ref.shape[2:]
+    d = ConvDesc(N, H, W, C, OH, OW, C, 3, 3, s, 1, 1, 2, 0)
+    wp = pack(w, C, 2)
+    y = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device=DEV)
+    stats = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    xh = nhwc(x)
+    call("adamml_dwconv_fwd", byref(d), ptr(xh), ptr(wp), ptr(scale), ptr(shift), ptr(y), ptr(stats))
+    close(nchw(y), ref.detach(), what="dw fwd")
+    yf = y.float().reshape(-1, C).double()
+    assert torch.allclose(stats[:C], yf.sum(0), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(stats[C:], (yf * yf).sum(0), rtol=1e-4, atol=1e-3)
+    gy = torch.randn_like(ref)
+    ref.backward(rb(gy))
+    dz = nhwc(gy)
+    dx = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=DEV)
+    call("adamml_dwconv_bwd_data", byref(d), ptr(dz), ptr(wp), ptr(dx), 0)
+    close(nchw(dx), xr.grad, what="dw dgrad")
+    dw = torch.zeros_like(w)
+    call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(xh), ptr(scale), ptr(shift), ptr(dw))
+    close(dw, wr.grad, what="dw wgrad")
+
+
+@pytest.mark.parametrize("C,P,act", [(64, 5000, 1), (24, 777, 0), (960, 300, 2), (2048, 98, 1)])
+def test_batchnorm_train_fwd_bwd(C, P, act):
+    torch.manual_seed(2)
+    z = rb(torch.randn(P, C, device=DEV) * 1.5 + 0.3)
+    gamma = (torch.rand(C, device=DEV) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, device=DEV) * 0.2).requires_grad_(True)
+    rm, rv = torch.randn(C, device=DEV) * 0.1, torch.rand(C, device=DEV) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    zr = z.clone().requires_grad_(True)
+    out = F.batch_norm(zr.t().reshape(1, C, P), rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5).reshape(C, P).t()
+    a = {0: out, 1: F.relu(out), 2: F.relu6(out)}[act]
+    # HIP
+    zb = z.to(torch.bfloat16).contiguous()
+    zd = zb.float().double()
+    stats = torch.cat([zd.sum(0), (zd * zd).sum(0)])
+    vec = torch.empty(4, C, device=DEV)
+    call("adamml_bn_finalize", ptr(stats), float(P), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5, ptr(vec[0]), ptr(vec[1]),
+         ptr(vec[2]), ptr(vec[3]), C)
+    assert torch.allclose(rm, rm_ref, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(rv, rv_ref, rtol=1e-4, atol=1e-5)
+    o = torch.empty(P, C, dtype=torch.bfloat16, device=DEV)
+    call("adamml_bn_act_add", ptr(zb), ptr(vec[0]), ptr(vec[1]), act, None, None, None, ptr(o), P, C)
+    close(o.float(), a.detach(), what="bn apply")
+    g = rb(torch.randn(P, C, device=DEV))
+    a.backward(g)
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    gb = g.to(torch.bfloat16).contiguous()
+    call("adamml_bn_bwd_reduce", ptr(gb), ptr(zb), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), act, ptr(sums), P, C)
+    dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    coef = torch.empty(3, C, device=DEV)
+    call("adamml_bn_bwd_finalize", ptr(sums), float(P), ptr(gamma), ptr(vec[3]), ptr(dgam), ptr(dbet), ptr(coef), C)
+    dz = torch.empty(P, C, dtype=torch.bfloat16, device=DEV)
+    call("adamml_bn_bwd_apply", ptr(gb), ptr(zb), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), act, ptr(coef), ptr(dz), P, C)
+    close(dgam, gamma.grad, what="dgamma")
+    close(dbet, beta.grad, what="dbeta")
+    close(dz.float(), zr.grad, what="bn dz")
+
+
+def test_residual_add_and_act_bwd():
+    torch.manual_seed(3)
+    P, C = 1000, 256
+    z, idn = rb(torch.randn(P, C, device=DEV)), rb(torch.randn(P, C, device=DEV))
+    s, t = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    s2, t2 = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    out = torch.empty(P, C, dtype=torch.bfloat16, device=DEV)
+    call("adamml_bn_act_add", ptr(z.bfloat16()), ptr(s), ptr(t), 1, ptr(idn.bfloat16()), ptr(s2), ptr(t2), ptr(out), P, C)
+    ref = F.relu(z * s + t + idn * s2 + t2)
+    close(out.float(), ref, what="bn+add+relu")
+    g = rb(torch.randn(P, C, device=DEV))
+    g2 = torch.empty_like(out)
+    call("adamml_act_bwd_from_output", ptr(g.bfloat16()), ptr(out), 1, ptr(g2), P * C)
+    assert torch.equal(g2.float(), g * (out.float() > 0))
+
+
+def test_maxpool_fwd_bwd():
+    torch.manual_seed(4)
+    N, C, H, W = 3, 64, 30, 30
+    x = rb(torch.randn(N, C, H, W, device=DEV))
+    s, t = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.2
+    a = rb(F.relu(x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)))
+    # random (not relu-tied) positive offset avoids arg-max ties between bf16 and fp32 orderings
+    ar = a.clone().requires_grad_(True)
+    ref = F.max_pool2d(ar, 3, 2, 1)
+    OH, OW = ref.shape[2:]
+    y = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device=DEV)
+    idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=DEV)
+    call("adamml_maxpool2d_fwd", ptr(nhwc(x)), ptr(s), ptr(t), 1, ptr(y), ptr(idx), N, H, W, C, OH, OW)
+    close(nchw(y), ref.detach(), what="maxpool")
+    g = rb(torch.randn_like(ref))
+    gx = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=DEV)
+    call("adamml_maxpool2d_bwd", ptr(nhwc(g)), ptr(idx), ptr(gx), N, H, W, C, OH, OW, 0)
+    # the scatter of the gradient must conserve mass per (n, c) and land on arg-max positions
+    got = nchw(gx)
+    assert torch.allclose(got.sum((2, 3)), g.sum((2, 3)), rtol=2e-2, atol=0.3)
+    ref.backward(g)
+    pos = a > 0          # ties only occur among relu zeros
+    assert ((got - ar.grad).abs() * pos).max().item() < 0.1
+
+
+@pytest.mark.parametrize("T,mode", [(8, 0), (4, 0), (2, 0), (1, 0), (8, 1), (4, 1)])
+def test_temporal_pool(T, mode):
+    torch.manual_seed(5)
+    NB, C, H, W = 2, 32, 6, 6
+    x = rb(torch.randn(NB * T, C, H, W, device=DEV)).requires_grad_(True)
+    v = x.view(NB, T, C, H, W).transpose(1, 2)
+    pool = torch.nn.MaxPool3d((3, 1, 1), (2, 1, 1), (1, 0, 0)) if mode == 0 else torch.nn.AvgPool3d((3, 1, 1), (2, 1, 1), (1, 0, 0))
+    ref = pool(v).transpose(1, 2).contiguous().view(-1, C, H, W)
+    To = ref.shape[0] // NB
+    y = torch.empty(NB * To, H, W, C, dtype=torch.bfloat16, device=DEV)
+    xh = nhwc(x.detach())
+    call("adamml_temporal_pool_fwd", ptr(xh), None, None, 0, ptr(y), NB, T, H * W * C, C, mode)
+    close(nchw(y), ref.detach(), what="tpool")
+    g = rb(torch.randn_like(ref))
+    ref.backward(g)
+    gx = torch.empty(NB * T, H, W, C, dtype=torch.bfloat16, device=DEV)
+    call("adamml_temporal_pool_bwd", ptr(nhwc(g)), ptr(xh), None, None, 0, ptr(gx), NB, T, H * W * C, C, mode)
+    close(nchw(gx), x.grad, what="tpool bwd")
+
+
+def test_temporal_avg_rejects_short_T():
+    x = torch.zeros(2, 2, 2, 8, dtype=torch.bfloat16, device=DEV)
+    y = torch.zeros(1, 2, 2, 8, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError):
+        call("adamml_temporal_pool_fwd", ptr(x), None, None, 0, ptr(y), 1, 2, 32, 8, 1)
+
+
+def test_gap():
+    torch.manual_seed(6)
+    N, C, H, W = 5, 1280, 5, 5
+    x = rb(torch.randn(N, C, H, W, device=DEV))
+    s, t = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    f = torch.empty(N, C, device=DEV)
+    call("adamml_gap_fwd", ptr(nhwc(x)), ptr(s), ptr(t), 2, ptr(f), N, H * W, C)
+    ref = torch.clamp(x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1), 0, 6).mean((2, 3))
+    assert torch.allclose(f, ref, rtol=1e-4, atol=1e-4)
+    g = torch.randn(N, C, device=DEV)
+    gx = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=DEV)
+    call("adamml_gap_bwd", ptr(g), ptr(gx), N, H * W, C)
+    close(nchw(gx), (g / (H * W)).view(N, C, 1, 1).expand(N, C, H, W), what="gap bwd")
+
+
+def test_clip_to_nhwc_and_resize():
+    torch.manual_seed(7)
+    B, S, Fr, C, H = 2, 3, 8, 3, 56
+    x = torch.randn(B, S * Fr * C, H, H, device=DEV)
+    y = clip_to_nhwc(x, S, Fr, C)
+    ref = x.view(B, S, Fr * C, H, H).transpose(0, 1).reshape(S, B * Fr, C, H, H)
+    assert torch.equal(y[..., :C].float(), rb(ref).permute(0, 1, 3, 4, 2))
+    assert y[..., C:].float().abs().max().item() == 0
+    # policy input: bilinear to 40x40, frames 0,2,4,6 (models/adamml.py:59-62)
+    y2 = clip_to_nhwc(x, S, Fr, C, out_hw=(40, 40), frame_step=2)
+    t = F.interpolate(x, size=(40, 40), mode="bilinear").view(B, S, Fr, C, 40, 40)[:, :, 0::2]
+    ref2 = t.transpose(0, 1).reshape(S, B * 4, C, 40, 40).permute(0, 1, 3, 4, 2)
+    assert torch.allclose(y2[..., :C].float(), ref2, rtol=1e-2, atol=2e-2)
+    # sound: [B, S, 64, 64] -> [S, B, 64, 64, 8]
+    xs = torch.randn(B, S, 64, 64, device=DEV)
+    ys = clip_to_nhwc(xs, S, 1, 1)
+    assert torch.equal(ys[..., 0].float(), rb(xs.transpose(0, 1)))
+
+
+def test_gemm_f32_variants():
+    torch.manual_seed(8)
+    a, b = torch.randn(70, 300, device=DEV), torch.randn(129, 300, device=DEV)
+    bias = torch.randn(129, device=DEV)
+    assert torch.allclose(gemm_f32(a, b, bias=bias, act=1), F.relu(a @ b.t() + bias), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(gemm_f32(a, b.t().contiguous(), trans_b=False), a @ b.t(), rtol=1e-4, atol=1e-4)
+    g = torch.randn(70, 129, device=DEV)
+    out = torch.ones(129, 300, device=DEV)
+    gemm_f32(g, a, out=out, trans_a=True, trans_b=False, accumulate=True)
+    assert torch.allclose(out, 1 + g.t() @ a, rtol=1e-4, atol=1e-3)
+
+
+def test_fused_optimizers_match_torch():
+    torch.manual_seed(9)
+    n = 100003
+    p0, g = torch.randn(n, device=DEV), torch.randn(n, device=DEV)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pt], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    p, mom = p0.clone(), torch.zeros(n, device=DEV)
+    for step in range(3):
+        pt.grad = g.clone()
+        opt.step()
+        call("adamml_sgd_step", ptr(p), ptr(g), ptr(mom), n, 0.01, 0.9, 5e-4, 0, 1 if step == 0 else 0)
+    assert torch.allclose(p, pt.detach(), rtol=1e-5, atol=1e-6)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-3, weight_decay=5e-4)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(3):
+        pt.grad = g.clone()
+        opt.step()
+        call("adamml_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 5e-4, step + 1)
+    assert torch.allclose(p, pt.detach(), rtol=1e-4, atol=1e-6)
