@@ -111,6 +111,7 @@ class ResNet(HipBackbone, MeanStdMixin):
         y = gemm_f32(feat, self.fc.weight, bias=self.fc.bias)          # [N*T', classes]
         tprime = y.shape[0] // n
         out = y.view(n, tprime, -1).mean(dim=1) if tprime > 1 else y.view(n, -1)
+        rt.end_forward()
         if need_grad:
             fcw, fcb = self.fc.weight, self.fc.bias
 

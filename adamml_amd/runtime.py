@@ -107,9 +107,17 @@ class NetRT:
     def begin_forward(self, device, training, need_grad):
         self.training = training
         self.tape = Tape(need_grad)
+        self.touched_bns = []
         if training:
             self.fwd_arena.reset(device)
         return self.tape
+
+    def end_forward(self):
+        """nn.BatchNorm2d bookkeeping: num_batches_tracked += 1 for every BN evaluated in train mode
+        (one multi-tensor launch per backbone call instead of one per layer)."""
+        if self.training and self.touched_bns:
+            torch._foreach_add_([b.num_batches_tracked for b in self.touched_bns], 1)
+        self.touched_bns = []
 
 
 # ------------------------------------------------------------------------------------------ conv state
@@ -197,6 +205,7 @@ def conv_bn(rt, x, cs, bn, act):
         stats = rt.fwd_arena.take(2 * C)
         call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), ptr(stats))
         vec = _bn_vectors(rt, bn, stats, count, C, dev)
+        rt.touched_bns.append(bn)
     else:
         call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), None)
         vec = _bn_eval_vectors(bn, C, dev)

@@ -5,11 +5,15 @@ build container (where the reference is importable) and the GPU box (where it
 is not) regenerate bit-identical fp32 values from the recipe alone; only
 outputs have to be stored as golden fixtures.
 """
+import re
 import zlib
 import numpy as np
 import torch
 
 __all__ = ["det_normal", "det_uniform", "synth_state_dict", "synth_inputs", "synth_gumbel_exponential"]
+
+
+_RESIDUAL_BN = re.compile(r"(bn3\.weight|features\.\d+\.conv\.(3|7)\.weight)$")
 
 
 def _rng(name: str, seed: int) -> np.random.Generator:
@@ -47,7 +51,12 @@ def synth_state_dict(ref_sd, seed=1234):
             out[k] = det_normal(k, shp, seed, 0.0, (1.0 / shp[1]) ** 0.5)
         elif v.dim() == 1:
             # BN weight vs (BN|linear|lstm) bias: BN weights are named '*.weight' with 1 dim
-            if k.endswith("weight"):
+            if _RESIDUAL_BN.search(k):
+                # last BN of a residual branch: small gain ("zero-init residual" regime).  With O(1) gains on
+                # every branch a randomly initialised 16-block residual stack is chaotic: rounding only the
+                # weights to bf16 moves fp32 logits by 20 %, so no reduced-precision parity could be stated.
+                out[k] = det_uniform(k, shp, seed, 0.1, 0.3)
+            elif k.endswith("weight"):
                 out[k] = det_uniform(k, shp, seed, 0.5, 1.5)
             else:
                 out[k] = det_normal(k, shp, seed, 0.0, 0.1)

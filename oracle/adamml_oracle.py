@@ -27,6 +27,30 @@ RESNET_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}  # mo
 MBV2_CFG = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
 
 
+# ----------------------------------------------------------------------------- bf16-storage emulation hook
+# QUANT is None for the exact fp32 restatement (the one pinned against the reference goldens).  The parity tests
+# set it to a straight-through bf16 rounding to emulate WHERE the HIP path stores bf16 (dense-conv operands, every
+# conv output, residual / pooling outputs) while keeping all arithmetic fp32: the HIP path must match that emulation
+# tightly, and the emulation's own distance from the fp32 result is the stated, intrinsic bf16 tolerance.
+QUANT = None
+
+
+def bf16_straight_through(x):
+    return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
+
+
+def _q(x):
+    return x if QUANT is None else QUANT(x)
+
+
+def conv(x, w, stride=1, padding=0, groups=1):
+    """nn.Conv2d(bias=False).  Emulation: dense convs read bf16 activations and bf16 weights; depthwise convs
+    read the fp32-evaluated activation and fp32 weights; every conv output is stored in bf16."""
+    if groups == 1:
+        return _q(F.conv2d(_q(x), _q(w), stride=stride, padding=padding))
+    return _q(F.conv2d(x, w, stride=stride, padding=padding, groups=groups))
+
+
 # ----------------------------------------------------------------------------- primitives
 def batchnorm(sd, p, x, training):
     """nn.BatchNorm2d forward incl. running-stat side effects (train mode updates
@@ -72,18 +96,18 @@ def dropout(x, p, training, mask=None):
 # ----------------------------------------------------------------------------- ResNet (A5)
 def _bottleneck(sd, p, x, stride, has_down, training):
     """models/resnet.py:94-113."""
-    out = F.conv2d(x, sd[p + ".conv1.weight"])
+    out = conv(x, sd[p + ".conv1.weight"])
     out = F.relu(batchnorm(sd, p + ".bn1", out, training))
-    out = F.conv2d(out, sd[p + ".conv2.weight"], stride=stride, padding=1)
+    out = conv(out, sd[p + ".conv2.weight"], stride=stride, padding=1)
     out = F.relu(batchnorm(sd, p + ".bn2", out, training))
-    out = F.conv2d(out, sd[p + ".conv3.weight"])
+    out = conv(out, sd[p + ".conv3.weight"])
     out = batchnorm(sd, p + ".bn3", out, training)
     if has_down:
-        idt = F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride)
+        idt = conv(x, sd[p + ".downsample.0.weight"], stride=stride)
         idt = batchnorm(sd, p + ".downsample.1", idt, training)
     else:
         idt = x
-    return F.relu(out + idt)
+    return _q(F.relu(out + idt))
 
 
 def resnet_features(sd, p, x, num_frames, depth=50, pooling_method="max", without_t_stride=False, training=False):
@@ -91,9 +115,9 @@ def resnet_features(sd, p, x, num_frames, depth=50, pooling_method="max", withou
     n, c_t, h, w = x.shape
     if c_t != 1:
         x = x.reshape(n * num_frames, c_t // num_frames, h, w)
-    x = F.conv2d(x, sd[p + "conv1.weight"], stride=2, padding=3)
+    x = conv(x, sd[p + "conv1.weight"], stride=2, padding=3)
     x = F.relu(batchnorm(sd, p + "bn1", x, training))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = _q(F.max_pool2d(x, 3, 2, 1))
     frames = num_frames
     inplanes = 64
     for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), RESNET_BLOCKS[depth])):
@@ -104,7 +128,7 @@ def resnet_features(sd, p, x, num_frames, depth=50, pooling_method="max", withou
             x = _bottleneck(sd, "%slayer%d.%d" % (p, li + 1, bi), x, s, has_down, training)
             inplanes = planes * 4
         if li < 3 and not without_t_stride:
-            x = temporal_pool(x, frames, pooling_method.lower())   # models/resnet.py:145-153
+            x = _q(temporal_pool(x, frames, pooling_method.lower()))   # models/resnet.py:145-153
             frames = max(1, frames // 2)
     return x
 
@@ -124,7 +148,7 @@ def resnet_forward(sd, p, x, num_frames, depth=50, pooling_method="max", without
 def sound_mbv2_features(sd, p, x, training):
     """models/sound_mobilenet_v2.py:120-131,152-155 (torchvision-style naming)."""
     def cbr(pp, x, stride=1, groups=1, k=3):
-        x = F.conv2d(x, sd[pp + ".0.weight"], stride=stride, padding=(k - 1) // 2, groups=groups)
+        x = conv(x, sd[pp + ".0.weight"], stride=stride, padding=(k - 1) // 2, groups=groups)
         return F.relu6(batchnorm(sd, pp + ".1", x, training))
 
     x = cbr(p + "features.0", x, stride=2)
@@ -142,9 +166,9 @@ def sound_mbv2_features(sd, p, x, training):
                 j += 1
             y = cbr("%s.%d" % (pp, j), y, stride=stride, groups=hid)
             j += 1
-            y = F.conv2d(y, sd["%s.%d.weight" % (pp, j)])
+            y = conv(y, sd["%s.%d.weight" % (pp, j)])
             y = batchnorm(sd, "%s.%d" % (pp, j + 1), y, training)
-            x = x + y if (stride == 1 and inp == c) else y
+            x = _q(x + y) if (stride == 1 and inp == c) else y
             inp = c
             idx += 1
     return cbr("%sfeatures.%d" % (p, idx), x, k=1)
@@ -163,7 +187,7 @@ def policy_mbv2_features(sd, p, x, num_frames, training):
     max-pool placement of :120-130 (first block of the c=64 and c=160 stages)."""
     n, c_t, h, w = x.shape
     x = x.reshape(n * num_frames, c_t // num_frames, h, w)
-    x = F.conv2d(x, sd[p + "features.0.0.weight"], stride=2, padding=1)
+    x = conv(x, sd[p + "features.0.0.weight"], stride=2, padding=1)
     x = F.relu6(batchnorm(sd, p + "features.0.1", x, training))
     inp, idx, cur = 32, 1, num_frames
     for t, c, nrep, s in MBV2_CFG:
@@ -173,23 +197,23 @@ def policy_mbv2_features(sd, p, x, num_frames, training):
             hid = round(inp * t)
             pp = "%sfeatures.%d.conv" % (p, idx)
             if i == 0 and has_tp and cur not in (0, 1):
-                x = temporal_pool(x, cur, "max")
+                x = _q(temporal_pool(x, cur, "max"))
             y = x
             j = 0
             if t != 1:
-                y = F.conv2d(y, sd["%s.0.weight" % pp])
+                y = conv(y, sd["%s.0.weight" % pp])
                 y = F.relu6(batchnorm(sd, "%s.1" % pp, y, training))
                 j = 3
-            y = F.conv2d(y, sd["%s.%d.weight" % (pp, j)], stride=stride, padding=1, groups=hid)
+            y = conv(y, sd["%s.%d.weight" % (pp, j)], stride=stride, padding=1, groups=hid)
             y = F.relu6(batchnorm(sd, "%s.%d" % (pp, j + 1), y, training))
-            y = F.conv2d(y, sd["%s.%d.weight" % (pp, j + 3)])
+            y = conv(y, sd["%s.%d.weight" % (pp, j + 3)])
             y = batchnorm(sd, "%s.%d" % (pp, j + 4), y, training)
-            x = x + y if (stride == 1 and inp == c) else y
+            x = _q(x + y) if (stride == 1 and inp == c) else y
             inp = c
             idx += 1
         if has_tp:
             cur //= 2
-    x = F.conv2d(x, sd[p + "conv.0.weight"])
+    x = conv(x, sd[p + "conv.0.weight"])
     x = F.relu6(batchnorm(sd, p + "conv.1", x, training))
     return x.mean(dim=(2, 3))
 
@@ -233,9 +257,9 @@ def policy_forward(sd, p, p_x, modality, num_frames, temperature, expo, causalit
     logits = None
     for s in range(S):
         if s == 0:
-            prev = torch.zeros(B, 2 * M, dtype=feats[0].dtype)
-            h = torch.zeros(B, 256, dtype=feats[0].dtype)
-            c = torch.zeros(B, 256, dtype=feats[0].dtype)
+            prev = torch.zeros(B, 2 * M, dtype=feats[0].dtype, device=feats[0].device)
+            h = torch.zeros(B, 256, dtype=feats[0].dtype, device=feats[0].device)
+            c = torch.zeros(B, 256, dtype=feats[0].dtype, device=feats[0].device)
         else:
             prev = logits.reshape(M, B, 2).permute(1, 0, 2).reshape(B, 2 * M)   # :353
         xin = torch.cat((feats[s], prev), dim=-1)

@@ -202,12 +202,14 @@ def test_residual_add_and_act_bwd():
     s, t = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
     s2, t2 = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
     out = torch.empty(P, C, dtype=torch.bfloat16, device=DEV)
-    call("adamml_bn_act_add", ptr(z.bfloat16()), ptr(s), ptr(t), 1, ptr(idn.bfloat16()), ptr(s2), ptr(t2), ptr(out), P, C)
+    zb, ib = z.bfloat16(), idn.bfloat16()          # keep the operands alive across the async launch
+    call("adamml_bn_act_add", ptr(zb), ptr(s), ptr(t), 1, ptr(ib), ptr(s2), ptr(t2), ptr(out), P, C)
     ref = F.relu(z * s + t + idn * s2 + t2)
     close(out.float(), ref, what="bn+add+relu")
     g = rb(torch.randn(P, C, device=DEV))
     g2 = torch.empty_like(out)
-    call("adamml_act_bwd_from_output", ptr(g.bfloat16()), ptr(out), 1, ptr(g2), P * C)
+    gb = g.bfloat16()
+    call("adamml_act_bwd_from_output", ptr(gb), ptr(out), 1, ptr(g2), P * C)
     assert torch.equal(g2.float(), g * (out.float() > 0))
 
 
@@ -216,24 +218,24 @@ def test_maxpool_fwd_bwd():
     N, C, H, W = 3, 64, 30, 30
     x = rb(torch.randn(N, C, H, W, device=DEV))
     s, t = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.2
-    a = rb(F.relu(x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)))
-    # random (not relu-tied) positive offset avoids arg-max ties between bf16 and fp32 orderings
-    ar = a.clone().requires_grad_(True)
-    ref = F.max_pool2d(ar, 3, 2, 1)
-    OH, OW = ref.shape[2:]
+    OH = OW = 15
     y = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device=DEV)
     idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=DEV)
-    call("adamml_maxpool2d_fwd", ptr(nhwc(x)), ptr(s), ptr(t), 1, ptr(y), ptr(idx), N, H, W, C, OH, OW)
-    close(nchw(y), ref.detach(), what="maxpool")
+    xh = nhwc(x)
+    # lazy input: relu(scale*x+shift) is evaluated in fp32 inside the kernel, then pooled
+    call("adamml_maxpool2d_fwd", ptr(xh), ptr(s), ptr(t), 1, ptr(y), ptr(idx), N, H, W, C, OH, OW)
+    close(nchw(y), F.max_pool2d(F.relu(x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)), 3, 2, 1), what="maxpool lazy")
+    # plain input: identical operand values on both sides -> identical first-arg-max routing
+    ar = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(ar, 3, 2, 1)
+    call("adamml_maxpool2d_fwd", ptr(xh), None, None, 0, ptr(y), ptr(idx), N, H, W, C, OH, OW)
+    assert torch.equal(nchw(y), ref.detach())
     g = rb(torch.randn_like(ref))
+    gh = nhwc(g)
     gx = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=DEV)
-    call("adamml_maxpool2d_bwd", ptr(nhwc(g)), ptr(idx), ptr(gx), N, H, W, C, OH, OW, 0)
-    # the scatter of the gradient must conserve mass per (n, c) and land on arg-max positions
-    got = nchw(gx)
-    assert torch.allclose(got.sum((2, 3)), g.sum((2, 3)), rtol=2e-2, atol=0.3)
+    call("adamml_maxpool2d_bwd", ptr(gh), ptr(idx), ptr(gx), N, H, W, C, OH, OW, 0)
     ref.backward(g)
-    pos = a > 0          # ties only occur among relu zeros
-    assert ((got - ar.grad).abs() * pos).max().item() < 0.1
+    close(nchw(gx), ar.grad, what="maxpool bwd")
 
 
 @pytest.mark.parametrize("T,mode", [(8, 0), (4, 0), (2, 0), (1, 0), (8, 1), (4, 1)])
