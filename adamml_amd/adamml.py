@@ -1,0 +1,163 @@
+"""Top-level AdaMML module on libadamml_hip: input re-layout, policy net, gated main net over segments.
+Mirrors models/adamml.py:12-171 (class AdaMML, factory adamml(); same state_dict, same caller-visible surface)."""
+import torch
+import torch.nn as nn
+
+from . import hip
+from .backbone import FlatBuffers
+from .common import MeanStdMixin
+from .joint_resnet_mobilenetv2 import joint_resnet_mobilenetv2
+from .policy_net import p_joint_mobilenet
+from .runtime import clip_to_nhwc, SyncCtx
+
+__all__ = ['adamml']
+
+
+class AdaMML(nn.Module, MeanStdMixin):
+
+    def __init__(self, policy_net, main_net, num_frames, num_segments, modality, rng_policy, rng_threshold, num_classes,
+                 input_channels=None):
+        super().__init__()
+        self.rng_policy = rng_policy
+        self.policy_net = policy_net
+        self.main_net = main_net
+        self.num_segments = num_segments
+        self.num_frames = num_frames * num_segments
+        self.num_frames_per_segment = num_frames
+        self.modality = modality
+        self.input_channels = input_channels
+        if 'rgbdiff' in modality and 'flow' in modality:
+            self.num_modality = len(modality) - 1
+        else:
+            self.num_modality = len(modality)
+        self.p_data_idx = [self.modality.index(x) for x in self.policy_net.modality]
+        self.m_data_idx = [self.modality.index(x) for x in self.main_net.modality]
+        self.rng_threshold = rng_threshold
+        self.decay_ratio = 0.965
+        self.update_policy_net = True
+        self.update_main_net = True
+        self._flat_policy = FlatBuffers(self.policy_net)
+        self._flat_main = FlatBuffers(self.main_net)
+        if self.rng_policy:
+            self.freeze_policy_net()
+            del self.policy_net.fcs
+
+    # -- data layer (models/adamml.py:42-67) as one re-layout launch per modality and consumer ----------------
+    def data_layer(self, x, num_segments, p_rgb_size=(160, 160)):
+        p_x, m_x = [], []
+        f = self.num_frames_per_segment
+        for idx, (x_, m) in enumerate(zip(x, self.modality)):
+            hip.require_gpu(x_)
+            if m == 'sound':
+                if x_.size(-1) != x_.size(-2):
+                    # legacy "consecutive segments stacked along the last dim" layout (:49-51)
+                    x_ = torch.stack(x_.chunk(num_segments, dim=-1), dim=1).reshape(x_.size(0), -1, x_.size(-2),
+                                                                                    x_.size(-1) // num_segments)
+                c = x_.size(1) // num_segments
+                t = clip_to_nhwc(x_, num_segments, 1, c)
+                p_x.append(t)
+                m_x.append(t)
+                continue
+            c = x_.size(1) // (num_segments * f)
+            if idx in self.p_data_idx:
+                p_x.append(clip_to_nhwc(x_, num_segments, f, c, out_hw=p_rgb_size, frame_step=2))
+            if idx in self.m_data_idx:
+                m_x.append(clip_to_nhwc(x_, num_segments, f, c))
+        return p_x, m_x, num_segments
+
+    def forward(self, x, num_segments=None, gumbel_exponential=None):
+        """x: list over modality of [N, S*F*C, H, W] fp32 GPU tensors.  Returns (logits [N, classes], decisions [N,S,M]).
+        gumbel_exponential (optional, [S, M*N, 2]) replaces the device-side Exponential(1) draw for parity runs."""
+        num_segments = num_segments if num_segments else self.num_segments
+        dev = x[0].device
+        self._flat_policy.ensure(dev)
+        self._flat_main.ensure(dev)
+        if self.training and torch.is_grad_enabled():
+            self._flat_policy.ensure_grads()
+            self._flat_main.ensure_grads()
+        p_x, m_x, num_segments = self.data_layer(x, num_segments)
+        if not self.rng_policy:
+            decisions, decision_logits = self.policy_net(p_x, gumbel_exponential)
+            self.last_policy_logits = decision_logits
+        else:
+            decisions = (torch.rand((num_segments, self.num_modality, x[0].size(0)), dtype=x[0].dtype, device=dev)
+                         > self.rng_threshold).float()
+        all_logits = []
+        for i in range(num_segments):
+            tmp_x = [m_x[m_i][i] for m_i in range(self.num_modality)]
+            all_logits.append(self.main_net(tmp_x, decisions[i]))
+        final_logits = torch.stack(all_logits, dim=1).mean(dim=1)
+        return final_logits, decisions.permute((2, 0, 1))
+
+    @property
+    def network_name(self):
+        name = 'adamml'
+        if self.rng_policy:
+            name += '-rng-{:.1f}'.format(self.rng_threshold)
+        else:
+            name += '-{}'.format(self.policy_net.network_name)
+        name += '-{}'.format(self.main_net.network_name)
+        return name
+
+    def decay_temperature(self, decay_ratio=None):
+        self.policy_net.decay_temperature(decay_ratio if decay_ratio else self.decay_ratio)
+
+    def freeze_policy_net(self):
+        self.update_policy_net = False
+        for param in self.policy_net.parameters():
+            param.requires_grad = False
+
+    def unfreeze_policy_net(self):
+        self.update_policy_net = True
+        for param in self.policy_net.parameters():
+            param.requires_grad = True
+
+    def freeze_main_net(self):
+        self.update_main_net = False
+        for param in self.main_net.parameters():
+            param.requires_grad = False
+
+    def unfreeze_main_net(self):
+        self.update_main_net = True
+        for param in self.main_net.parameters():
+            param.requires_grad = True
+
+    # -- MI355X extensions (not in the reference surface) -------------------------------------------------------
+    def backbones(self):
+        nets = list(self.main_net.nets)
+        if hasattr(self.policy_net, "joint_net"):
+            nets += list(self.policy_net.joint_net.nets)
+        return nets
+
+    def enable_sync_bn(self, group=None):
+        """SyncBatchNorm (train_adamml.py:126-127): BN statistic sums are all-reduced over RCCL."""
+        for net in self.backbones():
+            net.rt.sync = SyncCtx(group, True)
+
+    def flat_grad_buffers(self):
+        """Flat fp32 gradient buffers (policy, main) for one bucketed RCCL all-reduce each."""
+        return [fb.flat_grad for fb in (self._flat_policy, self._flat_main) if fb.flat_grad is not None]
+
+
+def adamml(groups, modality, input_channels, num_segments, rng_policy, rng_threshold, causality_modeling,
+           num_classes, depth, without_t_stride, dropout, pooling_method, fusion_point,
+           unimodality_pretrained, learnable_lf_weights, **kwargs):
+    """Factory with the signature of models/adamml.py:134-171 (tolerates the whole argparse namespace as kwargs)."""
+    if 'rgbdiff' in modality and 'flow' in modality:
+        p_modality = [x for x in modality if x != 'flow']
+        m_modality = [x for x in modality if x != 'rgbdiff']
+        p_input_channels = [x for x, m in zip(input_channels, modality) if m != 'flow']
+        m_input_channels = [x for x, m in zip(input_channels, modality) if m != 'rgbdiff']
+    else:
+        p_modality, m_modality = modality, modality
+        p_input_channels, m_input_channels = input_channels, input_channels
+    policy_net = p_joint_mobilenet(num_frames=max(1, groups // 2), modality=p_modality,
+                                   input_channels=p_input_channels, causality_modeling=causality_modeling)
+    main_net = joint_resnet_mobilenetv2(depth=depth, num_classes=num_classes, without_t_stride=without_t_stride,
+                                        groups=groups, dropout=dropout, pooling_method=pooling_method,
+                                        input_channels=m_input_channels, fusion_point=fusion_point, modality=m_modality,
+                                        unimodality_pretrained=unimodality_pretrained,
+                                        learnable_lf_weights=learnable_lf_weights)
+    return AdaMML(policy_net, main_net, num_frames=groups, num_segments=num_segments, modality=modality,
+                  rng_policy=rng_policy, rng_threshold=rng_threshold, num_classes=num_classes,
+                  input_channels=input_channels)

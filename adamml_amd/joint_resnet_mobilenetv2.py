@@ -1,0 +1,85 @@
+"""Main net of AdaMML: one backbone per modality (ResNet for visual streams, MobileNetV2 for sound), per-sample
+decision masking of the logits and learnable late fusion.
+Mirrors models/joint_resnet_mobilenetv2.py:11-157 (fusion_point='logits', the only path the policy can drive)."""
+import torch
+import torch.nn as nn
+
+from .common import MeanStdMixin
+from .resnet import ResNet
+from .sound_mobilenet_v2 import MobileNetV2
+
+__all__ = ['joint_resnet_mobilenetv2']
+
+
+class JointResNetMobileNetV2(nn.Module, MeanStdMixin):
+
+    def __init__(self, depth, num_frames, modality, num_classes=1000, dropout=0.5, zero_init_residual=False,
+                 without_t_stride=False, pooling_method='max', input_channels=None, fusion_point='logits',
+                 learnable_lf_weights=False):
+        super().__init__()
+        if fusion_point != 'logits':
+            # models/joint_resnet_mobilenetv2.py:96 -- the decision mask only exists for 'logits'; AdaMML never uses 'fc2'
+            raise ValueError("only support logits mode")
+        self.depth = depth
+        self.num_frames = num_frames
+        self.without_t_stride = without_t_stride
+        self.pooling_method = pooling_method
+        self.fusion_point = fusion_point
+        self.modality = modality
+        self.learnable_lf_weights = learnable_lf_weights
+        self.nets = nn.ModuleList()
+        self.last_channels = []
+        for i, m in enumerate(modality):
+            if m != 'sound':
+                net = ResNet(depth, num_frames, num_classes, dropout, zero_init_residual, without_t_stride, pooling_method,
+                             input_channels[i])
+                self.last_channels.append(2048)
+            else:
+                net = MobileNetV2(num_classes, dropout=dropout, input_channels=input_channels[i])
+                self.last_channels.append(net.last_channel)
+            net.flat_owner = None           # parameters are flattened once for the whole main net
+            self.nets.append(net)
+        self.lf_weights = None
+        if learnable_lf_weights:
+            init_prob = 1.0 / len(self.modality)
+            self.lf_weights = nn.Parameter(torch.tensor([init_prob] * (len(self.modality) - 1)))
+
+    @property
+    def network_name(self):
+        name = 'joint_resnet-{}_mobilenet_v2-{}'.format(self.depth, self.fusion_point)
+        if self.lf_weights is not None:
+            name += "-llf" if self.learnable_lf_weights else '-llfc'
+        if not self.without_t_stride:
+            name += "-ts-{}".format(self.pooling_method)
+        return name
+
+    def forward(self, multi_modalities, decisions=None):
+        """multi_modalities: list of NHWC bf16 frame tensors of ONE segment; decisions [M, B] or None."""
+        out = []
+        for i, x in enumerate(multi_modalities):
+            tmp = self.nets[i].forward_nhwc(x)                   # [B, classes] fp32
+            if decisions is not None:
+                tmp = tmp * decisions[i].view((tmp.size(0), 1))  # :94
+            out.append(tmp)
+        out = torch.stack(out, dim=0)                            # M x B x C
+        if self.lf_weights is not None:
+            comple = torch.ones(1, dtype=self.lf_weights.dtype, device=self.lf_weights.device) - torch.sum(self.lf_weights, dim=0)
+            weights = torch.cat((self.lf_weights, comple), dim=0).view(-1, 1, 1)
+            return torch.sum(out * weights, dim=0)
+        return torch.mean(out, dim=0)
+
+
+def joint_resnet_mobilenetv2(depth, num_classes, without_t_stride, groups, dropout, pooling_method, input_channels,
+                             fusion_point, modality, unimodality_pretrained, learnable_lf_weights, **kwargs):
+    model = JointResNetMobileNetV2(depth, num_frames=groups, num_classes=num_classes, without_t_stride=without_t_stride,
+                                   dropout=dropout, pooling_method=pooling_method, input_channels=input_channels,
+                                   fusion_point=fusion_point, modality=modality, learnable_lf_weights=learnable_lf_weights)
+    if len(unimodality_pretrained) > 0:
+        if len(unimodality_pretrained) != len(model.nets):
+            raise ValueError("the number of pretrained models is incorrect.")
+        for i, m in enumerate(modality):
+            print("Loading unimodality pretrained model from: {}".format(unimodality_pretrained[i]))
+            state_dict = torch.load(unimodality_pretrained[i], map_location='cpu')['state_dict']
+            new_state_dict = {key.replace("module.", ""): v for key, v in state_dict.items()}
+            model.nets[i].load_state_dict(new_state_dict, strict=True)
+    return model

@@ -1,0 +1,25 @@
+"""Shared executor of the two MobileNetV2 variants (sound main net, policy net): inverted-residual blocks as
+pointwise MFMA convs + depthwise VALU convs with lazily applied BatchNorm/ReLU6."""
+from .runtime import conv_bn, add_act, temporal_pool, ACT_NONE, ACT_RELU6
+
+
+class BlockPlan:
+    __slots__ = ("pw", "dw", "pwl", "residual", "tpool")
+
+    def __init__(self, pw, dw, pwl, residual, tpool=None):
+        self.pw, self.dw, self.pwl, self.residual, self.tpool = pw, dw, pwl, residual, tpool
+
+
+def run_blocks(rt, h, plans):
+    """plans: list of BlockPlan; pw/dw/pwl are (ConvState, BatchNorm2d) pairs (pw may be None)."""
+    for bp in plans:
+        x = h
+        if bp.tpool:
+            x = temporal_pool(rt, x, bp.tpool, "max")
+        y = x
+        if bp.pw is not None:
+            y = conv_bn(rt, y, bp.pw[0], bp.pw[1], ACT_RELU6)
+        y = conv_bn(rt, y, bp.dw[0], bp.dw[1], ACT_RELU6)
+        y = conv_bn(rt, y, bp.pwl[0], bp.pwl[1], ACT_NONE)
+        h = add_act(rt, y, x, ACT_NONE) if bp.residual else y
+    return h

@@ -1,0 +1,217 @@
+"""Block-level composition parity (tight): a few consecutive residual blocks executed through the HIP runtime
+(lazy BatchNorm, tape, gradient aliasing / accumulation) against plain torch fp32 autograd of the same blocks with
+bf16 rounding emulated at the HIP storage points.  Shallow stacks are far less chaotic than the full nets:
+activations 1.5e-2 of scale (= one bf16 ulp at the top binade); gradient tensors 8e-2 relative L2 -- the floor is set
+by ReLU gates: 1-ulp differences of stored bf16 activations flip a fraction f ~ 1e-3 of the gates of a layer, which
+moves a gradient tensor by ~sqrt(2 f) ~ 4-5 % (measured 0.2-6 % here), independent of the kernel arithmetic."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from adamml_amd.runtime import Lazy, conv_bn, add_act, temporal_pool, ACT_NONE, ACT_RELU, ACT_RELU6  # noqa: E402
+from adamml_amd.mobilenet_common import run_blocks  # noqa: E402
+from adamml_amd.hip import call, ptr  # noqa: E402
+
+DEV = "cuda"
+
+
+def q(x):
+    return x + (x.to(torch.bfloat16).float() - x).detach()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+
+
+def nchw(t):
+    return t.float().permute(0, 3, 1, 2)
+
+
+def rel_l2(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+def randomize(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = torch.rand(m.weight.shape, generator=g) + 0.5
+            m.bias.data = torch.randn(m.bias.shape, generator=g) * 0.2
+
+
+def bn_train(x, bn):
+    return F.batch_norm(x, None, None, bn.weight, bn.bias, True, 0.1, 1e-5)
+
+
+def tpool_ref(x, frames):
+    nt, c, h, w = x.shape
+    v = x.view(nt // frames, frames, c, h, w).transpose(1, 2)
+    return F.max_pool3d(v, (3, 1, 1), (2, 1, 1), (1, 0, 0)).transpose(1, 2).reshape(-1, c, h, w)
+
+
+def materialize(l):
+    n, h, w, C = l.shape
+    out = torch.empty_like(l.data)
+    call("adamml_bn_act_add", ptr(l.data), ptr(l.scale), ptr(l.shift), l.act, None, None, None, ptr(out), n * h * w, C)
+    return nchw(out)
+
+
+def test_resnet_bottlenecks():
+    from adamml_amd.resnet import ResNet
+    torch.manual_seed(0)
+    net = ResNet(50, num_frames=4, num_classes=31, dropout=0.0)
+    randomize(net, 1)
+    blocks = [net.layer2[0], net.layer2[1]]
+    frames = 4
+    x = torch.randn(2 * frames, 256, 20, 20, device=DEV)
+
+    def hip_fn(rt, h):
+        h = temporal_pool(rt, h, frames, "max")
+        for b in blocks:
+            o = conv_bn(rt, h, b._cs1, b.bn1, ACT_RELU)
+            o = conv_bn(rt, o, b._cs2, b.bn2, ACT_RELU)
+            o = conv_bn(rt, o, b._cs3, b.bn3, ACT_NONE)
+            idn = conv_bn(rt, h, b._csd, b.downsample[1], ACT_NONE) if b._csd is not None else h
+            h = add_act(rt, o, idn, ACT_RELU)
+        return h
+
+    plist = [(n, p) for n, p in net.named_parameters() if n.startswith(("layer2.0.", "layer2.1."))]
+
+    def ref_fn(h):
+        ws = {n: p.detach().clone().requires_grad_(True) for n, p in plist}
+        h = q(tpool_ref(h, frames))
+        for bi, b in enumerate(blocks):
+            pre = "layer2.%d." % bi
+
+            class _bn:  # noqa: N801
+                def __init__(s, n):
+                    s.weight, s.bias = ws[pre + n + ".weight"], ws[pre + n + ".bias"]
+            o = q(F.conv2d(q(h), q(ws[pre + "conv1.weight"])))
+            o = F.relu(bn_train(o, _bn("bn1")))
+            o = q(F.conv2d(q(o), q(ws[pre + "conv2.weight"]), stride=b.stride, padding=1))
+            o = F.relu(bn_train(o, _bn("bn2")))
+            o = q(F.conv2d(q(o), q(ws[pre + "conv3.weight"])))
+            o = bn_train(o, _bn("bn3"))
+            if b.downsample is not None:
+                idn = q(F.conv2d(q(h), q(ws[pre + "downsample.0.weight"]), stride=b.stride))
+                idn = bn_train(idn, _bn("downsample.1"))
+            else:
+                idn = h
+            h = q(F.relu(o + idn))
+        ref_fn.ws = ws
+        return h
+
+    run_and_compare_with_ref(net, hip_fn, ref_fn, x, plist)
+
+
+def run_and_compare_with_ref(net, hip_fn, ref_fn, x, plist):
+    net.to(DEV)
+    net.train()
+    for p in net.parameters():
+        p.grad = torch.zeros_like(p)
+    rt = net.rt
+    rt.begin_forward(x.device, True, True)
+    net._repack(True)
+    xin = Lazy(nhwc(x), requires_grad=True)
+    out = hip_fn(rt, xin)
+    got = materialize(out)
+    xr = q(x.clone()).requires_grad_(True)
+    ref = ref_fn(xr)
+    scale = ref.abs().max().item()
+    err = (got - ref.detach()).abs().max().item()
+    print("forward max err %.4g of scale %.4g" % (err, scale))
+    assert err <= 1.5e-2 * scale + 1e-3
+    R = torch.randn_like(ref)
+    out.grad = nhwc(R)
+    rt.bwd_arena.reset(x.device)
+    rt.tape.backward()
+    ref.backward(q(R))
+    e = rel_l2(nchw(xin.grad), xr.grad)
+    print("input grad rel-L2 %.4f" % e)
+    worst = (0.0, None)
+    params = dict(net.named_parameters())
+    gmax = max(w.grad.norm().item() for w in ref_fn.ws.values() if w.grad is not None)
+    for name, w in ref_fn.ws.items():
+        if w.grad is None or w.grad.norm().item() < 1e-3 * gmax:     # analytically-zero (bias feeding a BatchNorm)
+            continue
+        r = rel_l2(params[name].grad, w.grad)
+        if r > worst[0]:
+            worst = (r, name)
+    assert e < 8e-2
+    print("worst param grad rel-L2 %.4f at %s" % worst)
+    assert worst[0] < 1e-1, worst
+
+
+def _mbv2_ref(blocks_spec, ws, h):
+    """blocks_spec: list of (prefix, names(pw conv, pw bn, dw conv, dw bn, pwl conv, pwl bn), stride, residual, tpool)."""
+    for pre, nm, stride, residual, tp in blocks_spec:
+        class _bn:  # noqa: N801
+            def __init__(s, n):
+                s.weight, s.bias = ws[pre + n + ".weight"], ws[pre + n + ".bias"]
+        x = h
+        if tp:
+            x = q(tpool_ref(x, tp))
+        y = x
+        if nm[0] is not None:
+            y = q(F.conv2d(q(y), q(ws[pre + nm[0] + ".weight"])))
+            y = F.relu6(bn_train(y, _bn(nm[1])))
+        wdw = ws[pre + nm[2] + ".weight"]
+        y = q(F.conv2d(y, wdw, stride=stride, padding=1, groups=wdw.shape[0]))
+        y = F.relu6(bn_train(y, _bn(nm[3])))
+        y = q(F.conv2d(q(y), q(ws[pre + nm[4] + ".weight"])))
+        y = bn_train(y, _bn(nm[5]))
+        h = q(x + y) if residual else y
+    return h
+
+
+def test_policy_mobilenet_blocks_with_temporal_pool():
+    from adamml_amd.policy_net import MobileNetV2
+    torch.manual_seed(0)
+    net = MobileNetV2(num_frames=4, input_channels=3)
+    randomize(net, 2)
+    # features[7] = first block of the c=64 stage (temporal pool over 4 frames, stride 2), features[8] residual
+    idx = [6, 7, 8]
+    plans = [net._plans[i - 1] for i in idx]
+    x = torch.randn(2 * 4, 32, 20, 20, device=DEV)
+    spec = []
+    for i in idx:
+        blk = net.features[i]
+        spec.append(("features.%d.conv." % i, ("0", "1", "3", "4", "6", "7"), blk.conv[3].stride[0], blk.identity, blk.tpool_frames))
+    names = [n for n, _ in net.named_parameters() if n.startswith(tuple(s[0] for s in spec))]
+
+    def ref_fn(h):
+        params = dict(net.named_parameters())
+        ws = {n: params[n].detach().clone().requires_grad_(True) for n in names}
+        ref_fn.ws = ws
+        return _mbv2_ref(spec, ws, h)
+
+    run_and_compare_with_ref(net, lambda rt, h: run_blocks(rt, h, plans), ref_fn, x, None)
+
+
+def test_sound_mobilenet_blocks():
+    from adamml_amd.sound_mobilenet_v2 import MobileNetV2
+    torch.manual_seed(0)
+    net = MobileNetV2(num_classes=31, input_channels=1, dropout=0.0)
+    randomize(net, 3)
+    idx = [1, 2, 3]          # t=1 block (no expand), stride-2 block, residual block
+    plans = [net._plans[i - 1] for i in idx]
+    x = torch.randn(3, 32, 24, 24, device=DEV)
+    spec = []
+    for i in idx:
+        blk = net.features[i]
+        if blk.expand:
+            nm = ("0.0", "0.1", "1.0", "1.1", "2", "3")
+        else:
+            nm = (None, None, "0.0", "0.1", "1", "2")
+        spec.append(("features.%d.conv." % i, nm, blk.stride, blk.use_res_connect, None))
+    names = [n for n, _ in net.named_parameters() if n.startswith(tuple(s[0] for s in spec))]
+
+    def ref_fn(h):
+        params = dict(net.named_parameters())
+        ws = {n: params[n].detach().clone().requires_grad_(True) for n in names}
+        ref_fn.ws = ws
+        return _mbv2_ref(spec, ws, h)
+
+    run_and_compare_with_ref(net, lambda rt, h: run_blocks(rt, h, plans), ref_fn, x, None)

@@ -72,8 +72,22 @@ def build_adamml(c):
 
 
 def run_case(name, c):
+    """For AdaMML cases the Gumbel seed is searched (7, 8, ...) until every hard decision of every mode has a margin
+    |(l1+g1)-(l0+g0)| > 0.25, so that decisions are robust to reduced-precision logit errors; the chosen seed is
+    stored in the fixture."""
+    if c["kind"] != "adamml":
+        return _run_case(name, c, 7)
+    for seed in range(7, 200):
+        out = _run_case(name, c, seed)
+        if out["min_decision_margin"] > 0.25:
+            return out
+    raise RuntimeError("no robust gumbel seed found for " + name)
+
+
+def _run_case(name, c, gumbel_seed):
     torch.manual_seed(0)
-    out = {}
+    out = {"gumbel_seed": np.array(gumbel_seed)}
+    margins = []
     kind = c["kind"]
     if kind == "resnet":
         model = models.resnet(depth=50, num_classes=31, without_t_stride=False, groups=c["groups"], dropout=0.0,
@@ -99,8 +113,10 @@ def run_case(name, c):
         model.zero_grad()
         if kind == "adamml":
             M = model.num_modality
-            _EXPO["q"] = synth.synth_gumbel_exponential(S, M, B, seed=7)
+            _EXPO["q"] = synth.synth_gumbel_exponential(S, M, B, seed=gumbel_seed)
             _EXPO["i"] = 0
+            cap = {}
+            hook = model.policy_net.register_forward_hook(lambda mod, i, o: cap.__setitem__("plog", o[1].detach()))
             model.policy_net.set_temperature(c.get("tau", 5.0))
             model.unfreeze_policy_net()
             model.unfreeze_main_net()
@@ -117,6 +133,11 @@ def run_case(name, c):
                     model.freeze_main_net()
             y = model(xs)
         if kind == "adamml":
+            hook.remove()
+            plog = cap["plog"]                                   # [S, M, B, 2]
+            out[mode + ".policy_logits"] = plog.numpy()
+            gn = -_EXPO["q"].log().reshape(plog.shape[0], plog.shape[1], -1, 2) if plog.dim() == 4 else None
+            margins.append(float(((plog[..., 1] + gn[..., 1]) - (plog[..., 0] + gn[..., 0])).abs().min()))
             logits, sel = y
             out[mode + ".logits"] = logits.detach().numpy()
             out[mode + ".decisions"] = sel.detach().numpy()
@@ -144,14 +165,9 @@ def run_case(name, c):
             out[mode + ".stat_names"] = np.array(sorted(st.keys()))
             out[mode + ".stat_probe"] = np.stack([st[k] for k in sorted(st.keys())])
     if kind == "adamml":
-        # policy logits [S,M,B,2] in eval mode (for margin-aware decision checks)
-        model.load_state_dict(sd)
-        model.eval()
-        _EXPO["i"] = 0
+        out["min_decision_margin"] = np.array(min(margins))
         with torch.no_grad():
             p_x, m_x, _ = model.data_layer(xs, S)
-            dec, plog = model.policy_net(p_x)
-        out["eval.policy_logits"] = plog.numpy()
         out["eval.p_x_probe"] = np.stack([stat_probe(t) for t in p_x])
         out["eval.m_x_probe"] = np.stack([stat_probe(t) for t in m_x])
     out["n_state"] = np.array(len(sd))
