@@ -135,8 +135,12 @@ class AdaMML(nn.Module, MeanStdMixin):
             net.rt.sync = SyncCtx(group, True)
 
     def flat_grad_buffers(self):
-        """Flat fp32 gradient buffers (policy, main) for one bucketed RCCL all-reduce each."""
-        return [fb.flat_grad for fb in (self._flat_policy, self._flat_main) if fb.flat_grad is not None]
+        """Flat fp32 gradient buffers of the TRAINABLE sub-networks (one RCCL all-reduce each)."""
+        out = []
+        for fb, on in ((self._flat_policy, self.update_policy_net), (self._flat_main, self.update_main_net)):
+            if on and fb.flat_grad is not None:
+                out.append(fb.flat_grad)
+        return out
 
 
 def adamml(groups, modality, input_channels, num_segments, rng_policy, rng_threshold, causality_modeling,

@@ -80,9 +80,41 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+class LaunchProfiler:
+    """Optional per-launch HIP-event timing (bench.py roofline leg): every C-ABI launch is bracketed by events on the
+    stream it is enqueued on; `meta` = (algorithmic flops, algorithmic HBM bytes) supplied by the caller."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, s, e, meta in self.records:
+            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a["launches"] += 1
+            a["ms"] += s.elapsed_time(e)
+            a["flops"] += meta[0]
+            a["bytes"] += meta[1]
+        return agg
+
+
+profiler = None
+next_meta = (0.0, 0.0)
+
+
 def call(name, *args):
+    global next_meta
     lib = load()
-    rc = getattr(lib, name)(*args, _stream())
+    if profiler is not None:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = getattr(lib, name)(*args, _stream())
+        e.record()
+        profiler.records.append((name, s, e, next_meta))
+        next_meta = (0.0, 0.0)
+    else:
+        rc = getattr(lib, name)(*args, _stream())
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.adamml_last_error_string().decode()))
 

@@ -201,6 +201,11 @@ def conv_bn(rt, x, cs, bn, act):
     C = d.Cout
     count = d.N * d.OH * d.OW
     fwd = "adamml_dwconv_fwd" if cs.depthwise else "adamml_conv_fwd"
+    # algorithmic work of this layer (true input channels, each tensor touched once), for the roofline report
+    macs = float(count) * C * cs.kh * cs.kw * (1 if cs.depthwise else cs.cin_true)
+    in_b, out_b = 2.0 * d.N * d.H * d.W * cs.cin_true, 2.0 * count * C
+    w_b = 2.0 * C * cs.kh * cs.kw * (1 if cs.depthwise else cs.cin_true)
+    hip.next_meta = (2 * macs, in_b + out_b + w_b)
     if rt.training:
         stats = rt.fwd_arena.take(2 * C)
         call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), ptr(stats))
@@ -216,6 +221,7 @@ def conv_bn(rt, x, cs, bn, act):
                 return
             dz = _bn_backward(rt, out, y, vec, bn, act, count)
             if cs.weight.requires_grad:
+                hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b)
                 if cs.depthwise:
                     call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(cs.weight.grad))
                 else:
@@ -226,6 +232,7 @@ def conv_bn(rt, x, cs, bn, act):
                 if x.grad is None:
                     x.grad = torch.empty_like(x.data)
                     acc = 0
+                hip.next_meta = (2 * macs, in_b * (1 + acc) + out_b + w_b)
                 if cs.depthwise:
                     call("adamml_dwconv_bwd_data", byref(d), ptr(dz), ptr(cs.w_fwd), ptr(x.grad), acc)
                 else:

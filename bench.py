@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: clips/sec, train fwd+bwd, RGB+Audio AdaMML (ResNet-50 + Sound-MobileNetV2 +
+MobileNetV2/LSTM policy), 224^2, 8 frames/segment, 5 segments, bf16.
+
+One "step" = one main-net-stage training iteration (policy frozen, train_adamml.py:344-345) over one batch of
+synthetic videos already resident in HBM: forward of policy + main nets, CE loss, backward of the main nets,
+gradient all-reduce (N > 1), fused SGD step.  N = 1 runs BASELINE.json configs[1] (B = 72 videos = 360 clips per step);
+N > 1 keeps B = 72 per GPU (weak scaling) with SyncBN + RCCL gradient all-reduce (configs[2]).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched with torch.distributed.run)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0          # HBM3E spec peak, same table
+CLIP_GFLOP_MAIN_STAGE = 86.7   # algorithmic GFLOP per clip, main-net stage
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("ADAMML_BENCH_BATCH", 72)), help="videos per GPU")
+    ap.add_argument("--segments", type=int, default=5)
+    ap.add_argument("--stage", default="main", choices=["main", "policy"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-sync-bn", action="store_true")
+    return ap.parse_args()
+
+
+def build(args, device):
+    from adamml_amd import adamml, synth
+    mod = ["rgb", "sound"]
+    model = adamml(groups=8, modality=mod, input_channels=[3, 1], num_segments=args.segments, rng_policy=False,
+                   rng_threshold=0.5, causality_modeling="lstm", num_classes=31, depth=50, without_t_stride=False,
+                   dropout=0.5, pooling_method="max", fusion_point="logits", unimodality_pretrained=[],
+                   learnable_lf_weights=True)
+    sd = synth.synth_state_dict(model.state_dict(), seed=1234)       # random-init weights of the named architecture
+    model.load_state_dict(sd)
+    model.to(device)
+    return model
+
+
+def synth_batch(args, device, rank):
+    g = torch.Generator(device="cpu").manual_seed(42 + rank)
+    b, s = args.batch, args.segments
+    # generated on the device in chunks (a [72,120,224,224] fp32 clip tensor is 1.7 GB)
+    torch.manual_seed(42 + rank)
+    rgb = torch.randn(b, s * 8 * 3, 224, 224, device=device)
+    snd = torch.randn(b, s, 256, 256, device=device) * 3.0 - 5.0
+    tgt = torch.randint(0, 31, (b,), generator=g).to(device)
+    return [rgb, snd], tgt
+
+
+def cpu_baseline(args):
+    """ORACLE (CPU fp32 restatement, pinned to the reference goldens) timed on this host on a bounded sample of the
+    same workload: B=2 videos x 5 segments = 10 clips per iteration, main-net stage fwd+bwd+SGD."""
+    from adamml_amd import adamml, synth
+    from oracle import adamml_oracle as O
+    mod = ["rgb", "sound"]
+    b, s = 2, args.segments
+    shapes = adamml(groups=8, modality=mod, input_channels=[3, 1], num_segments=s, rng_policy=False, rng_threshold=0.5,
+                    causality_modeling="lstm", num_classes=31, depth=50, without_t_stride=False, dropout=0.5,
+                    pooling_method="max", fusion_point="logits", unimodality_pretrained=[], learnable_lf_weights=True).state_dict()
+    sd = O.make_leaf_state(synth.synth_state_dict(shapes, seed=1234), ("main_net.",))
+    xs = synth.synth_inputs(mod, b, s, 8, 224, 256, seed=42)
+    tgt = synth.synth_labels(b, 31, seed=42)
+    expo = synth.synth_gumbel_exponential(s, 2, b, seed=7)
+    cores = torch.get_num_threads()
+    times = []
+    for it in range(2):
+        t0 = time.time()
+        logits, sel, _ = O.adamml_forward(sd, xs, mod, s, 8, 50, 5.0, expo, "lstm", "max", False, 0.5, True)
+        loss = F.cross_entropy(logits, tgt)
+        loss.backward()
+        with torch.no_grad():
+            for k, v in sd.items():
+                if v.grad is not None:
+                    v -= 0.01 * v.grad
+                    v.grad = None
+        times.append(time.time() - t0)
+    t = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": round(b * s / t, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": "oracle (CPU fp32 restatement of the reference, torch %s) main-net-stage train step, B=2 videos x %d "
+                      "segments (10 clips) per iteration, 1 warm-up + 1 timed iteration" % (torch.__version__, s)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)     # "nccl" == RCCL on ROCm
+
+    import __graft_entry__ as ge
+    if rank == 0 and not os.path.exists(ge.LIB):
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from adamml_amd import hip
+    from adamml_amd.distributed import HipDDP
+    from adamml_amd.optim import FlatSGD, FlatAdam
+
+    model = build(args, device)
+    ddp = HipDDP(model, sync_bn=(world > 1 and not args.no_sync_bn))
+    if args.stage == "main":
+        model.freeze_policy_net()
+    else:
+        model.freeze_main_net()
+    model.train()
+    images, target = synth_batch(args, device, rank)
+    opt = p_opt = None
+
+    def step():
+        nonlocal opt, p_opt
+        out, sel = ddp(images)
+        loss = F.cross_entropy(out, target)
+        if model.update_policy_net:
+            usage = sel.mean(dim=1) ** 2
+            loss = loss + usage.mean()
+        loss.backward()
+        ddp.reduce_gradients()
+        if model.update_main_net:
+            if opt is None:
+                opt = FlatSGD(model._flat_main, lr=0.001, momentum=0.9, weight_decay=5e-4)
+            opt.step()
+            opt.zero_grad()
+        if model.update_policy_net:
+            if p_opt is None:
+                p_opt = FlatAdam(model._flat_policy, lr=1e-4, weight_decay=5e-4)
+            p_opt.step()
+            p_opt.zero_grad()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    clips = world * args.batch * args.segments
+    value = clips / (ms_per_step / 1e3)
+    peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+
+    roof = None
+    breakdown = None
+    if rank == 0 and not args.no_roofline:
+        hip.profiler = hip.LaunchProfiler()
+        step()
+        agg = hip.profiler.summary()
+        hip.profiler = None
+        tot_ms = sum(a["ms"] for a in agg.values())
+        breakdown = {k: {"launches": a["launches"], "ms": round(a["ms"], 3), "pct": round(100 * a["ms"] / tot_ms, 1),
+                         "tflops": round(a["flops"] / (a["ms"] * 1e9), 1) if a["ms"] > 0 else 0,
+                         "gbs": round(a["bytes"] / (a["ms"] * 1e6), 1) if a["ms"] > 0 else 0}
+                     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        name, a = dom
+        per_launch_ms = a["ms"] / a["launches"]
+        tfl = a["flops"] / (a["ms"] * 1e9)
+        gbs = a["bytes"] / (a["ms"] * 1e6)
+        f_mfma, f_hbm = tfl / PEAK_BF16_TFLOPS, gbs / PEAK_HBM_GBS
+        if f_hbm >= f_mfma:
+            roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(f_hbm, 4)}
+        else:
+            roof = {"bound": "mfma", "achieved": round(tfl, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(f_mfma, 4)}
+        roof.update({"traffic": None, "kernel": name, "launches_per_step": a["launches"],
+                     "avg_launch_us": round(per_launch_ms * 1e3, 2), "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4),
+                     "share_of_device_time": round(a["ms"] / tot_ms, 3)})
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        res = {
+            "metric": "clips/sec (train fwd+bwd) RGB+Audio AdaMML @224^2, 5 seg", "value": round(value, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "AdaMML RGB+Audio (ResNet-50 + Sound-MobileNetV2 + MobileNetV2/LSTM policy), %s-net "
+                                   "stage train step, %d segments x 8 frames, 224^2 / 256^2 spectrogram" % (args.stage, args.segments),
+                       "videos_per_gpu": args.batch, "clips_per_step": clips, "segments": args.segments,
+                       "parallelism": "dp%d%s" % (world, "+syncbn" if (world > 1 and not args.no_sync_bn) else ""),
+                       "optimizer": "fused flat SGD(momentum 0.9, wd 5e-4)"},
+            "videos_per_s": round(value / args.segments, 2),
+            "model_tflops": round(value * CLIP_GFLOP_MAIN_STAGE / 1e3, 1) if args.stage == "main" else None,
+            "model_mfma_frac": round(value * CLIP_GFLOP_MAIN_STAGE / 1e3 / (PEAK_BF16_TFLOPS * world), 4) if args.stage == "main" else None,
+            "peak_mem_gib": round(peak_mem, 1), "loss": round(float(loss.item()), 4),
+            "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
+        }
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
