@@ -28,28 +28,6 @@ struct ConvP {
     int P, K, cin_shift, n_ptiles, n_ctiles;
 };
 
-// 16-lane recursive-halving reduction: on return v[0] holds, for channel index (lane & (NV-1)), the sum
-// over the 16 lanes of a DPP row (lane bits 0..3).
-template <int NV>
-__device__ __noinline__ float row16_reduce(float (&v)[NV], int lane) {
-#pragma unroll
-    for (int b = NV / 2; b >= 1; b >>= 1) {
-        const bool hi = (lane & b) != 0;
-#pragma unroll
-        for (int c = 0; c < b; ++c) {
-            float send = hi ? v[c] : v[c + b];
-            float keep = hi ? v[c + b] : v[c];
-            v[c] = keep + __shfl_xor(send, b, 64);
-        }
-    }
-    float r = v[0];
-    if (NV < 16) {
-#pragma unroll
-        for (int b = NV; b < 16; b <<= 1) r += __shfl_xor(r, b, 64);
-    }
-    return r;
-}
-
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     // 64-byte rows, 16-byte chunks, chunk ^= 2*((row>>3)&1): conflict-free ds_read_b128 for the
     // 16-lane service groups of gfx950 (MI355X_MICROARCH.md LDS table)
@@ -61,8 +39,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
     constexpr int WROWS = BC / 64;          // weight rows staged per thread
     constexpr int TILE_BYTES = (BP + BC) * 64;
-    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES + 2 * BC * 4];
-    float* s_stats = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);
+    constexpr int EPI_BYTES = BP * (BC * 2 + 16);
+    constexpr int SMEM_BYTES = (2 * TILE_BYTES + 2 * BC * 4) > EPI_BYTES ? (2 * TILE_BYTES + 2 * BC * 4) : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -192,50 +171,71 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
         __syncthreads();
     }
 
-    // ---- epilogue: bf16 store (4 consecutive cout per lane) + BN statistics ---------------------
-    float ssum[WCT * 4], ssq[WCT * 4];
+    // ---- epilogue: stage the bf16 tile through LDS, store 16 B per lane fully coalesced, and accumulate the
+    //      per-channel sum / sum-of-squares of the stored (rounded) values on the way out -------------------
+    constexpr int CROW = BC * 2 + 16;                  // LDS row stride (bytes): +16 B skews the banks
+    static_assert(BP * CROW <= SMEM_BYTES, "epilogue tile must fit the staging buffers");
+    // (the last K step ended with __syncthreads(): every wave is done reading the operand tiles)
 #pragma unroll
-    for (int i = 0; i < WCT * 4; ++i) ssum[i] = ssq[i] = 0.f;
-#pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-        const int pp = p0 + wp * 64 + pt * 16 + li;
+    for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
         for (int ct = 0; ct < WCT; ++ct) {
-            const int co = c0 + wc * (BC / 2) + ct * 16 + lg * 4;
-            f32x4 v = acc[ct][pt];
-            if (pp < p.P && co < p.Cout) {
-                bf16_t* dst = p.y + (size_t)pp * p.Cout + co;
-                if (p.accumulate) {
-                    f32x4 old = bf4_to_f32(*reinterpret_cast<const bf16x4*>(dst));
-                    v += old;
-                }
-                bf16x4 o = f32_to_bf4(v);
-                *reinterpret_cast<bf16x4*>(dst) = o;
-                v = bf4_to_f32(o);      // statistics of what was actually stored
+            const int prow = wp * 64 + pt * 16 + li;
+            const int ccol = wc * (BC / 2) + ct * 16 + lg * 4;
+            *reinterpret_cast<bf16x4*>(smem + prow * CROW + ccol * 2) = f32_to_bf4(acc[ct][pt]);
+        }
+    __syncthreads();
+    constexpr int CPR = BC / 8;                        // 16-byte chunks per tile row
+    constexpr int RSTEP = NTHREADS / CPR;              // rows covered per pass
+    const int ech = tid % CPR, erow0 = tid / CPR;
+    const int eco = c0 + ech * 8;
+    f32x8 esum, esq;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ssum[ct * 4 + r] += v[r];
-                    ssq[ct * 4 + r] += v[r] * v[r];
-                }
+    for (int i = 0; i < 8; ++i) esum[i] = esq[i] = 0.f;
+    if (eco < p.Cout) {
+#pragma unroll
+        for (int r = erow0; r < BP; r += RSTEP) {
+            const int pp = p0 + r;
+            if (pp >= p.P) break;
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16);
+            bf16_t* dst = p.y + (size_t)pp * p.Cout + eco;
+            f32x8 f = bf8_to_f32(v);
+            if (p.accumulate) {
+                f += bf8_to_f32(*reinterpret_cast<const bf16x8*>(dst));
+                v = f32_to_bf8(f);
+                f = bf8_to_f32(v);
             }
+            *reinterpret_cast<bf16x8*>(dst) = v;
+            esum += f;
+            esq += f * f;
         }
     }
     if (p.stats) {
-        for (int i = tid; i < 2 * BC; i += NTHREADS) s_stats[i] = 0.f;
+        __syncthreads();                               // tile reads done: reuse the front of smem for the channel sums
+        float* cs = reinterpret_cast<float*>(smem);
+        for (int i = tid; i < 2 * BC; i += NTHREADS) cs[i] = 0.f;
         __syncthreads();
-        float s = row16_reduce<WCT * 4>(ssum, lane);
-        float q = row16_reduce<WCT * 4>(ssq, lane);
-        const int cidx = lane & (WCT * 4 - 1);
-        if ((lane & 15) == cidx) {       // for WCT*4 < 16 only the low copies publish
-            const int cl = wc * (BC / 2) + (cidx >> 2) * 16 + lg * 4 + (cidx & 3);
-            atomicAdd(&s_stats[cl], s);
-            atomicAdd(&s_stats[BC + cl], q);
+        // lanes l, l+CPR, l+2*CPR.. of a wave hold the same channel chunk: fold them first
+#pragma unroll
+        for (int off = CPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                esum[i] += __shfl_xor(esum[i], off, 64);
+                esq[i] += __shfl_xor(esq[i], off, 64);
+            }
+        if (lane < CPR && eco < p.Cout) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                atomicAdd(&cs[ech * 8 + i], esum[i]);
+                atomicAdd(&cs[BC + ech * 8 + i], esq[i]);
+            }
         }
         __syncthreads();
+        double* slot = p.stats + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * p.Cout;
         for (int i = tid; i < BC; i += NTHREADS) {
             if (c0 + i < p.Cout) {
-                atomicAdd(&p.stats[c0 + i], (double)s_stats[i]);
-                atomicAdd(&p.stats[p.Cout + c0 + i], (double)s_stats[BC + i]);
+                atomicAdd(&slot[c0 + i], (double)cs[i]);
+                atomicAdd(&slot[p.Cout + c0 + i], (double)cs[BC + i]);
             }
         }
     }
@@ -252,8 +252,16 @@ struct WgradP {
     const float* in_shift;
     float* dw;             // OIHW fp32, Cin_true input channels
     int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, act, cin_true;
-    int P, pix_per_block, n_cotiles, cin_shift, NK;   // NK = KH*KW*Cin: flattened (tap, ci) GEMM-N extent
+    int P, pix_per_block, n_cotiles, n_tiles, cin_shift, NK;   // NK = KH*KW*Cin: flattened (tap, ci) GEMM-N extent
 };
+
+// LDS image of one K step: [32 pixels][CH channels] bf16, row-major, 8-byte units XOR-swizzled so that the
+// ds_read_b64_tr_b16 of a 32-lane service group (rows {r..r+3} U {r+8..r+11}) touches 64 distinct banks.
+template <int CH>
+__device__ __forceinline__ int tr_swz(int row) {
+    if (CH >= 128) return ((row & 3) | (((row >> 3) & 1) << 2)) << 2;       // 256-byte rows: all rows start at bank 0
+    return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 2;               // 128-byte rows: parity picks the bank half
+}
 
 template <int BM, int BN>
 __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
@@ -265,9 +273,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int co0 = (blockIdx.y % p.n_cotiles) * BM;
-    const int n0 = (blockIdx.y / p.n_cotiles) * BN;     // offset in the flattened (tap, ci) axis
-    const int ps = blockIdx.x * p.pix_per_block;
+    // block -> (tile, pixel split): the tiles of one pixel range run back-to-back on ONE XCD (block b lives on XCD
+    // b % 8), so the dz / activation rows they all re-read come from that XCD's L2 instead of HBM
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = j % p.n_tiles;
+    const int split = (j / p.n_tiles) * 8 + xcd;
+    const int co0 = (tile % p.n_cotiles) * BM;
+    const int n0 = (tile / p.n_cotiles) * BN;           // offset in the flattened (tap, ci) axis
+    const int ps = split * p.pix_per_block;
     const int pe = min(p.P, ps + p.pix_per_block);
     if (ps >= pe) return;
 
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
     constexpr int AL = (32 * ACH) / NTHREADS, BL = (32 * BCH) / NTHREADS;
     bf16x8 ra[AL], rb[BL];
     bool rbv[BL];
-    int b_kh[BL], b_kw[BL], b_ci[BL];
+    int b_kh[BL], b_kw[BL], b_ci[BL], b_n[BL], b_oh[BL], b_ow[BL];
     bool b_ok[BL];
 #pragma unroll
     for (int l = 0; l < BL; ++l) {
@@ -285,8 +298,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
         b_ok[l] = n < p.NK;
         int tap = n >> p.cin_shift;
         b_ci[l] = n - (tap << p.cin_shift);
-        b_kh[l] = tap / p.KW;
-        b_kw[l] = tap - b_kh[l] * p.KW;
+        b_kh[l] = tap / p.KW - p.pad;
+        b_kw[l] = tap - (tap / p.KW) * p.KW - p.pad;
+        int pp = ps + row;                                   // pixel of this chunk at K step 0; advanced by 32 per step
+        b_n[l] = pp / (p.OH * p.OW);
+        int rem = pp - b_n[l] * (p.OH * p.OW);
+        b_oh[l] = rem / p.OW;
+        b_ow[l] = rem - b_oh[l] * p.OW;
     }
 
     auto issue_loads = [&](int pbase) {
@@ -302,21 +320,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
         for (int l = 0; l < BL; ++l) {
             int e = tid + l * NTHREADS;
-            int row = e / BCH, ch = e - row * BCH;
-            int pp = pbase + row;
-            (void)ch;
+            int row = e / BCH;
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            bool ok = pp < pe && b_ok[l];
-            if (ok) {
-                int n = pp / (p.OH * p.OW);
-                int rem = pp - n * (p.OH * p.OW);
-                int oh = rem / p.OW, ow = rem - oh * p.OW;
-                int ih = oh * p.stride - p.pad + b_kh[l], iw = ow * p.stride - p.pad + b_kw[l];
-                ok = ih >= 0 && iw >= 0 && ih < p.H && iw < p.W;
-                if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + ((size_t)(n * p.H + ih) * p.W + iw) * p.Cin + b_ci[l]);
-            }
+            int ih = b_oh[l] * p.stride + b_kh[l], iw = b_ow[l] * p.stride + b_kw[l];
+            bool ok = (pbase + row < pe) && b_ok[l] && ih >= 0 && iw >= 0 && ih < p.H && iw < p.W;
+            if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + ((size_t)(b_n[l] * p.H + ih) * p.W + iw) * p.Cin + b_ci[l]);
             rbv[l] = ok;
             rb[l] = v;
+            // advance this chunk's pixel by one K step (32 output pixels)
+            b_ow[l] += 32;
+            while (b_ow[l] >= p.OW) { b_ow[l] -= p.OW; ++b_oh[l]; }
+            while (b_oh[l] >= p.OH) { b_oh[l] -= p.OH; ++b_n[l]; }
         }
     };
     auto store_tile = [&](int buf) {
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
         for (int l = 0; l < AL; ++l) {
             int e = tid + l * NTHREADS;
             int row = e / ACH, ch = e - row * ACH;
-            *reinterpret_cast<bf16x8*>(base + row * AROW + ch * 16) = ra[l];
+            *reinterpret_cast<bf16x8*>(base + row * AROW + ((ch ^ (tr_swz<BM>(row) >> 1)) << 4)) = ra[l];
         }
 #pragma unroll
         for (int l = 0; l < BL; ++l) {
@@ -333,7 +347,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
             int row = e / BCH, ch = e - row * BCH;
             bf16x8 v = rb[l];
             if (p.in_scale && rbv[l]) v = f32_to_bf8(transform8(v, p.in_scale, p.in_shift, b_ci[l], p.act));
-            *reinterpret_cast<bf16x8*>(base + 32 * AROW + row * BROW + ch * 16) = v;
+            *reinterpret_cast<bf16x8*>(base + 32 * AROW + row * BROW + ((ch ^ (tr_swz<BN>(row) >> 1)) << 4)) = v;
         }
     };
 
@@ -341,16 +355,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int jn = 0; jn < NT; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (pe - ps + 31) / 32;
     issue_loads(ps);
     store_tile(0);
     __syncthreads();
     const int li = lane & 15, lg = lane >> 4;
-    // transpose-read addressing: lane li of a 16-lane group supplies the 8-byte chunk
-    // [pixel row 8*lg + (li>>2) (+4)][channel 4*(li&3) ..+3]; it receives channel li of rows 0..3.
-    const int trow = 8 * lg + (li >> 2), tcol = 4 * (li & 3);
+    // transpose-read addressing: lane li of a 16-lane group supplies the 8-byte unit
+    // [pixel row 8*lg + (li>>2) (+4)][channels 4*(li&3) ..+3]; it receives channel li of rows 0..3.
+    const int trow = 8 * lg + (li >> 2), tq = li & 3;
+    const int a_lo = trow * AROW, a_hi = (trow + 4) * AROW, b_lo = trow * BROW, b_hi = (trow + 4) * BROW;
+    const int ax_lo = tr_swz<BM>(trow), ax_hi = tr_swz<BM>(trow + 4), bx_lo = tr_swz<BN>(trow), bx_hi = tr_swz<BN>(trow + 4);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) issue_loads(ps + (kt + 1) * 32);
@@ -358,21 +374,21 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
         bf16x8 fa[MT], fb[NT];
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            const char* a0 = base + trow * AROW + (wm * (BM / 2) + t * 16 + tcol) * 2;
-            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * AROW));
-            union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-            u.s.a = lo; u.s.b = hi;
-            fa[t] = u.v;
+            const int u = (wm * (BM / 2) + t * 16) / 4 + tq;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a_lo + ((u ^ ax_lo) << 3)));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a_hi + ((u ^ ax_hi) << 3)));
+            union { struct { s16x4 a, b; } s; bf16x8 v; } cvt;
+            cvt.s.a = lo; cvt.s.b = hi;
+            fa[t] = cvt.v;
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const char* b0 = base + 32 * AROW + trow * BROW + (wn * (BN / 2) + t * 16 + tcol) * 2;
-            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b0));
-            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b0 + 4 * BROW));
-            union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-            u.s.a = lo; u.s.b = hi;
-            fb[t] = u.v;
+            const int u = (wn * (BN / 2) + t * 16) / 4 + tq;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 32 * AROW + b_lo + ((u ^ bx_lo) << 3)));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 32 * AROW + b_hi + ((u ^ bx_hi) << 3)));
+            union { struct { s16x4 a, b; } s; bf16x8 v; } cvt;
+            cvt.s.a = lo; cvt.s.b = hi;
+            fb[t] = cvt.v;
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -427,7 +443,9 @@ extern "C" int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const
         if (p.cin_shift < 0) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd: KxK conv needs power-of-two Cin (got %d)", d->Cin);
     }
     if (p.P <= 0) return ADAMML_OK;
-    const bool narrow = d->Cout <= 64 || (d->Cout % 128 != 0 && d->Cout < 256);
+    bool narrow = d->Cout <= 64 || (d->Cout % 128 != 0 && d->Cout < 256);
+    // small problems: halve the cout tile so that at least ~2 workgroups per CU exist
+    if (!narrow && (long)ceil_div(p.P, BP) * ceil_div(d->Cout, 128) < 512) narrow = true;
     const int BC = narrow ? 64 : 128;
     p.n_ptiles = ceil_div(p.P, BP);
     p.n_ctiles = ceil_div(d->Cout, BC);
@@ -476,13 +494,14 @@ extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* d
     const int BN = p.NK <= 64 ? 64 : 128;
     p.n_cotiles = ceil_div(d->Cout, BM);
     const int n_ntiles = ceil_div(p.NK, BN);
-    const int tiles = p.n_cotiles * n_ntiles;
-    int nsplit = ceil_div(2048, tiles);
+    p.n_tiles = p.n_cotiles * n_ntiles;
+    // pixel splits: a multiple of 8 (one per XCD per round), ~1024 workgroups in total, >= 256 pixels each
+    int nsplit = ceil_div(ceil_div(1024, p.n_tiles), 8) * 8;
     int ppb = ceil_div(ceil_div(p.P, nsplit), 32) * 32;
     if (ppb < 256) ppb = 256;
-    nsplit = ceil_div(p.P, ppb);
+    nsplit = ceil_div(ceil_div(p.P, ppb), 8) * 8;
     p.pix_per_block = ppb;
-    dim3 grid(nsplit, p.n_cotiles * n_ntiles, 1), block(NTHREADS);
+    dim3 grid(nsplit * p.n_tiles, 1, 1), block(NTHREADS);
     if (BM == 64 && BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, stream, p);
     else if (BM == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, block, 0, stream, p);
     else if (BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, block, 0, stream, p);

@@ -29,60 +29,91 @@ struct DwP {
     const float* in_shift;
     bf16_t* y;
     double* stats;
-    int N, H, W, C, OH, OW, stride, pad, act, accumulate;
+    int N, H, W, C, OH, OW, stride, pad, act, accumulate, nseg, seglen;
     size_t P, ppb;
 };
 
+// "Row walker": one thread owns 8 channels of ONE output row and slides a 3x3 register window along it, so every
+// input element is loaded (and BatchNorm+ReLU6-transformed) once per output row instead of nine times, with no
+// per-pixel index arithmetic.  Adjacent threads own adjacent channel chunks -> 16 B/lane coalesced rows.
+template <int S>
 __global__ __launch_bounds__(NT) void dwconv_fwd_kernel(DwP p) {
     __shared__ float smem[2 * MAXC];
-    ChanMap m(p.C, threadIdx.x);
+    const int nchunk = p.C >> 3;
+    const int gid = blockIdx.x * NT + threadIdx.x;
+    const int chunk = gid % nchunk, tsk = gid / nchunk;
+    const int seg = tsk % p.nseg, row = tsk / p.nseg;          // a thread walks `seglen` outputs of one row
+    const bool active = row < p.N * p.OH;
     float s[8], q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
-    const size_t pb = (size_t)blockIdx.x * p.ppb;
-    const size_t pe = pb + p.ppb < p.P ? pb + p.ppb : p.P;
-    if (m.active) {
-        const int c = m.chunk * 8;
+    if (active) {
+        const int c = chunk * 8;
+        const int n = row / p.OH, oh = row - n * p.OH;
         f32x8 wt[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) wt[t] = load_f32x8(p.w + (size_t)t * p.C + c);
-        for (size_t pp = pb + m.rslot; pp < pe; pp += m.rows_per_pass) {
-            const int ow = (int)(pp % p.OW);
-            size_t r = pp / p.OW;
-            const int oh = (int)(r % p.OH);
-            const int n = (int)(r / p.OH);
+        const bf16_t* rowp[3];
+        bool rok[3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * S - p.pad + kh;
+            rok[kh] = ih >= 0 && ih < p.H;
+            rowp[kh] = p.x + ((size_t)n * p.H + (rok[kh] ? ih : 0)) * p.W * p.C + c;
+        }
+        auto load_col = [&](int iw, f32x8 (&col)[3]) {
+            const bool cok = iw >= 0 && iw < p.W;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                f32x8 v;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = 0.f;
+                if (cok && rok[kh])
+                    v = transform8(*reinterpret_cast<const bf16x8*>(rowp[kh] + (size_t)iw * p.C), p.in_scale, p.in_shift, c, p.act);
+                col[kh] = v;
+            }
+        };
+        f32x8 w0[3], w1[3], w2[3];
+        const int ow_b = seg * p.seglen, ow_e = min(p.OW, ow_b + p.seglen);
+        load_col(ow_b * S - p.pad, w0);
+        load_col(ow_b * S + 1 - p.pad, w1);
+        bf16_t* yrow = p.y + (size_t)row * p.OW * p.C + c;
+        for (int ow = ow_b; ow < ow_e; ++ow) {
+            load_col(ow * S + 2 - p.pad, w2);
             f32x8 acc;
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = 0.f;
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
-                    if (ih < 0 || iw < 0 || ih >= p.H || iw >= p.W) continue;
-                    f32x8 v = transform8(*reinterpret_cast<const bf16x8*>(p.x + (((size_t)n * p.H + ih) * p.W + iw) * p.C + c),
-                                         p.in_scale, p.in_shift, c, p.act);
-                    acc += v * wt[kh * 3 + kw];
-                }
+            for (int kh = 0; kh < 3; ++kh) acc += w0[kh] * wt[kh * 3] + w1[kh] * wt[kh * 3 + 1] + w2[kh] * wt[kh * 3 + 2];
             bf16x8 o = f32_to_bf8(acc);
-            *reinterpret_cast<bf16x8*>(p.y + pp * p.C + c) = o;
+            *reinterpret_cast<bf16x8*>(yrow + (size_t)ow * p.C) = o;
             f32x8 rv = bf8_to_f32(o);
 #pragma unroll
             for (int i = 0; i < 8; ++i) { s[i] += rv[i]; q[i] += rv[i] * rv[i]; }
+            if (S == 1) {
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) { w0[kh] = w1[kh]; w1[kh] = w2[kh]; }
+            } else {
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) w0[kh] = w2[kh];
+                load_col((ow + 1) * S + 1 - p.pad, w1);
+            }
         }
     }
     if (p.stats) {
         for (int i = threadIdx.x; i < 2 * p.C; i += NT) smem[i] = 0.f;
         __syncthreads();
-        if (m.active) {
+        if (active) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                atomicAdd(&smem[m.chunk * 8 + i], s[i]);
-                atomicAdd(&smem[p.C + m.chunk * 8 + i], q[i]);
+                atomicAdd(&smem[chunk * 8 + i], s[i]);
+                atomicAdd(&smem[p.C + chunk * 8 + i], q[i]);
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < 2 * p.C; i += NT) atomicAdd(&p.stats[i], (double)smem[i]);
+        double* slot = p.stats + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * p.C;
+        for (int i = threadIdx.x; i < 2 * p.C; i += NT)
+            if (smem[i] != 0.f) atomicAdd(&slot[i], (double)smem[i]);
     }
 }
 
@@ -129,40 +160,75 @@ struct DwWP {
     const float* in_scale;
     const float* in_shift;
     float* dw;            // [C][3][3] fp32
-    int N, H, W, C, OH, OW, stride, pad, act;
+    int N, H, W, C, OH, OW, stride, pad, act, rows_per_thread, nseg, seglen;
     size_t P, ppb;
 };
 
+template <int S>
 __global__ __launch_bounds__(NT) void dwconv_bwd_weight_kernel(DwWP p) {
     extern __shared__ float dsm[];        // [9][C]
-    ChanMap m(p.C, threadIdx.x);
+    const int nchunk = p.C >> 3;
     for (int i = threadIdx.x; i < 9 * p.C; i += NT) dsm[i] = 0.f;
     __syncthreads();
-    const size_t pb = (size_t)blockIdx.x * p.ppb;
-    const size_t pe = pb + p.ppb < p.P ? pb + p.ppb : p.P;
-    if (m.active) {
-        const int c = m.chunk * 8;
+    // each thread walks ROWS_PER_THREAD consecutive output rows of its channel chunk (same row-walker as the forward)
+    const int gid = blockIdx.x * NT + threadIdx.x;
+    const int chunk = gid % nchunk, tsk = gid / nchunk;
+    const int seg = tsk % p.nseg, rgrp = tsk / p.nseg;
+    const int total_rows = p.N * p.OH;
+    const int r0 = rgrp * p.rows_per_thread;
+    if (r0 < total_rows) {
+        const int ow_b = seg * p.seglen, ow_e = min(p.OW, ow_b + p.seglen);
+        const int c = chunk * 8;
         f32x8 acc[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
-        for (size_t pp = pb + m.rslot; pp < pe; pp += m.rows_per_pass) {
-            const int ow = (int)(pp % p.OW);
-            size_t r = pp / p.OW;
-            const int oh = (int)(r % p.OH);
-            const int n = (int)(r / p.OH);
-            f32x8 g = bf8_to_f32(*reinterpret_cast<const bf16x8*>(p.dz + pp * p.C + c));
+        const int r1 = min(total_rows, r0 + p.rows_per_thread);
+        for (int row = r0; row < r1; ++row) {
+            const int n = row / p.OH, oh = row - n * p.OH;
+            const bf16_t* rowp[3];
+            bool rok[3];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = oh * S - p.pad + kh;
+                rok[kh] = ih >= 0 && ih < p.H;
+                rowp[kh] = p.x + ((size_t)n * p.H + (rok[kh] ? ih : 0)) * p.W * p.C + c;
+            }
+            auto load_col = [&](int iw, f32x8 (&col)[3]) {
+                const bool cok = iw >= 0 && iw < p.W;
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
-                    if (ih < 0 || iw < 0 || ih >= p.H || iw >= p.W) continue;
-                    f32x8 v = transform8(*reinterpret_cast<const bf16x8*>(p.x + (((size_t)n * p.H + ih) * p.W + iw) * p.C + c),
-                                         p.in_scale, p.in_shift, c, p.act);
-                    acc[kh * 3 + kw] += g * v;
+                for (int kh = 0; kh < 3; ++kh) {
+                    f32x8 v;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+                    if (cok && rok[kh])
+                        v = transform8(*reinterpret_cast<const bf16x8*>(rowp[kh] + (size_t)iw * p.C), p.in_scale, p.in_shift, c, p.act);
+                    col[kh] = v;
                 }
+            };
+            f32x8 w0[3], w1[3], w2[3];
+            load_col(ow_b * S - p.pad, w0);
+            load_col(ow_b * S + 1 - p.pad, w1);
+            const bf16_t* grow = p.dz + (size_t)row * p.OW * p.C + c;
+            for (int ow = ow_b; ow < ow_e; ++ow) {
+                load_col(ow * S + 2 - p.pad, w2);
+                f32x8 g = bf8_to_f32(*reinterpret_cast<const bf16x8*>(grow + (size_t)ow * p.C));
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    acc[kh * 3] += g * w0[kh];
+                    acc[kh * 3 + 1] += g * w1[kh];
+                    acc[kh * 3 + 2] += g * w2[kh];
+                }
+                if (S == 1) {
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) { w0[kh] = w1[kh]; w1[kh] = w2[kh]; }
+                } else {
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) w0[kh] = w2[kh];
+                    load_col((ow + 1) * S + 1 - p.pad, w1);
+                }
+            }
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -172,7 +238,7 @@ __global__ __launch_bounds__(NT) void dwconv_bwd_weight_kernel(DwWP p) {
     __syncthreads();
     for (int i = threadIdx.x; i < 9 * p.C; i += NT) {
         const int t = i / p.C, c = i - t * p.C;
-        atomicAdd(&p.dw[(size_t)c * 9 + t], dsm[i]);
+        if (dsm[i] != 0.f) atomicAdd(&p.dw[(size_t)c * 9 + t], dsm[i]);
     }
 }
 
@@ -271,8 +337,13 @@ extern "C" int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, con
     p.act = d->act; p.accumulate = 0;
     p.P = (size_t)d->N * d->OH * d->OW;
     if (!p.P) return ADAMML_OK;
-    int nblk = dw_blocks(p.P, p.C, &p.ppb);
-    hipLaunchKernelGGL(dwconv_fwd_kernel, dim3(nblk), dim3(NT), 0, stream, p);
+    p.ppb = 0;
+    p.seglen = d->OW >= 32 ? 8 : (d->OW >= 8 ? 4 : d->OW);
+    p.nseg = (d->OW + p.seglen - 1) / p.seglen;
+    const long threads = (long)d->N * d->OH * p.nseg * (p.C / 8);
+    const int nblk = (int)((threads + NT - 1) / NT);
+    if (d->stride == 1) hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3(nblk), dim3(NT), 0, stream, p);
+    else hipLaunchKernelGGL(dwconv_fwd_kernel<2>, dim3(nblk), dim3(NT), 0, stream, p);
     return adamml_check_launch("dwconv_fwd");
 }
 
@@ -283,7 +354,7 @@ extern "C" int adamml_dwconv_bwd_data(const adamml_conv_desc_t* d, const void* d
     DwP p;
     p.x = (const bf16_t*)dz; p.w = w; p.in_scale = nullptr; p.in_shift = nullptr; p.y = (bf16_t*)dx; p.stats = nullptr;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.pad = d->pad;
-    p.act = 0; p.accumulate = accumulate;
+    p.act = 0; p.accumulate = accumulate; p.nseg = 1; p.seglen = 0;
     p.P = (size_t)d->N * d->H * d->W;
     if (!p.P) return ADAMML_OK;
     int nblk = dw_blocks(p.P, p.C, &p.ppb);
@@ -300,12 +371,19 @@ extern "C" int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void*
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.pad = d->pad; p.act = d->act;
     p.P = (size_t)d->N * d->OH * d->OW;
     if (!p.P) return ADAMML_OK;
-    const int rows = NT / (p.C / 8) > 0 ? NT / (p.C / 8) : 1;
-    size_t ppb = (size_t)rows * 32;
-    size_t nblk = (p.P + ppb - 1) / ppb;
-    if (nblk > 1024) { ppb = ((p.P + 1023) / 1024 + rows - 1) / rows * rows; nblk = (p.P + ppb - 1) / ppb; }
-    p.ppb = ppb;
-    hipLaunchKernelGGL(dwconv_bwd_weight_kernel, dim3((unsigned)nblk), dim3(NT), 9 * p.C * sizeof(float), stream, p);
+    // rows per thread: keep >= ~8 waves per CU in flight while amortising the 72-accumulator LDS reduction
+    const long rows = (long)d->N * d->OH, nchunk = p.C / 8;
+    p.seglen = d->OW >= 32 ? 16 : (d->OW >= 8 ? 8 : d->OW);
+    p.nseg = (d->OW + p.seglen - 1) / p.seglen;
+    int rpt = (int)(rows * p.nseg * nchunk / (256L * 4096L));
+    if (rpt < 1) rpt = 1;
+    if (rpt > 8) rpt = 8;
+    p.rows_per_thread = rpt;
+    p.ppb = 0;
+    const long threads = ((rows + rpt - 1) / rpt) * p.nseg * nchunk;
+    const int nblk = (int)((threads + NT - 1) / NT);
+    if (d->stride == 1) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<1>, dim3(nblk), dim3(NT), 9 * p.C * sizeof(float), stream, p);
+    else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<2>, dim3(nblk), dim3(NT), 9 * p.C * sizeof(float), stream, p);
     return adamml_check_launch("dwconv_bwd_weight");
 }
 

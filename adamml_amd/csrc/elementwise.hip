@@ -45,17 +45,42 @@ __device__ __forceinline__ void block_channel_publish(const float (&s)[8], const
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += NT) atomicAdd(&out[i], (double)smem[i]);
+    double* slot = out + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += NT) atomicAdd(&slot[i], (double)smem[i]);
 }
 
 // ------------------------------------------------------------------------------------------------ BN
-__global__ void bn_finalize_kernel(const double* stats, double count, const float* gamma, const float* beta, float* rm,
+__global__ void stats_collapse_kernel(double* stats, int C) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * C) return;
+    double s = 0.0;
+    for (int k = 0; k < ADAMML_STAT_SLOTS; ++k) s += stats[(size_t)k * 2 * C + i];
+    stats[i] = s;
+}
+
+// one 32-lane group per channel: lane k reads slot k, the group folds with xor-shuffles (slot-parallel loads)
+__device__ __forceinline__ void slot_sums(const double* stats, int nslots, int C, int c, int k, double& s1, double& s2) {
+    s1 = 0.0; s2 = 0.0;
+    if (c < C && k < nslots) {
+        s1 = stats[(size_t)k * 2 * C + c];
+        s2 = stats[(size_t)k * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* stats, int nslots, double count, const float* gamma, const float* beta, float* rm,
                                    float* rv, float momentum, float eps, float* scale, float* shift, float* mean,
                                    float* invstd, int C) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double mu = stats[c] / count;
-    double var = stats[C + c] / count - mu * mu;
+    const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), k = threadIdx.x & 31;
+    double s1, s2;
+    slot_sums(stats, nslots, C, c, k, s1, s2);
+    if (c >= C || k != 0) return;
+    double mu = s1 / count;
+    double var = s2 / count - mu * mu;
     if (var < 0.0) var = 0.0;
     float is = (float)(1.0 / sqrt(var + (double)eps));
     float sc = gamma[c] * is;
@@ -137,11 +162,12 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const bf16_t* g, cons
     block_channel_publish(s, q, m, smem, C, sums);
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* sums, double count, const float* gamma, const float* invstd,
+__global__ void bn_bwd_finalize_kernel(const double* sums, int nslots, double count, const float* gamma, const float* invstd,
                                        float* dgamma, float* dbeta, float* coef, int C) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double sg = sums[c], sgz = sums[C + c];
+    const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), k = threadIdx.x & 31;
+    double sg, sgz;
+    slot_sums(sums, nslots, C, c, k, sg, sgz);
+    if (c >= C || k != 0) return;
     if (dgamma) dgamma[c] += (float)sgz;
     if (dbeta) dbeta[c] += (float)sg;
     coef[c] = gamma[c] * invstd[c];
@@ -446,11 +472,18 @@ __global__ void adam_step_kernel(float* p, const float* g, float* m, float* v, s
     if ((C) % 8 != 0 || (C) > MAXC || (C) <= 0)                                                              \
         return adamml_set_error(ADAMML_EINVAL, name ": C=%d must be a multiple of 8 in (0, %d]", (C), MAXC);
 
-extern "C" int adamml_bn_finalize(const double* stats, double count, const float* gamma, const float* beta, float* rm,
+extern "C" int adamml_stats_collapse(double* stats, int C, hipStream_t stream) {
+    if (!stats) return adamml_set_error(ADAMML_EINVAL, "stats_collapse: null argument");
+    hipLaunchKernelGGL(stats_collapse_kernel, dim3(ceil_div(2 * C, 128)), dim3(128), 0, stream, stats, C);
+    return adamml_check_launch("stats_collapse");
+}
+
+extern "C" int adamml_bn_finalize(const double* stats, int nslots, double count, const float* gamma, const float* beta, float* rm,
                                   float* rv, float momentum, float eps, float* scale, float* shift, float* mean,
                                   float* invstd, int C, hipStream_t stream) {
     if (!stats || !gamma || !beta || !scale || !shift || !mean || !invstd) return adamml_set_error(ADAMML_EINVAL, "bn_finalize: null argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, stats, count, gamma, beta, rm, rv,
+    if (nslots < 1 || nslots > ADAMML_STAT_SLOTS) return adamml_set_error(ADAMML_EINVAL, "bn_finalize: nslots=%d", nslots);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, stream, stats, nslots, count, gamma, beta, rm, rv,
                        momentum, eps, scale, shift, mean, invstd, C);
     return adamml_check_launch("bn_finalize");
 }
@@ -492,9 +525,10 @@ extern "C" int adamml_bn_bwd_reduce(const void* g, const void* z, const float* s
     return adamml_check_launch("bn_bwd_reduce");
 }
 
-extern "C" int adamml_bn_bwd_finalize(const double* sums, double count, const float* gamma, const float* invstd, float* dgamma,
+extern "C" int adamml_bn_bwd_finalize(const double* sums, int nslots, double count, const float* gamma, const float* invstd, float* dgamma,
                                       float* dbeta, float* coef, int C, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, stream, sums, count, gamma, invstd, dgamma,
+    if (nslots < 1 || nslots > ADAMML_STAT_SLOTS) return adamml_set_error(ADAMML_EINVAL, "bn_bwd_finalize: nslots=%d", nslots);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, stream, sums, nslots, count, gamma, invstd, dgamma,
                        dbeta, coef, C);
     return adamml_check_launch("bn_bwd_finalize");
 }

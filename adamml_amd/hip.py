@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libadamml_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+STAT_SLOTS = 32          # ADAMML_STAT_SLOTS in include/adamml_hip.h
 
 
 class ConvDesc(Structure):
@@ -31,12 +32,13 @@ SIGNATURES = {
     "adamml_dwconv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "adamml_dwconv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
     "adamml_dwconv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _P],
-    "adamml_bn_finalize": [_P, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
+    "adamml_stats_collapse": [_P, _I, _P],
+    "adamml_bn_finalize": [_P, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
     "adamml_bn_eval_affine": [_P, _P, _P, _P, _F, _P, _P, _I, _P],
     "adamml_bn_act_add": [_P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _P],
     "adamml_act_bwd_from_output": [_P, _P, _I, _P, _Z, _P],
     "adamml_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _I, _P, _Z, _I, _P],
-    "adamml_bn_bwd_finalize": [_P, _D, _P, _P, _P, _P, _P, _I, _P],
+    "adamml_bn_bwd_finalize": [_P, _I, _D, _P, _P, _P, _P, _P, _I, _P],
     "adamml_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _I, _P],
     "adamml_maxpool2d_fwd": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "adamml_maxpool2d_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 
 from . import hip
-from .hip import ConvDesc, ACT_NONE, ACT_RELU, ACT_RELU6, call, ptr
+from .hip import ConvDesc, ACT_NONE, ACT_RELU, ACT_RELU6, STAT_SLOTS, call, ptr
 from ctypes import byref
 
 BN_EPS = 1e-5
@@ -89,9 +89,14 @@ class SyncCtx:
         self.enabled = enabled and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.enabled else 1
 
-    def reduce(self, t):
-        if self.enabled:
-            dist.all_reduce(t, group=self.group)
+    def reduce(self, t, C):
+        """t: [STAT_SLOTS][2C] slot-interleaved sums.  Returns the number of slots the finalize kernel must sum:
+        under SyncBN the slots are collapsed into slot 0 first so that only 2C doubles cross xGMI."""
+        if not self.enabled:
+            return STAT_SLOTS
+        call("adamml_stats_collapse", ptr(t), C)
+        dist.all_reduce(t[:2 * C], group=self.group)
+        return 1
 
 
 class NetRT:
@@ -160,8 +165,8 @@ class ConvState:
 
 def _bn_vectors(rt, bn, stats, count, C, device):
     vec = torch.empty(4, C, dtype=torch.float32, device=device)
-    rt.sync.reduce(stats)
-    call("adamml_bn_finalize", ptr(stats), float(count * rt.sync.world), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+    nslots = rt.sync.reduce(stats, C)
+    call("adamml_bn_finalize", ptr(stats), nslots, float(count * rt.sync.world), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
          ptr(bn.running_var), BN_MOMENTUM, BN_EPS, ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), C)
     return vec
 
@@ -179,12 +184,12 @@ def _bn_backward(rt, out, y, vec, bn, act, count):
     out.grad = None
     n, oh, ow, C = y.shape
     P = n * oh * ow
-    sums = rt.bwd_arena.take(2 * C)
+    sums = rt.bwd_arena.take(2 * C * STAT_SLOTS)
     call("adamml_bn_bwd_reduce", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), act, ptr(sums), P, C)
-    rt.sync.reduce(sums)
+    nslots = rt.sync.reduce(sums, C)
     coef = torch.empty(3, C, dtype=torch.float32, device=y.device)
     train_bn = bn.weight.requires_grad
-    call("adamml_bn_bwd_finalize", ptr(sums), float(count * rt.sync.world), ptr(bn.weight), ptr(vec[3]),
+    call("adamml_bn_bwd_finalize", ptr(sums), nslots, float(count * rt.sync.world), ptr(bn.weight), ptr(vec[3]),
          ptr(bn.weight.grad) if train_bn else None, ptr(bn.bias.grad) if train_bn else None, ptr(coef), C)
     dz = torch.empty_like(y)
     call("adamml_bn_bwd_apply", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), act, ptr(coef), ptr(dz), P, C)
@@ -207,7 +212,7 @@ def conv_bn(rt, x, cs, bn, act):
     w_b = 2.0 * C * cs.kh * cs.kw * (1 if cs.depthwise else cs.cin_true)
     hip.next_meta = (2 * macs, in_b + out_b + w_b)
     if rt.training:
-        stats = rt.fwd_arena.take(2 * C)
+        stats = rt.fwd_arena.take(2 * C * STAT_SLOTS)
         call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), ptr(stats))
         vec = _bn_vectors(rt, bn, stats, count, C, dev)
         rt.touched_bns.append(bn)

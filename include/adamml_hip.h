@@ -20,6 +20,11 @@ extern "C" {
 
 typedef struct ihipStream_t* hipStream_t;
 
+/* Per-channel reductions (BatchNorm statistics, BatchNorm-backward sums) are accumulated with fp64 atomics into
+ * ADAMML_STAT_SLOTS interleaved copies ([slot][2*C], slot = block index mod ADAMML_STAT_SLOTS) so that thousands of
+ * workgroups do not serialise on the same 2*C addresses; the finalize kernels sum the slots. */
+#define ADAMML_STAT_SLOTS 32
+
 #define ADAMML_ACT_NONE 0
 #define ADAMML_ACT_RELU 1
 #define ADAMML_ACT_RELU6 2
@@ -38,7 +43,8 @@ const char* adamml_last_error_string(void);
 
 /* nn.Conv2d(bias=False) forward (models/resnet.py:37-43,138; sound_mobilenet_v2.py:37,60; policy_net.py:40,48,76,84)
  * fused with the PRODUCER's BatchNorm+ReLU/ReLU6 on load and with the per-channel sum / sum-of-squares of its own
- * output (stats[0..C) = sum, stats[C..2C) = sumsq, fp64, caller zeroes) for this layer's train-mode BatchNorm. */
+ * output (stats[slot][0..C) = sum, [slot][C..2C) = sumsq, fp64 [ADAMML_STAT_SLOTS][2C], caller zeroes) for this layer's
+ * train-mode BatchNorm. */
 int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
                     const float* in_shift, void* y, double* stats, hipStream_t stream);
 /* autograd of the above w.r.t. its input (d = forward descriptor; w packed with mode 1) */
@@ -62,7 +68,9 @@ int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const 
 
 /* nn.BatchNorm2d: train-mode statistics -> (scale, shift) consumed lazily by the next op, saved mean / invstd,
  * running-stat momentum update (unbiased variance).  count = elements per channel (global count under SyncBN). */
-int adamml_bn_finalize(const double* stats, double count, const float* gamma, const float* beta, float* running_mean,
+/* sums the ADAMML_STAT_SLOTS copies into slot 0 (used before a SyncBN all-reduce of [2C]) */
+int adamml_stats_collapse(double* stats, int C, hipStream_t stream);
+int adamml_bn_finalize(const double* stats, int nslots, double count, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
                        float* invstd, int C, hipStream_t stream);
 /* eval-mode BatchNorm folded to (scale, shift) from the running statistics */
@@ -74,11 +82,11 @@ int adamml_bn_act_add(const void* z, const float* scale, const float* shift, int
                       const float* id_scale, const float* id_shift, void* out, size_t P, int C, hipStream_t stream);
 /* g = g_out * act'(out) evaluated from the stored block output */
 int adamml_act_bwd_from_output(const void* g_out, const void* out, int act, void* g, size_t n, hipStream_t stream);
-/* BatchNorm backward: per-channel sums of g' = g*act'(scale*z+shift) and g'*zhat (sums fp64 [2C], caller zeroes) */
+/* BatchNorm backward: per-channel sums of g' = g*act'(scale*z+shift) and g'*zhat (sums fp64 [ADAMML_STAT_SLOTS][2C], caller zeroes) */
 int adamml_bn_bwd_reduce(const void* g, const void* z, const float* scale, const float* shift, const float* mean,
                          const float* invstd, int act, double* sums, size_t P, int C, hipStream_t stream);
 /* dgamma += sum(g' zhat); dbeta += sum(g'); coef[0..C) = gamma*invstd, [C..2C) = sum g'/count, [2C..3C) = sum g' zhat/count */
-int adamml_bn_bwd_finalize(const double* sums, double count, const float* gamma, const float* invstd, float* dgamma,
+int adamml_bn_bwd_finalize(const double* sums, int nslots, double count, const float* gamma, const float* invstd, float* dgamma,
                            float* dbeta, float* coef, int C, hipStream_t stream);
 /* dz = coef0 * (g' - coef1 - zhat*coef2) */
 int adamml_bn_bwd_apply(const void* g, const void* z, const float* scale, const float* shift, const float* mean,

@@ -10,7 +10,7 @@ from ctypes import byref
 pytestmark = pytest.mark.gpu
 
 from adamml_amd import hip  # noqa: E402
-from adamml_amd.hip import ConvDesc, call, ptr  # noqa: E402
+from adamml_amd.hip import ConvDesc, call, ptr, STAT_SLOTS  # noqa: E402
 from adamml_amd.runtime import pad8, gemm_f32, clip_to_nhwc  # noqa: E402
 
 DEV = "cuda"
@@ -97,8 +97,9 @@ def test_conv_fwd_bwd(case, lazy):
     OH, OW = ref.shape[2:]
     d = ConvDesc(N, H, W, cp, OH, OW, Cout, k, k, s, p, 1, act, 0)
     y = torch.empty(N, OH, OW, Cout, dtype=torch.bfloat16, device=DEV)
-    stats = torch.zeros(2 * Cout, dtype=torch.float64, device=DEV)
+    stats = torch.zeros(STAT_SLOTS, 2 * Cout, dtype=torch.float64, device=DEV)
     call("adamml_conv_fwd", byref(d), ptr(xh), ptr(pack(w, cp, 0)), ptr(scale), ptr(shift), ptr(y), ptr(stats))
+    stats = stats.sum(0)
     got = nchw(y)
     close(got, ref.detach(), what="conv fwd")
     # statistics of the stored (rounded) output
@@ -139,9 +140,10 @@ def test_dwconv(case):
     d = ConvDesc(N, H, W, C, OH, OW, C, 3, 3, s, 1, 1, 2, 0)
     wp = pack(w, C, 2)
     y = torch.empty(N, OH, OW, C, dtype=torch.bfloat16, device=DEV)
-    stats = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    stats = torch.zeros(STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
     xh = nhwc(x)
     call("adamml_dwconv_fwd", byref(d), ptr(xh), ptr(wp), ptr(scale), ptr(shift), ptr(y), ptr(stats))
+    stats = stats.sum(0)
     close(nchw(y), ref.detach(), what="dw fwd")
     yf = y.float().reshape(-1, C).double()
     assert torch.allclose(stats[:C], yf.sum(0), rtol=1e-4, atol=1e-3)
@@ -173,7 +175,7 @@ def test_batchnorm_train_fwd_bwd(C, P, act):
     zd = zb.float().double()
     stats = torch.cat([zd.sum(0), (zd * zd).sum(0)])
     vec = torch.empty(4, C, device=DEV)
-    call("adamml_bn_finalize", ptr(stats), float(P), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5, ptr(vec[0]), ptr(vec[1]),
+    call("adamml_bn_finalize", ptr(stats), 1, float(P), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5, ptr(vec[0]), ptr(vec[1]),
          ptr(vec[2]), ptr(vec[3]), C)
     assert torch.allclose(rm, rm_ref, rtol=1e-4, atol=1e-5)
     assert torch.allclose(rv, rv_ref, rtol=1e-4, atol=1e-5)
@@ -182,12 +184,12 @@ def test_batchnorm_train_fwd_bwd(C, P, act):
     close(o.float(), a.detach(), what="bn apply")
     g = rb(torch.randn(P, C, device=DEV))
     a.backward(g)
-    sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    sums = torch.zeros(STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
     gb = g.to(torch.bfloat16).contiguous()
     call("adamml_bn_bwd_reduce", ptr(gb), ptr(zb), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), act, ptr(sums), P, C)
     dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     coef = torch.empty(3, C, device=DEV)
-    call("adamml_bn_bwd_finalize", ptr(sums), float(P), ptr(gamma), ptr(vec[3]), ptr(dgam), ptr(dbet), ptr(coef), C)
+    call("adamml_bn_bwd_finalize", ptr(sums), STAT_SLOTS, float(P), ptr(gamma), ptr(vec[3]), ptr(dgam), ptr(dbet), ptr(coef), C)
     dz = torch.empty(P, C, dtype=torch.bfloat16, device=DEV)
     call("adamml_bn_bwd_apply", ptr(gb), ptr(zb), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), act, ptr(coef), ptr(dz), P, C)
     close(dgam, gamma.grad, what="dgamma")
