@@ -34,13 +34,15 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * 64 + ((chunk ^ (((row >> 3) & 1) << 1)) << 4);
 }
 
-template <int BC, bool MULTITAP>
+// MODE 0: 1x1 conv; MODE 1: KxK conv, fast tap addressing (per-row validity mask + LDS tap-offset table);
+// MODE 2: generic path with zero-upsampled input (data gradient of strided convs).
+template <int BC, int MODE>
 __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
     constexpr int WROWS = BC / 64;          // weight rows staged per thread
     constexpr int TILE_BYTES = (BP + BC) * 64;
     constexpr int EPI_BYTES = BP * (BC * 2 + 16);
-    constexpr int SMEM_BYTES = (2 * TILE_BYTES + 2 * BC * 4) > EPI_BYTES ? (2 * TILE_BYTES + 2 * BC * 4) : EPI_BYTES;
+    constexpr int SMEM_BYTES = ((2 * TILE_BYTES + 2 * BC * 4) > EPI_BYTES ? (2 * TILE_BYTES + 2 * BC * 4) : EPI_BYTES) + 256;
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
 
     const int tid = threadIdx.x;
@@ -65,8 +67,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
     // ---- per-thread staging coordinates -------------------------------------------------------
     const int chunk = tid & 3;
     const int row_a = tid >> 2;             // 0..63 (+64 for second row)
-    int a_n[2], a_h0[2], a_w0[2];
+    int a_n[2], a_h0[2], a_w0[2], a_base[2];
+    unsigned long long a_mask[2];
     bool a_ok[2];
+    int* s_tapoff = reinterpret_cast<int*>(smem + SMEM_BYTES - 64 * 4);       // MODE 1: element offset of each tap
+    if (MODE == 1) {
+        if (tid < p.KH * p.KW) {
+            const int kh = tid / p.KW, kw = tid - kh * p.KW;
+            s_tapoff[tid] = (kh * p.W + kw) * p.Cin;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         int pp = p0 + row_a + r * 64;
@@ -79,6 +89,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
         a_n[r] = n;
         a_h0[r] = oh * p.stride - p.pad;
         a_w0[r] = ow * p.stride - p.pad;
+        a_base[r] = ((n * p.H + a_h0[r]) * p.W + a_w0[r]) * p.Cin;      // may point before the row start for padded taps
+        unsigned long long m = 0;
+        if (MODE == 1 && a_ok[r]) {
+            for (int kh = 0; kh < p.KH; ++kh) {
+                const bool hok = (unsigned)(a_h0[r] + kh) < (unsigned)p.H;
+                for (int kw = 0; kw < p.KW; ++kw)
+                    if (hok && (unsigned)(a_w0[r] + kw) < (unsigned)p.W) m |= 1ull << (kh * p.KW + kw);
+            }
+        }
+        a_mask[r] = m;
     }
     const bf16_t* wrow[WROWS];
     bool w_ok[WROWS];
@@ -88,6 +108,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
         w_ok[r] = co < p.Cout;
         wrow[r] = p.w + (size_t)(w_ok[r] ? co : 0) * p.K;
     }
+    if (MODE == 1) __syncthreads();          // tap-offset table visible
 
     bf16x8 ra[2], rw[WROWS];
     int rci = 0;
@@ -96,28 +117,47 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
     auto issue_loads = [&](int kt) {
         const int k = kt * BK + chunk * 8;
         const bool kok = k < p.K;
-        int kh = 0, kw = 0, ci = k;
-        if (MULTITAP) {
-            int tap = k >> p.cin_shift;
-            ci = k & (p.Cin - 1);
-            kh = tap / p.KW;
-            kw = tap - kh * p.KW;
-        }
-        rci = ci;
+        if (MODE == 0) {
+            rci = k;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            int ih = a_h0[r] + kh, iw = a_w0[r] + kw;
-            bool ok = a_ok[r] && kok && ih >= 0 && iw >= 0;
-            if (p.up > 1) {
+            for (int r = 0; r < 2; ++r) {
+                const bool ok = a_ok[r] && kok;
+                rav[r] = ok;
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + (size_t)(unsigned)(a_base[r] + k));
+                ra[r] = v;
+            }
+        } else if (MODE == 1) {
+            const int tap = kok ? (k >> p.cin_shift) : 0;
+            const int ci = k & (p.Cin - 1);
+            const int toff = s_tapoff[tap] + ci;
+            rci = ci;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const bool ok = kok && ((a_mask[r] >> tap) & 1ull);
+                rav[r] = ok;
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + (size_t)(unsigned)(a_base[r] + toff));
+                ra[r] = v;
+            }
+        } else {
+            const int tap = k >> p.cin_shift;
+            const int ci = k - (tap << p.cin_shift);
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            rci = ci;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                int ih = a_h0[r] + kh, iw = a_w0[r] + kw;
+                bool ok = a_ok[r] && kok && ih >= 0 && iw >= 0;
                 ok = ok && ((ih | iw) & (p.up - 1)) == 0;
                 ih >>= p.up_shift;
                 iw >>= p.up_shift;
+                ok = ok && ih < p.H && iw < p.W;
+                rav[r] = ok;
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + ((size_t)(a_n[r] * p.H + ih) * p.W + iw) * p.Cin + ci);
+                ra[r] = v;
             }
-            ok = ok && ih < p.H && iw < p.W;
-            rav[r] = ok;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + ((size_t)(a_n[r] * p.H + ih) * p.W + iw) * p.Cin + ci);
-            ra[r] = v;
         }
 #pragma unroll
         for (int r = 0; r < WROWS; ++r) {
@@ -174,7 +214,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
     // ---- epilogue: stage the bf16 tile through LDS, store 16 B per lane fully coalesced, and accumulate the
     //      per-channel sum / sum-of-squares of the stored (rounded) values on the way out -------------------
     constexpr int CROW = BC * 2 + 16;                  // LDS row stride (bytes): +16 B skews the banks
-    static_assert(BP * CROW <= SMEM_BYTES, "epilogue tile must fit the staging buffers");
+    static_assert(BP * CROW <= SMEM_BYTES - 256, "epilogue tile must fit the staging buffers");
     // (the last K step ended with __syncthreads(): every wave is done reading the operand tiles)
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt)
@@ -251,6 +291,9 @@ struct WgradP {
     const float* in_scale;
     const float* in_shift;
     float* dw;             // OIHW fp32, Cin_true input channels
+    float* ws;             // optional [nsplit][numel(dw)] partial buffer (plain stores) instead of atomics
+    size_t dw_numel;
+    int nsplit;
     int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, act, cin_true;
     int P, pix_per_block, n_cotiles, n_tiles, cin_shift, NK;   // NK = KH*KW*Cin: flattened (tap, ci) GEMM-N extent
 };
@@ -282,7 +325,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
     const int n0 = (tile / p.n_cotiles) * BN;           // offset in the flattened (tap, ci) axis
     const int ps = split * p.pix_per_block;
     const int pe = min(p.P, ps + p.pix_per_block);
-    if (ps >= pe) return;
+    if (split >= p.nsplit) return;                            // padding blocks of the XCD-rounded grid
 
     constexpr int ACH = BM / 8, BCH = BN / 8;                 // 16-byte chunks per row
     constexpr int AL = (32 * ACH) / NTHREADS, BL = (32 * BCH) / NTHREADS;
@@ -357,9 +400,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
         for (int jn = 0; jn < NT; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (pe - ps + 31) / 32;
-    issue_loads(ps);
-    store_tile(0);
+    const int nk = pe > ps ? (pe - ps + 31) / 32 : 0;
+    if (nk > 0) {
+        issue_loads(ps);
+        store_tile(0);
+    }
     __syncthreads();
     const int li = lane & 15, lg = lane >> 4;
     // transpose-read addressing: lane li of a 16-lane group supplies the 8-byte unit
@@ -410,9 +455,207 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + wm * (BM / 2) + mt * 16 + lg * 4 + r;
-                if (co < p.Cout) atomicAdd(p.dw + ((size_t)co * p.cin_true + ci) * taps + tap, acc[mt][nt][r]);
+                if (co >= p.Cout) continue;
+                const size_t idx = ((size_t)co * p.cin_true + ci) * taps + tap;
+                if (p.ws) p.ws[(size_t)split * p.dw_numel + idx] = acc[mt][nt][r];
+                else atomicAdd(p.dw + idx, acc[mt][nt][r]);
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 weight gradient, all nine taps per workgroup.  One K step = up to 32 output pixels of one image (a row
+// segment, or floor(32/OW) whole rows); the matching input patch (with its 1-pixel halo) is staged ONCE in LDS and
+// the nine shifted B operands are fetched from it with per-lane transpose reads, so dz and the activations are
+// read once per (co-tile, ci-tile) instead of once per tap.  Tile: 64 co x (9 taps x 64 ci); wave w owns the 16-ci
+// slice w for all taps and all 64 co (36 accumulator tiles = 144 VGPRs).
+struct W3P {
+    const bf16_t* dz;
+    const bf16_t* x;
+    const float* in_scale;
+    const float* in_shift;
+    float* dw;
+    float* ws;
+    size_t dw_numel;
+    int nsplit;
+    int N, H, W, Cin, OH, OW, Cout, pad, act, cin_true;
+    int cw, rows, PR, PC, units_per_img, units_per_row, total_units, units_per_block, n_cotiles, n_tiles;
+};
+
+template <int S>
+__global__ __launch_bounds__(NTHREADS, 2) void conv3x3_wgrad_kernel(W3P p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int patch_bytes = p.PR * p.PC * 128;
+    const int buf_bytes = 32 * 128 + patch_bytes;               // dz tile [32][64] + patch [PR*PC][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tile = jb % p.n_tiles;
+    const int split = (jb / p.n_tiles) * 8 + xcd;
+    const int co0 = (tile % p.n_cotiles) * 64;
+    const int ci0 = (tile / p.n_cotiles) * 64;
+    const int u0 = split * p.units_per_block;
+    const int u1 = min(p.total_units, u0 + p.units_per_block);
+    if (split >= p.nsplit) return;
+
+    // ---- fixed per-thread staging slots ---------------------------------------------------------------------
+    // dz tile: 32 rows x 8 chunks = 256 chunks -> one per thread
+    const int a_j = tid >> 3, a_ch = tid & 7;
+    const int a_r = a_j / p.cw, a_c = a_j - a_r * p.cw;
+    // patch: PR*PC pixels x 8 chunks, up to 6 slots per thread
+    constexpr int MAXSLOT = 6;
+    const int n_chunks = p.PR * p.PC * 8;
+    int s_pr[MAXSLOT], s_pc[MAXSLOT];
+#pragma unroll
+    for (int l = 0; l < MAXSLOT; ++l) {
+        const int e = tid + l * NTHREADS;
+        const int pix = e >> 3;
+        s_pr[l] = pix / p.PC;
+        s_pc[l] = pix - s_pr[l] * p.PC;
+    }
+    const int b_ch = tid & 7;                                   // chunk within the 64-ci row (same for all slots)
+    bf16x8 ra, rb[MAXSLOT];
+    bool rbv[MAXSLOT];
+
+    auto decode = [&](int u, int& n, int& oh0, int& ow0) {
+        n = u / p.units_per_img;
+        int rem = u - n * p.units_per_img;
+        int ug = rem / p.units_per_row;                         // row group
+        int seg = rem - ug * p.units_per_row;
+        oh0 = ug * p.rows;
+        ow0 = seg * p.cw;
+    };
+    auto issue_loads = [&](int u) {
+        int n, oh0, ow0;
+        decode(u, n, oh0, ow0);
+        {
+            const int oh = oh0 + a_r, ow = ow0 + a_c;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (a_r < p.rows && oh < p.OH && ow < p.OW)
+                v = *reinterpret_cast<const bf16x8*>(p.dz + ((size_t)(n * p.OH + oh) * p.OW + ow) * p.Cout + co0 + a_ch * 8);
+            ra = v;
+        }
+        const int ih0 = oh0 * S - p.pad, iw0 = ow0 * S - p.pad;
+#pragma unroll
+        for (int l = 0; l < MAXSLOT; ++l) {
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int ih = ih0 + s_pr[l], iw = iw0 + s_pc[l];
+            const bool ok = (tid + l * NTHREADS) < n_chunks && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + ((size_t)(n * p.H + ih) * p.W + iw) * p.Cin + ci0 + b_ch * 8);
+            rbv[l] = ok;
+            rb[l] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* base = smem + buf * buf_bytes;
+        *reinterpret_cast<bf16x8*>(base + a_j * 128 + ((a_ch ^ (tr_swz<64>(a_j) >> 1)) << 4)) = ra;
+        char* pb = base + 32 * 128;
+#pragma unroll
+        for (int l = 0; l < MAXSLOT; ++l) {
+            if (tid + l * NTHREADS < n_chunks) {
+                bf16x8 v = rb[l];
+                if (p.in_scale && rbv[l]) v = f32_to_bf8(transform8(v, p.in_scale, p.in_shift, ci0 + b_ch * 8, p.act));
+                const int pix = s_pr[l] * p.PC + s_pc[l];
+                // 16-byte chunk swizzle by patch column: neighbouring columns that share a bank half get distinct slots
+                *reinterpret_cast<bf16x8*>(pb + pix * 128 + ((b_ch ^ (((s_pc[l] >> 1) & 3) << 1)) << 4)) = v;
+            }
+        }
+    };
+
+    f32x4 acc[4][9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fixed per-lane fragment addressing -----------------------------------------------------------------
+    const int trow = 8 * lg + (li >> 2), tq = li & 3;
+    const int a_lo = trow * 128, a_hi = (trow + 4) * 128;
+    const int ax_lo = tr_swz<64>(trow), ax_hi = tr_swz<64>(trow + 4);
+    int b_base[2], b_col[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = trow + 4 * h;
+        int r = j / p.cw, c = j - r * p.cw;
+        if (r >= p.rows) { r = 0; c = 0; }                       // padding k-rows (dz row is zero): read any FINITE patch pixel
+        b_col[h] = c * S;                                        // patch column of tap (.,0) for k-row j
+        b_base[h] = r * S * p.PC + c * S;                        // patch pixel index of tap (0,0)
+    }
+    const int b_unit = wave * 4 + tq;                            // 8-byte unit of this lane's 4 ci inside the 64-ci row
+
+    if (u0 < u1) {
+        issue_loads(u0);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int u = u0; u < u1; ++u) {
+        const int buf = (u - u0) & 1;
+        if (u + 1 < u1) issue_loads(u + 1);
+        const char* base = smem + buf * buf_bytes;
+        const char* pb = base + 32 * 128;
+        bf16x8 fa[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int un = t * 4 + tq;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a_lo + ((un ^ ax_lo) << 3)));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a_hi + ((un ^ ax_hi) << 3)));
+            union { struct { s16x4 a, b; } s; bf16x8 v; } cvt;
+            cvt.s.a = lo; cvt.s.b = hi;
+            fa[t] = cvt.v;
+        }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                s16x4 half[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int pix = b_base[h] + kh * p.PC + kw;
+                    const int un = b_unit ^ ((((b_col[h] + kw) >> 1) & 3) << 2);
+                    half[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb + pix * 128 + (un << 3)));
+                }
+                union { struct { s16x4 a, b; } s; bf16x8 v; } cvt;
+                cvt.s.a = half[0]; cvt.s.b = half[1];
+                const bf16x8 fb = cvt.v;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt][kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb, acc[mt][kh * 3 + kw], 0, 0, 0);
+            }
+        if (u + 1 < u1) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    const int ci = ci0 + wave * 16 + li;
+    if (ci < p.cin_true) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + mt * 16 + lg * 4 + r;
+                    const size_t idx = ((size_t)co * p.cin_true + ci) * 9 + t;
+                    if (p.ws) p.ws[(size_t)split * p.dw_numel + idx] = acc[mt][t][r];
+                    else atomicAdd(p.dw + idx, acc[mt][t][r]);
+                }
+    }
+}
+
+// dw[i] += sum_s ws[s][i]: 16 indices x 16 split lanes per workgroup (the split loop is the long axis)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dw, size_t n, int nsplit) {
+    __shared__ float red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + tx;
+    float a = 0.f;
+    if (i < n)
+        for (int s = ty; s < nsplit; s += 16) a += ws[(size_t)s * n + i];
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][tx];
+        dw[i] += t;
+    }
 }
 
 int ilog2_exact(int v) {
@@ -450,13 +693,18 @@ extern "C" int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const
     p.n_ptiles = ceil_div(p.P, BP);
     p.n_ctiles = ceil_div(d->Cout, BC);
     dim3 grid(p.n_ptiles * p.n_ctiles), block(NTHREADS);
+    const int taps = d->KH * d->KW;
+    // MODE 0 needs the whole row base in 32-bit element offsets (true for every layer of the hot path)
+    if ((long)d->N * d->H * d->W * d->Cin >= (1L << 31)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd: input tensor exceeds 2^31 elements");
+    const int mode = p.up > 1 ? 2 : (multitap ? (taps <= 64 ? 1 : 2) : 0);
+    if (mode == 2 && !multitap) { p.cin_shift = 30; }      // 1x1 strided dgrad: tap = k >> 30 = 0, ci = k
+#define LAUNCH_CONV(BCV, MODEV) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV>), grid, block, 0, stream, p)
     if (BC == 64) {
-        if (multitap) hipLaunchKernelGGL((conv_gemm_kernel<64, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_kernel<64, false>), grid, block, 0, stream, p);
+        if (mode == 0) LAUNCH_CONV(64, 0); else if (mode == 1) LAUNCH_CONV(64, 1); else LAUNCH_CONV(64, 2);
     } else {
-        if (multitap) hipLaunchKernelGGL((conv_gemm_kernel<128, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_kernel<128, false>), grid, block, 0, stream, p);
+        if (mode == 0) LAUNCH_CONV(128, 0); else if (mode == 1) LAUNCH_CONV(128, 1); else LAUNCH_CONV(128, 2);
     }
+#undef LAUNCH_CONV
     return adamml_check_launch("conv_fwd");
 }
 
@@ -473,38 +721,97 @@ extern "C" int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz,
     return adamml_conv_fwd(&g, dz, w_dgrad_packed, nullptr, nullptr, dx, nullptr, stream);
 }
 
+// split plan shared by the workspace query and the launcher
+struct WgradPlan { bool use3x3; int nsplit, per_block, n_cotiles, n_tiles, BM, BN, NK, cin_shift; int cw, rows, PR, PC, upi, upr, total_units, buf_bytes; };
+
+static int wgrad_plan(const adamml_conv_desc_t* d, int cin_true, WgradPlan* pl) {
+    const int taps = d->KH * d->KW;
+    pl->use3x3 = false;
+    if (d->KH == 3 && d->KW == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2) && d->Cin % 64 == 0 && d->Cout % 64 == 0 &&
+        cin_true == d->Cin) {
+        if (d->OW > 32) { pl->cw = 32; pl->rows = 1; pl->upr = ceil_div(d->OW, 32); }
+        else { pl->cw = d->OW; pl->rows = 32 / d->OW; pl->upr = 1; }
+        pl->PR = (pl->rows - 1) * d->stride + 3;
+        pl->PC = (pl->cw - 1) * d->stride + 3;
+        pl->upi = ceil_div(d->OH, pl->rows) * pl->upr;
+        pl->total_units = d->N * pl->upi;
+        pl->buf_bytes = 32 * 128 + pl->PR * pl->PC * 128;
+        if (pl->PR * pl->PC * 8 <= 6 * NTHREADS && 2 * pl->buf_bytes <= 64 * 1024 && pl->total_units > 0) {
+            pl->use3x3 = true;
+            pl->n_cotiles = d->Cout / 64;
+            pl->n_tiles = pl->n_cotiles * (d->Cin / 64);
+            int nsplit = ceil_div(512, pl->n_tiles);
+            int upb = ceil_div(pl->total_units, nsplit);
+            if (upb < 4) upb = 4;
+            pl->nsplit = ceil_div(pl->total_units, upb);
+            pl->per_block = upb;
+            return 0;
+        }
+    }
+    pl->NK = taps * d->Cin;
+    pl->cin_shift = 30;                     // 1x1: tap = n >> 30 = 0
+    if (taps > 1) {
+        pl->cin_shift = ilog2_exact(d->Cin);
+        if (pl->cin_shift < 0) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_weight: KxK conv needs power-of-two Cin (got %d)", d->Cin);
+    }
+    pl->BM = d->Cout <= 64 ? 64 : 128;
+    pl->BN = pl->NK <= 64 ? 64 : 128;
+    pl->n_cotiles = ceil_div(d->Cout, pl->BM);
+    pl->n_tiles = pl->n_cotiles * ceil_div(pl->NK, pl->BN);
+    const int P = d->N * d->OH * d->OW;
+    int nsplit = ceil_div(768, pl->n_tiles);
+    int ppb = ceil_div(ceil_div(P, nsplit), 32) * 32;
+    if (ppb < 256) ppb = 256;
+    pl->nsplit = ceil_div(P, ppb);
+    pl->per_block = ppb;
+    return 0;
+}
+
+extern "C" size_t adamml_conv_bwd_weight_workspace(const adamml_conv_desc_t* d, int cin_true) {
+    WgradPlan pl;
+    if (!d || wgrad_plan(d, cin_true, &pl)) return 0;
+    return (size_t)pl.nsplit * d->Cout * cin_true * d->KH * d->KW * sizeof(float);
+}
+
 extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
-                                      const float* in_shift, float* dw, int cin_true, hipStream_t stream) {
+                                      const float* in_shift, float* dw, int cin_true, void* workspace, size_t workspace_bytes,
+                                      hipStream_t stream) {
     if (!d || !dz || !x || !dw) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_weight: null argument");
     if (d->Cin % 8 || d->Cout % 8) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_weight: channels must be multiples of 8");
-    WgradP p;
-    p.dz = (const bf16_t*)dz; p.x = (const bf16_t*)x; p.in_scale = in_scale; p.in_shift = in_shift; p.dw = dw;
-    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
-    p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.act = d->act; p.cin_true = cin_true;
-    p.P = d->N * d->OH * d->OW;
-    if (p.P <= 0) return ADAMML_OK;
-    const int taps = d->KH * d->KW;
-    p.NK = taps * d->Cin;
-    p.cin_shift = 30;                       // 1x1: tap = n >> 30 = 0
-    if (taps > 1) {
-        p.cin_shift = ilog2_exact(d->Cin);
-        if (p.cin_shift < 0) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_weight: KxK conv needs power-of-two Cin (got %d)", d->Cin);
+    if ((long)d->N * d->OH * d->OW <= 0) return ADAMML_OK;
+    WgradPlan pl;
+    int rc = wgrad_plan(d, cin_true, &pl);
+    if (rc) return rc;
+    const size_t dw_numel = (size_t)d->Cout * cin_true * d->KH * d->KW;
+    float* ws = nullptr;
+    if (workspace && workspace_bytes >= (size_t)pl.nsplit * dw_numel * sizeof(float)) ws = (float*)workspace;
+    const int nsplit8 = ceil_div(pl.nsplit, 8) * 8;
+    dim3 grid(nsplit8 * pl.n_tiles), block(NTHREADS);
+    if (pl.use3x3) {
+        W3P q;
+        q.dz = (const bf16_t*)dz; q.x = (const bf16_t*)x; q.in_scale = in_scale; q.in_shift = in_shift; q.dw = dw;
+        q.ws = ws; q.dw_numel = dw_numel; q.nsplit = pl.nsplit;
+        q.N = d->N; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.OH = d->OH; q.OW = d->OW; q.Cout = d->Cout; q.pad = d->pad;
+        q.act = d->act; q.cin_true = cin_true;
+        q.cw = pl.cw; q.rows = pl.rows; q.PR = pl.PR; q.PC = pl.PC; q.units_per_img = pl.upi; q.units_per_row = pl.upr;
+        q.total_units = pl.total_units; q.units_per_block = pl.per_block; q.n_cotiles = pl.n_cotiles; q.n_tiles = pl.n_tiles;
+        if (d->stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, block, 2 * pl.buf_bytes, stream, q);
+        else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, block, 2 * pl.buf_bytes, stream, q);
+    } else {
+        WgradP p;
+        p.dz = (const bf16_t*)dz; p.x = (const bf16_t*)x; p.in_scale = in_scale; p.in_shift = in_shift; p.dw = dw;
+        p.ws = ws; p.dw_numel = dw_numel; p.nsplit = pl.nsplit;
+        p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
+        p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.act = d->act; p.cin_true = cin_true;
+        p.P = d->N * d->OH * d->OW; p.NK = pl.NK; p.cin_shift = pl.cin_shift; p.n_cotiles = pl.n_cotiles; p.n_tiles = pl.n_tiles;
+        p.pix_per_block = pl.per_block;
+        if (pl.BM == 64 && pl.BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, stream, p);
+        else if (pl.BM == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, block, 0, stream, p);
+        else if (pl.BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, stream, p);
     }
-    const int BM = d->Cout <= 64 ? 64 : 128;
-    const int BN = p.NK <= 64 ? 64 : 128;
-    p.n_cotiles = ceil_div(d->Cout, BM);
-    const int n_ntiles = ceil_div(p.NK, BN);
-    p.n_tiles = p.n_cotiles * n_ntiles;
-    // pixel splits: a multiple of 8 (one per XCD per round), ~1024 workgroups in total, >= 256 pixels each
-    int nsplit = ceil_div(ceil_div(1024, p.n_tiles), 8) * 8;
-    int ppb = ceil_div(ceil_div(p.P, nsplit), 32) * 32;
-    if (ppb < 256) ppb = 256;
-    nsplit = ceil_div(ceil_div(p.P, ppb), 8) * 8;
-    p.pix_per_block = ppb;
-    dim3 grid(nsplit * p.n_tiles, 1, 1), block(NTHREADS);
-    if (BM == 64 && BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, stream, p);
-    else if (BM == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, block, 0, stream, p);
-    else if (BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, stream, p);
-    return adamml_check_launch("conv_bwd_weight");
+    rc = adamml_check_launch("conv_bwd_weight");
+    if (rc || !ws) return rc;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((dw_numel + 15) / 16)), dim3(256), 0, stream, ws, dw, dw_numel, pl.nsplit);
+    return adamml_check_launch("conv_bwd_weight(reduce)");
 }

@@ -27,7 +27,7 @@ _DESC = POINTER(ConvDesc)
 SIGNATURES = {
     "adamml_conv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "adamml_conv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
-    "adamml_conv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _I, _P],
+    "adamml_conv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _I, _P, _Z, _P],
     "adamml_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "adamml_dwconv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "adamml_dwconv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
@@ -68,6 +68,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.argtypes = argt
         fn.restype = c_int
+    lib.adamml_conv_bwd_weight_workspace.argtypes = [_DESC, _I]
+    lib.adamml_conv_bwd_weight_workspace.restype = c_size_t
     lib.adamml_version.restype = c_int
     lib.adamml_last_error_string.restype = c_char_p
     _lib = lib
@@ -119,6 +121,19 @@ def call(name, *args):
         rc = getattr(lib, name)(*args, _stream())
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.adamml_last_error_string().decode()))
+
+
+_wgrad_ws = {}
+
+
+def wgrad_workspace(desc, cin_true, device):
+    """Persistent per-device scratch for the split weight-gradient partial tiles (grown on demand)."""
+    need = load().adamml_conv_bwd_weight_workspace(ctypes.byref(desc), cin_true)
+    buf = _wgrad_ws.get(device)
+    if buf is None or buf.numel() * 4 < need:
+        buf = torch.empty(max(need // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
+        _wgrad_ws[device] = buf
+    return buf
 
 
 def require_gpu(t):

@@ -196,8 +196,26 @@ def _bn_backward(rt, out, y, vec, bn, act, count):
     return dz
 
 
+def materialize(rt, x):
+    """Evaluate a lazy tensor once into a plain bf16 tensor.  Used in front of KxK dense convs: their implicit-GEMM
+    loader would otherwise re-apply the producer's BatchNorm+ReLU once per tap (9x for 3x3) on the VALU."""
+    n, h, w, C = x.shape
+    out_t = torch.empty_like(x.data)
+    call("adamml_bn_act_add", ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, None, None, None, ptr(out_t), n * h * w, C)
+    a = Lazy(out_t, requires_grad=x.requires_grad)
+    if rt.tape.need_grad:
+        def bwd():
+            g, a.grad = a.grad, None
+            if g is not None:
+                _accum_grad(x, g)          # d/d(activated value) is the same quantity on both sides
+        rt.tape.record(bwd)
+    return a
+
+
 def conv_bn(rt, x, cs, bn, act):
     """conv (dense or depthwise) + train/eval BatchNorm + activation, as one lazy tensor."""
+    if x.scale is not None and not cs.depthwise and cs.kh * cs.kw > 1:
+        x = materialize(rt, x)
     d = cs.desc(x.shape, x.act)
     if x.shape[3] != cs.cin:
         raise RuntimeError("conv_bn: input has %d channels, weight pack expects %d" % (x.shape[3], cs.cin))
@@ -230,8 +248,9 @@ def conv_bn(rt, x, cs, bn, act):
                 if cs.depthwise:
                     call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(cs.weight.grad))
                 else:
+                    ws = hip.wgrad_workspace(d, cs.cin_true, dz.device)
                     call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift),
-                         ptr(cs.weight.grad), cs.cin_true)
+                         ptr(cs.weight.grad), cs.cin_true, ptr(ws), ws.numel() * 4)
             if x.requires_grad:
                 acc = 1
                 if x.grad is None:

@@ -50,9 +50,14 @@ int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const void* w_pa
 /* autograd of the above w.r.t. its input (d = forward descriptor; w packed with mode 1) */
 int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
                          int accumulate, hipStream_t stream);
-/* autograd w.r.t. the weight: dw (fp32 OIHW, cin_true input channels) += ...  (atomic accumulate) */
+/* autograd w.r.t. the weight: dw (fp32 OIHW, cin_true input channels) += dz^T * im2col(act(x)).  The pixel axis is
+ * split over workgroups; with a workspace of adamml_conv_bwd_weight_workspace() bytes the partial tiles are written
+ * with plain stores and summed by a second launch (device-scope fp32 atomics run at ~20 G/s on MI355X and would
+ * otherwise bound the kernel); workspace == NULL falls back to atomic accumulation. */
+size_t adamml_conv_bwd_weight_workspace(const adamml_conv_desc_t* d, int cin_true);
 int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
-                           const float* in_shift, float* dw, int cin_true, hipStream_t stream);
+                           const float* in_shift, float* dw, int cin_true, void* workspace, size_t workspace_bytes,
+                           hipStream_t stream);
 /* fp32 OIHW master weight -> bf16 GEMM operand.  mode 0: [Cout][KH*KW][cin_pad] (forward);
  * mode 1: [cin_pad][KH*KW flipped][Cout] (data gradient); mode 2: depthwise [KH*KW][C] fp32. */
 int adamml_pack_conv_weight(const float* w, void* out, int cout, int cin_true, int cin_pad, int kh, int kw, int mode,

@@ -121,8 +121,12 @@ def test_conv_fwd_bwd(case, lazy):
     call("adamml_conv_bwd_data", byref(d), ptr(dz), ptr(pack(w, cp, 1)), ptr(dx), 1)
     close(nchw(dx, Cin), 2 * xr.grad, rtol=2e-2, atol_frac=2e-2, what="conv dgrad acc")
     dw = torch.zeros_like(w)
-    call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(xh), ptr(scale), ptr(shift), ptr(dw), Cin)
-    close(dw, wr.grad, what="conv wgrad")
+    call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(xh), ptr(scale), ptr(shift), ptr(dw), Cin, None, 0)
+    close(dw, wr.grad, what="conv wgrad (atomic path)")
+    ws = hip.wgrad_workspace(d, Cin, dz.device)
+    dw2 = torch.ones_like(w)          # accumulate semantics: dw += ...
+    call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(xh), ptr(scale), ptr(shift), ptr(dw2), Cin, ptr(ws), ws.numel() * 4)
+    close(dw2 - 1, wr.grad, what="conv wgrad (workspace path)")
 
 
 @pytest.mark.parametrize("case", [(2, 40, 40, 32, 1), (2, 41, 41, 96, 2), (1, 20, 20, 144, 2), (2, 10, 10, 960, 1), (1, 16, 16, 576, 2)])

@@ -62,7 +62,9 @@ def main():
         by = 2.0 * (n * h * h * cin + n * oh * oh * cout)
         t_f = timeit(lambda: call("adamml_conv_fwd", byref(d), ptr(x), ptr(w), ptr(sc), ptr(sh), ptr(y), ptr(stats)))
         t_d = timeit(lambda: call("adamml_conv_bwd_data", byref(d), ptr(dz), ptr(wd), ptr(dx), 0))
-        t_w = timeit(lambda: call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x), ptr(sc), ptr(sh), ptr(dw), cin))
+        from adamml_amd import hip as _hip
+        ws = _hip.wgrad_workspace(d, cin, dz.device)
+        t_w = timeit(lambda: call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x), ptr(sc), ptr(sh), ptr(dw), cin, ptr(ws), ws.numel() * 4))
         row = "%4d %4d %d %d %4d %3d x%d" % (cin, cout, k, s, n, h, cnt)
         cells = []
         for key, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
