@@ -21,6 +21,8 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2 };
 // error plumbing (api.hip)
 int adamml_set_error(int code, const char* fmt, ...);
 int adamml_check_launch(const char* what);
+// dw[i] += sum_{s<nsplit} ws[s*n + i]   (conv_gemm.hip)
+int adamml_launch_split_reduce(const float* ws, float* dw, size_t n, int nsplit, hipStream_t stream);
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.f);
@@ -55,6 +57,16 @@ __device__ __forceinline__ f32x8 transform8(bf16x8 raw, const float* scale, cons
         f32x8 s = load_f32x8(scale + c), t = load_f32x8(shift + c);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = apply_act(fmaf(v[i], s[i], t[i]), act);
+    }
+    return v;
+}
+
+__device__ __forceinline__ f32x4 transform4(bf16x4 raw, const float* scale, const float* shift, int c, int act) {
+    f32x4 v = bf4_to_f32(raw);
+    if (scale) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(scale + c), t = *reinterpret_cast<const f32x4*>(shift + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = apply_act(fmaf(v[i], s[i], t[i]), act);
     }
     return v;
 }

@@ -767,6 +767,11 @@ static int wgrad_plan(const adamml_conv_desc_t* d, int cin_true, WgradPlan* pl) 
     return 0;
 }
 
+int adamml_launch_split_reduce(const float* ws, float* dw, size_t n, int nsplit, hipStream_t stream) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, ws, dw, n, nsplit);
+    return adamml_check_launch("split_reduce");
+}
+
 extern "C" size_t adamml_conv_bwd_weight_workspace(const adamml_conv_desc_t* d, int cin_true) {
     WgradPlan pl;
     if (!d || wgrad_plan(d, cin_true, &pl)) return 0;
@@ -812,6 +817,5 @@ extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* d
     }
     rc = adamml_check_launch("conv_bwd_weight");
     if (rc || !ws) return rc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((dw_numel + 15) / 16)), dim3(256), 0, stream, ws, dw, dw_numel, pl.nsplit);
-    return adamml_check_launch("conv_bwd_weight(reduce)");
+    return adamml_launch_split_reduce(ws, dw, dw_numel, pl.nsplit, stream);
 }

@@ -33,26 +33,25 @@ struct DwP {
     size_t P, ppb;
 };
 
-// "Row walker": one thread owns 8 channels of ONE output row and slides a 3x3 register window along it, so every
-// input element is loaded (and BatchNorm+ReLU6-transformed) once per output row instead of nine times, with no
-// per-pixel index arithmetic.  Adjacent threads own adjacent channel chunks -> 16 B/lane coalesced rows.
+// "Row walker": one thread owns 4 channels of a short run of outputs in ONE output row and slides a 3x3 register
+// window along it, so every input element is loaded (and BatchNorm+ReLU6-transformed) ~once per output row instead
+// of nine times, with no per-pixel index arithmetic.  4 channels (8 B) per lane keeps the window + weights + sums at
+// ~100 VGPRs (4-5 waves/SIMD); adjacent lanes own adjacent channel groups -> contiguous 512 B per wave access.
 template <int S>
 __global__ __launch_bounds__(NT) void dwconv_fwd_kernel(DwP p) {
     __shared__ float smem[2 * MAXC];
-    const int nchunk = p.C >> 3;
+    const int nchunk = p.C >> 2;
     const int gid = blockIdx.x * NT + threadIdx.x;
     const int chunk = gid % nchunk, tsk = gid / nchunk;
     const int seg = tsk % p.nseg, row = tsk / p.nseg;          // a thread walks `seglen` outputs of one row
     const bool active = row < p.N * p.OH;
-    float s[8], q[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     if (active) {
-        const int c = chunk * 8;
+        const int c = chunk * 4;
         const int n = row / p.OH, oh = row - n * p.OH;
-        f32x8 wt[9];
+        f32x4 wt[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = load_f32x8(p.w + (size_t)t * p.C + c);
+        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(p.w + (size_t)t * p.C + c);
         const bf16_t* rowp[3];
         bool rok[3];
 #pragma unroll
@@ -61,35 +60,31 @@ __global__ __launch_bounds__(NT) void dwconv_fwd_kernel(DwP p) {
             rok[kh] = ih >= 0 && ih < p.H;
             rowp[kh] = p.x + ((size_t)n * p.H + (rok[kh] ? ih : 0)) * p.W * p.C + c;
         }
-        auto load_col = [&](int iw, f32x8 (&col)[3]) {
+        auto load_col = [&](int iw, f32x4 (&col)[3]) {
             const bool cok = iw >= 0 && iw < p.W;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                f32x8 v;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = 0.f;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (cok && rok[kh])
-                    v = transform8(*reinterpret_cast<const bf16x8*>(rowp[kh] + (size_t)iw * p.C), p.in_scale, p.in_shift, c, p.act);
+                    v = transform4(*reinterpret_cast<const bf16x4*>(rowp[kh] + (size_t)iw * p.C), p.in_scale, p.in_shift, c, p.act);
                 col[kh] = v;
             }
         };
-        f32x8 w0[3], w1[3], w2[3];
+        f32x4 w0[3], w1[3], w2[3];
         const int ow_b = seg * p.seglen, ow_e = min(p.OW, ow_b + p.seglen);
         load_col(ow_b * S - p.pad, w0);
         load_col(ow_b * S + 1 - p.pad, w1);
         bf16_t* yrow = p.y + (size_t)row * p.OW * p.C + c;
         for (int ow = ow_b; ow < ow_e; ++ow) {
             load_col(ow * S + 2 - p.pad, w2);
-            f32x8 acc;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) acc += w0[kh] * wt[kh * 3] + w1[kh] * wt[kh * 3 + 1] + w2[kh] * wt[kh * 3 + 2];
-            bf16x8 o = f32_to_bf8(acc);
-            *reinterpret_cast<bf16x8*>(yrow + (size_t)ow * p.C) = o;
-            f32x8 rv = bf8_to_f32(o);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { s[i] += rv[i]; q[i] += rv[i] * rv[i]; }
+            bf16x4 o = f32_to_bf4(acc);
+            *reinterpret_cast<bf16x4*>(yrow + (size_t)ow * p.C) = o;
+            f32x4 rv = bf4_to_f32(o);
+            s += rv;
+            q += rv * rv;
             if (S == 1) {
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) { w0[kh] = w1[kh]; w1[kh] = w2[kh]; }
@@ -105,9 +100,9 @@ __global__ __launch_bounds__(NT) void dwconv_fwd_kernel(DwP p) {
         __syncthreads();
         if (active) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                atomicAdd(&smem[chunk * 8 + i], s[i]);
-                atomicAdd(&smem[p.C + chunk * 8 + i], q[i]);
+            for (int i = 0; i < 4; ++i) {
+                atomicAdd(&smem[chunk * 4 + i], s[i]);
+                atomicAdd(&smem[p.C + chunk * 4 + i], q[i]);
             }
         }
         __syncthreads();
@@ -160,6 +155,7 @@ struct DwWP {
     const float* in_scale;
     const float* in_shift;
     float* dw;            // [C][3][3] fp32
+    float* ws;            // optional [gridDim.x][9*C] partial buffer in dw layout
     int N, H, W, C, OH, OW, stride, pad, act, rows_per_thread, nseg, seglen;
     size_t P, ppb;
 };
@@ -167,23 +163,29 @@ struct DwWP {
 template <int S>
 __global__ __launch_bounds__(NT) void dwconv_bwd_weight_kernel(DwWP p) {
     extern __shared__ float dsm[];        // [9][C]
-    const int nchunk = p.C >> 3;
+    const int nchunk = p.C >> 2;
     for (int i = threadIdx.x; i < 9 * p.C; i += NT) dsm[i] = 0.f;
     __syncthreads();
-    // each thread walks ROWS_PER_THREAD consecutive output rows of its channel chunk (same row-walker as the forward)
+    // each thread walks a run of outputs in `rows_per_thread` consecutive rows of its 4-channel group
+    // capped grid (<= 540 workgroups, thread count a multiple of every channel-group count of MobileNetV2) with a
+    // task loop: a thread keeps its 4-channel group, so 36 register accumulators are published once per thread and
+    // the 9*C global atomics once per workgroup -- not thousands of workgroups hammering the same 9*C addresses
     const int gid = blockIdx.x * NT + threadIdx.x;
-    const int chunk = gid % nchunk, tsk = gid / nchunk;
-    const int seg = tsk % p.nseg, rgrp = tsk / p.nseg;
+    const int nthreads = gridDim.x * NT;
+    const int chunk = gid % nchunk;
     const int total_rows = p.N * p.OH;
-    const int r0 = rgrp * p.rows_per_thread;
-    if (r0 < total_rows) {
+    const long ntasks = (long)nchunk * p.nseg * ((total_rows + p.rows_per_thread - 1) / p.rows_per_thread);
+    const int c = chunk * 4;
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool any = false;
+    for (long task = gid; task < ntasks; task += nthreads) {
+        const int tsk = (int)(task / nchunk);
+        const int seg = tsk % p.nseg, rgrp = tsk / p.nseg;
+        const int r0 = rgrp * p.rows_per_thread;
         const int ow_b = seg * p.seglen, ow_e = min(p.OW, ow_b + p.seglen);
-        const int c = chunk * 8;
-        f32x8 acc[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[t][i] = 0.f;
+        any = true;
         const int r1 = min(total_rows, r0 + p.rows_per_thread);
         for (int row = r0; row < r1; ++row) {
             const int n = row / p.OH, oh = row - n * p.OH;
@@ -195,25 +197,23 @@ __global__ __launch_bounds__(NT) void dwconv_bwd_weight_kernel(DwWP p) {
                 rok[kh] = ih >= 0 && ih < p.H;
                 rowp[kh] = p.x + ((size_t)n * p.H + (rok[kh] ? ih : 0)) * p.W * p.C + c;
             }
-            auto load_col = [&](int iw, f32x8 (&col)[3]) {
+            auto load_col = [&](int iw, f32x4 (&col)[3]) {
                 const bool cok = iw >= 0 && iw < p.W;
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
-                    f32x8 v;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     if (cok && rok[kh])
-                        v = transform8(*reinterpret_cast<const bf16x8*>(rowp[kh] + (size_t)iw * p.C), p.in_scale, p.in_shift, c, p.act);
+                        v = transform4(*reinterpret_cast<const bf16x4*>(rowp[kh] + (size_t)iw * p.C), p.in_scale, p.in_shift, c, p.act);
                     col[kh] = v;
                 }
             };
-            f32x8 w0[3], w1[3], w2[3];
+            f32x4 w0[3], w1[3], w2[3];
             load_col(ow_b * S - p.pad, w0);
             load_col(ow_b * S + 1 - p.pad, w1);
             const bf16_t* grow = p.dz + (size_t)row * p.OW * p.C + c;
             for (int ow = ow_b; ow < ow_e; ++ow) {
                 load_col(ow * S + 2 - p.pad, w2);
-                f32x8 g = bf8_to_f32(*reinterpret_cast<const bf16x8*>(grow + (size_t)ow * p.C));
+                f32x4 g = bf4_to_f32(*reinterpret_cast<const bf16x4*>(grow + (size_t)ow * p.C));
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
                     acc[kh * 3] += g * w0[kh];
@@ -230,15 +230,18 @@ __global__ __launch_bounds__(NT) void dwconv_bwd_weight_kernel(DwWP p) {
                 }
             }
         }
+    }
+    if (any) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) atomicAdd(&dsm[t * p.C + c + i], acc[t][i]);
+            for (int i = 0; i < 4; ++i) atomicAdd(&dsm[t * p.C + c + i], acc[t][i]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 9 * p.C; i += NT) {
-        const int t = i / p.C, c = i - t * p.C;
-        if (dsm[i] != 0.f) atomicAdd(&p.dw[(size_t)c * 9 + t], dsm[i]);
+        const int t = i / p.C, cc = i - t * p.C;
+        if (p.ws) p.ws[(size_t)blockIdx.x * 9 * p.C + (size_t)cc * 9 + t] = dsm[i];
+        else if (dsm[i] != 0.f) atomicAdd(&p.dw[(size_t)cc * 9 + t], dsm[i]);
     }
 }
 
@@ -340,7 +343,7 @@ extern "C" int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, con
     p.ppb = 0;
     p.seglen = d->OW >= 32 ? 8 : (d->OW >= 8 ? 4 : d->OW);
     p.nseg = (d->OW + p.seglen - 1) / p.seglen;
-    const long threads = (long)d->N * d->OH * p.nseg * (p.C / 8);
+    const long threads = (long)d->N * d->OH * p.nseg * (p.C / 4);
     const int nblk = (int)((threads + NT - 1) / NT);
     if (d->stride == 1) hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3(nblk), dim3(NT), 0, stream, p);
     else hipLaunchKernelGGL(dwconv_fwd_kernel<2>, dim3(nblk), dim3(NT), 0, stream, p);
@@ -362,8 +365,28 @@ extern "C" int adamml_dwconv_bwd_data(const adamml_conv_desc_t* d, const void* d
     return adamml_check_launch("dwconv_bwd_data");
 }
 
+static int dw_wgrad_blocks(const adamml_conv_desc_t* d, int* seglen, int* nseg) {
+    const long rows = (long)d->N * d->OH, nchunk = d->Cin / 4;
+    *seglen = d->OW >= 32 ? 16 : (d->OW >= 8 ? 8 : d->OW);
+    *nseg = (d->OW + *seglen - 1) / *seglen;
+    const long threads = rows * *nseg * nchunk;
+    long nb = (threads + NT - 1) / NT;
+    // NT * nblk must be a multiple of nchunk (a thread keeps its channel group across tasks): 45 | nblk covers every
+    // C/4 in {8,12,24,36,48,96,144,240}; otherwise fall back to a multiple of nchunk
+    int nblk = nb >= 540 ? 540 : (int)((nb + 44) / 45 * 45);
+    if ((NT * (long)nblk) % nchunk != 0) nblk = (int)((nblk + nchunk - 1) / nchunk * nchunk);
+    return nblk;
+}
+
+extern "C" size_t adamml_dwconv_bwd_weight_workspace(const adamml_conv_desc_t* d) {
+    if (!d || d->Cin % 8) return 0;
+    int a, b;
+    return (size_t)dw_wgrad_blocks(d, &a, &b) * 9 * d->Cin * sizeof(float);
+}
+
 extern "C" int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
-                                        const float* in_shift, float* dw, hipStream_t stream) {
+                                        const float* in_shift, float* dw, void* workspace, size_t workspace_bytes,
+                                        hipStream_t stream) {
     int rc = check_dw(d, "dwconv_bwd_weight");
     if (rc) return rc;
     DwWP p;
@@ -371,19 +394,17 @@ extern "C" int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void*
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.pad = d->pad; p.act = d->act;
     p.P = (size_t)d->N * d->OH * d->OW;
     if (!p.P) return ADAMML_OK;
-    // rows per thread: keep >= ~8 waves per CU in flight while amortising the 72-accumulator LDS reduction
-    const long rows = (long)d->N * d->OH, nchunk = p.C / 8;
-    p.seglen = d->OW >= 32 ? 16 : (d->OW >= 8 ? 8 : d->OW);
-    p.nseg = (d->OW + p.seglen - 1) / p.seglen;
-    int rpt = (int)(rows * p.nseg * nchunk / (256L * 4096L));
-    if (rpt < 1) rpt = 1;
-    if (rpt > 8) rpt = 8;
-    p.rows_per_thread = rpt;
+    p.rows_per_thread = 1;
     p.ppb = 0;
-    const long threads = ((rows + rpt - 1) / rpt) * p.nseg * nchunk;
-    const int nblk = (int)((threads + NT - 1) / NT);
+    const int nblk = dw_wgrad_blocks(d, &p.seglen, &p.nseg);
+    p.ws = (workspace && workspace_bytes >= (size_t)nblk * 9 * p.C * sizeof(float)) ? (float*)workspace : nullptr;
     if (d->stride == 1) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<1>, dim3(nblk), dim3(NT), 9 * p.C * sizeof(float), stream, p);
     else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<2>, dim3(nblk), dim3(NT), 9 * p.C * sizeof(float), stream, p);
+    if (p.ws) {
+        rc = adamml_check_launch("dwconv_bwd_weight");
+        if (rc) return rc;
+        return adamml_launch_split_reduce(p.ws, dw, (size_t)9 * p.C, nblk, stream);
+    }
     return adamml_check_launch("dwconv_bwd_weight");
 }
 

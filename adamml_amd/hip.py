@@ -31,7 +31,7 @@ SIGNATURES = {
     "adamml_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "adamml_dwconv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "adamml_dwconv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
-    "adamml_dwconv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _P],
+    "adamml_dwconv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _P, _Z, _P],
     "adamml_stats_collapse": [_P, _I, _P],
     "adamml_bn_finalize": [_P, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
     "adamml_bn_eval_affine": [_P, _P, _P, _P, _F, _P, _P, _I, _P],
@@ -70,6 +70,8 @@ def load():
         fn.restype = c_int
     lib.adamml_conv_bwd_weight_workspace.argtypes = [_DESC, _I]
     lib.adamml_conv_bwd_weight_workspace.restype = c_size_t
+    lib.adamml_dwconv_bwd_weight_workspace.argtypes = [_DESC]
+    lib.adamml_dwconv_bwd_weight_workspace.restype = c_size_t
     lib.adamml_version.restype = c_int
     lib.adamml_last_error_string.restype = c_char_p
     _lib = lib
@@ -126,9 +128,12 @@ def call(name, *args):
 _wgrad_ws = {}
 
 
-def wgrad_workspace(desc, cin_true, device):
+def wgrad_workspace(desc, cin_true, device, depthwise=False):
     """Persistent per-device scratch for the split weight-gradient partial tiles (grown on demand)."""
-    need = load().adamml_conv_bwd_weight_workspace(ctypes.byref(desc), cin_true)
+    if depthwise:
+        need = load().adamml_dwconv_bwd_weight_workspace(ctypes.byref(desc))
+    else:
+        need = load().adamml_conv_bwd_weight_workspace(ctypes.byref(desc), cin_true)
     buf = _wgrad_ws.get(device)
     if buf is None or buf.numel() * 4 < need:
         buf = torch.empty(max(need // 4 + 1, 1 << 20), dtype=torch.float32, device=device)

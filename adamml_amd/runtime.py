@@ -246,7 +246,9 @@ def conv_bn(rt, x, cs, bn, act):
             if cs.weight.requires_grad:
                 hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b)
                 if cs.depthwise:
-                    call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(cs.weight.grad))
+                    ws = hip.wgrad_workspace(d, 0, dz.device, depthwise=True)
+                    call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(cs.weight.grad),
+                         ptr(ws), ws.numel() * 4)
                 else:
                     ws = hip.wgrad_workspace(d, cs.cin_true, dz.device)
                     call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift),

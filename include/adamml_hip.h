@@ -68,8 +68,9 @@ int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, const float* w
                       const float* in_shift, void* y, double* stats, hipStream_t stream);
 int adamml_dwconv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const float* w_tapmajor, void* dx,
                            int accumulate, hipStream_t stream);
+size_t adamml_dwconv_bwd_weight_workspace(const adamml_conv_desc_t* d);
 int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
-                             const float* in_shift, float* dw, hipStream_t stream);
+                             const float* in_shift, float* dw, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 /* nn.BatchNorm2d: train-mode statistics -> (scale, shift) consumed lazily by the next op, saved mean / invstd,
  * running-stat momentum update (unbiased variance).  count = elements per channel (global count under SyncBN). */

@@ -1,0 +1,156 @@
+"""CPU-only checks (no GPU, no reference): the C-ABI library loads and exports every declared symbol, the model
+registry reproduces the reference state_dict contract, the MAC counts of the stage plan match the constants in the
+reference (utils/utils.py:512-523), and the product path refuses to run without a GPU."""
+import ctypes
+import gzip
+import json
+import os
+import re
+
+import pytest
+import torch
+
+import __graft_entry__ as ge
+from tests.golden_cases import CASES, CH
+from tests.oracle_harness import manifest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    ge.build()
+    return ge.LIB
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "adamml_hip.h")).read()
+    declared = set(re.findall(r"\b(adamml_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 28
+    lib = ctypes.CDLL(built)
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), "missing export " + sym
+    from adamml_amd import hip
+    hip.load()
+    assert set(hip.SIGNATURES) <= declared
+    assert lib.adamml_version() >= 100
+
+
+def _build(c):
+    from adamml_amd import adamml
+    mod = c["modality"]
+    return adamml(groups=c["groups"], modality=mod, input_channels=[CH[m] for m in mod], num_segments=c["S"], rng_policy=False,
+                  rng_threshold=0.5, causality_modeling=c.get("causality", "lstm"), num_classes=31, depth=50,
+                  without_t_stride=False, dropout=0.5, pooling_method="max", fusion_point="logits", unimodality_pretrained=[],
+                  learnable_lf_weights=True)
+
+
+@pytest.mark.parametrize("name", ["adamml_rgb_sound", "adamml_rgb_sound_nolstm", "adamml_rgb_flow_rgbdiff", "adamml_4mod"])
+def test_state_dict_contract_matches_reference(name):
+    c = CASES[name]
+    sd = _build(c).state_dict()
+    man = manifest(c)
+    assert list(sd.keys()) == list(man.keys())
+    for k in man:
+        assert tuple(sd[k].shape) == tuple(man[k].shape) and sd[k].dtype == man[k].dtype, k
+    if name == "adamml_rgb_sound":
+        assert len(sd) == 1271            # 644 params + 627 buffers
+
+
+def test_unimodal_registry_and_surface():
+    import argparse
+    from adamml_amd import build_model, MODEL_TABLE
+    assert set(MODEL_TABLE) == {"adamml", "resnet", "sound_mobilenet_v2"}
+    ns = argparse.Namespace(backbone_net="adamml", groups=8, modality=["rgb", "sound"], input_channels=[3, 1], num_segments=5,
+                            rng_policy=False, rng_threshold=0.5, causality_modeling="lstm", num_classes=31, depth=50,
+                            without_t_stride=False, dropout=0.5, pooling_method="max", fusion_point="logits",
+                            unimodality_pretrained=[], learnable_lf_weights=True, dataset="kinetics-sounds", dense_sampling=False,
+                            frames_per_group=1, lr_scheduler="multisteps", sync_bn=True, batch_size=72, prefix="", epochs=20,
+                            extra_flag_ignored=123)
+    model, arch = build_model(ns)
+    assert arch == ("kinetics-sounds-rgb-sound-adamml-j_mobilenet_v2-lstm-joint_resnet-50_mobilenet_v2-logits-llf-ts-max-f8"
+                    "-multisteps-syncbn-bs72-e20")
+    assert model.mean("rgb") == [0.485, 0.456, 0.406] and model.mean("sound") == [0.5]
+    assert model.policy_net.temperature == 5.0
+    model.decay_temperature()
+    assert abs(model.policy_net.temperature - 5.0 * 0.965) < 1e-9
+    model.freeze_policy_net()
+    assert not model.update_policy_net and not any(p.requires_grad for p in model.policy_net.parameters())
+    model.unfreeze_policy_net()
+    model.freeze_main_net()
+    assert not model.update_main_net and all(p.requires_grad for p in model.policy_net.parameters())
+    n_pol = sum(p.numel() for p in model.policy_net.parameters())
+    n_main = sum(p.numel() for p in model.main_net.parameters())
+    assert round((n_pol + n_main) / 1e6, 2) == 42.09       # 42.09 M parameters
+
+
+def test_mac_counts_match_reference_constants():
+    """utils/utils.py:512-523 hard-codes per-segment MAC counts; the conv/linear layers of our containers reproduce them."""
+    from adamml_amd.resnet import ResNet
+    from adamml_amd.sound_mobilenet_v2 import MobileNetV2 as SoundNet
+    from adamml_amd.policy_net import MobileNetV2 as PolicyNet
+
+    def macs_resnet(cin):
+        net = ResNet(50, 8, 31, input_channels=cin)
+        t, h = 8, 224
+        total = 8 * (112 * 112) * 64 * 49 * cin
+        h = 56
+        inpl = 64
+        for li, (planes, layer) in enumerate(zip((64, 128, 256, 512), (net.layer1, net.layer2, net.layer3, net.layer4))):
+            for b in layer:
+                s = b.stride
+                total += t * h * h * inpl * planes
+                ho = h // s
+                total += t * ho * ho * planes * planes * 9
+                total += t * ho * ho * planes * planes * 4
+                if b.downsample is not None:
+                    total += t * ho * ho * inpl * planes * 4
+                h = ho
+                inpl = planes * 4
+            if li < 3:
+                t = max(1, t // 2)
+        return total                      # the reference constants count convolutions only (no FC)
+
+    assert macs_resnet(3) == 14135984128
+    assert macs_resnet(10) == 16338911232
+
+    def macs_mbv2(net, h, t, cin, plans, last_c, policy):
+        total = t * (h // 2) ** 2 * 32 * 9 * cin
+        h //= 2
+        for bp in plans:
+            if bp.tpool:
+                t = t // 2
+            if bp.pw is not None:
+                total += t * h * h * bp.pw[0].cin_true * bp.pw[0].cout
+            s = bp.dw[0].stride
+            h = (h + 2 - 3) // s + 1
+            total += t * h * h * bp.dw[0].cout * 9
+            total += t * h * h * bp.pwl[0].cin_true * bp.pwl[0].cout
+        total += t * h * h * last_c[0] * last_c[1]
+        return total
+
+    snd = SoundNet(num_classes=31, input_channels=1)
+    assert macs_mbv2(snd, 256, 1, 1, snd._plans, (320, 1280), False) == 381739008
+    pol = PolicyNet(num_frames=4, input_channels=3)
+    assert macs_mbv2(pol, 160, 4, 3, pol._plans, (320, 1280), True) == 375446400
+    # (the reference's rgbdiff constant 909 283 200 is not reproduced by its own 4-frame x 15-channel policy net --
+    #  that architecture gives 463 920 000 -- so it is not asserted)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from adamml_amd.resnet import resnet
+    m = resnet(depth=50, num_classes=31, without_t_stride=False, groups=8, dropout=0.5, pooling_method="max", input_channels=3,
+               imagenet_pretrained=False)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(torch.zeros(1, 24, 64, 64))
+
+
+def test_unsupported_options_raise_like_the_reference():
+    from adamml_amd.joint_resnet_mobilenetv2 import JointResNetMobileNetV2
+    with pytest.raises(ValueError, match="only support logits mode"):
+        JointResNetMobileNetV2(50, 8, ["rgb"], 31, input_channels=[3], fusion_point="fc2")
+    from adamml_amd.runtime import temporal_pool, NetRT, Lazy
+    with pytest.raises(ValueError, match="only support avg or max"):
+        temporal_pool(NetRT(), Lazy(torch.zeros(8, 1, 1, 8, dtype=torch.bfloat16)), 8, "median")

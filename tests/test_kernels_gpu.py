@@ -159,8 +159,12 @@ def test_dwconv(case):
     call("adamml_dwconv_bwd_data", byref(d), ptr(dz), ptr(wp), ptr(dx), 0)
     close(nchw(dx), xr.grad, what="dw dgrad")
     dw = torch.zeros_like(w)
-    call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(xh), ptr(scale), ptr(shift), ptr(dw))
-    close(dw, wr.grad, what="dw wgrad")
+    call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(xh), ptr(scale), ptr(shift), ptr(dw), None, 0)
+    close(dw, wr.grad, what="dw wgrad (atomic path)")
+    ws = hip.wgrad_workspace(d, 0, dz.device, depthwise=True)
+    dw2 = torch.ones_like(w)
+    call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(xh), ptr(scale), ptr(shift), ptr(dw2), ptr(ws), ws.numel() * 4)
+    close(dw2 - 1, wr.grad, what="dw wgrad (workspace path)")
 
 
 @pytest.mark.parametrize("C,P,act", [(64, 5000, 1), (24, 777, 0), (960, 300, 2), (2048, 98, 1)])
