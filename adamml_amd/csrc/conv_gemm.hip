@@ -26,6 +26,10 @@ struct ConvP {
     double* stats;
     int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, up, up_shift, act, accumulate;
     int P, K, cin_shift, n_ptiles, n_ctiles;
+    // data-gradient epilogue fused with the BatchNorm backward reduction of the tensor the gradient flows into
+    const bf16_t* bn_z;          // raw conv output that produced the consumer's input (same shape as y), or null
+    const float* bn_vec;         // [4][Cout']: scale, shift, mean, invstd of that BatchNorm
+    int bn_act;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -232,7 +236,27 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
     f32x8 esum, esq;
 #pragma unroll
     for (int i = 0; i < 8; ++i) esum[i] = esq[i] = 0.f;
-    if (eco < p.Cout) {
+    if (eco < p.Cout && p.bn_z) {
+        // data gradient w.r.t. a lazily normalised tensor: apply the activation mask here, store g' and accumulate
+        // sum(g') and sum(g' * zhat) -- the BatchNorm-backward reduction pass never has to re-read g and z
+        const f32x8 sc = load_f32x8(p.bn_vec + eco), sh = load_f32x8(p.bn_vec + p.Cout + eco);
+        const f32x8 mu = load_f32x8(p.bn_vec + 2 * p.Cout + eco), is = load_f32x8(p.bn_vec + 3 * p.Cout + eco);
+#pragma unroll
+        for (int r = erow0; r < BP; r += RSTEP) {
+            const int pp = p0 + r;
+            if (pp >= p.P) break;
+            f32x8 f = bf8_to_f32(*reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16));
+            const f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(p.bn_z + (size_t)pp * p.Cout + eco));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] *= act_mask(fmaf(zv[i], sc[i], sh[i]), p.bn_act);
+            const bf16x8 v = f32_to_bf8(f);
+            *reinterpret_cast<bf16x8*>(p.y + (size_t)pp * p.Cout + eco) = v;
+            f = bf8_to_f32(v);
+            esum += f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) esq[i] += f[i] * (zv[i] - mu[i]) * is[i];
+        }
+    } else if (eco < p.Cout) {
 #pragma unroll
         for (int r = erow0; r < BP; r += RSTEP) {
             const int pp = p0 + r;
@@ -666,13 +690,15 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
-extern "C" int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
-                               const float* in_shift, void* y, double* stats, hipStream_t stream) {
+static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
+                       const float* in_shift, void* y, double* stats, const void* bn_z, const float* bn_vec, int bn_act,
+                       hipStream_t stream) {
     if (!d || !x || !w_packed || !y) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: null argument");
     if (d->Cin % 8 || d->Cout % 8) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: channels must be multiples of 8 (Cin=%d Cout=%d)", d->Cin, d->Cout);
     ConvP p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.in_scale = in_scale; p.in_shift = in_shift;
     p.y = (bf16_t*)y; p.stats = stats;
+    p.bn_z = (const bf16_t*)bn_z; p.bn_vec = bn_vec; p.bn_act = bn_act;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.up = d->up < 1 ? 1 : d->up;
     p.up_shift = ilog2_exact(p.up);
@@ -706,6 +732,22 @@ extern "C" int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const
     }
 #undef LAUNCH_CONV
     return adamml_check_launch("conv_fwd");
+}
+
+extern "C" int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
+                               const float* in_shift, void* y, double* stats, hipStream_t stream) {
+    return conv_launch(d, x, w_packed, in_scale, in_shift, y, stats, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int adamml_conv_bwd_data_bn(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
+                                       const void* z_in, const float* bn_vec, int act, double* sums, hipStream_t stream) {
+    if (!d || !z_in || !bn_vec || !sums) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_bn: null argument");
+    adamml_conv_desc_t g = *d;
+    g.N = d->N; g.H = d->OH; g.W = d->OW; g.Cin = d->Cout;
+    g.OH = d->H; g.OW = d->W; g.Cout = d->Cin;
+    g.stride = 1; g.up = d->stride; g.pad = d->KH - 1 - d->pad;
+    g.act = ACT_NONE; g.accumulate = 0;
+    return conv_launch(&g, dz, w_dgrad_packed, nullptr, nullptr, dx, sums, z_in, bn_vec, act, stream);
 }
 
 extern "C" int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,

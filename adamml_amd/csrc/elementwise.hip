@@ -162,6 +162,57 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const bf16_t* g, cons
     block_channel_publish(s, q, m, smem, C, sums);
 }
 
+// Residual-add backward (models/resnet.py:110-111 / sound_mobilenet_v2.py:67): g2 = g_out * act'(out), plus the
+// BatchNorm-backward sums of the one or two lazily normalised operands of the add (bn3 and, in the first block of a
+// stage, the downsample BN) in the same pass over g_out / out.
+__global__ __launch_bounds__(NT) void residual_bwd_kernel(const bf16_t* g_out, const bf16_t* out, int act, bf16_t* g2,
+                                                          const bf16_t* za, const float* veca, double* sumsa,
+                                                          const bf16_t* zb, const float* vecb, double* sumsb,
+                                                          size_t P, int C, size_t ppb) {
+    __shared__ float smem[2 * MAXC];
+    ChanMap m(C, threadIdx.x);
+    float sa[8], qa[8], sb[8], qb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sa[i] = qa[i] = sb[i] = qb[i] = 0.f;
+    const size_t pb = (size_t)blockIdx.x * ppb;
+    const size_t pe = pb + ppb < P ? pb + ppb : P;
+    if (m.active) {
+        const int c = m.chunk * 8;
+        f32x8 mua, isa, mub, isb;
+        if (za) { mua = load_f32x8(veca + 2 * C + c); isa = load_f32x8(veca + 3 * C + c); }
+        if (zb) { mub = load_f32x8(vecb + 2 * C + c); isb = load_f32x8(vecb + 3 * C + c); }
+        for (size_t p = pb + m.rslot; p < pe; p += m.rows_per_pass) {
+            f32x8 gv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(g_out + p * C + c));
+            const f32x8 ov = bf8_to_f32(*reinterpret_cast<const bf16x8*>(out + p * C + c));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float mk = 1.f;
+                if (act == ACT_RELU) mk = ov[i] > 0.f ? 1.f : 0.f;
+                else if (act == ACT_RELU6) mk = (ov[i] > 0.f && ov[i] < 6.f) ? 1.f : 0.f;
+                gv[i] *= mk;
+            }
+            const bf16x8 gb = f32_to_bf8(gv);
+            if (g2 != g_out || act != ACT_NONE) *reinterpret_cast<bf16x8*>(g2 + p * C + c) = gb;
+            gv = bf8_to_f32(gb);
+            if (za) {
+                const f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(za + p * C + c));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { sa[i] += gv[i]; qa[i] += gv[i] * (zv[i] - mua[i]) * isa[i]; }
+            }
+            if (zb) {
+                const f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(zb + p * C + c));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { sb[i] += gv[i]; qb[i] += gv[i] * (zv[i] - mub[i]) * isb[i]; }
+            }
+        }
+    }
+    if (za) block_channel_publish(sa, qa, m, smem, C, sumsa);
+    if (zb) {
+        __syncthreads();
+        block_channel_publish(sb, qb, m, smem, C, sumsb);
+    }
+}
+
 __global__ void bn_bwd_finalize_kernel(const double* sums, int nslots, double count, const float* gamma, const float* invstd,
                                        float* dgamma, float* dbeta, float* coef, int C) {
     const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), k = threadIdx.x & 31;
@@ -523,6 +574,21 @@ extern "C" int adamml_bn_bwd_reduce(const void* g, const void* z, const float* s
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)nblk), dim3(NT), 0, stream, (const bf16_t*)g, (const bf16_t*)z, scale,
                        shift, mean, invstd, act, sums, P, C, ppb);
     return adamml_check_launch("bn_bwd_reduce");
+}
+
+extern "C" int adamml_residual_bwd(const void* g_out, const void* out, int act, void* g2, const void* za, const float* veca,
+                                   double* sumsa, const void* zb, const float* vecb, double* sumsb, size_t P, int C,
+                                   hipStream_t stream) {
+    CHECK_C(C, "residual_bwd");
+    if (!P) return ADAMML_OK;
+    if ((za && (!veca || !sumsa)) || (zb && (!vecb || !sumsb))) return adamml_set_error(ADAMML_EINVAL, "residual_bwd: null BN operands");
+    const int rows = NT / (C / 8) > 0 ? NT / (C / 8) : 1;
+    size_t ppb = (size_t)rows * 16;
+    size_t nblk = (P + ppb - 1) / ppb;
+    if (nblk > 2048) { ppb = ((P + 2047) / 2048 + rows - 1) / rows * rows; nblk = (P + ppb - 1) / ppb; }
+    hipLaunchKernelGGL(residual_bwd_kernel, dim3((unsigned)nblk), dim3(NT), 0, stream, (const bf16_t*)g_out, (const bf16_t*)out, act,
+                       (bf16_t*)g2, (const bf16_t*)za, veca, sumsa, (const bf16_t*)zb, vecb, sumsb, P, C, ppb);
+    return adamml_check_launch("residual_bwd");
 }
 
 extern "C" int adamml_bn_bwd_finalize(const double* sums, int nslots, double count, const float* gamma, const float* invstd, float* dgamma,

@@ -20,6 +20,6 @@ def run_blocks(rt, h, plans):
         if bp.pw is not None:
             y = conv_bn(rt, y, bp.pw[0], bp.pw[1], ACT_RELU6)
         y = conv_bn(rt, y, bp.dw[0], bp.dw[1], ACT_RELU6)
-        y = conv_bn(rt, y, bp.pwl[0], bp.pwl[1], ACT_NONE)
+        y = conv_bn(rt, y, bp.pwl[0], bp.pwl[1], ACT_NONE, sole_consumer=True)      # the dw output feeds only this conv
         h = add_act(rt, y, x, ACT_NONE) if bp.residual else y
     return h

@@ -95,10 +95,10 @@ class ResNet(HipBackbone, MeanStdMixin):
         for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
             for b in layer:
                 o = conv_bn(rt, h, b._cs1, b.bn1, ACT_RELU)
-                o = conv_bn(rt, o, b._cs2, b.bn2, ACT_RELU)
-                o = conv_bn(rt, o, b._cs3, b.bn3, ACT_NONE)
+                o = conv_bn(rt, o, b._cs2, b.bn2, ACT_RELU, sole_consumer=True)
+                o = conv_bn(rt, o, b._cs3, b.bn3, ACT_NONE, sole_consumer=True)
                 idn = conv_bn(rt, h, b._csd, b.downsample[1], ACT_NONE) if b._csd is not None else h
-                h = add_act(rt, o, idn, ACT_RELU)
+                h = add_act(rt, o, idn, ACT_RELU, idn_sole=b._csd is not None)
             if li < 3 and not self.without_t_stride:
                 h = temporal_pool(rt, h, frames, self.pooling_method)
                 frames = max(1, frames // 2)

@@ -24,12 +24,15 @@ def pad8(c):
 
 class Lazy:
     """Activation tensor [N,H,W,C] bf16 whose value is act(scale*data + shift) (scale None -> data)."""
-    __slots__ = ("data", "scale", "shift", "act", "grad", "requires_grad")
+    __slots__ = ("data", "scale", "shift", "act", "grad", "requires_grad", "vec", "src", "pre_sums")
 
     def __init__(self, data, scale=None, shift=None, act=ACT_NONE, requires_grad=True):
         self.data, self.scale, self.shift, self.act = data, scale, shift, act
         self.grad = None            # gradient w.r.t. the ACTIVATED value, bf16, same shape
         self.requires_grad = requires_grad
+        self.vec = None             # train-mode BatchNorm vectors [4,C] (scale, shift, mean, invstd) of a lazy tensor
+        self.src = None             # lazy tensor this plain tensor is the materialisation of
+        self.pre_sums = None        # BatchNorm-backward sums already accumulated by the producer of .grad
 
     @property
     def shape(self):
@@ -184,8 +187,11 @@ def _bn_backward(rt, out, y, vec, bn, act, count):
     out.grad = None
     n, oh, ow, C = y.shape
     P = n * oh * ow
-    sums = rt.bwd_arena.take(2 * C * STAT_SLOTS)
-    call("adamml_bn_bwd_reduce", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), act, ptr(sums), P, C)
+    if out.pre_sums is not None:            # reduction fused into the kernel that produced g (already activation-masked)
+        sums, out.pre_sums = out.pre_sums, None
+    else:
+        sums = rt.bwd_arena.take(2 * C * STAT_SLOTS)
+        call("adamml_bn_bwd_reduce", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), act, ptr(sums), P, C)
     nslots = rt.sync.reduce(sums, C)
     coef = torch.empty(3, C, dtype=torch.float32, device=y.device)
     train_bn = bn.weight.requires_grad
@@ -203,6 +209,7 @@ def materialize(rt, x):
     out_t = torch.empty_like(x.data)
     call("adamml_bn_act_add", ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, None, None, None, ptr(out_t), n * h * w, C)
     a = Lazy(out_t, requires_grad=x.requires_grad)
+    a.src = x
     if rt.tape.need_grad:
         def bwd():
             g, a.grad = a.grad, None
@@ -212,8 +219,10 @@ def materialize(rt, x):
     return a
 
 
-def conv_bn(rt, x, cs, bn, act):
-    """conv (dense or depthwise) + train/eval BatchNorm + activation, as one lazy tensor."""
+def conv_bn(rt, x, cs, bn, act, sole_consumer=False):
+    """conv (dense or depthwise) + train/eval BatchNorm + activation, as one lazy tensor.
+    sole_consumer=True promises that this conv is the ONLY consumer of x: its data-gradient epilogue may then apply
+    x's activation mask and accumulate x's BatchNorm-backward sums (no separate reduction pass over g and z)."""
     if x.scale is not None and not cs.depthwise and cs.kh * cs.kw > 1:
         x = materialize(rt, x)
     d = cs.desc(x.shape, x.act)
@@ -238,6 +247,8 @@ def conv_bn(rt, x, cs, bn, act):
         call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), None)
         vec = _bn_eval_vectors(bn, C, dev)
     out = Lazy(y, vec[0], vec[1], act)
+    if rt.training:
+        out.vec = vec
     if rt.tape.need_grad:
         def bwd():
             if out.grad is None:
@@ -259,8 +270,15 @@ def conv_bn(rt, x, cs, bn, act):
                     x.grad = torch.empty_like(x.data)
                     acc = 0
                 hip.next_meta = (2 * macs, in_b * (1 + acc) + out_b + w_b)
+                tgt = x.src if x.src is not None else x
                 if cs.depthwise:
                     call("adamml_dwconv_bwd_data", byref(d), ptr(dz), ptr(cs.w_fwd), ptr(x.grad), acc)
+                elif sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None:
+                    sums = rt.bwd_arena.take(2 * d.Cin * STAT_SLOTS)
+                    hip.next_meta = (2 * macs, 2 * in_b + out_b + w_b)
+                    call("adamml_conv_bwd_data_bn", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), ptr(tgt.data), ptr(tgt.vec),
+                         tgt.act, ptr(sums))
+                    tgt.pre_sums = sums
                 else:
                     call("adamml_conv_bwd_data", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc)
         rt.tape.record(bwd)
@@ -277,8 +295,9 @@ def _accum_grad(t, g):
         call("adamml_bn_act_add", ptr(t.grad), None, None, ACT_NONE, ptr(g), None, None, ptr(t.grad), n, g.shape[-1])
 
 
-def add_act(rt, z, idn, act):
-    """out = act(value(z) + value(idn)); idn may be None (pure materialisation)."""
+def add_act(rt, z, idn, act, idn_sole=False):
+    """out = act(value(z) + value(idn)); idn may be None (pure materialisation).  z must have no other consumer;
+    idn_sole=True promises the same for a lazily normalised idn (the downsample branch of a bottleneck)."""
     n, h, w, C = z.shape
     if z.act != ACT_NONE or (idn is not None and idn.act != ACT_NONE):
         raise RuntimeError("add_act: operands must be linear (no pending activation)")
@@ -292,11 +311,21 @@ def add_act(rt, z, idn, act):
             out.grad = None
             if g is None:
                 return
-            if act != ACT_NONE:
-                g2 = torch.empty_like(g)
+            fa = z.requires_grad and z.vec is not None and z.grad is None
+            fb = idn is not None and idn_sole and idn.requires_grad and idn.vec is not None and idn.grad is None
+            g2 = torch.empty_like(g) if act != ACT_NONE else g
+            if fa or fb:
+                sa = rt.bwd_arena.take(2 * C * STAT_SLOTS) if fa else None
+                sb = rt.bwd_arena.take(2 * C * STAT_SLOTS) if fb else None
+                call("adamml_residual_bwd", ptr(g), ptr(out_t), act, ptr(g2), ptr(z.data) if fa else None,
+                     ptr(z.vec) if fa else None, ptr(sa), ptr(idn.data) if fb else None, ptr(idn.vec) if fb else None, ptr(sb),
+                     n * h * w, C)
+                if fa:
+                    z.pre_sums = sa
+                if fb:
+                    idn.pre_sums = sb
+            elif act != ACT_NONE:
                 call("adamml_act_bwd_from_output", ptr(g), ptr(out_t), act, ptr(g2), g.numel())
-            else:
-                g2 = g
             _accum_grad(z, g2)
             if idn is not None:
                 _accum_grad(idn, g2)

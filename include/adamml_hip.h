@@ -50,6 +50,11 @@ int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const void* w_pa
 /* autograd of the above w.r.t. its input (d = forward descriptor; w packed with mode 1) */
 int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
                          int accumulate, hipStream_t stream);
+/* same, when dx is the gradient w.r.t. a lazily normalised tensor act(BN(z_in)) with a single consumer: the epilogue
+ * multiplies by act'(scale*z_in+shift), stores g' and accumulates the BatchNorm-backward sums (sum g', sum g'*zhat) into
+ * sums[ADAMML_STAT_SLOTS][2*Cin]; bn_vec = [4][Cin] (scale, shift, mean, invstd).  adamml_bn_bwd_reduce is then skipped. */
+int adamml_conv_bwd_data_bn(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx, const void* z_in,
+                            const float* bn_vec, int act, double* sums, hipStream_t stream);
 /* autograd w.r.t. the weight: dw (fp32 OIHW, cin_true input channels) += dz^T * im2col(act(x)).  The pixel axis is
  * split over workgroups; with a workspace of adamml_conv_bwd_weight_workspace() bytes the partial tiles are written
  * with plain stores and summed by a second launch (device-scope fp32 atomics run at ~20 G/s on MI355X and would
@@ -88,6 +93,10 @@ int adamml_bn_act_add(const void* z, const float* scale, const float* shift, int
                       const float* id_scale, const float* id_shift, void* out, size_t P, int C, hipStream_t stream);
 /* g = g_out * act'(out) evaluated from the stored block output */
 int adamml_act_bwd_from_output(const void* g_out, const void* out, int act, void* g, size_t n, hipStream_t stream);
+/* residual-add backward: g2 = g_out * act'(out) fused with the BatchNorm-backward sums of up to two lazily normalised
+ * operands of the add (za/veca/sumsa and zb/vecb/sumsb; vec = [4][C]); any of the two may be NULL */
+int adamml_residual_bwd(const void* g_out, const void* out, int act, void* g2, const void* za, const float* veca, double* sumsa,
+                        const void* zb, const float* vecb, double* sumsb, size_t P, int C, hipStream_t stream);
 /* BatchNorm backward: per-channel sums of g' = g*act'(scale*z+shift) and g'*zhat (sums fp64 [ADAMML_STAT_SLOTS][2C], caller zeroes) */
 int adamml_bn_bwd_reduce(const void* g, const void* z, const float* scale, const float* shift, const float* mean,
                          const float* invstd, int act, double* sums, size_t P, int C, hipStream_t stream);
