@@ -24,17 +24,15 @@ int adamml_check_launch(const char* what);
 // dw[i] += sum_{s<nsplit} ws[s*n + i]   (conv_gemm.hip)
 int adamml_launch_split_reduce(const float* ws, float* dw, size_t n, int nsplit, hipStream_t stream);
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == ACT_RELU) return fmaxf(v, 0.f);
-    if (act == ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
-    return v;
-}
+// Activations as a clamp to [lo, hi] with wave-uniform bounds (none: [-inf, inf], ReLU: [0, inf], ReLU6: [0, 6]):
+// branch-free per element (the runtime `act` is folded into two scalars once per call site).
+__device__ __forceinline__ float act_lo(int act) { return act == ACT_NONE ? -INFINITY : 0.f; }
+__device__ __forceinline__ float act_hi(int act) { return act == ACT_RELU6 ? 6.f : INFINITY; }
+__device__ __forceinline__ float clamp_act(float v, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(v, lo), hi); }
+__device__ __forceinline__ float apply_act(float v, int act) { return clamp_act(v, act_lo(act), act_hi(act)); }
 // derivative mask of the activation evaluated at pre-activation value v
-__device__ __forceinline__ float act_mask(float v, int act) {
-    if (act == ACT_RELU) return v > 0.f ? 1.f : 0.f;
-    if (act == ACT_RELU6) return (v > 0.f && v < 6.f) ? 1.f : 0.f;
-    return 1.f;
-}
+__device__ __forceinline__ float mask_act(float v, float lo, float hi) { return (v > lo && v < hi) ? 1.f : 0.f; }
+__device__ __forceinline__ float act_mask(float v, int act) { return mask_act(v, act_lo(act), act_hi(act)); }
 
 __device__ __forceinline__ f32x8 bf8_to_f32(bf16x8 v) { return __builtin_convertvector(v, f32x8); }
 __device__ __forceinline__ bf16x8 f32_to_bf8(f32x8 v) { return __builtin_convertvector(v, bf16x8); }
@@ -55,8 +53,9 @@ __device__ __forceinline__ f32x8 transform8(bf16x8 raw, const float* scale, cons
     f32x8 v = bf8_to_f32(raw);
     if (scale) {
         f32x8 s = load_f32x8(scale + c), t = load_f32x8(shift + c);
+        const float lo = act_lo(act), hi = act_hi(act);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = apply_act(fmaf(v[i], s[i], t[i]), act);
+        for (int i = 0; i < 8; ++i) v[i] = clamp_act(fmaf(v[i], s[i], t[i]), lo, hi);
     }
     return v;
 }
@@ -65,8 +64,9 @@ __device__ __forceinline__ f32x4 transform4(bf16x4 raw, const float* scale, cons
     f32x4 v = bf4_to_f32(raw);
     if (scale) {
         f32x4 s = *reinterpret_cast<const f32x4*>(scale + c), t = *reinterpret_cast<const f32x4*>(shift + c);
+        const float lo = act_lo(act), hi = act_hi(act);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = apply_act(fmaf(v[i], s[i], t[i]), act);
+        for (int i = 0; i < 4; ++i) v[i] = clamp_act(fmaf(v[i], s[i], t[i]), lo, hi);
     }
     return v;
 }

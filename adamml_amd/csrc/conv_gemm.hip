@@ -25,7 +25,7 @@ struct ConvP {
     bf16_t* y;
     double* stats;
     int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, up, up_shift, act, accumulate;
-    int P, K, cin_shift, n_ptiles, n_ctiles;
+    int P, K, cin_shift, n_ptiles, n_ctiles, tpb;
     // data-gradient epilogue fused with the BatchNorm backward reduction of the tensor the gradient flows into
     const bf16_t* bn_z;          // raw conv output that produced the consumer's input (same shape as y), or null
     const float* bn_vec;         // [4][Cout']: scale, shift, mean, invstd of that BatchNorm
@@ -41,12 +41,13 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 // MODE 0: 1x1 conv; MODE 1: KxK conv, fast tap addressing (per-row validity mask + LDS tap-offset table);
 // MODE 2: generic path with zero-upsampled input (data gradient of strided convs).
 template <int BC, int MODE>
-__global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
+__global__ __launch_bounds__(NTHREADS, (BC == 128 ? 3 : 4)) void conv_gemm_kernel(ConvP p) {
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
     constexpr int WROWS = BC / 64;          // weight rows staged per thread
     constexpr int TILE_BYTES = (BP + BC) * 64;
     constexpr int EPI_BYTES = BP * (BC * 2 + 16);
-    constexpr int SMEM_BYTES = ((2 * TILE_BYTES + 2 * BC * 4) > EPI_BYTES ? (2 * TILE_BYTES + 2 * BC * 4) : EPI_BYTES) + 256;
+    constexpr int STAGE_BYTES = (2 * TILE_BYTES) > EPI_BYTES ? (2 * TILE_BYTES) : EPI_BYTES;
+    constexpr int SMEM_BYTES = STAGE_BYTES + 2 * BC * 4 + 256;       // + per-channel sums + tap-offset table
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
 
     const int tid = threadIdx.x;
@@ -64,16 +65,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int ctile = bid % p.n_ctiles;
-    const int ptile = bid / p.n_ctiles;
+    const int pgrp = bid / p.n_ctiles;
     const int c0 = ctile * BC;
-    const int p0 = ptile * BP;
 
-    // ---- per-thread staging coordinates -------------------------------------------------------
     const int chunk = tid & 3;
     const int row_a = tid >> 2;             // 0..63 (+64 for second row)
-    int a_n[2], a_h0[2], a_w0[2], a_base[2];
-    unsigned long long a_mask[2];
-    bool a_ok[2];
     int* s_tapoff = reinterpret_cast<int*>(smem + SMEM_BYTES - 64 * 4);       // MODE 1: element offset of each tap
     if (MODE == 1) {
         if (tid < p.KH * p.KW) {
@@ -81,6 +77,37 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
             s_tapoff[tid] = (kh * p.W + kw) * p.Cin;
         }
     }
+    const bf16_t* wrow[WROWS];
+    bool w_ok[WROWS];
+#pragma unroll
+    for (int r = 0; r < WROWS; ++r) {
+        int co = c0 + row_a + r * 64;
+        w_ok[r] = co < p.Cout;
+        wrow[r] = p.w + (size_t)(w_ok[r] ? co : 0) * p.K;
+    }
+    const int li = lane & 15, lg = lane >> 4;
+    // epilogue thread mapping (fixed across the tiles of this workgroup, so the per-channel sums live in registers)
+    constexpr int CROW = BC * 2 + 16;                  // LDS row stride (bytes): +16 B skews the banks
+    static_assert(BP * CROW <= STAGE_BYTES, "epilogue tile must fit the staging buffers");
+    float* cs = reinterpret_cast<float*>(smem + STAGE_BYTES);          // [2*BC] channel sums, live across the tile loop
+    if (p.stats) {
+        for (int i = tid; i < 2 * BC; i += NTHREADS) cs[i] = 0.f;
+    }
+    constexpr int CPR = BC / 8;                        // 16-byte chunks per tile row
+    constexpr int RSTEP = NTHREADS / CPR;              // rows covered per pass
+    const int ech = tid % CPR, erow0 = tid / CPR;
+    const int eco = c0 + ech * 8;
+
+    // a workgroup walks `tpb` consecutive pixel tiles of its cout tile: statistics are published once per workgroup
+    for (int it = 0; it < p.tpb; ++it) {
+    const int ptile = pgrp * p.tpb + it;
+    if (ptile >= p.n_ptiles) break;
+    const int p0 = ptile * BP;
+
+    // ---- per-thread staging coordinates -------------------------------------------------------
+    int a_n[2], a_h0[2], a_w0[2], a_base[2];
+    unsigned long long a_mask[2];
+    bool a_ok[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         int pp = p0 + row_a + r * 64;
@@ -104,15 +131,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
         }
         a_mask[r] = m;
     }
-    const bf16_t* wrow[WROWS];
-    bool w_ok[WROWS];
-#pragma unroll
-    for (int r = 0; r < WROWS; ++r) {
-        int co = c0 + row_a + r * 64;
-        w_ok[r] = co < p.Cout;
-        wrow[r] = p.w + (size_t)(w_ok[r] ? co : 0) * p.K;
-    }
-    if (MODE == 1) __syncthreads();          // tap-offset table visible
+    if (MODE == 1 && it == 0) __syncthreads();          // tap-offset table visible
 
     bf16x8 ra[2], rw[WROWS];
     int rci = 0;
@@ -194,7 +213,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
     store_tile(0);
     __syncthreads();
 
-    const int li = lane & 15, lg = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) issue_loads(kt + 1);
@@ -217,9 +235,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
 
     // ---- epilogue: stage the bf16 tile through LDS, store 16 B per lane fully coalesced, and accumulate the
     //      per-channel sum / sum-of-squares of the stored (rounded) values on the way out -------------------
-    constexpr int CROW = BC * 2 + 16;                  // LDS row stride (bytes): +16 B skews the banks
-    static_assert(BP * CROW <= SMEM_BYTES - 256, "epilogue tile must fit the staging buffers");
     // (the last K step ended with __syncthreads(): every wave is done reading the operand tiles)
+    f32x8 esum, esq;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) esum[i] = esq[i] = 0.f;
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
@@ -229,13 +248,6 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
             *reinterpret_cast<bf16x4*>(smem + prow * CROW + ccol * 2) = f32_to_bf4(acc[ct][pt]);
         }
     __syncthreads();
-    constexpr int CPR = BC / 8;                        // 16-byte chunks per tile row
-    constexpr int RSTEP = NTHREADS / CPR;              // rows covered per pass
-    const int ech = tid % CPR, erow0 = tid / CPR;
-    const int eco = c0 + ech * 8;
-    f32x8 esum, esq;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) esum[i] = esq[i] = 0.f;
     if (eco < p.Cout && p.bn_z) {
         // data gradient w.r.t. a lazily normalised tensor: apply the activation mask here, store g' and accumulate
         // sum(g') and sum(g' * zhat) -- the BatchNorm-backward reduction pass never has to re-read g and z
@@ -275,11 +287,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
         }
     }
     if (p.stats) {
-        __syncthreads();                               // tile reads done: reuse the front of smem for the channel sums
-        float* cs = reinterpret_cast<float*>(smem);
-        for (int i = tid; i < 2 * BC; i += NTHREADS) cs[i] = 0.f;
-        __syncthreads();
-        // lanes l, l+CPR, l+2*CPR.. of a wave hold the same channel chunk: fold them first
+        // lanes l, l+CPR, l+2*CPR.. of a wave hold the same channel chunk: fold them, then one LDS atomic per channel
 #pragma unroll
         for (int off = CPR; off < 64; off <<= 1)
 #pragma unroll
@@ -294,6 +302,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_gemm_kernel(ConvP p) {
                 atomicAdd(&cs[BC + ech * 8 + i], esq[i]);
             }
         }
+    }
+    __syncthreads();                                   // staging tile consumed before the next tile's operands land
+    }   // tile loop
+    if (p.stats) {
         __syncthreads();
         double* slot = p.stats + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * p.Cout;
         for (int i = tid; i < BC; i += NTHREADS) {
@@ -718,7 +730,11 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     const int BC = narrow ? 64 : 128;
     p.n_ptiles = ceil_div(p.P, BP);
     p.n_ctiles = ceil_div(d->Cout, BC);
-    dim3 grid(p.n_ptiles * p.n_ctiles), block(NTHREADS);
+    // consecutive pixel tiles per workgroup (amortises the statistics publication), keeping >= ~2048 workgroups
+    p.tpb = (int)((long)p.n_ptiles * p.n_ctiles / 2048);
+    if (p.tpb < 1) p.tpb = 1;
+    if (p.tpb > 8) p.tpb = 8;
+    dim3 grid(ceil_div(p.n_ptiles, p.tpb) * p.n_ctiles), block(NTHREADS);
     const int taps = d->KH * d->KW;
     // MODE 0 needs the whole row base in 32-bit element offsets (true for every layer of the hot path)
     if ((long)d->N * d->H * d->W * d->Cin >= (1L << 31)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd: input tensor exceeds 2^31 elements");

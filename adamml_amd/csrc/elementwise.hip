@@ -124,13 +124,9 @@ __global__ void act_bwd_from_output_kernel(const bf16_t* g_out, const bf16_t* ou
     for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nchunks; e += (size_t)gridDim.x * NT) {
         f32x8 gv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(g_out + e * 8));
         f32x8 ov = bf8_to_f32(*reinterpret_cast<const bf16x8*>(out + e * 8));
+        const float lo = act_lo(act), hi = act_hi(act);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float m = 1.f;
-            if (act == ACT_RELU) m = ov[i] > 0.f ? 1.f : 0.f;
-            else if (act == ACT_RELU6) m = (ov[i] > 0.f && ov[i] < 6.f) ? 1.f : 0.f;
-            gv[i] *= m;
-        }
+        for (int i = 0; i < 8; ++i) gv[i] *= mask_act(ov[i], lo, hi);
         *reinterpret_cast<bf16x8*>(g + e * 8) = f32_to_bf8(gv);
     }
 }
@@ -184,13 +180,9 @@ __global__ __launch_bounds__(NT) void residual_bwd_kernel(const bf16_t* g_out, c
         for (size_t p = pb + m.rslot; p < pe; p += m.rows_per_pass) {
             f32x8 gv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(g_out + p * C + c));
             const f32x8 ov = bf8_to_f32(*reinterpret_cast<const bf16x8*>(out + p * C + c));
+            const float lo = act_lo(act), hi = act_hi(act);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float mk = 1.f;
-                if (act == ACT_RELU) mk = ov[i] > 0.f ? 1.f : 0.f;
-                else if (act == ACT_RELU6) mk = (ov[i] > 0.f && ov[i] < 6.f) ? 1.f : 0.f;
-                gv[i] *= mk;
-            }
+            for (int i = 0; i < 8; ++i) gv[i] *= mask_act(ov[i], lo, hi);
             const bf16x8 gb = f32_to_bf8(gv);
             if (g2 != g_out || act != ACT_NONE) *reinterpret_cast<bf16x8*>(g2 + p * C + c) = gb;
             gv = bf8_to_f32(gb);
