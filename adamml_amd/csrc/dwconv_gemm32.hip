@@ -39,59 +39,70 @@ struct DwP {
 // ~100 VGPRs (4-5 waves/SIMD); adjacent lanes own adjacent channel groups -> contiguous 512 B per wave access.
 template <int S>
 __global__ __launch_bounds__(NT) void dwconv_fwd_kernel(DwP p) {
+    constexpr int SEG = S == 1 ? 8 : 4;                 // outputs per thread (compile-time: all loads issue up front)
+    constexpr int NCOL = (SEG - 1) * S + 3;             // input columns feeding them
     __shared__ float smem[2 * MAXC];
     const int nchunk = p.C >> 2;
     const int gid = blockIdx.x * NT + threadIdx.x;
     const int chunk = gid % nchunk, tsk = gid / nchunk;
-    const int seg = tsk % p.nseg, row = tsk / p.nseg;          // a thread walks `seglen` outputs of one row
+    const int seg = tsk % p.nseg, row = tsk / p.nseg;
     const bool active = row < p.N * p.OH;
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     if (active) {
         const int c = chunk * 4;
         const int n = row / p.OH, oh = row - n * p.OH;
-        f32x4 wt[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(p.w + (size_t)t * p.C + c);
-        const bf16_t* rowp[3];
-        bool rok[3];
+        const int ow_b = seg * SEG;
+        const int iw_b = ow_b * S - p.pad;
+        bf16x4 raw[3][NCOL];
+        bool vok[3][NCOL];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int ih = oh * S - p.pad + kh;
-            rok[kh] = ih >= 0 && ih < p.H;
-            rowp[kh] = p.x + ((size_t)n * p.H + (rok[kh] ? ih : 0)) * p.W * p.C + c;
-        }
-        auto load_col = [&](int iw, f32x4 (&col)[3]) {
-            const bool cok = iw >= 0 && iw < p.W;
+            const bool rok = ih >= 0 && ih < p.H;
+            const bf16_t* rp = p.x + (((size_t)n * p.H + (rok ? ih : 0)) * p.W) * p.C + c;
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (cok && rok[kh])
-                    v = transform4(*reinterpret_cast<const bf16x4*>(rowp[kh] + (size_t)iw * p.C), p.in_scale, p.in_shift, c, p.act);
-                col[kh] = v;
+            for (int j = 0; j < NCOL; ++j) {
+                const int iw = iw_b + j;
+                const bool ok = rok && iw >= 0 && iw < p.W;
+                vok[kh][j] = ok;
+                bf16x4 v = {0, 0, 0, 0};
+                if (ok) v = *reinterpret_cast<const bf16x4*>(rp + (size_t)iw * p.C);
+                raw[kh][j] = v;
             }
-        };
-        f32x4 w0[3], w1[3], w2[3];
-        const int ow_b = seg * p.seglen, ow_e = min(p.OW, ow_b + p.seglen);
-        load_col(ow_b * S - p.pad, w0);
-        load_col(ow_b * S + 1 - p.pad, w1);
+        }
+        f32x4 wt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(p.w + (size_t)t * p.C + c);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        const float lo = p.in_scale ? act_lo(p.act) : -INFINITY, hi = p.in_scale ? act_hi(p.act) : INFINITY;
+        if (p.in_scale) {
+            sc = *reinterpret_cast<const f32x4*>(p.in_scale + c);
+            sh = *reinterpret_cast<const f32x4*>(p.in_shift + c);
+        }
+        f32x4 win[3][NCOL];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                f32x4 v = bf4_to_f32(raw[kh][j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = vok[kh][j] ? clamp_act(fmaf(v[i], sc[i], sh[i]), lo, hi) : 0.f;
+                win[kh][j] = v;
+            }
         bf16_t* yrow = p.y + (size_t)row * p.OW * p.C + c;
-        for (int ow = ow_b; ow < ow_e; ++ow) {
-            load_col(ow * S + 2 - p.pad, w2);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) acc += w0[kh] * wt[kh * 3] + w1[kh] * wt[kh * 3 + 1] + w2[kh] * wt[kh * 3 + 2];
-            bf16x4 o = f32_to_bf4(acc);
-            *reinterpret_cast<bf16x4*>(yrow + (size_t)ow * p.C) = o;
-            f32x4 rv = bf4_to_f32(o);
-            s += rv;
-            q += rv * rv;
-            if (S == 1) {
+        for (int o = 0; o < SEG; ++o) {
+            if (ow_b + o < p.OW) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh) { w0[kh] = w1[kh]; w1[kh] = w2[kh]; }
-            } else {
+                for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh) w0[kh] = w2[kh];
-                load_col((ow + 1) * S + 1 - p.pad, w1);
+                    for (int kw = 0; kw < 3; ++kw) acc += win[kh][o * S + kw] * wt[kh * 3 + kw];
+                bf16x4 ob = f32_to_bf4(acc);
+                *reinterpret_cast<bf16x4*>(yrow + (size_t)(ow_b + o) * p.C) = ob;
+                f32x4 rv = bf4_to_f32(ob);
+                s += rv;
+                q += rv * rv;
             }
         }
     }
@@ -341,7 +352,7 @@ extern "C" int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, con
     p.P = (size_t)d->N * d->OH * d->OW;
     if (!p.P) return ADAMML_OK;
     p.ppb = 0;
-    p.seglen = d->OW >= 32 ? 8 : (d->OW >= 8 ? 4 : d->OW);
+    p.seglen = d->stride == 1 ? 8 : 4;          // == SEG of dwconv_fwd_kernel<S>
     p.nseg = (d->OW + p.seglen - 1) / p.seglen;
     const long threads = (long)d->N * d->OH * p.nseg * (p.C / 4);
     const int nblk = (int)((threads + NT - 1) / NT);

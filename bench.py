@@ -105,11 +105,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    # (ADAMML_DIST_BACKEND=gloo lets the N>1 code path be exercised with several ranks on ONE GPU; default is RCCL)
+    backend = os.environ.get("ADAMML_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)     # "nccl" == RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world)     # "nccl" == RCCL on ROCm
 
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(ge.LIB):
