@@ -36,6 +36,8 @@ class AdaMML(nn.Module, MeanStdMixin):
         self.decay_ratio = 0.965
         self.update_policy_net = True
         self.update_main_net = True
+        self.use_side_stream = True
+        self._side = None
         self._flat_policy = FlatBuffers(self.policy_net)
         self._flat_main = FlatBuffers(self.main_net)
         if self.rng_policy:
@@ -76,18 +78,39 @@ class AdaMML(nn.Module, MeanStdMixin):
             self._flat_policy.ensure_grads()
             self._flat_main.ensure_grads()
         p_x, m_x, num_segments = self.data_layer(x, num_segments)
+        # Two HIP streams: the ResNet(s) stay on the caller's stream; the MobileNetV2 policy nets and the sound main net
+        # (hundreds of small launches) are enqueued on a side stream and overlap them.  The main nets never depend on the
+        # decisions before the logit mask (models/adamml.py:81-86), so the policy runs concurrently with segment 0..S-1.
+        main = torch.cuda.current_stream()
+        side = self._side_stream(dev) if self.use_side_stream else None
+        if side is not None:
+            side.wait_stream(main)
         if not self.rng_policy:
-            decisions, decision_logits = self.policy_net(p_x, gumbel_exponential)
+            if side is not None:
+                with torch.cuda.stream(side):
+                    decisions, decision_logits = self.policy_net(p_x, gumbel_exponential)
+            else:
+                decisions, decision_logits = self.policy_net(p_x, gumbel_exponential)
             self.last_policy_logits = decision_logits
         else:
             decisions = (torch.rand((num_segments, self.num_modality, x[0].size(0)), dtype=x[0].dtype, device=dev)
                          > self.rng_threshold).float()
-        all_logits = []
+        seg_logits = []
         for i in range(num_segments):
             tmp_x = [m_x[m_i][i] for m_i in range(self.num_modality)]
-            all_logits.append(self.main_net(tmp_x, decisions[i]))
+            seg_logits.append(self.main_net.backbone_logits(tmp_x, side))
+        if side is not None:
+            main.wait_stream(side)
+            for t in [decisions] + [l for seg in seg_logits for l in seg]:
+                t.record_stream(main)
+        all_logits = [self.main_net.fuse(seg_logits[i], decisions[i]) for i in range(num_segments)]
         final_logits = torch.stack(all_logits, dim=1).mean(dim=1)
         return final_logits, decisions.permute((2, 0, 1))
+
+    def _side_stream(self, dev):
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
 
     @property
     def network_name(self):

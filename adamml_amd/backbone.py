@@ -73,6 +73,16 @@ class _NetCall(torch.autograd.Function):
         net.rt.bwd_arena.reset(g.device)
         ctx.tape.grad_out = g.contiguous()
         ctx.tape.backward()
+        side = torch.cuda.current_stream()
+        if side != torch.cuda.default_stream(g.device) and not getattr(net, "_join_queued", False):
+            # the HIP weight-gradient kernels wrote .grad on a side stream without going through AccumulateGrad: make
+            # the default stream wait for them once, when the whole backward pass has been enqueued
+            net._join_queued = True
+
+            def _join():
+                net._join_queued = False
+                torch.cuda.default_stream(g.device).wait_stream(side)
+            torch.autograd.Variable._execution_engine.queue_callback(_join)
         return None, None, None, None
 
 

@@ -136,10 +136,11 @@ def wgrad_workspace(desc, cin_true, device, depthwise=False):
         need = load().adamml_dwconv_bwd_weight_workspace(ctypes.byref(desc))
     else:
         need = load().adamml_conv_bwd_weight_workspace(ctypes.byref(desc), cin_true)
-    buf = _wgrad_ws.get(device)
+    key = (device, torch.cuda.current_stream().cuda_stream)      # one scratch per stream: backbones run concurrently
+    buf = _wgrad_ws.get(key)
     if buf is None or buf.numel() * 4 < need:
         buf = torch.empty(max(need // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
-        _wgrad_ws[device] = buf
+        _wgrad_ws[key] = buf
     return buf
 
 

@@ -53,11 +53,22 @@ class JointResNetMobileNetV2(nn.Module, MeanStdMixin):
             name += "-ts-{}".format(self.pooling_method)
         return name
 
-    def forward(self, multi_modalities, decisions=None):
-        """multi_modalities: list of NHWC bf16 frame tensors of ONE segment; decisions [M, B] or None."""
+    def backbone_logits(self, multi_modalities, side_stream=None):
+        """Per-modality logits of ONE segment.  With a side stream the MobileNetV2 (sound) backbone is enqueued there so
+        that its many small launches overlap the ResNet's HBM-bound kernels; the caller joins the streams."""
         out = []
         for i, x in enumerate(multi_modalities):
-            tmp = self.nets[i].forward_nhwc(x)                   # [B, classes] fp32
+            net = self.nets[i]
+            if side_stream is not None and self.modality[i] == 'sound':
+                with torch.cuda.stream(side_stream):
+                    out.append(net.forward_nhwc(x))
+            else:
+                out.append(net.forward_nhwc(x))                  # [B, classes] fp32
+        return out
+
+    def fuse(self, logits, decisions=None):
+        out = []
+        for i, tmp in enumerate(logits):
             if decisions is not None:
                 tmp = tmp * decisions[i].view((tmp.size(0), 1))  # :94
             out.append(tmp)
@@ -67,6 +78,10 @@ class JointResNetMobileNetV2(nn.Module, MeanStdMixin):
             weights = torch.cat((self.lf_weights, comple), dim=0).view(-1, 1, 1)
             return torch.sum(out * weights, dim=0)
         return torch.mean(out, dim=0)
+
+    def forward(self, multi_modalities, decisions=None):
+        """multi_modalities: list of NHWC bf16 frame tensors of ONE segment; decisions [M, B] or None."""
+        return self.fuse(self.backbone_logits(multi_modalities), decisions)
 
 
 def joint_resnet_mobilenetv2(depth, num_classes, without_t_stride, groups, dropout, pooling_method, input_channels,
