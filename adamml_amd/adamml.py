@@ -83,11 +83,13 @@ class AdaMML(nn.Module, MeanStdMixin):
         # decisions before the logit mask (models/adamml.py:81-86), so the policy runs concurrently with segment 0..S-1.
         main = torch.cuda.current_stream()
         side = self._side_stream(dev) if self.use_side_stream else None
+        pside = self._side_stream(dev, 1) if self.use_side_stream else None      # policy nets: their own stream
         if side is not None:
             side.wait_stream(main)
+            pside.wait_stream(main)
         if not self.rng_policy:
             if side is not None:
-                with torch.cuda.stream(side):
+                with torch.cuda.stream(pside):
                     decisions, decision_logits = self.policy_net(p_x, gumbel_exponential)
             else:
                 decisions, decision_logits = self.policy_net(p_x, gumbel_exponential)
@@ -101,16 +103,17 @@ class AdaMML(nn.Module, MeanStdMixin):
             seg_logits.append(self.main_net.backbone_logits(tmp_x, side))
         if side is not None:
             main.wait_stream(side)
+            main.wait_stream(pside)
             for t in [decisions] + [l for seg in seg_logits for l in seg]:
                 t.record_stream(main)
         all_logits = [self.main_net.fuse(seg_logits[i], decisions[i]) for i in range(num_segments)]
         final_logits = torch.stack(all_logits, dim=1).mean(dim=1)
         return final_logits, decisions.permute((2, 0, 1))
 
-    def _side_stream(self, dev):
-        if self._side is None or self._side.device != dev:
-            self._side = torch.cuda.Stream(device=dev)
-        return self._side
+    def _side_stream(self, dev, idx=0):
+        if self._side is None or self._side[0].device != dev:
+            self._side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        return self._side[idx]
 
     @property
     def network_name(self):
