@@ -179,16 +179,28 @@ def main():
     roof = None
     breakdown = None
     if rank == 0 and not args.no_roofline:
+        # per-launch HIP-event timing of one more step, single stream (concurrent streams would inflate each launch)
+        model.use_side_stream = False
+        step()
         hip.profiler = hip.LaunchProfiler()
         step()
         agg = hip.profiler.summary()
         hip.profiler = None
+        model.use_side_stream = True
+        # the forward conv and the data gradient are ONE device kernel (conv_gemm_kernel): price them together
+        gemm = {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}
+        for k in ("adamml_conv_fwd", "adamml_conv_bwd_data", "adamml_conv_bwd_data_bn"):
+            if k in agg:
+                for f in gemm:
+                    gemm[f] += agg[k][f]
+        agg_k = {k: v for k, v in agg.items() if k not in ("adamml_conv_fwd", "adamml_conv_bwd_data", "adamml_conv_bwd_data_bn")}
+        agg_k["conv_gemm_kernel (adamml_conv_fwd + adamml_conv_bwd_data[_bn])"] = gemm
         tot_ms = sum(a["ms"] for a in agg.values())
         breakdown = {k: {"launches": a["launches"], "ms": round(a["ms"], 3), "pct": round(100 * a["ms"] / tot_ms, 1),
                          "tflops": round(a["flops"] / (a["ms"] * 1e9), 1) if a["ms"] > 0 else 0,
                          "gbs": round(a["bytes"] / (a["ms"] * 1e6), 1) if a["ms"] > 0 else 0}
                      for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
-        dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        dom = max(agg_k.items(), key=lambda kv: kv[1]["ms"])
         name, a = dom
         per_launch_ms = a["ms"] / a["launches"]
         tfl = a["flops"] / (a["ms"] * 1e9)
@@ -198,7 +210,15 @@ def main():
             roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(f_hbm, 4)}
         else:
             roof = {"bound": "mfma", "achieved": round(tfl, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(f_mfma, 4)}
-        roof.update({"traffic": None, "kernel": name, "launches_per_step": a["launches"],
+        traffic, tsrc = None, None
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if os.path.exists(tfile) and name.startswith("conv_gemm_kernel"):
+            t = json.load(open(tfile)).get("conv_gemm_kernel")
+            if t:
+                traffic = round(t["per_launch_bytes"] * a["launches"] / 1e9, 2)     # GB per step, same launch set
+                tsrc = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 gfx950 correction), profiles/r01_pmc_hbm_traffic.json"
+        roof.update({"traffic": traffic, "traffic_unit": "GB per step (all launches of this kernel)", "traffic_source": tsrc,
+                     "algorithmic_gb_per_step": round(a["bytes"] / 1e9, 2), "kernel": name, "launches_per_step": a["launches"],
                      "avg_launch_us": round(per_launch_ms * 1e3, 2), "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4),
                      "share_of_device_time": round(a["ms"] / tot_ms, 3)})
     cpu = None
