@@ -87,20 +87,28 @@ class AdaMML(nn.Module, MeanStdMixin):
         if side is not None:
             side.wait_stream(main)
             pside.wait_stream(main)
+        # host issue order: policy backbones of segment i, then main nets of segment i -- every stream has work queued
+        # from the first microseconds of the step (the policy's ~1100 launches are not issued ahead of the ResNet's)
+        seg_logits, feats = [], []
+        for i in range(num_segments):
+            if not self.rng_policy:
+                if side is not None:
+                    with torch.cuda.stream(pside):
+                        feats.append(self.policy_net.segment_features(p_x, i))
+                else:
+                    feats.append(self.policy_net.segment_features(p_x, i))
+            tmp_x = [m_x[m_i][i] for m_i in range(self.num_modality)]
+            seg_logits.append(self.main_net.backbone_logits(tmp_x, side))
         if not self.rng_policy:
             if side is not None:
                 with torch.cuda.stream(pside):
-                    decisions, decision_logits = self.policy_net(p_x, gumbel_exponential)
+                    decisions, decision_logits = self.policy_net.decide(feats, gumbel_exponential)
             else:
-                decisions, decision_logits = self.policy_net(p_x, gumbel_exponential)
+                decisions, decision_logits = self.policy_net.decide(feats, gumbel_exponential)
             self.last_policy_logits = decision_logits
         else:
             decisions = (torch.rand((num_segments, self.num_modality, x[0].size(0)), dtype=x[0].dtype, device=dev)
                          > self.rng_threshold).float()
-        seg_logits = []
-        for i in range(num_segments):
-            tmp_x = [m_x[m_i][i] for m_i in range(self.num_modality)]
-            seg_logits.append(self.main_net.backbone_logits(tmp_x, side))
         if side is not None:
             main.wait_stream(side)
             main.wait_stream(pside)

@@ -10,6 +10,7 @@
 // models/sound_mobilenet_v2.py:33-69 and models/policy_net.py:38-95 (nn.Conv2d + nn.BatchNorm2d + ReLU/ReLU6).
 #include "common.h"
 #include "../../include/adamml_hip.h"
+#include <type_traits>
 
 namespace {
 
@@ -40,8 +41,19 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 
 // MODE 0: 1x1 conv; MODE 1: KxK conv, fast tap addressing (per-row validity mask + LDS tap-offset table);
 // MODE 2: generic path with zero-upsampled input (data gradient of strided convs).
-template <int BC, int MODE>
-__global__ __launch_bounds__(NTHREADS, (BC == 128 ? 3 : 4)) void conv_gemm_kernel(ConvP p) {
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// PD = register prefetch depth (K steps of global loads in flight).  PD 1 keeps 3-4 workgroups per CU (latency hidden by
+// occupancy: best for the big, short-K layers); PD 3 is for small grids with long K loops (layer3/4), where a CU holds a
+// single workgroup and only explicit look-ahead hides the HBM round trip.
+template <int BC, int MODE, int PD>
+__global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
     constexpr int WROWS = BC / 64;          // weight rows staged per thread
     constexpr int TILE_BYTES = (BP + BC) * 64;
@@ -133,41 +145,46 @@ __global__ __launch_bounds__(NTHREADS, (BC == 128 ? 3 : 4)) void conv_gemm_kerne
     }
     if (MODE == 1 && it == 0) __syncthreads();          // tap-offset table visible
 
-    bf16x8 ra[2], rw[WROWS];
-    int rci = 0;
-    bool rav[2];
+    // register prefetch ring of depth PD: global loads run PD K-steps ahead of the MFMAs.  One K step of compute is
+    // ~0.15 us but an HBM round trip is 1-2 us, so a one-step look-ahead left the kernel latency-bound.
+    bf16x8 ra[PD][2], rw[PD][WROWS];
+    int rci[PD];
+    bool rav[PD][2];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) rci[i] = 0;
 
-    auto issue_loads = [&](int kt) {
+    auto issue_loads = [&](auto slot_c, int kt) {
+        constexpr int SL = decltype(slot_c)::value;
         const int k = kt * BK + chunk * 8;
         const bool kok = k < p.K;
         if (MODE == 0) {
-            rci = k;
+            rci[SL] = k;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const bool ok = a_ok[r] && kok;
-                rav[r] = ok;
+                rav[SL][r] = ok;
                 bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + (size_t)(unsigned)(a_base[r] + k));
-                ra[r] = v;
+                ra[SL][r] = v;
             }
         } else if (MODE == 1) {
             const int tap = kok ? (k >> p.cin_shift) : 0;
             const int ci = k & (p.Cin - 1);
             const int toff = s_tapoff[tap] + ci;
-            rci = ci;
+            rci[SL] = ci;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const bool ok = kok && ((a_mask[r] >> tap) & 1ull);
-                rav[r] = ok;
+                rav[SL][r] = ok;
                 bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + (size_t)(unsigned)(a_base[r] + toff));
-                ra[r] = v;
+                ra[SL][r] = v;
             }
         } else {
             const int tap = k >> p.cin_shift;
             const int ci = k - (tap << p.cin_shift);
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
-            rci = ci;
+            rci[SL] = ci;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 int ih = a_h0[r] + kh, iw = a_w0[r] + kw;
@@ -176,30 +193,31 @@ __global__ __launch_bounds__(NTHREADS, (BC == 128 ? 3 : 4)) void conv_gemm_kerne
                 ih >>= p.up_shift;
                 iw >>= p.up_shift;
                 ok = ok && ih < p.H && iw < p.W;
-                rav[r] = ok;
+                rav[SL][r] = ok;
                 bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + ((size_t)(a_n[r] * p.H + ih) * p.W + iw) * p.Cin + ci);
-                ra[r] = v;
+                ra[SL][r] = v;
             }
         }
 #pragma unroll
         for (int r = 0; r < WROWS; ++r) {
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (w_ok[r] && kok) v = *reinterpret_cast<const bf16x8*>(wrow[r] + k);
-            rw[r] = v;
+            rw[SL][r] = v;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](auto slot_c, int buf) {
+        constexpr int SL = decltype(slot_c)::value;
         char* base = smem + buf * TILE_BYTES;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            bf16x8 v = ra[r];
-            if (p.in_scale && rav[r]) v = f32_to_bf8(transform8(v, p.in_scale, p.in_shift, rci, p.act));
+            bf16x8 v = ra[SL][r];
+            if (p.in_scale && rav[SL][r]) v = f32_to_bf8(transform8(v, p.in_scale, p.in_shift, rci[SL], p.act));
             *reinterpret_cast<bf16x8*>(base + lds_off(row_a + r * 64, chunk)) = v;
         }
 #pragma unroll
         for (int r = 0; r < WROWS; ++r)
-            *reinterpret_cast<bf16x8*>(base + BP * 64 + lds_off(row_a + r * 64, chunk)) = rw[r];
+            *reinterpret_cast<bf16x8*>(base + BP * 64 + lds_off(row_a + r * 64, chunk)) = rw[SL][r];
     };
 
     f32x4 acc[WCT][4];
@@ -209,13 +227,7 @@ __global__ __launch_bounds__(NTHREADS, (BC == 128 ? 3 : 4)) void conv_gemm_kerne
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
-    issue_loads(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) issue_loads(kt + 1);
+    auto compute = [&](int buf) {
         const char* base = smem + buf * TILE_BYTES;
         bf16x8 fa[4], fw[WCT];
 #pragma unroll
@@ -229,9 +241,23 @@ __global__ __launch_bounds__(NTHREADS, (BC == 128 ? 3 : 4)) void conv_gemm_kerne
 #pragma unroll
             for (int pt = 0; pt < 4; ++pt)
                 acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ct], fa[pt], acc[ct][pt], 0, 0, 0);
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
+    };
+    // prologue: fill the ring
+    static_for<PD>([&](auto sc) {
+        if ((int)decltype(sc)::value < nk) issue_loads(sc, (int)decltype(sc)::value);
+    });
+    for (int kt0 = 0; kt0 < nk; kt0 += PD) {
+        static_for<PD>([&](auto sc) {
+            const int kt = kt0 + (int)decltype(sc)::value;
+            if (kt < nk) {                               // uniform
+                store_tile(sc, kt & 1);                  // waits (counted vmcnt) only for this slot's loads
+                if (kt + PD < nk) issue_loads(sc, kt + PD);
+                __syncthreads();                         // tile kt visible; everyone is past compute(kt-1)
+                compute(kt & 1);
+            }
+        });
     }
+    __syncthreads();                                     // operand tiles consumed: the epilogue reuses the LDS
 
     // ---- epilogue: stage the bf16 tile through LDS, store 16 B per lane fully coalesced, and accumulate the
     //      per-channel sum / sum-of-squares of the stored (rounded) values on the way out -------------------
@@ -740,7 +766,13 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     if ((long)d->N * d->H * d->W * d->Cin >= (1L << 31)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd: input tensor exceeds 2^31 elements");
     const int mode = p.up > 1 ? 2 : (multitap ? (taps <= 64 ? 1 : 2) : 0);
     if (mode == 2 && !multitap) { p.cin_shift = 30; }      // 1x1 strided dgrad: tap = k >> 30 = 0, ci = k
-#define LAUNCH_CONV(BCV, MODEV) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV>), grid, block, 0, stream, p)
+    const int nk = ceil_div(p.K, BK);
+    const bool deep = (long)grid.x <= 768 && nk >= 8;        // < 1 wave of workgroups per CU slot and a long K loop
+#define LAUNCH_CONV(BCV, MODEV)                                                                             \
+    do {                                                                                                    \
+        if (deep) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 3>), grid, block, 0, stream, p);          \
+        else hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1>), grid, block, 0, stream, p);               \
+    } while (0)
     if (BC == 64) {
         if (mode == 0) LAUNCH_CONV(64, 0); else if (mode == 1) LAUNCH_CONV(64, 1); else LAUNCH_CONV(64, 2);
     } else {

@@ -185,11 +185,20 @@ class PolicyNet(nn.Module):
         c = torch.sigmoid(gf) * c + torch.sigmoid(gi) * torch.tanh(gg)
         return torch.sigmoid(go) * torch.tanh(c), c
 
+    def segment_features(self, x, i):
+        """Joint feature [B, 2048] of segment i (models/policy_net.py:323-326); lets the caller interleave the policy
+        backbones of segment i with the main nets of segment i on different HIP streams."""
+        return self.joint_net.features([x[m_i][i] for m_i in range(self.num_modality)])
+
     def forward(self, x, gumbel_exponential=None):
         """x: list over modality of [S, B*Fk, H, W, C] NHWC bf16 frames.  Returns decisions [S,M,B], logits [S,M,B,2]."""
-        M = self.num_modality
         S = x[0].shape[0]
-        outs = [self.joint_net.features([x[m_i][i] for m_i in range(M)]) for i in range(S)]
+        return self.decide([self.segment_features(x, i) for i in range(S)], gumbel_exponential)
+
+    def decide(self, outs, gumbel_exponential=None):
+        """LSTM causality head + hard Gumbel-softmax over the per-segment features (models/policy_net.py:329-373)."""
+        M = self.num_modality
+        S = len(outs)
         B = outs[0].shape[0]
         if self.causality_modeling is None:
             o = torch.stack(outs, 0).view(S * B, -1)
