@@ -87,24 +87,21 @@ class AdaMML(nn.Module, MeanStdMixin):
         if side is not None:
             side.wait_stream(main)
             pside.wait_stream(main)
-        # host issue order: policy backbones of segment i, then main nets of segment i -- every stream has work queued
-        # from the first microseconds of the step (the policy's ~1100 launches are not issued ahead of the ResNet's)
-        seg_logits, feats = [], []
-        for i in range(num_segments):
-            if not self.rng_policy:
-                if side is not None:
-                    with torch.cuda.stream(pside):
-                        feats.append(self.policy_net.segment_features(p_x, i))
-                else:
-                    feats.append(self.policy_net.segment_features(p_x, i))
-            tmp_x = [m_x[m_i][i] for m_i in range(self.num_modality)]
-            seg_logits.append(self.main_net.backbone_logits(tmp_x, side))
+        # The S per-segment module calls of the reference (:151-160) run as ONE launch sequence per backbone with S
+        # BatchNorm groups (per-segment batch statistics, running statistics updated segment by segment): 5x fewer
+        # launches and 5x larger grids.  Host issue order: the main nets first (the ResNet is the long pole and must have
+        # work queued from the first microseconds of the step), then the policy nets on their own stream.
+        S = num_segments
+        B = x[0].size(0)
+        stacked = self.main_net.backbone_logits([m_x[m_i].flatten(0, 1) for m_i in range(self.num_modality)], side, groups=S)
+        seg_logits = [[l.view(S, B, -1)[i] for l in stacked] for i in range(S)]
         if not self.rng_policy:
             if side is not None:
                 with torch.cuda.stream(pside):
-                    decisions, decision_logits = self.policy_net.decide(feats, gumbel_exponential)
+                    decisions, decision_logits = self.policy_net.decide(self.policy_net.all_segment_features(p_x),
+                                                                        gumbel_exponential)
             else:
-                decisions, decision_logits = self.policy_net.decide(feats, gumbel_exponential)
+                decisions, decision_logits = self.policy_net.decide(self.policy_net.all_segment_features(p_x), gumbel_exponential)
             self.last_policy_logits = decision_logits
         else:
             decisions = (torch.rand((num_segments, self.num_modality, x[0].size(0)), dtype=x[0].dtype, device=dev)
@@ -112,7 +109,7 @@ class AdaMML(nn.Module, MeanStdMixin):
         if side is not None:
             main.wait_stream(side)
             main.wait_stream(pside)
-            for t in [decisions] + [l for seg in seg_logits for l in seg]:
+            for t in [decisions] + list(stacked):
                 t.record_stream(main)
         all_logits = [self.main_net.fuse(seg_logits[i], decisions[i]) for i in range(num_segments)]
         final_logits = torch.stack(all_logits, dim=1).mean(dim=1)

@@ -61,8 +61,8 @@ class _NetCall(torch.autograd.Function):
     gradients are accumulated straight into the flat gradient buffer by the HIP weight-grad kernels."""
 
     @staticmethod
-    def forward(ctx, anchor, net, x, extra):
-        out, tape = net._run(x, extra, need_grad=anchor.requires_grad)
+    def forward(ctx, anchor, net, x, groups):
+        out, tape = net._run(x, groups, need_grad=anchor.requires_grad)
         ctx.tape = tape
         ctx.net = net
         return out
@@ -117,14 +117,19 @@ class HipBackbone(nn.Module):
     def _trainable(self):
         return any(p.requires_grad for p in self.parameters())
 
-    def call(self, x, extra=None):
-        """x: NHWC bf16 frames tensor on the GPU.  Returns the fp32 head output."""
+    def call(self, x, groups=1):
+        """x: NHWC bf16 frames tensor on the GPU, `groups` independent module calls stacked along dim 0 (group-major):
+        each group gets its own train-mode BatchNorm statistics and running-stat update, exactly as `groups` successive
+        calls of the reference module would (models/adamml.py:151-160 loops the segments).  Returns the fp32 head output
+        of all groups stacked the same way."""
         hip.require_gpu(x)
+        if groups < 1 or x.shape[0] % groups:
+            raise RuntimeError("backbone call: %d images do not split into %d groups" % (x.shape[0], groups))
         need_grad = torch.is_grad_enabled() and self._trainable()
         if self._anchor is None or self._anchor.device != x.device:
             self._anchor = torch.zeros(1, device=x.device)
         anchor = self._anchor.detach().requires_grad_(need_grad)
-        return _NetCall.apply(anchor, self, x, extra)
+        return _NetCall.apply(anchor, self, x, groups)
 
-    def _run(self, x, extra, need_grad):
+    def _run(self, x, groups, need_grad):
         raise NotImplementedError

@@ -28,6 +28,8 @@ struct ConvP {
     int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, up, up_shift, act, accumulate;
     int P, K, cin_shift, n_ptiles, n_ctiles, tpb;
     // data-gradient epilogue fused with the BatchNorm backward reduction of the tensor the gradient flows into
+    size_t gx, gy;               // element strides between BatchNorm groups of x / y (blockIdx.y = group)
+    int in_gstride;
     const bf16_t* bn_z;          // raw conv output that produced the consumer's input (same shape as y), or null
     const float* bn_vec;         // [4][Cout']: scale, shift, mean, invstd of that BatchNorm
     int bn_act;
@@ -62,6 +64,14 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
     constexpr int SMEM_BYTES = STAGE_BYTES + 2 * BC * 4 + 256;       // + per-channel sums + tap-offset table
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
 
+    {   // BatchNorm group of this workgroup: one launch covers the S per-segment calls of the reference
+        const int g = blockIdx.y;
+        p.x += (size_t)g * p.gx;
+        p.y += (size_t)g * p.gy;
+        if (p.stats) p.stats += (size_t)g * ADAMML_STAT_SLOTS * 2 * p.Cout;
+        if (p.in_scale) { p.in_scale += (size_t)g * p.in_gstride; p.in_shift += (size_t)g * p.in_gstride; }
+        if (p.bn_z) { p.bn_z += (size_t)g * p.gy; p.bn_vec += (size_t)g * 4 * p.Cout; }
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -358,6 +368,8 @@ struct WgradP {
     int nsplit;
     int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, act, cin_true;
     int P, pix_per_block, n_cotiles, n_tiles, cin_shift, NK;   // NK = KH*KW*Cin: flattened (tap, ci) GEMM-N extent
+    size_t gdz, gx;        // element strides between BatchNorm groups (blockIdx.y = group)
+    int in_gstride;
 };
 
 // LDS image of one K step: [32 pixels][CH channels] bf16, row-major, 8-byte units XOR-swizzled so that the
@@ -376,6 +388,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
     constexpr int MT = BM / 32, NT = BN / 32;
     __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
 
+    const int grp = blockIdx.y;
+    p.dz += (size_t)grp * p.gdz;
+    p.x += (size_t)grp * p.gx;
+    if (p.in_scale) { p.in_scale += (size_t)grp * p.in_gstride; p.in_shift += (size_t)grp * p.in_gstride; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     // block -> (tile, pixel split): the tiles of one pixel range run back-to-back on ONE XCD (block b lives on XCD
@@ -519,7 +535,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
                 const int co = co0 + wm * (BM / 2) + mt * 16 + lg * 4 + r;
                 if (co >= p.Cout) continue;
                 const size_t idx = ((size_t)co * p.cin_true + ci) * taps + tap;
-                if (p.ws) p.ws[(size_t)split * p.dw_numel + idx] = acc[mt][nt][r];
+                if (p.ws) p.ws[((size_t)grp * p.nsplit + split) * p.dw_numel + idx] = acc[mt][nt][r];
                 else atomicAdd(p.dw + idx, acc[mt][nt][r]);
             }
         }
@@ -542,11 +558,17 @@ struct W3P {
     int nsplit;
     int N, H, W, Cin, OH, OW, Cout, pad, act, cin_true;
     int cw, rows, PR, PC, units_per_img, units_per_row, total_units, units_per_block, n_cotiles, n_tiles;
+    size_t gdz, gx;
+    int in_gstride;
 };
 
 template <int S>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_wgrad_kernel(W3P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int grp = blockIdx.y;
+    p.dz += (size_t)grp * p.gdz;
+    p.x += (size_t)grp * p.gx;
+    if (p.in_scale) { p.in_scale += (size_t)grp * p.in_gstride; p.in_shift += (size_t)grp * p.in_gstride; }
     const int patch_bytes = p.PR * p.PC * 128;
     const int buf_bytes = 32 * 128 + patch_bytes;               // dz tile [32][64] + patch [PR*PC][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -696,7 +718,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_wgrad_kernel(W3P p) {
                 for (int r = 0; r < 4; ++r) {
                     const int co = co0 + mt * 16 + lg * 4 + r;
                     const size_t idx = ((size_t)co * p.cin_true + ci) * 9 + t;
-                    if (p.ws) p.ws[(size_t)split * p.dw_numel + idx] = acc[mt][t][r];
+                    if (p.ws) p.ws[((size_t)grp * p.nsplit + split) * p.dw_numel + idx] = acc[mt][t][r];
                     else atomicAdd(p.dw + idx, acc[mt][t][r]);
                 }
     }
@@ -737,6 +759,10 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.in_scale = in_scale; p.in_shift = in_shift;
     p.y = (bf16_t*)y; p.stats = stats;
     p.bn_z = (const bf16_t*)bn_z; p.bn_vec = bn_vec; p.bn_act = bn_act;
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    p.gx = (size_t)d->N * d->H * d->W * d->Cin;
+    p.gy = (size_t)d->N * d->OH * d->OW * d->Cout;
+    p.in_gstride = d->in_gstride;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
     p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.up = d->up < 1 ? 1 : d->up;
     p.up_shift = ilog2_exact(p.up);
@@ -752,22 +778,22 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     if (p.P <= 0) return ADAMML_OK;
     bool narrow = d->Cout <= 64 || (d->Cout % 128 != 0 && d->Cout < 256);
     // small problems: halve the cout tile so that at least ~2 workgroups per CU exist
-    if (!narrow && (long)ceil_div(p.P, BP) * ceil_div(d->Cout, 128) < 512) narrow = true;
+    if (!narrow && (long)ceil_div(p.P, BP) * ceil_div(d->Cout, 128) * groups < 512) narrow = true;
     const int BC = narrow ? 64 : 128;
     p.n_ptiles = ceil_div(p.P, BP);
     p.n_ctiles = ceil_div(d->Cout, BC);
     // consecutive pixel tiles per workgroup (amortises the statistics publication), keeping >= ~2048 workgroups
-    p.tpb = (int)((long)p.n_ptiles * p.n_ctiles / 2048);
+    p.tpb = (int)((long)p.n_ptiles * p.n_ctiles * groups / 2048);
     if (p.tpb < 1) p.tpb = 1;
     if (p.tpb > 8) p.tpb = 8;
-    dim3 grid(ceil_div(p.n_ptiles, p.tpb) * p.n_ctiles), block(NTHREADS);
+    dim3 grid(ceil_div(p.n_ptiles, p.tpb) * p.n_ctiles, groups), block(NTHREADS);
     const int taps = d->KH * d->KW;
     // MODE 0 needs the whole row base in 32-bit element offsets (true for every layer of the hot path)
     if ((long)d->N * d->H * d->W * d->Cin >= (1L << 31)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd: input tensor exceeds 2^31 elements");
     const int mode = p.up > 1 ? 2 : (multitap ? (taps <= 64 ? 1 : 2) : 0);
     if (mode == 2 && !multitap) { p.cin_shift = 30; }      // 1x1 strided dgrad: tap = k >> 30 = 0, ci = k
     const int nk = ceil_div(p.K, BK);
-    const bool deep = (long)grid.x <= 768 && nk >= 8;        // < 1 wave of workgroups per CU slot and a long K loop
+    const bool deep = (long)grid.x * grid.y <= 768 && nk >= 8;        // < 1 wave of workgroups per CU slot and a long K loop
 #define LAUNCH_CONV(BCV, MODEV)                                                                             \
     do {                                                                                                    \
         if (deep) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 3>), grid, block, 0, stream, p);          \
@@ -794,7 +820,7 @@ extern "C" int adamml_conv_bwd_data_bn(const adamml_conv_desc_t* d, const void* 
     g.N = d->N; g.H = d->OH; g.W = d->OW; g.Cin = d->Cout;
     g.OH = d->H; g.OW = d->W; g.Cout = d->Cin;
     g.stride = 1; g.up = d->stride; g.pad = d->KH - 1 - d->pad;
-    g.act = ACT_NONE; g.accumulate = 0;
+    g.act = ACT_NONE; g.accumulate = 0; g.in_gstride = 0;
     return conv_launch(&g, dz, w_dgrad_packed, nullptr, nullptr, dx, sums, z_in, bn_vec, act, stream);
 }
 
@@ -807,7 +833,7 @@ extern "C" int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz,
     g.N = d->N; g.H = d->OH; g.W = d->OW; g.Cin = d->Cout;
     g.OH = d->H; g.OW = d->W; g.Cout = d->Cin;
     g.stride = 1; g.up = d->stride; g.pad = d->KH - 1 - d->pad;
-    g.act = ACT_NONE; g.accumulate = accumulate;
+    g.act = ACT_NONE; g.accumulate = accumulate; g.in_gstride = 0;
     return adamml_conv_fwd(&g, dz, w_dgrad_packed, nullptr, nullptr, dx, nullptr, stream);
 }
 
@@ -830,7 +856,7 @@ static int wgrad_plan(const adamml_conv_desc_t* d, int cin_true, WgradPlan* pl) 
             pl->use3x3 = true;
             pl->n_cotiles = d->Cout / 64;
             pl->n_tiles = pl->n_cotiles * (d->Cin / 64);
-            int nsplit = ceil_div(512, pl->n_tiles);
+            int nsplit = ceil_div(512, pl->n_tiles * (d->groups < 1 ? 1 : d->groups));
             int upb = ceil_div(pl->total_units, nsplit);
             if (upb < 4) upb = 4;
             pl->nsplit = ceil_div(pl->total_units, upb);
@@ -849,7 +875,7 @@ static int wgrad_plan(const adamml_conv_desc_t* d, int cin_true, WgradPlan* pl) 
     pl->n_cotiles = ceil_div(d->Cout, pl->BM);
     pl->n_tiles = pl->n_cotiles * ceil_div(pl->NK, pl->BN);
     const int P = d->N * d->OH * d->OW;
-    int nsplit = ceil_div(768, pl->n_tiles);
+    int nsplit = ceil_div(768, pl->n_tiles * (d->groups < 1 ? 1 : d->groups));
     int ppb = ceil_div(ceil_div(P, nsplit), 32) * 32;
     if (ppb < 256) ppb = 256;
     pl->nsplit = ceil_div(P, ppb);
@@ -865,7 +891,8 @@ int adamml_launch_split_reduce(const float* ws, float* dw, size_t n, int nsplit,
 extern "C" size_t adamml_conv_bwd_weight_workspace(const adamml_conv_desc_t* d, int cin_true) {
     WgradPlan pl;
     if (!d || wgrad_plan(d, cin_true, &pl)) return 0;
-    return (size_t)pl.nsplit * d->Cout * cin_true * d->KH * d->KW * sizeof(float);
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    return (size_t)groups * pl.nsplit * d->Cout * cin_true * d->KH * d->KW * sizeof(float);
 }
 
 extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
@@ -878,14 +905,17 @@ extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* d
     int rc = wgrad_plan(d, cin_true, &pl);
     if (rc) return rc;
     const size_t dw_numel = (size_t)d->Cout * cin_true * d->KH * d->KW;
+    const int groups = d->groups < 1 ? 1 : d->groups;
     float* ws = nullptr;
-    if (workspace && workspace_bytes >= (size_t)pl.nsplit * dw_numel * sizeof(float)) ws = (float*)workspace;
+    if (workspace && workspace_bytes >= (size_t)groups * pl.nsplit * dw_numel * sizeof(float)) ws = (float*)workspace;
     const int nsplit8 = ceil_div(pl.nsplit, 8) * 8;
-    dim3 grid(nsplit8 * pl.n_tiles), block(NTHREADS);
+    dim3 grid(nsplit8 * pl.n_tiles, groups), block(NTHREADS);
+    const size_t gdz = (size_t)d->N * d->OH * d->OW * d->Cout, gx = (size_t)d->N * d->H * d->W * d->Cin;
     if (pl.use3x3) {
         W3P q;
         q.dz = (const bf16_t*)dz; q.x = (const bf16_t*)x; q.in_scale = in_scale; q.in_shift = in_shift; q.dw = dw;
         q.ws = ws; q.dw_numel = dw_numel; q.nsplit = pl.nsplit;
+        q.gdz = gdz; q.gx = gx; q.in_gstride = d->in_gstride;
         q.N = d->N; q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.OH = d->OH; q.OW = d->OW; q.Cout = d->Cout; q.pad = d->pad;
         q.act = d->act; q.cin_true = cin_true;
         q.cw = pl.cw; q.rows = pl.rows; q.PR = pl.PR; q.PC = pl.PC; q.units_per_img = pl.upi; q.units_per_row = pl.upr;
@@ -896,6 +926,7 @@ extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* d
         WgradP p;
         p.dz = (const bf16_t*)dz; p.x = (const bf16_t*)x; p.in_scale = in_scale; p.in_shift = in_shift; p.dw = dw;
         p.ws = ws; p.dw_numel = dw_numel; p.nsplit = pl.nsplit;
+        p.gdz = gdz; p.gx = gx; p.in_gstride = d->in_gstride;
         p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.OH = d->OH; p.OW = d->OW; p.Cout = d->Cout;
         p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.act = d->act; p.cin_true = cin_true;
         p.P = d->N * d->OH * d->OW; p.NK = pl.NK; p.cin_shift = pl.cin_shift; p.n_cotiles = pl.n_cotiles; p.n_tiles = pl.n_tiles;
@@ -907,5 +938,5 @@ extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* d
     }
     rc = adamml_check_launch("conv_bwd_weight");
     if (rc || !ws) return rc;
-    return adamml_launch_split_reduce(ws, dw, dw_numel, pl.nsplit, stream);
+    return adamml_launch_split_reduce(ws, dw, dw_numel, groups * pl.nsplit, stream);
 }

@@ -31,6 +31,8 @@ struct DwP {
     double* stats;
     int N, H, W, C, OH, OW, stride, pad, act, accumulate, nseg, seglen;
     size_t P, ppb;
+    size_t gx, gy;        // element strides between BatchNorm groups of x / y (blockIdx.y = group)
+    int in_gstride;
 };
 
 // "Row walker": one thread owns 4 channels of a short run of outputs in ONE output row and slides a 3x3 register
@@ -42,6 +44,13 @@ __global__ __launch_bounds__(NT) void dwconv_fwd_kernel(DwP p) {
     constexpr int SEG = S == 1 ? 8 : 4;                 // outputs per thread (compile-time: all loads issue up front)
     constexpr int NCOL = (SEG - 1) * S + 3;             // input columns feeding them
     __shared__ float smem[2 * MAXC];
+    {
+        const int g = blockIdx.y;
+        p.x += (size_t)g * p.gx;
+        p.y += (size_t)g * p.gy;
+        if (p.stats) p.stats += (size_t)g * ADAMML_STAT_SLOTS * 2 * p.C;
+        if (p.in_scale) { p.in_scale += (size_t)g * p.in_gstride; p.in_shift += (size_t)g * p.in_gstride; }
+    }
     const int nchunk = p.C >> 2;
     const int gid = blockIdx.x * NT + threadIdx.x;
     const int chunk = gid % nchunk, tsk = gid / nchunk;
@@ -125,6 +134,8 @@ __global__ __launch_bounds__(NT) void dwconv_fwd_kernel(DwP p) {
 
 // dx[n,ih,iw,c] = sum_{kh,kw} dz[n,(ih+pad-kh)/s,(iw+pad-kw)/s,c] * w[kh,kw,c]
 __global__ __launch_bounds__(NT) void dwconv_bwd_data_kernel(DwP p) {   // p.x = dz [N,OH,OW,C], p.y = dx [N,H,W,C]
+    p.x += (size_t)blockIdx.y * p.gx;
+    p.y += (size_t)blockIdx.y * p.gy;
     ChanMap m(p.C, threadIdx.x);
     if (!m.active) return;
     const size_t pb = (size_t)blockIdx.x * p.ppb;
@@ -169,11 +180,16 @@ struct DwWP {
     float* ws;            // optional [gridDim.x][9*C] partial buffer in dw layout
     int N, H, W, C, OH, OW, stride, pad, act, rows_per_thread, nseg, seglen;
     size_t P, ppb;
+    size_t gdz, gx;
+    int in_gstride;
 };
 
 template <int S>
 __global__ __launch_bounds__(NT) void dwconv_bwd_weight_kernel(DwWP p) {
     extern __shared__ float dsm[];        // [9][C]
+    p.dz += (size_t)blockIdx.y * p.gdz;
+    p.x += (size_t)blockIdx.y * p.gx;
+    if (p.in_scale) { p.in_scale += (size_t)blockIdx.y * p.in_gstride; p.in_shift += (size_t)blockIdx.y * p.in_gstride; }
     const int nchunk = p.C >> 2;
     for (int i = threadIdx.x; i < 9 * p.C; i += NT) dsm[i] = 0.f;
     __syncthreads();
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(NT) void dwconv_bwd_weight_kernel(DwWP p) {
     __syncthreads();
     for (int i = threadIdx.x; i < 9 * p.C; i += NT) {
         const int t = i / p.C, cc = i - t * p.C;
-        if (p.ws) p.ws[(size_t)blockIdx.x * 9 * p.C + (size_t)cc * 9 + t] = dsm[i];
+        if (p.ws) p.ws[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 9 * p.C + (size_t)cc * 9 + t] = dsm[i];
         else if (dsm[i] != 0.f) atomicAdd(&p.dw[(size_t)cc * 9 + t], dsm[i]);
     }
 }
@@ -351,13 +367,15 @@ extern "C" int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, con
     p.act = d->act; p.accumulate = 0;
     p.P = (size_t)d->N * d->OH * d->OW;
     if (!p.P) return ADAMML_OK;
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    p.gx = (size_t)d->N * d->H * d->W * d->Cin; p.gy = p.P * d->Cin; p.in_gstride = d->in_gstride;
     p.ppb = 0;
     p.seglen = d->stride == 1 ? 8 : 4;          // == SEG of dwconv_fwd_kernel<S>
     p.nseg = (d->OW + p.seglen - 1) / p.seglen;
     const long threads = (long)d->N * d->OH * p.nseg * (p.C / 4);
     const int nblk = (int)((threads + NT - 1) / NT);
-    if (d->stride == 1) hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3(nblk), dim3(NT), 0, stream, p);
-    else hipLaunchKernelGGL(dwconv_fwd_kernel<2>, dim3(nblk), dim3(NT), 0, stream, p);
+    if (d->stride == 1) hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3(nblk, groups), dim3(NT), 0, stream, p);
+    else hipLaunchKernelGGL(dwconv_fwd_kernel<2>, dim3(nblk, groups), dim3(NT), 0, stream, p);
     return adamml_check_launch("dwconv_fwd");
 }
 
@@ -371,8 +389,10 @@ extern "C" int adamml_dwconv_bwd_data(const adamml_conv_desc_t* d, const void* d
     p.act = 0; p.accumulate = accumulate; p.nseg = 1; p.seglen = 0;
     p.P = (size_t)d->N * d->H * d->W;
     if (!p.P) return ADAMML_OK;
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    p.gx = (size_t)d->N * d->OH * d->OW * d->Cin; p.gy = p.P * d->Cin; p.in_gstride = 0;
     int nblk = dw_blocks(p.P, p.C, &p.ppb);
-    hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(nblk), dim3(NT), 0, stream, p);
+    hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(nblk, groups), dim3(NT), 0, stream, p);
     return adamml_check_launch("dwconv_bwd_data");
 }
 
@@ -392,7 +412,7 @@ static int dw_wgrad_blocks(const adamml_conv_desc_t* d, int* seglen, int* nseg) 
 extern "C" size_t adamml_dwconv_bwd_weight_workspace(const adamml_conv_desc_t* d) {
     if (!d || d->Cin % 8) return 0;
     int a, b;
-    return (size_t)dw_wgrad_blocks(d, &a, &b) * 9 * d->Cin * sizeof(float);
+    return (size_t)(d->groups < 1 ? 1 : d->groups) * dw_wgrad_blocks(d, &a, &b) * 9 * d->Cin * sizeof(float);
 }
 
 extern "C" int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
@@ -408,13 +428,15 @@ extern "C" int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void*
     p.rows_per_thread = 1;
     p.ppb = 0;
     const int nblk = dw_wgrad_blocks(d, &p.seglen, &p.nseg);
-    p.ws = (workspace && workspace_bytes >= (size_t)nblk * 9 * p.C * sizeof(float)) ? (float*)workspace : nullptr;
-    if (d->stride == 1) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<1>, dim3(nblk), dim3(NT), 9 * p.C * sizeof(float), stream, p);
-    else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<2>, dim3(nblk), dim3(NT), 9 * p.C * sizeof(float), stream, p);
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    p.gdz = p.P * d->Cin; p.gx = (size_t)d->N * d->H * d->W * d->Cin; p.in_gstride = d->in_gstride;
+    p.ws = (workspace && workspace_bytes >= (size_t)groups * nblk * 9 * p.C * sizeof(float)) ? (float*)workspace : nullptr;
+    if (d->stride == 1) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<1>, dim3(nblk, groups), dim3(NT), 9 * p.C * sizeof(float), stream, p);
+    else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<2>, dim3(nblk, groups), dim3(NT), 9 * p.C * sizeof(float), stream, p);
     if (p.ws) {
         rc = adamml_check_launch("dwconv_bwd_weight");
         if (rc) return rc;
-        return adamml_launch_split_reduce(p.ws, dw, (size_t)9 * p.C, nblk, stream);
+        return adamml_launch_split_reduce(p.ws, dw, (size_t)9 * p.C, groups * nblk, stream);
     }
     return adamml_check_launch("dwconv_bwd_weight");
 }

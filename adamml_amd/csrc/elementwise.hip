@@ -50,12 +50,16 @@ __device__ __forceinline__ void block_channel_publish(const float (&s)[8], const
 }
 
 // ------------------------------------------------------------------------------------------------ BN
-__global__ void stats_collapse_kernel(double* stats, int C) {
+// Every BatchNorm-related kernel below is batched over `groups` (blockIdx.y or an in-kernel loop): tensors are
+// [groups][P][C], statistic accumulators [groups][nslots][2C], BatchNorm vectors vec = [groups][4][C]
+// (scale, shift, mean, invstd), backward coefficients coef = [groups][3][C].
+__global__ void stats_collapse_kernel(const double* stats, double* out, int C, int groups) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * C) return;
+    if (i >= 2 * C * groups) return;
+    const int g = i / (2 * C), j = i - g * 2 * C;
     double s = 0.0;
-    for (int k = 0; k < ADAMML_STAT_SLOTS; ++k) s += stats[(size_t)k * 2 * C + i];
-    stats[i] = s;
+    for (int k = 0; k < ADAMML_STAT_SLOTS; ++k) s += stats[((size_t)g * ADAMML_STAT_SLOTS + k) * 2 * C + j];
+    out[i] = s;
 }
 
 // one 32-lane group per channel: lane k reads slot k, the group folds with xor-shuffles (slot-parallel loads)
@@ -72,27 +76,32 @@ __device__ __forceinline__ void slot_sums(const double* stats, int nslots, int C
     }
 }
 
-__global__ void bn_finalize_kernel(const double* stats, int nslots, double count, const float* gamma, const float* beta, float* rm,
-                                   float* rv, float momentum, float eps, float* scale, float* shift, float* mean,
-                                   float* invstd, int C) {
+// The running statistics see the groups IN ORDER (the reference updates them once per segment call).
+__global__ void bn_finalize_kernel(const double* stats, int nslots, int groups, double count, const float* gamma, const float* beta,
+                                   float* rm, float* rv, float momentum, float eps, float* vec, int C) {
     const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), k = threadIdx.x & 31;
-    double s1, s2;
-    slot_sums(stats, nslots, C, c, k, s1, s2);
-    if (c >= C || k != 0) return;
-    double mu = s1 / count;
-    double var = s2 / count - mu * mu;
-    if (var < 0.0) var = 0.0;
-    float is = (float)(1.0 / sqrt(var + (double)eps));
-    float sc = gamma[c] * is;
-    scale[c] = sc;
-    shift[c] = beta[c] - (float)mu * sc;
-    mean[c] = (float)mu;
-    invstd[c] = is;
-    if (rm) {
+    float rmean = 0.f, rvar = 0.f;
+    const bool lead = c < C && k == 0;
+    if (lead && rm) { rmean = rm[c]; rvar = rv[c]; }
+    for (int g = 0; g < groups; ++g) {
+        double s1, s2;
+        slot_sums(stats + (size_t)g * nslots * 2 * C, nslots, C, c, k, s1, s2);
+        if (!lead) continue;
+        double mu = s1 / count;
+        double var = s2 / count - mu * mu;
+        if (var < 0.0) var = 0.0;
+        float is = (float)(1.0 / sqrt(var + (double)eps));
+        float sc = gamma[c] * is;
+        float* v = vec + (size_t)g * 4 * C;
+        v[c] = sc;
+        v[C + c] = beta[c] - (float)mu * sc;
+        v[2 * C + c] = (float)mu;
+        v[3 * C + c] = is;
         double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mu;
-        rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unbiased;
+        rmean = (1.f - momentum) * rmean + momentum * (float)mu;
+        rvar = (1.f - momentum) * rvar + momentum * (float)unbiased;
     }
+    if (lead && rm) { rm[c] = rmean; rv[c] = rvar; }
 }
 
 __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -104,9 +113,15 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
     shift[c] = beta[c] - rm[c] * sc;
 }
 
-__global__ void bn_act_add_kernel(const bf16_t* z, const float* scale, const float* shift, int act, const bf16_t* idn,
-                                  const float* id_scale, const float* id_shift, bf16_t* out, size_t nchunks, int C) {
+__global__ void bn_act_add_kernel(const bf16_t* z, const float* scale, const float* shift, int z_gs, int act, const bf16_t* idn,
+                                  const float* id_scale, const float* id_shift, int id_gs, bf16_t* out, size_t nchunks, int C) {
     const int cpr = C >> 3;
+    const size_t goff = (size_t)blockIdx.y * nchunks * 8;
+    z += goff; out += goff;
+    if (idn) idn += goff;
+    if (scale) { scale += (size_t)blockIdx.y * z_gs; shift += (size_t)blockIdx.y * z_gs; }
+    if (id_scale) { id_scale += (size_t)blockIdx.y * id_gs; id_shift += (size_t)blockIdx.y * id_gs; }
+    const float lo = act_lo(act), hi = act_hi(act);
     for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nchunks; e += (size_t)gridDim.x * NT) {
         const int c = (int)(e % cpr) * 8;
         f32x8 v = transform8(*reinterpret_cast<const bf16x8*>(z + e * 8), scale, shift, c, ACT_NONE);
@@ -115,26 +130,29 @@ __global__ void bn_act_add_kernel(const bf16_t* z, const float* scale, const flo
             v += w;
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = apply_act(v[i], act);
+        for (int i = 0; i < 8; ++i) v[i] = clamp_act(v[i], lo, hi);
         *reinterpret_cast<bf16x8*>(out + e * 8) = f32_to_bf8(v);
     }
 }
 
 __global__ void act_bwd_from_output_kernel(const bf16_t* g_out, const bf16_t* out, int act, bf16_t* g, size_t nchunks) {
+    const float lo = act_lo(act), hi = act_hi(act);
     for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nchunks; e += (size_t)gridDim.x * NT) {
         f32x8 gv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(g_out + e * 8));
         f32x8 ov = bf8_to_f32(*reinterpret_cast<const bf16x8*>(out + e * 8));
-        const float lo = act_lo(act), hi = act_hi(act);
 #pragma unroll
         for (int i = 0; i < 8; ++i) gv[i] *= mask_act(ov[i], lo, hi);
         *reinterpret_cast<bf16x8*>(g + e * 8) = f32_to_bf8(gv);
     }
 }
 
-__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const bf16_t* g, const bf16_t* z, const float* scale,
-                                                           const float* shift, const float* mean, const float* invstd,
-                                                           int act, double* sums, size_t P, int C, size_t ppb) {
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const bf16_t* g, const bf16_t* z, const float* vec, int act, double* sums,
+                                                           size_t P, int C, size_t ppb) {
     __shared__ float smem[2 * MAXC];
+    g += (size_t)blockIdx.y * P * C;
+    z += (size_t)blockIdx.y * P * C;
+    vec += (size_t)blockIdx.y * 4 * C;
+    sums += (size_t)blockIdx.y * ADAMML_STAT_SLOTS * 2 * C;
     ChanMap m(C, threadIdx.x);
     float s[8], q[8];
 #pragma unroll
@@ -143,13 +161,14 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const bf16_t* g, cons
     const size_t pe = pb + ppb < P ? pb + ppb : P;
     if (m.active) {
         const int c = m.chunk * 8;
-        f32x8 sc = load_f32x8(scale + c), sh = load_f32x8(shift + c), mu = load_f32x8(mean + c), is = load_f32x8(invstd + c);
+        f32x8 sc = load_f32x8(vec + c), sh = load_f32x8(vec + C + c), mu = load_f32x8(vec + 2 * C + c), is = load_f32x8(vec + 3 * C + c);
+        const float lo = act_lo(act), hi = act_hi(act);
         for (size_t p = pb + m.rslot; p < pe; p += m.rows_per_pass) {
             f32x8 gv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(g + p * C + c));
             f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(z + p * C + c));
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float gp = gv[i] * act_mask(fmaf(zv[i], sc[i], sh[i]), act);
+                float gp = gv[i] * mask_act(fmaf(zv[i], sc[i], sh[i]), lo, hi);
                 s[i] += gp;
                 q[i] += gp * (zv[i] - mu[i]) * is[i];
             }
@@ -166,6 +185,12 @@ __global__ __launch_bounds__(NT) void residual_bwd_kernel(const bf16_t* g_out, c
                                                           const bf16_t* zb, const float* vecb, double* sumsb,
                                                           size_t P, int C, size_t ppb) {
     __shared__ float smem[2 * MAXC];
+    {
+        const size_t goff = (size_t)blockIdx.y * P * C;
+        g_out += goff; out += goff; g2 += goff;
+        if (za) { za += goff; veca += (size_t)blockIdx.y * 4 * C; sumsa += (size_t)blockIdx.y * ADAMML_STAT_SLOTS * 2 * C; }
+        if (zb) { zb += goff; vecb += (size_t)blockIdx.y * 4 * C; sumsb += (size_t)blockIdx.y * ADAMML_STAT_SLOTS * 2 * C; }
+    }
     ChanMap m(C, threadIdx.x);
     float sa[8], qa[8], sb[8], qb[8];
 #pragma unroll
@@ -177,10 +202,10 @@ __global__ __launch_bounds__(NT) void residual_bwd_kernel(const bf16_t* g_out, c
         f32x8 mua, isa, mub, isb;
         if (za) { mua = load_f32x8(veca + 2 * C + c); isa = load_f32x8(veca + 3 * C + c); }
         if (zb) { mub = load_f32x8(vecb + 2 * C + c); isb = load_f32x8(vecb + 3 * C + c); }
+        const float lo = act_lo(act), hi = act_hi(act);
         for (size_t p = pb + m.rslot; p < pe; p += m.rows_per_pass) {
             f32x8 gv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(g_out + p * C + c));
             const f32x8 ov = bf8_to_f32(*reinterpret_cast<const bf16x8*>(out + p * C + c));
-            const float lo = act_lo(act), hi = act_hi(act);
 #pragma unroll
             for (int i = 0; i < 8; ++i) gv[i] *= mask_act(ov[i], lo, hi);
             const bf16x8 gb = f32_to_bf8(gv);
@@ -205,33 +230,48 @@ __global__ __launch_bounds__(NT) void residual_bwd_kernel(const bf16_t* g_out, c
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* sums, int nslots, double count, const float* gamma, const float* invstd,
+__global__ void bn_bwd_finalize_kernel(const double* sums, int nslots, int groups, double count, const float* gamma, const float* vec,
                                        float* dgamma, float* dbeta, float* coef, int C) {
     const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), k = threadIdx.x & 31;
-    double sg, sgz;
-    slot_sums(sums, nslots, C, c, k, sg, sgz);
-    if (c >= C || k != 0) return;
-    if (dgamma) dgamma[c] += (float)sgz;
-    if (dbeta) dbeta[c] += (float)sg;
-    coef[c] = gamma[c] * invstd[c];
-    coef[C + c] = (float)(sg / count);
-    coef[2 * C + c] = (float)(sgz / count);
+    const bool lead = c < C && k == 0;
+    float dg = 0.f, db = 0.f;
+    for (int g = 0; g < groups; ++g) {
+        double sg, sgz;
+        slot_sums(sums + (size_t)g * nslots * 2 * C, nslots, C, c, k, sg, sgz);
+        if (!lead) continue;
+        dg += (float)sgz;
+        db += (float)sg;
+        float* cf = coef + (size_t)g * 3 * C;
+        cf[c] = gamma[c] * vec[(size_t)g * 4 * C + 3 * C + c];
+        cf[C + c] = (float)(sg / count);
+        cf[2 * C + c] = (float)(sgz / count);
+    }
+    if (lead) {
+        if (dgamma) dgamma[c] += dg;
+        if (dbeta) dbeta[c] += db;
+    }
 }
 
-__global__ void bn_bwd_apply_kernel(const bf16_t* g, const bf16_t* z, const float* scale, const float* shift,
-                                    const float* mean, const float* invstd, int act, const float* coef, bf16_t* dz,
+__global__ void bn_bwd_apply_kernel(const bf16_t* g, const bf16_t* z, const float* vec, int act, const float* coef, bf16_t* dz,
                                     size_t nchunks, int C) {
     const int cpr = C >> 3;
+    {
+        const size_t goff = (size_t)blockIdx.y * nchunks * 8;
+        g += goff; z += goff; dz += goff;
+        vec += (size_t)blockIdx.y * 4 * C;
+        coef += (size_t)blockIdx.y * 3 * C;
+    }
+    const float lo = act_lo(act), hi = act_hi(act);
     for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nchunks; e += (size_t)gridDim.x * NT) {
         const int c = (int)(e % cpr) * 8;
         f32x8 gv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(g + e * 8));
         f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(z + e * 8));
-        f32x8 sc = load_f32x8(scale + c), sh = load_f32x8(shift + c), mu = load_f32x8(mean + c), is = load_f32x8(invstd + c);
+        f32x8 sc = load_f32x8(vec + c), sh = load_f32x8(vec + C + c), mu = load_f32x8(vec + 2 * C + c), is = load_f32x8(vec + 3 * C + c);
         f32x8 k0 = load_f32x8(coef + c), k1 = load_f32x8(coef + C + c), k2 = load_f32x8(coef + 2 * C + c);
         f32x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float gp = gv[i] * act_mask(fmaf(zv[i], sc[i], sh[i]), act);
+            float gp = gv[i] * mask_act(fmaf(zv[i], sc[i], sh[i]), lo, hi);
             float zh = (zv[i] - mu[i]) * is[i];
             o[i] = k0[i] * (gp - k1[i] - zh * k2[i]);
         }
@@ -240,8 +280,12 @@ __global__ void bn_bwd_apply_kernel(const bf16_t* g, const bf16_t* z, const floa
 }
 
 // ------------------------------------------------------------------------------------------------ pooling
-__global__ void maxpool_fwd_kernel(const bf16_t* x, const float* scale, const float* shift, int act, bf16_t* y,
+__global__ void maxpool_fwd_kernel(const bf16_t* x, const float* scale, const float* shift, int gs, int act, bf16_t* y,
                                    uint8_t* idx, int N, int H, int W, int C, int OH, int OW) {
+    x += (size_t)blockIdx.y * N * H * W * C;
+    y += (size_t)blockIdx.y * N * OH * OW * C;
+    idx += (size_t)blockIdx.y * N * OH * OW * C;
+    if (scale) { scale += (size_t)blockIdx.y * gs; shift += (size_t)blockIdx.y * gs; }
     const int cpr = C >> 3;
     const size_t total = (size_t)N * OH * OW * cpr;
     for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
@@ -310,8 +354,11 @@ __global__ void maxpool_bwd_kernel(const bf16_t* gy, const uint8_t* idx, bf16_t*
 }
 
 // x: [NB, T, HWC] -> y: [NB, To, HWC], To = (T-1)/2+1
-__global__ void temporal_pool_fwd_kernel(const bf16_t* x, const float* scale, const float* shift, int act, bf16_t* y,
+__global__ void temporal_pool_fwd_kernel(const bf16_t* x, const float* scale, const float* shift, int gs, int act, bf16_t* y,
                                          int NB, int T, int To, size_t hwc8, int C, int mode) {
+    x += (size_t)blockIdx.y * NB * T * hwc8 * 8;
+    y += (size_t)blockIdx.y * NB * To * hwc8 * 8;
+    if (scale) { scale += (size_t)blockIdx.y * gs; shift += (size_t)blockIdx.y * gs; }
     const size_t total = (size_t)NB * To * hwc8;
     const int cpr = C >> 3;
     for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
@@ -337,8 +384,12 @@ __global__ void temporal_pool_fwd_kernel(const bf16_t* x, const float* scale, co
 }
 
 // gradient w.r.t. the ACTIVATED input value (the lazy transform's own backward is the producer's business)
-__global__ void temporal_pool_bwd_kernel(const bf16_t* gy, const bf16_t* x, const float* scale, const float* shift, int act,
+__global__ void temporal_pool_bwd_kernel(const bf16_t* gy, const bf16_t* x, const float* scale, const float* shift, int gs, int act,
                                          bf16_t* gx, int NB, int T, int To, size_t hwc8, int C, int mode) {
+    gy += (size_t)blockIdx.y * NB * To * hwc8 * 8;
+    x += (size_t)blockIdx.y * NB * T * hwc8 * 8;
+    gx += (size_t)blockIdx.y * NB * T * hwc8 * 8;
+    if (scale) { scale += (size_t)blockIdx.y * gs; shift += (size_t)blockIdx.y * gs; }
     const size_t total = (size_t)NB * T * hwc8;
     const int cpr = C >> 3;
     for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
@@ -380,8 +431,11 @@ __global__ void temporal_pool_bwd_kernel(const bf16_t* gy, const bf16_t* x, cons
     }
 }
 
-__global__ void gap_fwd_kernel(const bf16_t* x, const float* scale, const float* shift, int act, float* out, int N, int HW,
+__global__ void gap_fwd_kernel(const bf16_t* x, const float* scale, const float* shift, int gs, int act, float* out, int N, int HW,
                                int C) {
+    x += (size_t)blockIdx.y * N * HW * C;
+    out += (size_t)blockIdx.y * N * C;
+    if (scale) { scale += (size_t)blockIdx.y * gs; shift += (size_t)blockIdx.y * gs; }
     const int cpr = C >> 3;
     const int total = N * cpr;
     for (int e = blockIdx.x * NT + threadIdx.x; e < total; e += gridDim.x * NT) {
@@ -515,19 +569,18 @@ __global__ void adam_step_kernel(float* p, const float* g, float* m, float* v, s
     if ((C) % 8 != 0 || (C) > MAXC || (C) <= 0)                                                              \
         return adamml_set_error(ADAMML_EINVAL, name ": C=%d must be a multiple of 8 in (0, %d]", (C), MAXC);
 
-extern "C" int adamml_stats_collapse(double* stats, int C, hipStream_t stream) {
-    if (!stats) return adamml_set_error(ADAMML_EINVAL, "stats_collapse: null argument");
-    hipLaunchKernelGGL(stats_collapse_kernel, dim3(ceil_div(2 * C, 128)), dim3(128), 0, stream, stats, C);
+extern "C" int adamml_stats_collapse(const double* stats, double* out, int C, int groups, hipStream_t stream) {
+    if (!stats || !out) return adamml_set_error(ADAMML_EINVAL, "stats_collapse: null argument");
+    hipLaunchKernelGGL(stats_collapse_kernel, dim3(ceil_div(2 * C * groups, 128)), dim3(128), 0, stream, stats, out, C, groups);
     return adamml_check_launch("stats_collapse");
 }
 
-extern "C" int adamml_bn_finalize(const double* stats, int nslots, double count, const float* gamma, const float* beta, float* rm,
-                                  float* rv, float momentum, float eps, float* scale, float* shift, float* mean,
-                                  float* invstd, int C, hipStream_t stream) {
-    if (!stats || !gamma || !beta || !scale || !shift || !mean || !invstd) return adamml_set_error(ADAMML_EINVAL, "bn_finalize: null argument");
-    if (nslots < 1 || nslots > ADAMML_STAT_SLOTS) return adamml_set_error(ADAMML_EINVAL, "bn_finalize: nslots=%d", nslots);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, stream, stats, nslots, count, gamma, beta, rm, rv,
-                       momentum, eps, scale, shift, mean, invstd, C);
+extern "C" int adamml_bn_finalize(const double* stats, int nslots, int groups, double count, const float* gamma, const float* beta,
+                                  float* rm, float* rv, float momentum, float eps, float* vec, int C, hipStream_t stream) {
+    if (!stats || !gamma || !beta || !vec) return adamml_set_error(ADAMML_EINVAL, "bn_finalize: null argument");
+    if (nslots < 1 || nslots > ADAMML_STAT_SLOTS || groups < 1) return adamml_set_error(ADAMML_EINVAL, "bn_finalize: nslots=%d groups=%d", nslots, groups);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, stream, stats, nslots, groups, count, gamma, beta, rm, rv,
+                       momentum, eps, vec, C);
     return adamml_check_launch("bn_finalize");
 }
 
@@ -537,13 +590,15 @@ extern "C" int adamml_bn_eval_affine(const float* gamma, const float* beta, cons
     return adamml_check_launch("bn_eval_affine");
 }
 
-extern "C" int adamml_bn_act_add(const void* z, const float* scale, const float* shift, int act, const void* idn,
-                                 const float* id_scale, const float* id_shift, void* out, size_t P, int C, hipStream_t stream) {
+extern "C" int adamml_bn_act_add(const void* z, const float* scale, const float* shift, int z_gstride, int act, const void* idn,
+                                 const float* id_scale, const float* id_shift, int id_gstride, void* out, size_t P, int C, int groups,
+                                 hipStream_t stream) {
     CHECK_C(C, "bn_act_add");
     const size_t n = P * (size_t)(C / 8);
     if (!n) return ADAMML_OK;
-    hipLaunchKernelGGL(bn_act_add_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, (const bf16_t*)z, scale, shift, act,
-                       (const bf16_t*)idn, id_scale, id_shift, (bf16_t*)out, n, C);
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL(bn_act_add_kernel, dim3(grid_for(n, NT, 4096 / groups + 1), groups), dim3(NT), 0, stream, (const bf16_t*)z, scale, shift,
+                       z_gstride, act, (const bf16_t*)idn, id_scale, id_shift, id_gstride, (bf16_t*)out, n, C);
     return adamml_check_launch("bn_act_add");
 }
 
@@ -555,59 +610,69 @@ extern "C" int adamml_act_bwd_from_output(const void* g_out, const void* out, in
     return adamml_check_launch("act_bwd_from_output");
 }
 
-extern "C" int adamml_bn_bwd_reduce(const void* g, const void* z, const float* scale, const float* shift, const float* mean,
-                                    const float* invstd, int act, double* sums, size_t P, int C, hipStream_t stream) {
-    CHECK_C(C, "bn_bwd_reduce");
-    if (!P) return ADAMML_OK;
+static void reduce_grid(size_t P, int C, int groups, size_t* ppb_out, size_t* nblk_out) {
     const int rows = NT / (C / 8) > 0 ? NT / (C / 8) : 1;
     size_t ppb = (size_t)rows * 16;
     size_t nblk = (P + ppb - 1) / ppb;
-    if (nblk > 2048) { ppb = ((P + 2047) / 2048 + rows - 1) / rows * rows; nblk = (P + ppb - 1) / ppb; }
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)nblk), dim3(NT), 0, stream, (const bf16_t*)g, (const bf16_t*)z, scale,
-                       shift, mean, invstd, act, sums, P, C, ppb);
+    const size_t cap = 2048 / (groups < 1 ? 1 : groups) + 1;
+    if (nblk > cap) { ppb = ((P + cap - 1) / cap + rows - 1) / rows * rows; nblk = (P + ppb - 1) / ppb; }
+    *ppb_out = ppb;
+    *nblk_out = nblk;
+}
+
+extern "C" int adamml_bn_bwd_reduce(const void* g, const void* z, const float* vec, int act, double* sums, size_t P, int C, int groups,
+                                    hipStream_t stream) {
+    CHECK_C(C, "bn_bwd_reduce");
+    if (!P) return ADAMML_OK;
+    if (groups < 1) groups = 1;
+    size_t ppb, nblk;
+    reduce_grid(P, C, groups, &ppb, &nblk);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g, (const bf16_t*)z, vec, act,
+                       sums, P, C, ppb);
     return adamml_check_launch("bn_bwd_reduce");
 }
 
 extern "C" int adamml_residual_bwd(const void* g_out, const void* out, int act, void* g2, const void* za, const float* veca,
-                                   double* sumsa, const void* zb, const float* vecb, double* sumsb, size_t P, int C,
+                                   double* sumsa, const void* zb, const float* vecb, double* sumsb, size_t P, int C, int groups,
                                    hipStream_t stream) {
     CHECK_C(C, "residual_bwd");
     if (!P) return ADAMML_OK;
+    if (groups < 1) groups = 1;
     if ((za && (!veca || !sumsa)) || (zb && (!vecb || !sumsb))) return adamml_set_error(ADAMML_EINVAL, "residual_bwd: null BN operands");
-    const int rows = NT / (C / 8) > 0 ? NT / (C / 8) : 1;
-    size_t ppb = (size_t)rows * 16;
-    size_t nblk = (P + ppb - 1) / ppb;
-    if (nblk > 2048) { ppb = ((P + 2047) / 2048 + rows - 1) / rows * rows; nblk = (P + ppb - 1) / ppb; }
-    hipLaunchKernelGGL(residual_bwd_kernel, dim3((unsigned)nblk), dim3(NT), 0, stream, (const bf16_t*)g_out, (const bf16_t*)out, act,
+    size_t ppb, nblk;
+    reduce_grid(P, C, groups, &ppb, &nblk);
+    hipLaunchKernelGGL(residual_bwd_kernel, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g_out, (const bf16_t*)out, act,
                        (bf16_t*)g2, (const bf16_t*)za, veca, sumsa, (const bf16_t*)zb, vecb, sumsb, P, C, ppb);
     return adamml_check_launch("residual_bwd");
 }
 
-extern "C" int adamml_bn_bwd_finalize(const double* sums, int nslots, double count, const float* gamma, const float* invstd, float* dgamma,
-                                      float* dbeta, float* coef, int C, hipStream_t stream) {
-    if (nslots < 1 || nslots > ADAMML_STAT_SLOTS) return adamml_set_error(ADAMML_EINVAL, "bn_bwd_finalize: nslots=%d", nslots);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, stream, sums, nslots, count, gamma, invstd, dgamma,
+extern "C" int adamml_bn_bwd_finalize(const double* sums, int nslots, int groups, double count, const float* gamma, const float* vec,
+                                      float* dgamma, float* dbeta, float* coef, int C, hipStream_t stream) {
+    if (nslots < 1 || nslots > ADAMML_STAT_SLOTS || groups < 1) return adamml_set_error(ADAMML_EINVAL, "bn_bwd_finalize: nslots=%d groups=%d", nslots, groups);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, stream, sums, nslots, groups, count, gamma, vec, dgamma,
                        dbeta, coef, C);
     return adamml_check_launch("bn_bwd_finalize");
 }
 
-extern "C" int adamml_bn_bwd_apply(const void* g, const void* z, const float* scale, const float* shift, const float* mean,
-                                   const float* invstd, int act, const float* coef, void* dz, size_t P, int C, hipStream_t stream) {
+extern "C" int adamml_bn_bwd_apply(const void* g, const void* z, const float* vec, int act, const float* coef, void* dz, size_t P, int C,
+                                   int groups, hipStream_t stream) {
     CHECK_C(C, "bn_bwd_apply");
     const size_t n = P * (size_t)(C / 8);
     if (!n) return ADAMML_OK;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, (const bf16_t*)g, (const bf16_t*)z, scale, shift,
-                       mean, invstd, act, coef, (bf16_t*)dz, n, C);
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n, NT, 4096 / groups + 1), groups), dim3(NT), 0, stream, (const bf16_t*)g,
+                       (const bf16_t*)z, vec, act, coef, (bf16_t*)dz, n, C);
     return adamml_check_launch("bn_bwd_apply");
 }
 
-extern "C" int adamml_maxpool2d_fwd(const void* x, const float* scale, const float* shift, int act, void* y, uint8_t* idx, int N,
-                                    int H, int W, int C, int OH, int OW, hipStream_t stream) {
+extern "C" int adamml_maxpool2d_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, void* y, uint8_t* idx,
+                                    int N, int H, int W, int C, int OH, int OW, int groups, hipStream_t stream) {
     CHECK_C(C, "maxpool2d_fwd");
     const size_t n = (size_t)N * OH * OW * (C / 8);
     if (!n) return ADAMML_OK;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, (const bf16_t*)x, scale, shift, act, (bf16_t*)y,
-                       idx, N, H, W, C, OH, OW);
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n, NT, 4096 / groups + 1), groups), dim3(NT), 0, stream, (const bf16_t*)x, scale,
+                       shift, gstride, act, (bf16_t*)y, idx, N, H, W, C, OH, OW);
     return adamml_check_launch("maxpool2d_fwd");
 }
 
@@ -621,36 +686,40 @@ extern "C" int adamml_maxpool2d_bwd(const void* g_y, const uint8_t* idx, void* g
     return adamml_check_launch("maxpool2d_bwd");
 }
 
-extern "C" int adamml_temporal_pool_fwd(const void* x, const float* scale, const float* shift, int act, void* y, int NB, int T,
-                                        size_t HWC, int C, int mode, hipStream_t stream) {
+extern "C" int adamml_temporal_pool_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, void* y, int NB,
+                                        int T, size_t HWC, int C, int mode, int groups, hipStream_t stream) {
     CHECK_C(C, "temporal_pool_fwd");
     if (mode == 1 && T < 3)   // models/common.py:20 nn.AvgPool3d raises for T < kernel (torch: "input image smaller than kernel size")
         return adamml_set_error(ADAMML_EINVAL, "temporal_pool_fwd: avg pooling needs T >= 3 (got %d), as in the reference", T);
     const int To = (T - 1) / 2 + 1;
     const size_t n = (size_t)NB * To * (HWC / 8);
     if (!n) return ADAMML_OK;
-    hipLaunchKernelGGL(temporal_pool_fwd_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, (const bf16_t*)x, scale, shift, act,
-                       (bf16_t*)y, NB, T, To, HWC / 8, C, mode);
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL(temporal_pool_fwd_kernel, dim3(grid_for(n, NT, 4096 / groups + 1), groups), dim3(NT), 0, stream, (const bf16_t*)x,
+                       scale, shift, gstride, act, (bf16_t*)y, NB, T, To, HWC / 8, C, mode);
     return adamml_check_launch("temporal_pool_fwd");
 }
 
-extern "C" int adamml_temporal_pool_bwd(const void* g_y, const void* x, const float* scale, const float* shift, int act, void* g_x,
-                                        int NB, int T, size_t HWC, int C, int mode, hipStream_t stream) {
+extern "C" int adamml_temporal_pool_bwd(const void* g_y, const void* x, const float* scale, const float* shift, int gstride, int act,
+                                        void* g_x, int NB, int T, size_t HWC, int C, int mode, int groups, hipStream_t stream) {
     CHECK_C(C, "temporal_pool_bwd");
     const int To = (T - 1) / 2 + 1;
     const size_t n = (size_t)NB * T * (HWC / 8);
     if (!n) return ADAMML_OK;
-    hipLaunchKernelGGL(temporal_pool_bwd_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, (const bf16_t*)g_y, (const bf16_t*)x, scale,
-                       shift, act, (bf16_t*)g_x, NB, T, To, HWC / 8, C, mode);
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL(temporal_pool_bwd_kernel, dim3(grid_for(n, NT, 4096 / groups + 1), groups), dim3(NT), 0, stream, (const bf16_t*)g_y,
+                       (const bf16_t*)x, scale, shift, gstride, act, (bf16_t*)g_x, NB, T, To, HWC / 8, C, mode);
     return adamml_check_launch("temporal_pool_bwd");
 }
 
-extern "C" int adamml_gap_fwd(const void* x, const float* scale, const float* shift, int act, float* out, int N, int HW, int C,
-                              hipStream_t stream) {
+extern "C" int adamml_gap_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, float* out, int N, int HW,
+                              int C, int groups, hipStream_t stream) {
     CHECK_C(C, "gap_fwd");
     const size_t n = (size_t)N * (C / 8);
     if (!n) return ADAMML_OK;
-    hipLaunchKernelGGL(gap_fwd_kernel, dim3(grid_for(n, 64)), dim3(NT), 0, stream, (const bf16_t*)x, scale, shift, act, out, N, HW, C);
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(grid_for(n, 64), groups), dim3(NT), 0, stream, (const bf16_t*)x, scale, shift, gstride, act, out,
+                       N, HW, C);
     return adamml_check_launch("gap_fwd");
 }
 

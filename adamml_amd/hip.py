@@ -17,7 +17,12 @@ STAT_SLOTS = 32          # ADAMML_STAT_SLOTS in include/adamml_hip.h
 
 class ConvDesc(Structure):
     _fields_ = [(n, c_int32) for n in ("N", "H", "W", "Cin", "OH", "OW", "Cout", "KH", "KW", "stride", "pad", "up", "act",
-                                      "accumulate")]
+                                      "accumulate", "groups", "in_gstride")]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        if self.groups < 1:
+            self.groups = 1
 
 
 _P, _I, _F, _D, _Z, _L = c_void_p, c_int, c_float, c_double, c_size_t, c_int64
@@ -28,25 +33,25 @@ SIGNATURES = {
     "adamml_conv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "adamml_conv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
     "adamml_conv_bwd_data_bn": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
-    "adamml_residual_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _P],
+    "adamml_residual_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _P],
     "adamml_conv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _I, _P, _Z, _P],
     "adamml_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "adamml_dwconv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "adamml_dwconv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
     "adamml_dwconv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _P, _Z, _P],
-    "adamml_stats_collapse": [_P, _I, _P],
-    "adamml_bn_finalize": [_P, _I, _D, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
+    "adamml_stats_collapse": [_P, _P, _I, _I, _P],
+    "adamml_bn_finalize": [_P, _I, _I, _D, _P, _P, _P, _P, _F, _F, _P, _I, _P],
     "adamml_bn_eval_affine": [_P, _P, _P, _P, _F, _P, _P, _I, _P],
-    "adamml_bn_act_add": [_P, _P, _P, _I, _P, _P, _P, _P, _Z, _I, _P],
+    "adamml_bn_act_add": [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _Z, _I, _I, _P],
     "adamml_act_bwd_from_output": [_P, _P, _I, _P, _Z, _P],
-    "adamml_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _I, _P, _Z, _I, _P],
-    "adamml_bn_bwd_finalize": [_P, _I, _D, _P, _P, _P, _P, _P, _I, _P],
-    "adamml_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _Z, _I, _P],
-    "adamml_maxpool2d_fwd": [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "adamml_bn_bwd_reduce": [_P, _P, _P, _I, _P, _Z, _I, _I, _P],
+    "adamml_bn_bwd_finalize": [_P, _I, _I, _D, _P, _P, _P, _P, _P, _I, _P],
+    "adamml_bn_bwd_apply": [_P, _P, _P, _I, _P, _P, _Z, _I, _I, _P],
+    "adamml_maxpool2d_fwd": [_P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "adamml_maxpool2d_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "adamml_temporal_pool_fwd": [_P, _P, _P, _I, _P, _I, _I, _Z, _I, _I, _P],
-    "adamml_temporal_pool_bwd": [_P, _P, _P, _P, _I, _P, _I, _I, _Z, _I, _I, _P],
-    "adamml_gap_fwd": [_P, _P, _P, _I, _P, _I, _I, _I, _P],
+    "adamml_temporal_pool_fwd": [_P, _P, _P, _I, _I, _P, _I, _I, _Z, _I, _I, _I, _P],
+    "adamml_temporal_pool_bwd": [_P, _P, _P, _P, _I, _I, _P, _I, _I, _Z, _I, _I, _I, _P],
+    "adamml_gap_fwd": [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P],
     "adamml_gap_bwd": [_P, _P, _I, _I, _I, _P],
     "adamml_clip_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "adamml_gemm_f32": [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _I, _I, _P],

@@ -53,17 +53,18 @@ class JointResNetMobileNetV2(nn.Module, MeanStdMixin):
             name += "-ts-{}".format(self.pooling_method)
         return name
 
-    def backbone_logits(self, multi_modalities, side_stream=None):
-        """Per-modality logits of ONE segment.  With a side stream the MobileNetV2 (sound) backbone is enqueued there so
-        that its many small launches overlap the ResNet's HBM-bound kernels; the caller joins the streams."""
+    def backbone_logits(self, multi_modalities, side_stream=None, groups=1):
+        """Per-modality logits of `groups` segments stacked along dim 0 (each segment = one reference module call with
+        its own BatchNorm statistics).  With a side stream the MobileNetV2 (sound) backbone is enqueued there so that its
+        many small launches overlap the ResNet's HBM-bound kernels; the caller joins the streams."""
         out = []
         for i, x in enumerate(multi_modalities):
             net = self.nets[i]
             if side_stream is not None and self.modality[i] == 'sound':
                 with torch.cuda.stream(side_stream):
-                    out.append(net.forward_nhwc(x))
+                    out.append(net.forward_nhwc(x, groups))
             else:
-                out.append(net.forward_nhwc(x))                  # [B, classes] fp32
+                out.append(net.forward_nhwc(x, groups))          # [G*B, classes] fp32
         return out
 
     def fuse(self, logits, decisions=None):

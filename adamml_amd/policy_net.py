@@ -93,10 +93,10 @@ class MobileNetV2(HipBackbone, MeanStdMixin):
                 m.weight.data.normal_(0, 0.01)
                 m.bias.data.zero_()
 
-    def _run(self, x, extra, need_grad):
-        """x: [B*T, H, W, pad8(C)] bf16.  Returns pooled features fp32 [B*T', 1280] (feature_extraction, :142-149)."""
+    def _run(self, x, groups, need_grad):
+        """x: [G*B*T, H, W, pad8(C)] bf16.  Returns pooled features fp32 [G*B*T', 1280] (feature_extraction, :142-149)."""
         rt = self.rt
-        tape = rt.begin_forward(x.device, self.training, need_grad)
+        tape = rt.begin_forward(x.device, self.training, need_grad, groups)
         self._repack(need_grad)
         h = conv_bn(rt, Lazy(x, requires_grad=False), self._stem[0], self._stem[1], ACT_RELU6)
         h = run_blocks(rt, h, self._plans)
@@ -107,8 +107,8 @@ class MobileNetV2(HipBackbone, MeanStdMixin):
             tape.record(lambda: push(tape.grad_out))
         return feat, tape
 
-    def feature_extraction(self, frames_nhwc):
-        return self.call(frames_nhwc)
+    def feature_extraction(self, frames_nhwc, groups=1):
+        return self.call(frames_nhwc, groups)
 
     @property
     def network_name(self):
@@ -132,9 +132,9 @@ class JointMobileNetV2(nn.Module):
         self.last_channels = 2048
         self.joint = nn.Sequential(nn.Linear(sum(chans), 2048), nn.ReLU(True), nn.Linear(2048, 2048), nn.ReLU(True))
 
-    def features(self, multi_modalities):
-        """multi_modalities: list of NHWC bf16 frame tensors (one segment).  -> [B, 2048]."""
-        out = torch.cat([net.feature_extraction(x) for net, x in zip(self.nets, multi_modalities)], dim=1)
+    def features(self, multi_modalities, groups=1):
+        """multi_modalities: list of NHWC bf16 frame tensors (`groups` segments stacked along dim 0).  -> [G*B, 2048]."""
+        out = torch.cat([net.feature_extraction(x, groups) for net, x in zip(self.nets, multi_modalities)], dim=1)
         out = hip_linear(out, self.joint[0].weight, self.joint[0].bias, ACT_RELU)
         return hip_linear(out, self.joint[2].weight, self.joint[2].bias, ACT_RELU)
 
@@ -190,10 +190,16 @@ class PolicyNet(nn.Module):
         backbones of segment i with the main nets of segment i on different HIP streams."""
         return self.joint_net.features([x[m_i][i] for m_i in range(self.num_modality)])
 
+    def all_segment_features(self, x):
+        """Joint features of ALL segments in one batched pass (per-segment BatchNorm statistics are kept by the
+        `groups` mechanism of the backbones; the joint FCs have no batch statistics).  -> list of S tensors [B, 2048]."""
+        S = x[0].shape[0]
+        out = self.joint_net.features([x[m_i].flatten(0, 1) for m_i in range(self.num_modality)], groups=S)
+        return list(out.view(S, -1, out.shape[-1]).unbind(0))
+
     def forward(self, x, gumbel_exponential=None):
         """x: list over modality of [S, B*Fk, H, W, C] NHWC bf16 frames.  Returns decisions [S,M,B], logits [S,M,B,2]."""
-        S = x[0].shape[0]
-        return self.decide([self.segment_features(x, i) for i in range(S)], gumbel_exponential)
+        return self.decide(self.all_segment_features(x), gumbel_exponential)
 
     def decide(self, outs, gumbel_exponential=None):
         """LSTM causality head + hard Gumbel-softmax over the per-segment features (models/policy_net.py:329-373)."""

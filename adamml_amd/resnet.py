@@ -81,14 +81,14 @@ class ResNet(HipBackbone, MeanStdMixin):
         return nn.Sequential(*layers)
 
     # ------------------------------------------------------------------------------------------
-    def _run(self, x, extra, need_grad):
-        """x: [N*T, H, W, pad8(C)] bf16 frames.  Returns fp32 logits [N, num_classes]."""
+    def _run(self, x, groups, need_grad):
+        """x: [G*N*T, H, W, pad8(C)] bf16 frames (G groups of N clips).  Returns fp32 logits [G*N, num_classes]."""
         rt = self.rt
-        tape = rt.begin_forward(x.device, self.training, need_grad)
+        tape = rt.begin_forward(x.device, self.training, need_grad, groups)
         self._repack(need_grad)
         frames = self.orig_num_frames
         nt = x.shape[0]
-        n = nt // frames
+        n = nt // frames                              # clips over all groups
         h = Lazy(x, requires_grad=False)
         h = conv_bn(rt, h, self._stem, self.bn1, ACT_RELU)
         h = maxpool3x3s2(rt, h)
@@ -139,8 +139,8 @@ class ResNet(HipBackbone, MeanStdMixin):
         xs = clip_to_nhwc(x, 1, frames, c_t // frames)[0]
         return self.call(xs)
 
-    def forward_nhwc(self, frames_nhwc):
-        return self.call(frames_nhwc)
+    def forward_nhwc(self, frames_nhwc, groups=1):
+        return self.call(frames_nhwc, groups)
 
 
 def resnet(depth, num_classes, without_t_stride, groups, dropout, pooling_method,

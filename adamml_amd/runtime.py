@@ -23,14 +23,15 @@ def pad8(c):
 
 
 class Lazy:
-    """Activation tensor [N,H,W,C] bf16 whose value is act(scale*data + shift) (scale None -> data)."""
-    __slots__ = ("data", "scale", "shift", "act", "grad", "requires_grad", "vec", "src", "pre_sums")
+    """Activation tensor [G*N,H,W,C] bf16 (G BatchNorm groups, group-major) whose value is act(scale*data + shift)
+    (scale None -> data); group g uses scale + g*gs, shift + g*gs (gs == 0: one pair for all groups)."""
+    __slots__ = ("data", "scale", "shift", "gs", "act", "grad", "requires_grad", "vec", "src", "pre_sums")
 
-    def __init__(self, data, scale=None, shift=None, act=ACT_NONE, requires_grad=True):
-        self.data, self.scale, self.shift, self.act = data, scale, shift, act
+    def __init__(self, data, scale=None, shift=None, act=ACT_NONE, requires_grad=True, gs=0):
+        self.data, self.scale, self.shift, self.act, self.gs = data, scale, shift, act, gs
         self.grad = None            # gradient w.r.t. the ACTIVATED value, bf16, same shape
         self.requires_grad = requires_grad
-        self.vec = None             # train-mode BatchNorm vectors [4,C] (scale, shift, mean, invstd) of a lazy tensor
+        self.vec = None             # train-mode BatchNorm vectors [G,4,C] (scale, shift, mean, invstd) of a lazy tensor
         self.src = None             # lazy tensor this plain tensor is the materialisation of
         self.pre_sums = None        # BatchNorm-backward sums already accumulated by the producer of .grad
 
@@ -92,14 +93,15 @@ class SyncCtx:
         self.enabled = enabled and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.enabled else 1
 
-    def reduce(self, t, C):
-        """t: [STAT_SLOTS][2C] slot-interleaved sums.  Returns the number of slots the finalize kernel must sum:
-        under SyncBN the slots are collapsed into slot 0 first so that only 2C doubles cross xGMI."""
+    def reduce(self, t, C, groups):
+        """t: [groups][STAT_SLOTS][2C] slot-interleaved sums.  Returns (sums, nslots) for the finalize kernel: under
+        SyncBN the slots are collapsed first so that only groups*2C doubles cross xGMI, in ONE all-reduce."""
         if not self.enabled:
-            return STAT_SLOTS
-        call("adamml_stats_collapse", ptr(t), C)
-        dist.all_reduce(t[:2 * C], group=self.group)
-        return 1
+            return t, STAT_SLOTS
+        out = torch.empty(groups * 2 * C, dtype=torch.float64, device=t.device)
+        call("adamml_stats_collapse", ptr(t), ptr(out), C, groups)
+        dist.all_reduce(out, group=self.group)
+        return out, 1
 
 
 class NetRT:
@@ -110,10 +112,14 @@ class NetRT:
         self.bwd_arena = Arena()
         self.sync = SyncCtx()
         self.training = False
+        self.groups = 1
         self.tape = Tape(False)
 
-    def begin_forward(self, device, training, need_grad):
+    def begin_forward(self, device, training, need_grad, groups=1):
+        """groups = number of independent BatchNorm groups batched in this call: the S per-segment module calls of the
+        reference (models/adamml.py:151-160) become one launch sequence with per-group statistics."""
         self.training = training
+        self.groups = groups
         self.tape = Tape(need_grad)
         self.touched_bns = []
         if training:
@@ -121,10 +127,10 @@ class NetRT:
         return self.tape
 
     def end_forward(self):
-        """nn.BatchNorm2d bookkeeping: num_batches_tracked += 1 for every BN evaluated in train mode
+        """nn.BatchNorm2d bookkeeping: num_batches_tracked += 1 per group for every BN evaluated in train mode
         (one multi-tensor launch per backbone call instead of one per layer)."""
         if self.training and self.touched_bns:
-            torch._foreach_add_([b.num_batches_tracked for b in self.touched_bns], 1)
+            torch._foreach_add_([b.num_batches_tracked for b in self.touched_bns], self.groups)
         self.touched_bns = []
 
 
@@ -159,18 +165,20 @@ class ConvState:
                 self.w_dgrad = torch.empty(self.cin, self.kh * self.kw * self.cout, dtype=torch.bfloat16, device=w.device)
             call("adamml_pack_conv_weight", ptr(w), ptr(self.w_dgrad), self.cout, self.cin_true, self.cin, self.kh, self.kw, 1)
 
-    def desc(self, x_shape, act):
+    def desc(self, x_shape, act, groups=1, in_gstride=0):
         n, h, w, c = x_shape
         oh = (h + 2 * self.pad - self.kh) // self.stride + 1
         ow = (w + 2 * self.pad - self.kw) // self.stride + 1
-        return ConvDesc(n, h, w, c, oh, ow, self.cout, self.kh, self.kw, self.stride, self.pad, 1, act, 0)
+        return ConvDesc(n // groups, h, w, c, oh, ow, self.cout, self.kh, self.kw, self.stride, self.pad, 1, act, 0, groups,
+                        in_gstride)
 
 
 def _bn_vectors(rt, bn, stats, count, C, device):
-    vec = torch.empty(4, C, dtype=torch.float32, device=device)
-    nslots = rt.sync.reduce(stats, C)
-    call("adamml_bn_finalize", ptr(stats), nslots, float(count * rt.sync.world), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
-         ptr(bn.running_var), BN_MOMENTUM, BN_EPS, ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), C)
+    G = rt.groups
+    vec = torch.empty(G, 4, C, dtype=torch.float32, device=device)
+    stats, nslots = rt.sync.reduce(stats, C, G)
+    call("adamml_bn_finalize", ptr(stats), nslots, G, float(count * rt.sync.world), ptr(bn.weight), ptr(bn.bias),
+         ptr(bn.running_mean), ptr(bn.running_var), BN_MOMENTUM, BN_EPS, ptr(vec), C)
     return vec
 
 
@@ -186,19 +194,20 @@ def _bn_backward(rt, out, y, vec, bn, act, count):
     g = out.grad
     out.grad = None
     n, oh, ow, C = y.shape
-    P = n * oh * ow
+    G = rt.groups
+    P = n // G * oh * ow                    # pixels per group
     if out.pre_sums is not None:            # reduction fused into the kernel that produced g (already activation-masked)
         sums, out.pre_sums = out.pre_sums, None
     else:
-        sums = rt.bwd_arena.take(2 * C * STAT_SLOTS)
-        call("adamml_bn_bwd_reduce", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), act, ptr(sums), P, C)
-    nslots = rt.sync.reduce(sums, C)
-    coef = torch.empty(3, C, dtype=torch.float32, device=y.device)
+        sums = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS)
+        call("adamml_bn_bwd_reduce", ptr(g), ptr(y), ptr(vec), act, ptr(sums), P, C, G)
+    sums, nslots = rt.sync.reduce(sums, C, G)
+    coef = torch.empty(G, 3, C, dtype=torch.float32, device=y.device)
     train_bn = bn.weight.requires_grad
-    call("adamml_bn_bwd_finalize", ptr(sums), nslots, float(count * rt.sync.world), ptr(bn.weight), ptr(vec[3]),
+    call("adamml_bn_bwd_finalize", ptr(sums), nslots, G, float(count * rt.sync.world), ptr(bn.weight), ptr(vec),
          ptr(bn.weight.grad) if train_bn else None, ptr(bn.bias.grad) if train_bn else None, ptr(coef), C)
     dz = torch.empty_like(y)
-    call("adamml_bn_bwd_apply", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), act, ptr(coef), ptr(dz), P, C)
+    call("adamml_bn_bwd_apply", ptr(g), ptr(y), ptr(vec), act, ptr(coef), ptr(dz), P, C, G)
     return dz
 
 
@@ -207,7 +216,8 @@ def materialize(rt, x):
     loader would otherwise re-apply the producer's BatchNorm+ReLU once per tap (9x for 3x3) on the VALU."""
     n, h, w, C = x.shape
     out_t = torch.empty_like(x.data)
-    call("adamml_bn_act_add", ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, None, None, None, ptr(out_t), n * h * w, C)
+    call("adamml_bn_act_add", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, None, None, None, 0, ptr(out_t),
+         n // rt.groups * h * w, C, rt.groups)
     a = Lazy(out_t, requires_grad=x.requires_grad)
     a.src = x
     if rt.tape.need_grad:
@@ -225,30 +235,35 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False):
     x's activation mask and accumulate x's BatchNorm-backward sums (no separate reduction pass over g and z)."""
     if x.scale is not None and not cs.depthwise and cs.kh * cs.kw > 1:
         x = materialize(rt, x)
-    d = cs.desc(x.shape, x.act)
+    G = rt.groups
+    d = cs.desc(x.shape, x.act, G, x.gs)
     if x.shape[3] != cs.cin:
         raise RuntimeError("conv_bn: input has %d channels, weight pack expects %d" % (x.shape[3], cs.cin))
+    if x.shape[0] % G:
+        raise RuntimeError("conv_bn: %d images do not split into %d BatchNorm groups" % (x.shape[0], G))
     dev = x.data.device
-    y = torch.empty(d.N, d.OH, d.OW, d.Cout, dtype=torch.bfloat16, device=dev)
+    y = torch.empty(G * d.N, d.OH, d.OW, d.Cout, dtype=torch.bfloat16, device=dev)
     C = d.Cout
-    count = d.N * d.OH * d.OW
+    count = d.N * d.OH * d.OW               # elements per channel per group
     fwd = "adamml_dwconv_fwd" if cs.depthwise else "adamml_conv_fwd"
     # algorithmic work of this layer (true input channels, each tensor touched once), for the roofline report
-    macs = float(count) * C * cs.kh * cs.kw * (1 if cs.depthwise else cs.cin_true)
-    in_b, out_b = 2.0 * d.N * d.H * d.W * cs.cin_true, 2.0 * count * C
+    macs = float(count) * G * C * cs.kh * cs.kw * (1 if cs.depthwise else cs.cin_true)
+    in_b, out_b = 2.0 * G * d.N * d.H * d.W * cs.cin_true, 2.0 * G * count * C
     w_b = 2.0 * C * cs.kh * cs.kw * (1 if cs.depthwise else cs.cin_true)
     hip.next_meta = (2 * macs, in_b + out_b + w_b)
     if rt.training:
-        stats = rt.fwd_arena.take(2 * C * STAT_SLOTS)
+        stats = rt.fwd_arena.take(G * 2 * C * STAT_SLOTS)
         call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), ptr(stats))
         vec = _bn_vectors(rt, bn, stats, count, C, dev)
         rt.touched_bns.append(bn)
     else:
         call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), None)
         vec = _bn_eval_vectors(bn, C, dev)
-    out = Lazy(y, vec[0], vec[1], act)
     if rt.training:
+        out = Lazy(y, vec[0, 0], vec[0, 1], act, gs=4 * C)
         out.vec = vec
+    else:
+        out = Lazy(y, vec[0], vec[1], act)
     if rt.tape.need_grad:
         def bwd():
             if out.grad is None:
@@ -274,7 +289,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False):
                 if cs.depthwise:
                     call("adamml_dwconv_bwd_data", byref(d), ptr(dz), ptr(cs.w_fwd), ptr(x.grad), acc)
                 elif sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None:
-                    sums = rt.bwd_arena.take(2 * d.Cin * STAT_SLOTS)
+                    sums = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS)
                     hip.next_meta = (2 * macs, 2 * in_b + out_b + w_b)
                     call("adamml_conv_bwd_data_bn", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), ptr(tgt.data), ptr(tgt.vec),
                          tgt.act, ptr(sums))
@@ -292,7 +307,7 @@ def _accum_grad(t, g):
         t.grad = g
     else:
         n = g.numel() // g.shape[-1]
-        call("adamml_bn_act_add", ptr(t.grad), None, None, ACT_NONE, ptr(g), None, None, ptr(t.grad), n, g.shape[-1])
+        call("adamml_bn_act_add", ptr(t.grad), None, None, 0, ACT_NONE, ptr(g), None, None, 0, ptr(t.grad), n, g.shape[-1], 1)
 
 
 def add_act(rt, z, idn, act, idn_sole=False):
@@ -302,8 +317,11 @@ def add_act(rt, z, idn, act, idn_sole=False):
     if z.act != ACT_NONE or (idn is not None and idn.act != ACT_NONE):
         raise RuntimeError("add_act: operands must be linear (no pending activation)")
     out_t = torch.empty_like(z.data)
-    call("adamml_bn_act_add", ptr(z.data), ptr(z.scale), ptr(z.shift), act, ptr(idn.data) if idn is not None else None,
-         ptr(idn.scale) if idn is not None else None, ptr(idn.shift) if idn is not None else None, ptr(out_t), n * h * w, C)
+    G = rt.groups
+    P = n // G * h * w
+    call("adamml_bn_act_add", ptr(z.data), ptr(z.scale), ptr(z.shift), z.gs, act, ptr(idn.data) if idn is not None else None,
+         ptr(idn.scale) if idn is not None else None, ptr(idn.shift) if idn is not None else None,
+         idn.gs if idn is not None else 0, ptr(out_t), P, C, G)
     out = Lazy(out_t)
     if rt.tape.need_grad:
         def bwd():
@@ -315,11 +333,11 @@ def add_act(rt, z, idn, act, idn_sole=False):
             fb = idn is not None and idn_sole and idn.requires_grad and idn.vec is not None and idn.grad is None
             g2 = torch.empty_like(g) if act != ACT_NONE else g
             if fa or fb:
-                sa = rt.bwd_arena.take(2 * C * STAT_SLOTS) if fa else None
-                sb = rt.bwd_arena.take(2 * C * STAT_SLOTS) if fb else None
+                sa = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS) if fa else None
+                sb = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS) if fb else None
                 call("adamml_residual_bwd", ptr(g), ptr(out_t), act, ptr(g2), ptr(z.data) if fa else None,
                      ptr(z.vec) if fa else None, ptr(sa), ptr(idn.data) if fb else None, ptr(idn.vec) if fb else None, ptr(sb),
-                     n * h * w, C)
+                     P, C, G)
                 if fa:
                     z.pre_sums = sa
                 if fb:
@@ -338,7 +356,8 @@ def maxpool3x3s2(rt, x):
     oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
     y = torch.empty(n, oh, ow, C, dtype=torch.bfloat16, device=x.data.device)
     idx = torch.empty(n, oh, ow, C, dtype=torch.uint8, device=x.data.device)
-    call("adamml_maxpool2d_fwd", ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, ptr(y), ptr(idx), n, h, w, C, oh, ow)
+    G = rt.groups
+    call("adamml_maxpool2d_fwd", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(y), ptr(idx), n // G, h, w, C, oh, ow, G)
     out = Lazy(y)
     if rt.tape.need_grad:
         def bwd():
@@ -356,15 +375,16 @@ def maxpool3x3s2(rt, x):
 
 
 def temporal_pool(rt, x, frames, mode):
-    """models/common.py:4-33 on [N*T,H,W,C]; mode 'max' | 'avg'."""
+    """models/common.py:4-33 on [G*N*T,H,W,C]; mode 'max' | 'avg'."""
     nt, h, w, C = x.shape
-    nb = nt // frames
+    G = rt.groups
+    nb = nt // frames                       # clips over all groups
     to = (frames - 1) // 2 + 1
     m = {"max": 0, "avg": 1}.get(mode)
     if m is None:
         raise ValueError("only support avg or max")
     y = torch.empty(nb * to, h, w, C, dtype=torch.bfloat16, device=x.data.device)
-    call("adamml_temporal_pool_fwd", ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, ptr(y), nb, frames, h * w * C, C, m)
+    call("adamml_temporal_pool_fwd", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(y), nb // G, frames, h * w * C, C, m, G)
     out = Lazy(y)
     if rt.tape.need_grad:
         def bwd():
@@ -373,8 +393,8 @@ def temporal_pool(rt, x, frames, mode):
             if g is None or not x.requires_grad:
                 return
             gx = torch.empty_like(x.data)
-            call("adamml_temporal_pool_bwd", ptr(g), ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, ptr(gx), nb, frames,
-                 h * w * C, C, m)
+            call("adamml_temporal_pool_bwd", ptr(g), ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(gx), nb // G, frames,
+                 h * w * C, C, m, G)
             _accum_grad(x, gx)
         rt.tape.record(bwd)
     return out
@@ -383,8 +403,9 @@ def temporal_pool(rt, x, frames, mode):
 def gap(rt, x):
     """AdaptiveAvgPool2d(1): lazy [N,H,W,C] -> fp32 [N,C]; returns (tensor, grad_setter)."""
     n, h, w, C = x.shape
+    G = rt.groups
     f = torch.empty(n, C, dtype=torch.float32, device=x.data.device)
-    call("adamml_gap_fwd", ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, ptr(f), n, h * w, C)
+    call("adamml_gap_fwd", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(f), n // G, h * w, C, G)
 
     def push_grad(gf):
         if not x.requires_grad:

@@ -94,10 +94,10 @@ class MobileNetV2(HipBackbone, MeanStdMixin):
         self._last = (self._register_conv(fl[0]), fl[1])
         self.flat_owner = FlatBuffers(self)
 
-    def _run(self, x, extra, need_grad):
-        """x: [B, H, W, 8] bf16 (1 real channel).  Returns fp32 logits [B, num_classes]."""
+    def _run(self, x, groups, need_grad):
+        """x: [G*B, H, W, 8] bf16 (1 real channel).  Returns fp32 logits [G*B, num_classes]."""
         rt = self.rt
-        tape = rt.begin_forward(x.device, self.training, need_grad)
+        tape = rt.begin_forward(x.device, self.training, need_grad, groups)
         self._repack(need_grad)
         h = conv_bn(rt, Lazy(x, requires_grad=False), self._stem[0], self._stem[1], ACT_RELU6)
         h = run_blocks(rt, h, self._plans)
@@ -133,8 +133,8 @@ class MobileNetV2(HipBackbone, MeanStdMixin):
         xs = clip_to_nhwc(x, 1, 1, x.shape[1])[0]
         return self.call(xs)
 
-    def forward_nhwc(self, frames_nhwc):
-        return self.call(frames_nhwc)
+    def forward_nhwc(self, frames_nhwc, groups=1):
+        return self.call(frames_nhwc, groups)
 
 
 def sound_mobilenet_v2(num_classes, input_channels, dropout, imagenet_pretrained=True, **kwargs):

@@ -8,7 +8,12 @@
  *   - activations are NHWC bf16 with the channel count padded to a multiple of 8;
  *   - a "lazy" activation is (raw, scale, shift, act): value = act(scale[c]*raw + shift[c]); scale==NULL -> raw;
  *   - the caller owns all memory (no allocation inside); work is enqueued on `stream`, never synchronised;
- *   - return 0 on success, negative ADAMML_E* otherwise; adamml_last_error_string() describes the failure.
+ *   - return 0 on success, negative ADAMML_E* otherwise; adamml_last_error_string() describes the failure;
+ *   - GROUPS: AdaMML calls every backbone once per segment with per-call BatchNorm statistics (models/adamml.py:84-86).
+ *     All entry points that touch BatchNorm state take a `groups` count so that the S segment calls are ONE launch
+ *     over [groups*N, H, W, C] tensors with per-group statistics / scale / shift -- same arithmetic, S times fewer
+ *     launches and S times larger grids.  A `*_gstride` argument is the element stride between the groups of a
+ *     per-channel vector (0 = one vector shared by all groups, e.g. eval-mode BatchNorm).
  */
 #ifndef ADAMML_HIP_H
 #define ADAMML_HIP_H
@@ -36,6 +41,9 @@ typedef struct {
     int32_t up;                 /* internal: zero-upsampling of the input (dgrad); 1 for forward */
     int32_t act;                /* activation of the lazy INPUT transform             */
     int32_t accumulate;         /* epilogue adds into the existing output             */
+    int32_t groups;             /* BatchNorm groups batched in one launch (0/1 = one): tensors are [groups*N, ...], statistic /
+                                   sum buffers [groups][SLOTS][2C], BatchNorm vectors [groups][...] (see in_gstride)          */
+    int32_t in_gstride;         /* element stride between the groups of in_scale / in_shift (0 = shared by all groups)        */
 } adamml_conv_desc_t;
 
 int adamml_version(void);
@@ -52,7 +60,8 @@ int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const void
                          int accumulate, hipStream_t stream);
 /* same, when dx is the gradient w.r.t. a lazily normalised tensor act(BN(z_in)) with a single consumer: the epilogue
  * multiplies by act'(scale*z_in+shift), stores g' and accumulates the BatchNorm-backward sums (sum g', sum g'*zhat) into
- * sums[ADAMML_STAT_SLOTS][2*Cin]; bn_vec = [4][Cin] (scale, shift, mean, invstd).  adamml_bn_bwd_reduce is then skipped. */
+ * sums[groups][ADAMML_STAT_SLOTS][2*Cin]; bn_vec = [groups][4][Cin] (scale, shift, mean, invstd).  adamml_bn_bwd_reduce is
+ * then skipped. */
 int adamml_conv_bwd_data_bn(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx, const void* z_in,
                             const float* bn_vec, int act, double* sums, hipStream_t stream);
 /* autograd w.r.t. the weight: dw (fp32 OIHW, cin_true input channels) += dz^T * im2col(act(x)).  The pixel axis is
@@ -77,49 +86,60 @@ size_t adamml_dwconv_bwd_weight_workspace(const adamml_conv_desc_t* d);
 int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
                              const float* in_shift, float* dw, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
-/* nn.BatchNorm2d: train-mode statistics -> (scale, shift) consumed lazily by the next op, saved mean / invstd,
- * running-stat momentum update (unbiased variance).  count = elements per channel (global count under SyncBN). */
-/* sums the ADAMML_STAT_SLOTS copies into slot 0 (used before a SyncBN all-reduce of [2C]) */
-int adamml_stats_collapse(double* stats, int C, hipStream_t stream);
-int adamml_bn_finalize(const double* stats, int nslots, double count, const float* gamma, const float* beta, float* running_mean,
-                       float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
-                       float* invstd, int C, hipStream_t stream);
+/* Every entry point from here to adamml_gap_fwd is batched over `groups` independent BatchNorm groups (the S segment
+ * calls of one backbone, models/adamml.py:151-160): activations are [groups][P][C], statistic accumulators
+ * [groups][nslots][2C] fp64, BatchNorm vectors bn_vec = [groups][4][C] fp32 (scale, shift, mean, invstd), backward
+ * coefficients coef = [groups][3][C].  A *_gstride is the element stride between the groups of a (scale, shift) pair
+ * (0 = one pair shared by all groups, e.g. eval mode).
+ *
+ * nn.BatchNorm2d: train-mode statistics -> bn_vec consumed lazily by the next op, running-stat momentum update
+ * (unbiased variance) applied once per group IN GROUP ORDER, exactly as `groups` successive module calls would.
+ * count = elements per channel per group (global count under SyncBN). */
+/* out[groups][2C] = sum over the ADAMML_STAT_SLOTS copies (before a SyncBN all-reduce) */
+int adamml_stats_collapse(const double* stats, double* out, int C, int groups, hipStream_t stream);
+int adamml_bn_finalize(const double* stats, int nslots, int groups, double count, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, float* bn_vec, int C,
+                       hipStream_t stream);
 /* eval-mode BatchNorm folded to (scale, shift) from the running statistics */
 int adamml_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                           float eps, float* scale, float* shift, int C, hipStream_t stream);
 /* out = act(scale*z + shift + identity) -- BN apply + residual add + ReLU of a bottleneck / inverted-residual block
  * (models/resnet.py:104-111, sound_mobilenet_v2.py:66-67, policy_net.py:92-93).  identity may be lazy or NULL. */
-int adamml_bn_act_add(const void* z, const float* scale, const float* shift, int act, const void* idn,
-                      const float* id_scale, const float* id_shift, void* out, size_t P, int C, hipStream_t stream);
+int adamml_bn_act_add(const void* z, const float* scale, const float* shift, int z_gstride, int act, const void* idn,
+                      const float* id_scale, const float* id_shift, int id_gstride, void* out, size_t P, int C, int groups,
+                      hipStream_t stream);
 /* g = g_out * act'(out) evaluated from the stored block output */
 int adamml_act_bwd_from_output(const void* g_out, const void* out, int act, void* g, size_t n, hipStream_t stream);
 /* residual-add backward: g2 = g_out * act'(out) fused with the BatchNorm-backward sums of up to two lazily normalised
- * operands of the add (za/veca/sumsa and zb/vecb/sumsb; vec = [4][C]); any of the two may be NULL */
+ * operands of the add (za/veca/sumsa and zb/vecb/sumsb); any of the two may be NULL */
 int adamml_residual_bwd(const void* g_out, const void* out, int act, void* g2, const void* za, const float* veca, double* sumsa,
-                        const void* zb, const float* vecb, double* sumsb, size_t P, int C, hipStream_t stream);
-/* BatchNorm backward: per-channel sums of g' = g*act'(scale*z+shift) and g'*zhat (sums fp64 [ADAMML_STAT_SLOTS][2C], caller zeroes) */
-int adamml_bn_bwd_reduce(const void* g, const void* z, const float* scale, const float* shift, const float* mean,
-                         const float* invstd, int act, double* sums, size_t P, int C, hipStream_t stream);
-/* dgamma += sum(g' zhat); dbeta += sum(g'); coef[0..C) = gamma*invstd, [C..2C) = sum g'/count, [2C..3C) = sum g' zhat/count */
-int adamml_bn_bwd_finalize(const double* sums, int nslots, double count, const float* gamma, const float* invstd, float* dgamma,
-                           float* dbeta, float* coef, int C, hipStream_t stream);
+                        const void* zb, const float* vecb, double* sumsb, size_t P, int C, int groups, hipStream_t stream);
+/* BatchNorm backward: per-channel sums of g' = g*act'(scale*z+shift) and g'*zhat (sums [groups][SLOTS][2C], caller zeroes) */
+int adamml_bn_bwd_reduce(const void* g, const void* z, const float* bn_vec, int act, double* sums, size_t P, int C, int groups,
+                         hipStream_t stream);
+/* dgamma += sum_groups sum(g' zhat); dbeta += sum_groups sum(g');
+ * coef[g][0..C) = gamma*invstd, [C..2C) = sum g'/count, [2C..3C) = sum g' zhat/count */
+int adamml_bn_bwd_finalize(const double* sums, int nslots, int groups, double count, const float* gamma, const float* bn_vec,
+                           float* dgamma, float* dbeta, float* coef, int C, hipStream_t stream);
 /* dz = coef0 * (g' - coef1 - zhat*coef2) */
-int adamml_bn_bwd_apply(const void* g, const void* z, const float* scale, const float* shift, const float* mean,
-                        const float* invstd, int act, const float* coef, void* dz, size_t P, int C, hipStream_t stream);
+int adamml_bn_bwd_apply(const void* g, const void* z, const float* bn_vec, int act, const float* coef, void* dz, size_t P, int C,
+                        int groups, hipStream_t stream);
 
-/* nn.MaxPool2d(3, 2, 1) on a lazy input (models/resnet.py:141,202); idx = argmax tap (uint8) for the backward */
-int adamml_maxpool2d_fwd(const void* x, const float* scale, const float* shift, int act, void* y, uint8_t* idx, int N,
-                         int H, int W, int C, int OH, int OW, hipStream_t stream);
+/* nn.MaxPool2d(3, 2, 1) on a lazy input (models/resnet.py:141,202); idx = argmax tap (uint8) for the backward.
+ * N = images per group. */
+int adamml_maxpool2d_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, void* y, uint8_t* idx,
+                         int N, int H, int W, int C, int OH, int OW, int groups, hipStream_t stream);
 int adamml_maxpool2d_bwd(const void* g_y, const uint8_t* idx, void* g_x, int N, int H, int W, int C, int OH, int OW,
                          int accumulate, hipStream_t stream);
-/* TemporalPooling (models/common.py:4-33): k3 s2 p1 over the frame axis; mode 0 = max, 1 = avg (zeros counted) */
-int adamml_temporal_pool_fwd(const void* x, const float* scale, const float* shift, int act, void* y, int NB, int T,
-                             size_t HWC, int C, int mode, hipStream_t stream);
-int adamml_temporal_pool_bwd(const void* g_y, const void* x, const float* scale, const float* shift, int act, void* g_x,
-                             int NB, int T, size_t HWC, int C, int mode, hipStream_t stream);
-/* AdaptiveAvgPool2d(1) on a lazy input -> fp32 [N,C] (resnet.py:212, sound_mobilenet_v2.py:157, policy_net.py:147) */
-int adamml_gap_fwd(const void* x, const float* scale, const float* shift, int act, float* out, int N, int HW, int C,
-                   hipStream_t stream);
+/* TemporalPooling (models/common.py:4-33): k3 s2 p1 over the frame axis; mode 0 = max, 1 = avg (zeros counted).
+ * NB = clips per group. */
+int adamml_temporal_pool_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, void* y, int NB,
+                             int T, size_t HWC, int C, int mode, int groups, hipStream_t stream);
+int adamml_temporal_pool_bwd(const void* g_y, const void* x, const float* scale, const float* shift, int gstride, int act,
+                             void* g_x, int NB, int T, size_t HWC, int C, int mode, int groups, hipStream_t stream);
+/* AdaptiveAvgPool2d(1) on a lazy input -> fp32 [groups*N,C] (resnet.py:212, sound_mobilenet_v2.py:157, policy_net.py:147) */
+int adamml_gap_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, float* out, int N, int HW,
+                   int C, int groups, hipStream_t stream);
 int adamml_gap_bwd(const float* g, void* g_x, int N, int HW, int C, hipStream_t stream);
 
 /* AdaMML.data_layer (models/adamml.py:42-67): NCHW fp32 clip tensor [B, S*F*C, H, W] -> per-segment NHWC bf16

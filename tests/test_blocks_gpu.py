@@ -54,18 +54,20 @@ def tpool_ref(x, frames):
 def materialize(l):
     n, h, w, C = l.shape
     out = torch.empty_like(l.data)
-    call("adamml_bn_act_add", ptr(l.data), ptr(l.scale), ptr(l.shift), l.act, None, None, None, ptr(out), n * h * w, C)
+    G = 1 if l.vec is None else l.vec.shape[0]
+    call("adamml_bn_act_add", ptr(l.data), ptr(l.scale), ptr(l.shift), l.gs, l.act, None, None, None, 0, ptr(out), n // G * h * w, C, G)
     return nchw(out)
 
 
-def test_resnet_bottlenecks():
+@pytest.mark.parametrize("groups", [1, 3])
+def test_resnet_bottlenecks(groups):
     from adamml_amd.resnet import ResNet
     torch.manual_seed(0)
     net = ResNet(50, num_frames=4, num_classes=31, dropout=0.0)
     randomize(net, 1)
     blocks = [net.layer2[0], net.layer2[1]]
     frames = 4
-    x = torch.randn(2 * frames, 256, 20, 20, device=DEV)
+    x = torch.randn(groups * 2 * frames, 256, 20, 20, device=DEV)
 
     def hip_fn(rt, h):
         h = temporal_pool(rt, h, frames, "max")
@@ -80,7 +82,7 @@ def test_resnet_bottlenecks():
     plist = [(n, p) for n, p in net.named_parameters() if n.startswith(("layer2.0.", "layer2.1."))]
 
     def ref_fn(h):
-        ws = {n: p.detach().clone().requires_grad_(True) for n, p in plist}
+        ws = shared_ws(ref_fn, lambda: {n: p.detach().clone().requires_grad_(True) for n, p in plist})
         h = q(tpool_ref(h, frames))
         for bi, b in enumerate(blocks):
             pre = "layer2.%d." % bi
@@ -100,25 +102,34 @@ def test_resnet_bottlenecks():
             else:
                 idn = h
             h = q(F.relu(o + idn))
-        ref_fn.ws = ws
         return h
 
-    run_and_compare_with_ref(net, hip_fn, ref_fn, x, plist)
+    run_and_compare_with_ref(net, hip_fn, ref_fn, x, plist, groups)
 
 
-def run_and_compare_with_ref(net, hip_fn, ref_fn, x, plist):
+def shared_ws(ref_fn, make):
+    """The fp32 reference weights of one test: created on the first group's call, shared by the following ones."""
+    if getattr(ref_fn, "ws", None) is None:
+        ref_fn.ws = make()
+    return ref_fn.ws
+
+
+def run_and_compare_with_ref(net, hip_fn, ref_fn, x, plist, groups=1):
+    """groups > 1: x stacks `groups` independent module calls; the HIP runtime executes them as ONE launch sequence with
+    per-group BatchNorm statistics, the torch reference as `groups` successive calls sharing the weights."""
     net.to(DEV)
     net.train()
     for p in net.parameters():
         p.grad = torch.zeros_like(p)
     rt = net.rt
-    rt.begin_forward(x.device, True, True)
+    rt.begin_forward(x.device, True, True, groups)
     net._repack(True)
     xin = Lazy(nhwc(x), requires_grad=True)
     out = hip_fn(rt, xin)
     got = materialize(out)
     xr = q(x.clone()).requires_grad_(True)
-    ref = ref_fn(xr)
+    ref_fn.ws = None
+    ref = torch.cat([ref_fn(c) for c in xr.chunk(groups)], 0)
     scale = ref.abs().max().item()
     err = (got - ref.detach()).abs().max().item()
     print("forward max err %.4g of scale %.4g" % (err, scale))
@@ -166,7 +177,8 @@ def _mbv2_ref(blocks_spec, ws, h):
     return h
 
 
-def test_policy_mobilenet_blocks_with_temporal_pool():
+@pytest.mark.parametrize("groups", [1, 3])
+def test_policy_mobilenet_blocks_with_temporal_pool(groups):
     from adamml_amd.policy_net import MobileNetV2
     torch.manual_seed(0)
     net = MobileNetV2(num_frames=4, input_channels=3)
@@ -174,7 +186,7 @@ def test_policy_mobilenet_blocks_with_temporal_pool():
     # features[7] = first block of the c=64 stage (temporal pool over 4 frames, stride 2), features[8] residual
     idx = [6, 7, 8]
     plans = [net._plans[i - 1] for i in idx]
-    x = torch.randn(2 * 4, 32, 20, 20, device=DEV)
+    x = torch.randn(groups * 2 * 4, 32, 20, 20, device=DEV)
     spec = []
     for i in idx:
         blk = net.features[i]
@@ -183,21 +195,21 @@ def test_policy_mobilenet_blocks_with_temporal_pool():
 
     def ref_fn(h):
         params = dict(net.named_parameters())
-        ws = {n: params[n].detach().clone().requires_grad_(True) for n in names}
-        ref_fn.ws = ws
+        ws = shared_ws(ref_fn, lambda: {n: params[n].detach().clone().requires_grad_(True) for n in names})
         return _mbv2_ref(spec, ws, h)
 
-    run_and_compare_with_ref(net, lambda rt, h: run_blocks(rt, h, plans), ref_fn, x, None)
+    run_and_compare_with_ref(net, lambda rt, h: run_blocks(rt, h, plans), ref_fn, x, None, groups)
 
 
-def test_sound_mobilenet_blocks():
+@pytest.mark.parametrize("groups", [1, 3])
+def test_sound_mobilenet_blocks(groups):
     from adamml_amd.sound_mobilenet_v2 import MobileNetV2
     torch.manual_seed(0)
     net = MobileNetV2(num_classes=31, input_channels=1, dropout=0.0)
     randomize(net, 3)
     idx = [1, 2, 3]          # t=1 block (no expand), stride-2 block, residual block
     plans = [net._plans[i - 1] for i in idx]
-    x = torch.randn(3, 32, 24, 24, device=DEV)
+    x = torch.randn(groups * 3, 32, 24, 24, device=DEV)
     spec = []
     for i in idx:
         blk = net.features[i]
@@ -210,8 +222,7 @@ def test_sound_mobilenet_blocks():
 
     def ref_fn(h):
         params = dict(net.named_parameters())
-        ws = {n: params[n].detach().clone().requires_grad_(True) for n in names}
-        ref_fn.ws = ws
+        ws = shared_ws(ref_fn, lambda: {n: params[n].detach().clone().requires_grad_(True) for n in names})
         return _mbv2_ref(spec, ws, h)
 
-    run_and_compare_with_ref(net, lambda rt, h: run_blocks(rt, h, plans), ref_fn, x, None)
+    run_and_compare_with_ref(net, lambda rt, h: run_blocks(rt, h, plans), ref_fn, x, None, groups)

@@ -183,23 +183,22 @@ def test_batchnorm_train_fwd_bwd(C, P, act):
     zd = zb.float().double()
     stats = torch.cat([zd.sum(0), (zd * zd).sum(0)])
     vec = torch.empty(4, C, device=DEV)
-    call("adamml_bn_finalize", ptr(stats), 1, float(P), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5, ptr(vec[0]), ptr(vec[1]),
-         ptr(vec[2]), ptr(vec[3]), C)
+    call("adamml_bn_finalize", ptr(stats), 1, 1, float(P), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5, ptr(vec), C)
     assert torch.allclose(rm, rm_ref, rtol=1e-4, atol=1e-5)
     assert torch.allclose(rv, rv_ref, rtol=1e-4, atol=1e-5)
     o = torch.empty(P, C, dtype=torch.bfloat16, device=DEV)
-    call("adamml_bn_act_add", ptr(zb), ptr(vec[0]), ptr(vec[1]), act, None, None, None, ptr(o), P, C)
+    call("adamml_bn_act_add", ptr(zb), ptr(vec[0]), ptr(vec[1]), 0, act, None, None, None, 0, ptr(o), P, C, 1)
     close(o.float(), a.detach(), what="bn apply")
     g = rb(torch.randn(P, C, device=DEV))
     a.backward(g)
     sums = torch.zeros(STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
     gb = g.to(torch.bfloat16).contiguous()
-    call("adamml_bn_bwd_reduce", ptr(gb), ptr(zb), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), act, ptr(sums), P, C)
+    call("adamml_bn_bwd_reduce", ptr(gb), ptr(zb), ptr(vec), act, ptr(sums), P, C, 1)
     dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     coef = torch.empty(3, C, device=DEV)
-    call("adamml_bn_bwd_finalize", ptr(sums), STAT_SLOTS, float(P), ptr(gamma), ptr(vec[3]), ptr(dgam), ptr(dbet), ptr(coef), C)
+    call("adamml_bn_bwd_finalize", ptr(sums), STAT_SLOTS, 1, float(P), ptr(gamma), ptr(vec), ptr(dgam), ptr(dbet), ptr(coef), C)
     dz = torch.empty(P, C, dtype=torch.bfloat16, device=DEV)
-    call("adamml_bn_bwd_apply", ptr(gb), ptr(zb), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), act, ptr(coef), ptr(dz), P, C)
+    call("adamml_bn_bwd_apply", ptr(gb), ptr(zb), ptr(vec), act, ptr(coef), ptr(dz), P, C, 1)
     close(dgam, gamma.grad, what="dgamma")
     close(dbet, beta.grad, what="dbeta")
     close(dz.float(), zr.grad, what="bn dz")
@@ -213,7 +212,7 @@ def test_residual_add_and_act_bwd():
     s2, t2 = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
     out = torch.empty(P, C, dtype=torch.bfloat16, device=DEV)
     zb, ib = z.bfloat16(), idn.bfloat16()          # keep the operands alive across the async launch
-    call("adamml_bn_act_add", ptr(zb), ptr(s), ptr(t), 1, ptr(ib), ptr(s2), ptr(t2), ptr(out), P, C)
+    call("adamml_bn_act_add", ptr(zb), ptr(s), ptr(t), 0, 1, ptr(ib), ptr(s2), ptr(t2), 0, ptr(out), P, C, 1)
     ref = F.relu(z * s + t + idn * s2 + t2)
     close(out.float(), ref, what="bn+add+relu")
     g = rb(torch.randn(P, C, device=DEV))
@@ -233,12 +232,12 @@ def test_maxpool_fwd_bwd():
     idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=DEV)
     xh = nhwc(x)
     # lazy input: relu(scale*x+shift) is evaluated in fp32 inside the kernel, then pooled
-    call("adamml_maxpool2d_fwd", ptr(xh), ptr(s), ptr(t), 1, ptr(y), ptr(idx), N, H, W, C, OH, OW)
+    call("adamml_maxpool2d_fwd", ptr(xh), ptr(s), ptr(t), 0, 1, ptr(y), ptr(idx), N, H, W, C, OH, OW, 1)
     close(nchw(y), F.max_pool2d(F.relu(x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)), 3, 2, 1), what="maxpool lazy")
     # plain input: identical operand values on both sides -> identical first-arg-max routing
     ar = x.clone().requires_grad_(True)
     ref = F.max_pool2d(ar, 3, 2, 1)
-    call("adamml_maxpool2d_fwd", ptr(xh), None, None, 0, ptr(y), ptr(idx), N, H, W, C, OH, OW)
+    call("adamml_maxpool2d_fwd", ptr(xh), None, None, 0, 0, ptr(y), ptr(idx), N, H, W, C, OH, OW, 1)
     assert torch.equal(nchw(y), ref.detach())
     g = rb(torch.randn_like(ref))
     gh = nhwc(g)
@@ -259,12 +258,12 @@ def test_temporal_pool(T, mode):
     To = ref.shape[0] // NB
     y = torch.empty(NB * To, H, W, C, dtype=torch.bfloat16, device=DEV)
     xh = nhwc(x.detach())
-    call("adamml_temporal_pool_fwd", ptr(xh), None, None, 0, ptr(y), NB, T, H * W * C, C, mode)
+    call("adamml_temporal_pool_fwd", ptr(xh), None, None, 0, 0, ptr(y), NB, T, H * W * C, C, mode, 1)
     close(nchw(y), ref.detach(), what="tpool")
     g = rb(torch.randn_like(ref))
     ref.backward(g)
     gx = torch.empty(NB * T, H, W, C, dtype=torch.bfloat16, device=DEV)
-    call("adamml_temporal_pool_bwd", ptr(nhwc(g)), ptr(xh), None, None, 0, ptr(gx), NB, T, H * W * C, C, mode)
+    call("adamml_temporal_pool_bwd", ptr(nhwc(g)), ptr(xh), None, None, 0, 0, ptr(gx), NB, T, H * W * C, C, mode, 1)
     close(nchw(gx), x.grad, what="tpool bwd")
 
 
@@ -272,7 +271,7 @@ def test_temporal_avg_rejects_short_T():
     x = torch.zeros(2, 2, 2, 8, dtype=torch.bfloat16, device=DEV)
     y = torch.zeros(1, 2, 2, 8, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(RuntimeError):
-        call("adamml_temporal_pool_fwd", ptr(x), None, None, 0, ptr(y), 1, 2, 32, 8, 1)
+        call("adamml_temporal_pool_fwd", ptr(x), None, None, 0, 0, ptr(y), 1, 2, 32, 8, 1, 1)
 
 
 def test_gap():
@@ -281,7 +280,7 @@ def test_gap():
     x = rb(torch.randn(N, C, H, W, device=DEV))
     s, t = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
     f = torch.empty(N, C, device=DEV)
-    call("adamml_gap_fwd", ptr(nhwc(x)), ptr(s), ptr(t), 2, ptr(f), N, H * W, C)
+    call("adamml_gap_fwd", ptr(nhwc(x)), ptr(s), ptr(t), 0, 2, ptr(f), N, H * W, C, 1)
     ref = torch.clamp(x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1), 0, 6).mean((2, 3))
     assert torch.allclose(f, ref, rtol=1e-4, atol=1e-4)
     g = torch.randn(N, C, device=DEV)
@@ -341,3 +340,200 @@ def test_fused_optimizers_match_torch():
         opt.step()
         call("adamml_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 5e-4, step + 1)
     assert torch.allclose(p, pt.detach(), rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm groups
+# One launch over G stacked module calls must equal G launches with groups == 1 (which the tests above tie to torch):
+# bit-exact where no summation order is involved, 1e-5 where partial sums are combined in a different order.
+def _g(t, G):
+    return t.view(G, t.shape[0] // G, *t.shape[1:])
+
+
+@pytest.mark.parametrize("case", [(2, 28, 28, 64, 256, 1, 1, 0), (2, 14, 14, 64, 64, 3, 1, 1), (2, 15, 15, 128, 128, 3, 2, 1),
+                                  (2, 32, 32, 3, 64, 7, 2, 3), (1, 14, 14, 256, 512, 1, 2, 0), (2, 7, 7, 512, 2048, 1, 1, 0)])
+def test_conv_groups_equal_separate_launches(case):
+    torch.manual_seed(10)
+    G = 3
+    N, H, W, Cin, Cout, k, s, p = case
+    cp = pad8(Cin)
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    xh = nhwc(torch.randn(G * N, Cin, H, W, device=DEV))
+    w = torch.randn(Cout, Cin, k, k, device=DEV) * (2.0 / (Cin * k * k)) ** 0.5
+    wf, wd = pack(w, cp, 0), pack(w, cp, 1)
+    lazy = k == 1                        # the runtime materialises lazy inputs of KxK convs; 1x1 convs read them lazily
+    scale = (torch.rand(G, cp, device=DEV) + 0.5) if lazy else None
+    shift = (torch.randn(G, cp, device=DEV) * 0.3) if lazy else None
+    act = 1 if lazy else 0
+    dG = ConvDesc(N, H, W, cp, OH, OW, Cout, k, k, s, p, 1, act, 0, G, cp if lazy else 0)
+    d1 = ConvDesc(N, H, W, cp, OH, OW, Cout, k, k, s, p, 1, act, 0)
+    y = torch.empty(G * N, OH, OW, Cout, dtype=torch.bfloat16, device=DEV)
+    y1 = torch.empty_like(y)
+    st = torch.zeros(G, STAT_SLOTS, 2 * Cout, dtype=torch.float64, device=DEV)
+    st1 = torch.zeros_like(st)
+    call("adamml_conv_fwd", byref(dG), ptr(xh), ptr(wf), ptr(scale), ptr(shift), ptr(y), ptr(st))
+    for g in range(G):
+        call("adamml_conv_fwd", byref(d1), ptr(_g(xh, G)[g]), ptr(wf), ptr(scale[g]) if lazy else None,
+             ptr(shift[g]) if lazy else None, ptr(_g(y1, G)[g]), ptr(st1[g]))
+    assert torch.equal(y, y1)
+    assert torch.allclose(st.sum(1), st1.sum(1), rtol=1e-5, atol=1e-3)      # fp32 per-workgroup partials, different tiling
+    dz = nhwc(torch.randn(G * N, Cout, OH, OW, device=DEV))
+    dx, dx1 = torch.empty_like(xh), torch.empty_like(xh)
+    call("adamml_conv_bwd_data", byref(dG), ptr(dz), ptr(wd), ptr(dx), 0)
+    for g in range(G):
+        call("adamml_conv_bwd_data", byref(d1), ptr(_g(dz, G)[g]), ptr(wd), ptr(_g(dx1, G)[g]), 0)
+    assert torch.equal(dx, dx1)
+    # data gradient fused with the BatchNorm-backward reduction of the (lazy) input
+    vec = torch.randn(G, 4, cp, device=DEV)
+    vec[:, 3] = vec[:, 3].abs() + 0.5
+    sm = torch.zeros(G, STAT_SLOTS, 2 * cp, dtype=torch.float64, device=DEV)
+    sm1 = torch.zeros_like(sm)
+    call("adamml_conv_bwd_data_bn", byref(dG), ptr(dz), ptr(wd), ptr(dx), ptr(xh), ptr(vec), 1, ptr(sm))
+    for g in range(G):
+        call("adamml_conv_bwd_data_bn", byref(d1), ptr(_g(dz, G)[g]), ptr(wd), ptr(_g(dx1, G)[g]), ptr(_g(xh, G)[g]), ptr(vec[g]),
+             1, ptr(sm1[g]))
+    assert torch.equal(dx, dx1)
+    assert torch.allclose(sm.sum(1), sm1.sum(1), rtol=1e-5, atol=1e-3)
+    for use_ws in (False, True):
+        dw, dw1 = torch.zeros_like(w), torch.zeros_like(w)
+        ws = hip.wgrad_workspace(dG, Cin, DEV) if use_ws else None
+        call("adamml_conv_bwd_weight", byref(dG), ptr(dz), ptr(xh), ptr(scale), ptr(shift), ptr(dw), Cin, ptr(ws),
+             ws.numel() * 4 if use_ws else 0)
+        for g in range(G):
+            ws = hip.wgrad_workspace(d1, Cin, DEV) if use_ws else None
+            call("adamml_conv_bwd_weight", byref(d1), ptr(_g(dz, G)[g]), ptr(_g(xh, G)[g]), ptr(scale[g]) if lazy else None,
+                 ptr(shift[g]) if lazy else None, ptr(dw1), Cin, ptr(ws), ws.numel() * 4 if use_ws else 0)
+        close(dw, dw1, rtol=1e-3, atol_frac=1e-4, what="grouped wgrad (ws=%s)" % use_ws)
+
+
+@pytest.mark.parametrize("case", [(2, 20, 20, 96, 1), (2, 21, 21, 144, 2)])
+def test_dwconv_groups_equal_separate_launches(case):
+    torch.manual_seed(11)
+    G = 3
+    N, H, W, C, s = case
+    OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+    xh = nhwc(torch.randn(G * N, C, H, W, device=DEV))
+    w = torch.randn(C, 1, 3, 3, device=DEV) * 0.4
+    wp = pack(w, C, 2)
+    scale, shift = torch.rand(G, C, device=DEV) + 0.5, torch.randn(G, C, device=DEV) * 0.3
+    dG = ConvDesc(N, H, W, C, OH, OW, C, 3, 3, s, 1, 1, 2, 0, G, C)
+    d1 = ConvDesc(N, H, W, C, OH, OW, C, 3, 3, s, 1, 1, 2, 0)
+    y = torch.empty(G * N, OH, OW, C, dtype=torch.bfloat16, device=DEV)
+    y1 = torch.empty_like(y)
+    st = torch.zeros(G, STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
+    st1 = torch.zeros_like(st)
+    call("adamml_dwconv_fwd", byref(dG), ptr(xh), ptr(wp), ptr(scale), ptr(shift), ptr(y), ptr(st))
+    for g in range(G):
+        call("adamml_dwconv_fwd", byref(d1), ptr(_g(xh, G)[g]), ptr(wp), ptr(scale[g]), ptr(shift[g]), ptr(_g(y1, G)[g]), ptr(st1[g]))
+    assert torch.equal(y, y1)
+    assert torch.allclose(st.sum(1), st1.sum(1), rtol=1e-5, atol=1e-3)      # fp32 per-workgroup partials, different tiling
+    dz = nhwc(torch.randn(G * N, C, OH, OW, device=DEV))
+    dx, dx1 = torch.empty_like(xh), torch.empty_like(xh)
+    call("adamml_dwconv_bwd_data", byref(dG), ptr(dz), ptr(wp), ptr(dx), 0)
+    for g in range(G):
+        call("adamml_dwconv_bwd_data", byref(d1), ptr(_g(dz, G)[g]), ptr(wp), ptr(_g(dx1, G)[g]), 0)
+    assert torch.equal(dx, dx1)
+    for use_ws in (False, True):
+        dw, dw1 = torch.zeros_like(w), torch.zeros_like(w)
+        ws = hip.wgrad_workspace(dG, 0, DEV, depthwise=True) if use_ws else None
+        call("adamml_dwconv_bwd_weight", byref(dG), ptr(dz), ptr(xh), ptr(scale), ptr(shift), ptr(dw), ptr(ws),
+             ws.numel() * 4 if use_ws else 0)
+        for g in range(G):
+            ws = hip.wgrad_workspace(d1, 0, DEV, depthwise=True) if use_ws else None
+            call("adamml_dwconv_bwd_weight", byref(d1), ptr(_g(dz, G)[g]), ptr(_g(xh, G)[g]), ptr(scale[g]), ptr(shift[g]), ptr(dw1),
+                 ptr(ws), ws.numel() * 4 if use_ws else 0)
+        close(dw, dw1, rtol=1e-3, atol_frac=1e-4, what="grouped dw wgrad (ws=%s)" % use_ws)
+
+
+@pytest.mark.parametrize("C,P,act", [(64, 1500, 1), (24, 333, 2), (2048, 50, 0)])
+def test_batchnorm_groups_equal_successive_calls(C, P, act):
+    """bn_finalize over G groups == G successive nn.BatchNorm2d calls: per-group vectors, running statistics updated
+    group by group (momentum EMA is order dependent), gradients of gamma/beta summed over the calls."""
+    torch.manual_seed(12)
+    G = 3
+    z = (torch.randn(G, P, C, device=DEV) * torch.tensor([1.0, 2.0, 0.5], device=DEV).view(G, 1, 1) + 0.3).to(torch.bfloat16)
+    gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV) * 0.2
+    rm, rv = torch.randn(C, device=DEV) * 0.1, torch.rand(C, device=DEV) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    zr = z.float().requires_grad_(True)
+    outs = []
+    for g in range(G):          # torch: G successive module calls
+        o = F.batch_norm(zr[g].t().reshape(1, C, P), rm_ref, rv_ref, gr, br, True, 0.1, 1e-5).reshape(C, P).t()
+        outs.append({0: o, 1: F.relu(o), 2: F.relu6(o)}[act])
+    ref = torch.stack(outs)
+    zd = z.double()
+    stats = torch.zeros(G, STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
+    stats[:, 5, :C], stats[:, 7, C:] = zd.sum(1), (zd * zd).sum(1)
+    vec = torch.empty(G, 4, C, device=DEV)
+    call("adamml_bn_finalize", ptr(stats), STAT_SLOTS, G, float(P), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5, ptr(vec), C)
+    assert torch.allclose(rm, rm_ref, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(rv, rv_ref, rtol=1e-4, atol=1e-5)
+    col = torch.empty(G, 2 * C, dtype=torch.float64, device=DEV)
+    call("adamml_stats_collapse", ptr(stats), ptr(col), C, G)
+    assert torch.equal(col, stats.sum(1))
+    o = torch.empty(G, P, C, dtype=torch.bfloat16, device=DEV)
+    call("adamml_bn_act_add", ptr(z), ptr(vec[0, 0]), ptr(vec[0, 1]), 4 * C, act, None, None, None, 0, ptr(o), P, C, G)
+    close(o.float(), ref.detach(), what="grouped bn apply")
+    gup = rb(torch.randn(G, P, C, device=DEV))
+    ref.backward(gup)
+    gb = gup.to(torch.bfloat16)
+    sums = torch.zeros(G, STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
+    call("adamml_bn_bwd_reduce", ptr(gb), ptr(z), ptr(vec), act, ptr(sums), P, C, G)
+    dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    coef = torch.empty(G, 3, C, device=DEV)
+    call("adamml_bn_bwd_finalize", ptr(sums), STAT_SLOTS, G, float(P), ptr(gamma), ptr(vec), ptr(dgam), ptr(dbet), ptr(coef), C)
+    dz = torch.empty(G, P, C, dtype=torch.bfloat16, device=DEV)
+    call("adamml_bn_bwd_apply", ptr(gb), ptr(z), ptr(vec), act, ptr(coef), ptr(dz), P, C, G)
+    close(dgam, gr.grad, what="grouped dgamma")
+    close(dbet, br.grad, what="grouped dbeta")
+    close(dz.float(), zr.grad, what="grouped bn dz")
+    # residual-add backward with both operands lazily normalised: sums must equal the stand-alone reduction
+    out_t = torch.empty(G, P, C, dtype=torch.bfloat16, device=DEV)
+    call("adamml_bn_act_add", ptr(z), ptr(vec[0, 0]), ptr(vec[0, 1]), 4 * C, 1, ptr(z), ptr(vec[0, 0]), ptr(vec[0, 1]), 4 * C,
+         ptr(out_t), P, C, G)
+    g2 = torch.empty_like(gb)
+    sa = torch.zeros(G, STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
+    sb = torch.zeros_like(sa)
+    call("adamml_residual_bwd", ptr(gb), ptr(out_t), 1, ptr(g2), ptr(z), ptr(vec), ptr(sa), ptr(z), ptr(vec), ptr(sb), P, C, G)
+    assert torch.equal(g2.float(), gb.float() * (out_t.float() > 0))
+    chk = torch.zeros_like(sa)
+    call("adamml_bn_bwd_reduce", ptr(g2), ptr(z), ptr(vec), 0, ptr(chk), P, C, G)
+    assert torch.allclose(sa.sum(1), chk.sum(1), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(sb.sum(1), chk.sum(1), rtol=1e-5, atol=1e-4)
+
+
+def test_pools_groups_equal_separate_launches():
+    torch.manual_seed(13)
+    G, NB, T, H, W, C = 3, 2, 4, 12, 12, 64
+    x = nhwc(torch.randn(G * NB * T, C, H, W, device=DEV))
+    s, t = torch.rand(G, C, device=DEV) + 0.5, torch.randn(G, C, device=DEV) * 0.3
+    n = NB * T
+    # max pool 3x3 s2
+    OH = OW = 6
+    y, y1 = (torch.empty(G * n, OH, OW, C, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    ix, ix1 = (torch.empty(G * n, OH, OW, C, dtype=torch.uint8, device=DEV) for _ in range(2))
+    call("adamml_maxpool2d_fwd", ptr(x), ptr(s), ptr(t), C, 1, ptr(y), ptr(ix), n, H, W, C, OH, OW, G)
+    for g in range(G):
+        call("adamml_maxpool2d_fwd", ptr(_g(x, G)[g]), ptr(s[g]), ptr(t[g]), 0, 1, ptr(_g(y1, G)[g]), ptr(_g(ix1, G)[g]), n, H, W, C,
+             OH, OW, 1)
+    assert torch.equal(y, y1) and torch.equal(ix, ix1)
+    # temporal pool (max) fwd / bwd
+    To = 2
+    p, p1 = (torch.empty(G * NB * To, H, W, C, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+    call("adamml_temporal_pool_fwd", ptr(x), ptr(s), ptr(t), C, 1, ptr(p), NB, T, H * W * C, C, 0, G)
+    for g in range(G):
+        call("adamml_temporal_pool_fwd", ptr(_g(x, G)[g]), ptr(s[g]), ptr(t[g]), 0, 1, ptr(_g(p1, G)[g]), NB, T, H * W * C, C, 0, 1)
+    assert torch.equal(p, p1)
+    gp = torch.randn(G * NB * To, H, W, C, device=DEV).to(torch.bfloat16)
+    gx, gx1 = torch.empty_like(x), torch.empty_like(x)
+    call("adamml_temporal_pool_bwd", ptr(gp), ptr(x), ptr(s), ptr(t), C, 1, ptr(gx), NB, T, H * W * C, C, 0, G)
+    for g in range(G):
+        call("adamml_temporal_pool_bwd", ptr(_g(gp, G)[g]), ptr(_g(x, G)[g]), ptr(s[g]), ptr(t[g]), 0, 1, ptr(_g(gx1, G)[g]), NB, T,
+             H * W * C, C, 0, 1)
+    assert torch.equal(gx, gx1)
+    # global average pool
+    f, f1 = torch.empty(G * n, C, device=DEV), torch.empty(G * n, C, device=DEV)
+    call("adamml_gap_fwd", ptr(x), ptr(s), ptr(t), C, 2, ptr(f), n, H * W, C, G)
+    for g in range(G):
+        call("adamml_gap_fwd", ptr(_g(x, G)[g]), ptr(s[g]), ptr(t[g]), 0, 2, ptr(_g(f1, G)[g]), n, H * W, C, 1)
+    assert torch.equal(f, f1)

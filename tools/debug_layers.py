@@ -23,7 +23,7 @@ sdg = {k: v.cuda() for k, v in sd.items()}
 def mat(l):
     n, h, w, C = l.shape
     out = torch.empty_like(l.data)
-    call("adamml_bn_act_add", ptr(l.data), ptr(l.scale), ptr(l.shift), l.act, None, None, None, ptr(out), n*h*w, C)
+    call("adamml_bn_act_add", ptr(l.data), ptr(l.scale), ptr(l.shift), l.gs, l.act, None, None, None, 0, ptr(out), n*h*w, C, 1)
     return out.float().permute(0, 3, 1, 2)
 
 def cmp(tag, mine, ref):
