@@ -113,25 +113,37 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
     shift[c] = beta[c] - rm[c] * sc;
 }
 
-__global__ void bn_act_add_kernel(const bf16_t* z, const float* scale, const float* shift, int z_gs, int act, const bf16_t* idn,
-                                  const float* id_scale, const float* id_shift, int id_gs, bf16_t* out, size_t nchunks, int C) {
-    const int cpr = C >> 3;
-    const size_t goff = (size_t)blockIdx.y * nchunks * 8;
+// Row-walking elementwise kernels: a thread keeps ONE 8-channel chunk for all its pixels (ChanMap), so the per-channel
+// BatchNorm vectors are loaded into registers once per thread instead of once per 16 B of activation traffic (the
+// per-element form issued 14 cached vector loads per 2 streaming loads and ran at ~3.5 TB/s; this form streams at ~6).
+__global__ __launch_bounds__(NT) void bn_act_add_kernel(const bf16_t* z, const float* scale, const float* shift, int z_gs, int act,
+                                                        const bf16_t* idn, const float* id_scale, const float* id_shift, int id_gs,
+                                                        bf16_t* out, size_t P, int C, size_t ppb) {
+    const size_t goff = (size_t)blockIdx.y * P * C;
     z += goff; out += goff;
     if (idn) idn += goff;
-    if (scale) { scale += (size_t)blockIdx.y * z_gs; shift += (size_t)blockIdx.y * z_gs; }
-    if (id_scale) { id_scale += (size_t)blockIdx.y * id_gs; id_shift += (size_t)blockIdx.y * id_gs; }
-    const float lo = act_lo(act), hi = act_hi(act);
-    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nchunks; e += (size_t)gridDim.x * NT) {
-        const int c = (int)(e % cpr) * 8;
-        f32x8 v = transform8(*reinterpret_cast<const bf16x8*>(z + e * 8), scale, shift, c, ACT_NONE);
-        if (idn) {
-            f32x8 w = transform8(*reinterpret_cast<const bf16x8*>(idn + e * 8), id_scale, id_shift, c, ACT_NONE);
-            v += w;
-        }
+    ChanMap m(C, threadIdx.x);
+    if (!m.active) return;
+    const int c = m.chunk * 8;
+    f32x8 sc, sh, isc, ish;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = clamp_act(v[i], lo, hi);
-        *reinterpret_cast<bf16x8*>(out + e * 8) = f32_to_bf8(v);
+    for (int i = 0; i < 8; ++i) { sc[i] = 1.f; sh[i] = 0.f; isc[i] = 1.f; ish[i] = 0.f; }
+    if (scale) { sc = load_f32x8(scale + (size_t)blockIdx.y * z_gs + c); sh = load_f32x8(shift + (size_t)blockIdx.y * z_gs + c); }
+    if (idn && id_scale) { isc = load_f32x8(id_scale + (size_t)blockIdx.y * id_gs + c); ish = load_f32x8(id_shift + (size_t)blockIdx.y * id_gs + c); }
+    const float lo = act_lo(act), hi = act_hi(act);
+    const size_t pb = (size_t)blockIdx.x * ppb;
+    const size_t pe = pb + ppb < P ? pb + ppb : P;
+    for (size_t p = pb + m.rslot; p < pe; p += m.rows_per_pass) {
+        f32x8 v = bf8_to_f32(*reinterpret_cast<const bf16x8*>(z + p * C + c));
+        if (idn) {
+            const f32x8 w = bf8_to_f32(*reinterpret_cast<const bf16x8*>(idn + p * C + c));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = clamp_act(fmaf(v[i], sc[i], sh[i]) + fmaf(w[i], isc[i], ish[i]), lo, hi);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = clamp_act(fmaf(v[i], sc[i], sh[i]), lo, hi);
+        }
+        *reinterpret_cast<bf16x8*>(out + p * C + c) = f32_to_bf8(v);
     }
 }
 
@@ -252,22 +264,27 @@ __global__ void bn_bwd_finalize_kernel(const double* sums, int nslots, int group
     }
 }
 
-__global__ void bn_bwd_apply_kernel(const bf16_t* g, const bf16_t* z, const float* vec, int act, const float* coef, bf16_t* dz,
-                                    size_t nchunks, int C) {
-    const int cpr = C >> 3;
+// STREAM: the tensors are larger than the 256 MB Infinity Cache -> non-temporal accesses (nothing is re-used from cache);
+// smaller tensors keep default caching so that the consumers of dz (data / weight gradient) still find it in L2 / MALL.
+template <bool STREAM>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const bf16_t* g, const bf16_t* z, const float* vec, int act, const float* coef,
+                                                          bf16_t* dz, size_t P, int C, size_t ppb) {
     {
-        const size_t goff = (size_t)blockIdx.y * nchunks * 8;
+        const size_t goff = (size_t)blockIdx.y * P * C;
         g += goff; z += goff; dz += goff;
         vec += (size_t)blockIdx.y * 4 * C;
         coef += (size_t)blockIdx.y * 3 * C;
     }
+    ChanMap m(C, threadIdx.x);
+    if (!m.active) return;
+    const int c = m.chunk * 8;
+    const f32x8 sc = load_f32x8(vec + c), sh = load_f32x8(vec + C + c), mu = load_f32x8(vec + 2 * C + c), is = load_f32x8(vec + 3 * C + c);
+    const f32x8 k0 = load_f32x8(coef + c), k1 = load_f32x8(coef + C + c), k2 = load_f32x8(coef + 2 * C + c);
     const float lo = act_lo(act), hi = act_hi(act);
-    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < nchunks; e += (size_t)gridDim.x * NT) {
-        const int c = (int)(e % cpr) * 8;
-        f32x8 gv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(g + e * 8));
-        f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(z + e * 8));
-        f32x8 sc = load_f32x8(vec + c), sh = load_f32x8(vec + C + c), mu = load_f32x8(vec + 2 * C + c), is = load_f32x8(vec + 3 * C + c);
-        f32x8 k0 = load_f32x8(coef + c), k1 = load_f32x8(coef + C + c), k2 = load_f32x8(coef + 2 * C + c);
+    const size_t pb = (size_t)blockIdx.x * ppb;
+    const size_t pe = pb + ppb < P ? pb + ppb : P;
+    auto one = [&](bf16x8 graw, bf16x8 zraw) {
+        const f32x8 gv = bf8_to_f32(graw), zv = bf8_to_f32(zraw);
         f32x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -275,8 +292,29 @@ __global__ void bn_bwd_apply_kernel(const bf16_t* g, const bf16_t* z, const floa
             float zh = (zv[i] - mu[i]) * is[i];
             o[i] = k0[i] * (gp - k1[i] - zh * k2[i]);
         }
-        *reinterpret_cast<bf16x8*>(dz + e * 8) = f32_to_bf8(o);
+        return f32_to_bf8(o);
+    };
+    const size_t step = m.rows_per_pass;
+    size_t p = pb + m.rslot;
+    for (; p + step < pe; p += 2 * step) {            // two rows in flight per thread
+        const bf16x8* gp0 = reinterpret_cast<const bf16x8*>(g + p * C + c);
+        const bf16x8* gp1 = reinterpret_cast<const bf16x8*>(g + (p + step) * C + c);
+        const bf16x8* zp0 = reinterpret_cast<const bf16x8*>(z + p * C + c);
+        const bf16x8* zp1 = reinterpret_cast<const bf16x8*>(z + (p + step) * C + c);
+        bf16x8 g0, g1, z0, z1;
+        if (STREAM) {
+            g0 = __builtin_nontemporal_load(gp0); g1 = __builtin_nontemporal_load(gp1);
+            z0 = __builtin_nontemporal_load(zp0); z1 = __builtin_nontemporal_load(zp1);
+            __builtin_nontemporal_store(one(g0, z0), reinterpret_cast<bf16x8*>(dz + p * C + c));
+            __builtin_nontemporal_store(one(g1, z1), reinterpret_cast<bf16x8*>(dz + (p + step) * C + c));
+        } else {
+            g0 = *gp0; g1 = *gp1; z0 = *zp0; z1 = *zp1;
+            *reinterpret_cast<bf16x8*>(dz + p * C + c) = one(g0, z0);
+            *reinterpret_cast<bf16x8*>(dz + (p + step) * C + c) = one(g1, z1);
+        }
     }
+    if (p < pe) *reinterpret_cast<bf16x8*>(dz + p * C + c) = one(*reinterpret_cast<const bf16x8*>(g + p * C + c),
+                                                                *reinterpret_cast<const bf16x8*>(z + p * C + c));
 }
 
 // ------------------------------------------------------------------------------------------------ pooling
@@ -590,15 +628,27 @@ extern "C" int adamml_bn_eval_affine(const float* gamma, const float* beta, cons
     return adamml_check_launch("bn_eval_affine");
 }
 
+// rows per workgroup of the row-walking kernels: >= 16 passes per thread, <= ~4096 workgroups over all groups
+static void rowwalk_grid(size_t P, int C, int groups, int cap_total, size_t* ppb_out, size_t* nblk_out) {
+    const int rows = NT / (C / 8) > 0 ? NT / (C / 8) : 1;
+    size_t ppb = (size_t)rows * 16;
+    size_t nblk = (P + ppb - 1) / ppb;
+    const size_t cap = cap_total / (groups < 1 ? 1 : groups) + 1;
+    if (nblk > cap) { ppb = ((P + cap - 1) / cap + rows - 1) / rows * rows; nblk = (P + ppb - 1) / ppb; }
+    *ppb_out = ppb;
+    *nblk_out = nblk;
+}
+
 extern "C" int adamml_bn_act_add(const void* z, const float* scale, const float* shift, int z_gstride, int act, const void* idn,
                                  const float* id_scale, const float* id_shift, int id_gstride, void* out, size_t P, int C, int groups,
                                  hipStream_t stream) {
     CHECK_C(C, "bn_act_add");
-    const size_t n = P * (size_t)(C / 8);
-    if (!n) return ADAMML_OK;
+    if (!P) return ADAMML_OK;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL(bn_act_add_kernel, dim3(grid_for(n, NT, 4096 / groups + 1), groups), dim3(NT), 0, stream, (const bf16_t*)z, scale, shift,
-                       z_gstride, act, (const bf16_t*)idn, id_scale, id_shift, id_gstride, (bf16_t*)out, n, C);
+    size_t ppb, nblk;
+    rowwalk_grid(P, C, groups, 8192, &ppb, &nblk);
+    hipLaunchKernelGGL(bn_act_add_kernel, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)z, scale, shift, z_gstride, act,
+                       (const bf16_t*)idn, id_scale, id_shift, id_gstride, (bf16_t*)out, P, C, ppb);
     return adamml_check_launch("bn_act_add");
 }
 
@@ -611,13 +661,7 @@ extern "C" int adamml_act_bwd_from_output(const void* g_out, const void* out, in
 }
 
 static void reduce_grid(size_t P, int C, int groups, size_t* ppb_out, size_t* nblk_out) {
-    const int rows = NT / (C / 8) > 0 ? NT / (C / 8) : 1;
-    size_t ppb = (size_t)rows * 16;
-    size_t nblk = (P + ppb - 1) / ppb;
-    const size_t cap = 2048 / (groups < 1 ? 1 : groups) + 1;
-    if (nblk > cap) { ppb = ((P + cap - 1) / cap + rows - 1) / rows * rows; nblk = (P + ppb - 1) / ppb; }
-    *ppb_out = ppb;
-    *nblk_out = nblk;
+    rowwalk_grid(P, C, groups, 2048, ppb_out, nblk_out);
 }
 
 extern "C" int adamml_bn_bwd_reduce(const void* g, const void* z, const float* vec, int act, double* sums, size_t P, int C, int groups,
@@ -657,11 +701,16 @@ extern "C" int adamml_bn_bwd_finalize(const double* sums, int nslots, int groups
 extern "C" int adamml_bn_bwd_apply(const void* g, const void* z, const float* vec, int act, const float* coef, void* dz, size_t P, int C,
                                    int groups, hipStream_t stream) {
     CHECK_C(C, "bn_bwd_apply");
-    const size_t n = P * (size_t)(C / 8);
-    if (!n) return ADAMML_OK;
+    if (!P) return ADAMML_OK;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n, NT, 4096 / groups + 1), groups), dim3(NT), 0, stream, (const bf16_t*)g,
-                       (const bf16_t*)z, vec, act, coef, (bf16_t*)dz, n, C);
+    size_t ppb, nblk;
+    rowwalk_grid(P, C, groups, 8192, &ppb, &nblk);
+    if ((size_t)groups * P * C * 2 > ((size_t)256 << 20))
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g, (const bf16_t*)z,
+                           vec, act, coef, (bf16_t*)dz, P, C, ppb);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g, (const bf16_t*)z,
+                           vec, act, coef, (bf16_t*)dz, P, C, ppb);
     return adamml_check_launch("bn_bwd_apply");
 }
 

@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sync-bn", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="profiling aid: no side streams, so per-kernel durations "
+                    "in a rocprofv3 trace are not inflated by concurrently running kernels")
     return ap.parse_args()
 
 
@@ -131,6 +133,8 @@ def main():
     else:
         model.freeze_main_net()
     model.train()
+    if args.single_stream:
+        model.use_side_stream = False
     images, target = synth_batch(args, device, rank)
     opt = p_opt = None
 
@@ -186,7 +190,7 @@ def main():
         step()
         agg = hip.profiler.summary()
         hip.profiler = None
-        model.use_side_stream = True
+        model.use_side_stream = not args.single_stream
         # the forward conv and the data gradient are ONE device kernel (conv_gemm_kernel): price them together
         gemm = {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0}
         for k in ("adamml_conv_fwd", "adamml_conv_bwd_data", "adamml_conv_bwd_data_bn"):
