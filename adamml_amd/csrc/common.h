@@ -21,8 +21,8 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2 };
 // error plumbing (api.hip)
 int adamml_set_error(int code, const char* fmt, ...);
 int adamml_check_launch(const char* what);
-// dw[i] += sum_{s<nsplit} ws[s*n + i]   (conv_gemm.hip)
-int adamml_launch_split_reduce(const float* ws, float* dw, size_t n, int nsplit, hipStream_t stream);
+// dw[perm(i)] += sum_{s<nsplit} ws[s*n + i]; taps > 1: ws is [co][tap][cin], dw [co][cin][tap]   (conv_gemm.hip)
+int adamml_launch_split_reduce(const float* ws, float* dw, size_t n, int nsplit, hipStream_t stream, int taps = 1, int cin = 1);
 
 // Activations as a clamp to [lo, hi] with wave-uniform bounds (none: [-inf, inf], ReLU: [0, inf], ReLU6: [0, 6]):
 // branch-free per element (the runtime `act` is folded into two scalars once per call site).
@@ -72,3 +72,11 @@ __device__ __forceinline__ f32x4 transform4(bf16x4 raw, const float* scale, cons
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private L2.  This bijection gives XCD k
+// the k-th CONTIGUOUS eighth of the logical work list, in dispatch order, so neighbouring tiles (shared halo rows,
+// shared weight tiles) meet in one L2 instead of being fetched from HBM by up to 8 of them.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned lin, unsigned total) {
+    const unsigned q = total >> 3, r = total & 7, xcd = lin & 7, idx = lin >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}

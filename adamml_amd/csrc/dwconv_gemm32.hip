@@ -44,15 +44,17 @@ __global__ __launch_bounds__(NT) void dwconv_fwd_kernel(DwP p) {
     constexpr int SEG = S == 1 ? 8 : 4;                 // outputs per thread (compile-time: all loads issue up front)
     constexpr int NCOL = (SEG - 1) * S + 3;             // input columns feeding them
     __shared__ float smem[2 * MAXC];
+    const unsigned lb = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const unsigned bx = lb % gridDim.x;
     {
-        const int g = blockIdx.y;
+        const int g = lb / gridDim.x;
         p.x += (size_t)g * p.gx;
         p.y += (size_t)g * p.gy;
         if (p.stats) p.stats += (size_t)g * ADAMML_STAT_SLOTS * 2 * p.C;
         if (p.in_scale) { p.in_scale += (size_t)g * p.in_gstride; p.in_shift += (size_t)g * p.in_gstride; }
     }
     const int nchunk = p.C >> 2;
-    const int gid = blockIdx.x * NT + threadIdx.x;
+    const int gid = bx * NT + threadIdx.x;
     const int chunk = gid % nchunk, tsk = gid / nchunk;
     const int seg = tsk % p.nseg, row = tsk / p.nseg;
     const bool active = row < p.N * p.OH;
@@ -134,11 +136,12 @@ __global__ __launch_bounds__(NT) void dwconv_fwd_kernel(DwP p) {
 
 // dx[n,ih,iw,c] = sum_{kh,kw} dz[n,(ih+pad-kh)/s,(iw+pad-kw)/s,c] * w[kh,kw,c]
 __global__ __launch_bounds__(NT) void dwconv_bwd_data_kernel(DwP p) {   // p.x = dz [N,OH,OW,C], p.y = dx [N,H,W,C]
-    p.x += (size_t)blockIdx.y * p.gx;
-    p.y += (size_t)blockIdx.y * p.gy;
+    const unsigned lb = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    p.x += (size_t)(lb / gridDim.x) * p.gx;
+    p.y += (size_t)(lb / gridDim.x) * p.gy;
     ChanMap m(p.C, threadIdx.x);
     if (!m.active) return;
-    const size_t pb = (size_t)blockIdx.x * p.ppb;
+    const size_t pb = (size_t)(lb % gridDim.x) * p.ppb;
     const size_t pe = pb + p.ppb < p.P ? pb + p.ppb : p.P;
     const int c = m.chunk * 8;
     f32x8 wt[9];
