@@ -33,6 +33,11 @@ struct ConvP {
     const bf16_t* bn_z;          // raw conv output that produced the consumer's input (same shape as y), or null
     const float* bn_vec;         // [4][Cout']: scale, shift, mean, invstd of that BatchNorm
     int bn_act;
+    // MODE 3 (one parity class of the data gradient of a stride-2 conv, see conv_dgrad_stride2)
+    int wK;                      // weight row stride in elements (== K except in MODE 3, where K covers the class taps only)
+    int cls_nt;                  // taps of this class (0..4)
+    unsigned cls_code;           // per tap, 8 bits: dh | dw << 1 | weight-pack tap index << 2
+    int oH, oW, o_ph, o_pw;      // output rows are scattered: pixel (i, j) of the class grid -> (2i + o_ph, 2j + o_pw) of [oH, oW]
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -42,7 +47,9 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 }
 
 // MODE 0: 1x1 conv; MODE 1: KxK conv, fast tap addressing (per-row validity mask + LDS tap-offset table);
-// MODE 2: generic path with zero-upsampled input (data gradient of strided convs).
+// MODE 2: generic path with zero-upsampled input (data gradient of strided convs other than the stride-2 fast path);
+// MODE 3: one parity class of a stride-2 data gradient: MODE 1 addressing over the class's tap subset (input and weight
+//         tap tables), output rows scattered with stride 2 -- no MFMA or load is spent on the zeros of the up-sampling.
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (N > 0) {
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
     constexpr int TILE_BYTES = (BP + BC) * 64;
     constexpr int EPI_BYTES = BP * (BC * 2 + 16);
     constexpr int STAGE_BYTES = (2 * TILE_BYTES) > EPI_BYTES ? (2 * TILE_BYTES) : EPI_BYTES;
-    constexpr int SMEM_BYTES = STAGE_BYTES + 2 * BC * 4 + 256;       // + per-channel sums + tap-offset table
+    constexpr int SMEM_BYTES = STAGE_BYTES + 2 * BC * 4 + 256 + (MODE == 3 ? BP * 4 + 16 : 0);   // + per-channel sums + tap-offset table (+ MODE 3: output row table, weight tap table)
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
 
     {   // BatchNorm group of this workgroup: one launch covers the S per-segment calls of the reference
@@ -92,11 +99,20 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
 
     const int chunk = tid & 3;
     const int row_a = tid >> 2;             // 0..63 (+64 for second row)
-    int* s_tapoff = reinterpret_cast<int*>(smem + SMEM_BYTES - 64 * 4);       // MODE 1: element offset of each tap
+    int* s_tapoff = reinterpret_cast<int*>(smem + STAGE_BYTES + 2 * BC * 4);  // MODE 1/3: element offset of each tap
+    int* s_wtap = s_tapoff + 64;                                              // MODE 3: weight offset of each class tap [4]
+    int* s_orow = s_wtap + 4;                                                 // MODE 3: output row of each tile pixel [BP]
     if (MODE == 1) {
         if (tid < p.KH * p.KW) {
             const int kh = tid / p.KW, kw = tid - kh * p.KW;
             s_tapoff[tid] = (kh * p.W + kw) * p.Cin;
+        }
+    }
+    if (MODE == 3) {
+        if (tid < p.cls_nt) {
+            const unsigned code = (p.cls_code >> (8 * tid)) & 0xffu;
+            s_tapoff[tid] = ((int)(code & 1) * p.W + (int)((code >> 1) & 1)) * p.Cin;
+            s_wtap[tid] = (int)(code >> 2) * p.Cin;
         }
     }
     const bf16_t* wrow[WROWS];
@@ -105,7 +121,7 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
     for (int r = 0; r < WROWS; ++r) {
         int co = c0 + row_a + r * 64;
         w_ok[r] = co < p.Cout;
-        wrow[r] = p.w + (size_t)(w_ok[r] ? co : 0) * p.K;
+        wrow[r] = p.w + (size_t)(w_ok[r] ? co : 0) * p.wK;
     }
     const int li = lane & 15, lg = lane >> 4;
     // epilogue thread mapping (fixed across the tiles of this workgroup, so the per-channel sums live in registers)
@@ -151,9 +167,27 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
                     if (hok && (unsigned)(a_w0[r] + kw) < (unsigned)p.W) m |= 1ull << (kh * p.KW + kw);
             }
         }
+        if (MODE == 3 && a_ok[r]) {
+            for (int t = 0; t < p.cls_nt; ++t) {
+                const unsigned code = (p.cls_code >> (8 * t)) & 0xffu;
+                if ((unsigned)(a_h0[r] + (int)(code & 1)) < (unsigned)p.H && (unsigned)(a_w0[r] + (int)((code >> 1) & 1)) < (unsigned)p.W)
+                    m |= 1ull << t;
+            }
+        }
         a_mask[r] = m;
     }
-    if (MODE == 1 && it == 0) __syncthreads();          // tap-offset table visible
+    if (MODE == 3 && tid < BP) {
+        // scattered output rows of this tile (read by the epilogue, after at least one barrier)
+        const int pp = p0 + tid;
+        int orow = 0;
+        if (pp < p.P) {
+            const int n = pp / (p.OH * p.OW), rem = pp - n * (p.OH * p.OW);
+            const int i = rem / p.OW, j = rem - i * p.OW;
+            orow = (n * p.oH + 2 * i + p.o_ph) * p.oW + 2 * j + p.o_pw;
+        }
+        s_orow[tid] = orow;
+    }
+    if ((MODE == 1 || MODE == 3) && it == 0) __syncthreads();          // tap-offset tables visible
 
     // register prefetch ring of depth PD: global loads run PD K-steps ahead of the MFMAs.  One K step of compute is
     // ~0.15 us but an HBM round trip is 1-2 us, so a one-step look-ahead left the kernel latency-bound.
@@ -167,6 +201,7 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
         constexpr int SL = decltype(slot_c)::value;
         const int k = kt * BK + chunk * 8;
         const bool kok = k < p.K;
+        int kw_off = k;                                  // offset of this K chunk in a weight row
         if (MODE == 0) {
             rci[SL] = k;
 #pragma unroll
@@ -177,10 +212,11 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
                 if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + (size_t)(unsigned)(a_base[r] + k));
                 ra[SL][r] = v;
             }
-        } else if (MODE == 1) {
+        } else if (MODE == 1 || MODE == 3) {
             const int tap = kok ? (k >> p.cin_shift) : 0;
             const int ci = k & (p.Cin - 1);
             const int toff = s_tapoff[tap] + ci;
+            if (MODE == 3) kw_off = s_wtap[tap] + ci;
             rci[SL] = ci;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -212,7 +248,7 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
 #pragma unroll
         for (int r = 0; r < WROWS; ++r) {
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (w_ok[r] && kok) v = *reinterpret_cast<const bf16x8*>(wrow[r] + k);
+            if (w_ok[r] && kok) v = *reinterpret_cast<const bf16x8*>(wrow[r] + kw_off);
             rw[SL][r] = v;
         }
     };
@@ -291,14 +327,14 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
         const f32x8 mu = load_f32x8(p.bn_vec + 2 * p.Cout + eco), is = load_f32x8(p.bn_vec + 3 * p.Cout + eco);
 #pragma unroll
         for (int r = erow0; r < BP; r += RSTEP) {
-            const int pp = p0 + r;
-            if (pp >= p.P) break;
+            if (p0 + r >= p.P) break;
+            const size_t pp = MODE == 3 ? (size_t)s_orow[r] : (size_t)(p0 + r);
             f32x8 f = bf8_to_f32(*reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16));
-            const f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(p.bn_z + (size_t)pp * p.Cout + eco));
+            const f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(p.bn_z + pp * p.Cout + eco));
 #pragma unroll
             for (int i = 0; i < 8; ++i) f[i] *= act_mask(fmaf(zv[i], sc[i], sh[i]), p.bn_act);
             const bf16x8 v = f32_to_bf8(f);
-            *reinterpret_cast<bf16x8*>(p.y + (size_t)pp * p.Cout + eco) = v;
+            *reinterpret_cast<bf16x8*>(p.y + pp * p.Cout + eco) = v;
             f = bf8_to_f32(v);
             esum += f;
 #pragma unroll
@@ -307,10 +343,10 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
     } else if (eco < p.Cout) {
 #pragma unroll
         for (int r = erow0; r < BP; r += RSTEP) {
-            const int pp = p0 + r;
-            if (pp >= p.P) break;
+            if (p0 + r >= p.P) break;
+            const size_t pp = MODE == 3 ? (size_t)s_orow[r] : (size_t)(p0 + r);
             bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16);
-            bf16_t* dst = p.y + (size_t)pp * p.Cout + eco;
+            bf16_t* dst = p.y + pp * p.Cout + eco;
             f32x8 f = bf8_to_f32(v);
             if (p.accumulate) {
                 f += bf8_to_f32(*reinterpret_cast<const bf16x8*>(dst));
@@ -756,9 +792,12 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
+// one parity class (ph, pw) of the data gradient of a stride-2 conv (see conv_dgrad_stride2)
+struct DgradClass { int nt; unsigned code; int ph, pw, OHc, OWc; };
+
 static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
                        const float* in_shift, void* y, double* stats, const void* bn_z, const float* bn_vec, int bn_act,
-                       hipStream_t stream) {
+                       hipStream_t stream, const DgradClass* cls = nullptr) {
     if (!d || !x || !w_packed || !y) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: null argument");
     if (d->Cin % 8 || d->Cout % 8) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: channels must be multiples of 8 (Cin=%d Cout=%d)", d->Cin, d->Cout);
     ConvP p;
@@ -775,7 +814,15 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     if (p.up_shift < 0) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd: up=%d is not a power of two", p.up);
     p.act = d->act; p.accumulate = d->accumulate;
     p.P = d->N * d->OH * d->OW; p.K = d->KH * d->KW * d->Cin;
-    const bool multitap = d->KH * d->KW > 1;
+    p.wK = p.K;
+    p.cls_nt = 0; p.cls_code = 0; p.oH = d->OH; p.oW = d->OW; p.o_ph = p.o_pw = 0;
+    if (cls) {
+        p.cls_nt = cls->nt; p.cls_code = cls->code; p.o_ph = cls->ph; p.o_pw = cls->pw;
+        p.OH = cls->OHc; p.OW = cls->OWc;
+        p.P = d->N * cls->OHc * cls->OWc;
+        p.K = cls->nt * d->Cin;
+    }
+    const bool multitap = d->KH * d->KW > 1 || cls;
     p.cin_shift = 0;
     if (multitap) {
         p.cin_shift = ilog2_exact(d->Cin);
@@ -796,7 +843,7 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     const int taps = d->KH * d->KW;
     // MODE 0 needs the whole row base in 32-bit element offsets (true for every layer of the hot path)
     if ((long)d->N * d->H * d->W * d->Cin >= (1L << 31)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd: input tensor exceeds 2^31 elements");
-    const int mode = p.up > 1 ? 2 : (multitap ? (taps <= 64 ? 1 : 2) : 0);
+    const int mode = cls ? 3 : (p.up > 1 ? 2 : (multitap ? (taps <= 64 ? 1 : 2) : 0));
     if (mode == 2 && !multitap) { p.cin_shift = 30; }      // 1x1 strided dgrad: tap = k >> 30 = 0, ci = k
     const int nk = ceil_div(p.K, BK);
     const bool deep = (long)grid.x * grid.y <= 768 && nk >= 8;        // < 1 wave of workgroups per CU slot and a long K loop
@@ -806,9 +853,11 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
         else hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1>), grid, block, 0, stream, p);               \
     } while (0)
     if (BC == 64) {
-        if (mode == 0) LAUNCH_CONV(64, 0); else if (mode == 1) LAUNCH_CONV(64, 1); else LAUNCH_CONV(64, 2);
+        if (mode == 0) LAUNCH_CONV(64, 0); else if (mode == 1) LAUNCH_CONV(64, 1); else if (mode == 2) LAUNCH_CONV(64, 2);
+        else hipLaunchKernelGGL((conv_gemm_kernel<64, 3, 1>), grid, block, 0, stream, p);
     } else {
-        if (mode == 0) LAUNCH_CONV(128, 0); else if (mode == 1) LAUNCH_CONV(128, 1); else LAUNCH_CONV(128, 2);
+        if (mode == 0) LAUNCH_CONV(128, 0); else if (mode == 1) LAUNCH_CONV(128, 1); else if (mode == 2) LAUNCH_CONV(128, 2);
+        else hipLaunchKernelGGL((conv_gemm_kernel<128, 3, 1>), grid, block, 0, stream, p);
     }
 #undef LAUNCH_CONV
     return adamml_check_launch("conv_fwd");
@@ -819,9 +868,53 @@ extern "C" int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const
     return conv_launch(d, x, w_packed, in_scale, in_shift, y, stats, nullptr, nullptr, 0, stream);
 }
 
+// Data gradient of a stride-2 conv (3x3 pad 1 / 1x1 pad 0: every strided conv of the hot path) WITHOUT the 4x wasted work
+// of a zero-upsampled stride-1 conv: the dx pixels split into 4 parity classes (ih % 2, iw % 2); class (ph, pw) only
+// receives the taps with kh == ph + pad (mod 2), kw likewise -- 1, 2, 2 and 4 of the 9 taps of a 3x3, 1/0/0/0 of a 1x1 --
+// and is a dense stride-1 conv of dz with that tap subset whose output rows are scattered with stride 2.  A class
+// without taps is zero-filled (or skipped when accumulating).
+static int conv_dgrad_stride2(const adamml_conv_desc_t* d, const void* dz, const void* w, void* dx, int accumulate, double* sums,
+                              const void* z_in, const float* bn_vec, int act, hipStream_t stream) {
+    adamml_conv_desc_t g = *d;
+    g.N = d->N; g.H = d->OH; g.W = d->OW; g.Cin = d->Cout;
+    g.OH = d->H; g.OW = d->W; g.Cout = d->Cin;
+    g.stride = 1; g.up = 1; g.pad = 0;
+    g.act = ACT_NONE; g.accumulate = accumulate; g.in_gstride = 0;
+    const int taps = d->KH * d->KW;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            DgradClass c;
+            c.nt = 0; c.code = 0; c.ph = ph; c.pw = pw;
+            c.OHc = (d->H - ph + 1) / 2; c.OWc = (d->W - pw + 1) / 2;
+            if (c.OHc <= 0 || c.OWc <= 0) continue;
+            for (int kh = 0; kh < d->KH; ++kh) {
+                if ((ph + d->pad - kh) & 1) continue;
+                const int dh = (ph + d->pad - kh) / 2;           // dz row = i + dh, in {0, 1} for the supported shapes
+                for (int kw = 0; kw < d->KW; ++kw) {
+                    if ((pw + d->pad - kw) & 1) continue;
+                    const int dw = (pw + d->pad - kw) / 2;
+                    const unsigned wt = (unsigned)(taps - 1 - (kh * d->KW + kw));     // tap index in the flipped weight pack
+                    c.code |= ((unsigned)dh | ((unsigned)dw << 1) | (wt << 2)) << (8 * c.nt);
+                    ++c.nt;
+                }
+            }
+            if (c.nt == 0 && accumulate) continue;
+            int rc = conv_launch(&g, dz, w, nullptr, nullptr, dx, sums, z_in, bn_vec, act, stream, &c);
+            if (rc) return rc;
+        }
+    return ADAMML_OK;
+}
+
+static bool dgrad_stride2_ok(const adamml_conv_desc_t* d) {
+    const bool k3 = d->KH == 3 && d->KW == 3 && d->pad == 1, k1 = d->KH == 1 && d->KW == 1 && d->pad == 0;
+    return d->stride == 2 && (k3 || k1) && (d->up <= 1) && ilog2_exact(d->Cout) >= 0 &&
+           d->OH == (d->H + 2 * d->pad - d->KH) / 2 + 1 && d->OW == (d->W + 2 * d->pad - d->KW) / 2 + 1;
+}
+
 extern "C" int adamml_conv_bwd_data_bn(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
                                        const void* z_in, const float* bn_vec, int act, double* sums, hipStream_t stream) {
     if (!d || !z_in || !bn_vec || !sums) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_bn: null argument");
+    if (dgrad_stride2_ok(d)) return conv_dgrad_stride2(d, dz, w_dgrad_packed, dx, 0, sums, z_in, bn_vec, act, stream);
     adamml_conv_desc_t g = *d;
     g.N = d->N; g.H = d->OH; g.W = d->OW; g.Cin = d->Cout;
     g.OH = d->H; g.OW = d->W; g.Cout = d->Cin;
@@ -835,6 +928,7 @@ extern "C" int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz,
     // d describes the FORWARD conv; the data gradient is a stride-1 conv of the (zero-upsampled) dz with the
     // flipped / transposed weight pack (adamml_pack_conv_weight, mode 1).
     if (!d) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data: null desc");
+    if (dgrad_stride2_ok(d)) return conv_dgrad_stride2(d, dz, w_dgrad_packed, dx, accumulate, nullptr, nullptr, nullptr, 0, stream);
     adamml_conv_desc_t g = *d;
     g.N = d->N; g.H = d->OH; g.W = d->OW; g.Cin = d->Cout;
     g.OH = d->H; g.OW = d->W; g.Cout = d->Cin;

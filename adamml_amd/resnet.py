@@ -94,10 +94,12 @@ class ResNet(HipBackbone, MeanStdMixin):
         h = maxpool3x3s2(rt, h)
         for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
             for b in layer:
+                # the downsample branch is issued FIRST so that its data gradient runs LAST in the reversed tape: it then
+                # accumulates into the gradient conv1 already wrote, and a stride-2 1x1 only touches a quarter of the pixels
+                idn = conv_bn(rt, h, b._csd, b.downsample[1], ACT_NONE) if b._csd is not None else h
                 o = conv_bn(rt, h, b._cs1, b.bn1, ACT_RELU)
                 o = conv_bn(rt, o, b._cs2, b.bn2, ACT_RELU, sole_consumer=True)
                 o = conv_bn(rt, o, b._cs3, b.bn3, ACT_NONE, sole_consumer=True)
-                idn = conv_bn(rt, h, b._csd, b.downsample[1], ACT_NONE) if b._csd is not None else h
                 h = add_act(rt, o, idn, ACT_RELU, idn_sole=b._csd is not None)
             if li < 3 and not self.without_t_stride:
                 h = temporal_pool(rt, h, frames, self.pooling_method)
