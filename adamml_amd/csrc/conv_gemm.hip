@@ -354,24 +354,76 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
                 f = bf8_to_f32(v);
             }
             *reinterpret_cast<bf16x8*>(dst) = v;
-            esum += f;
-            esq += f * f;
         }
     }
-    if (p.stats) {
-        // lanes l, l+CPR, l+2*CPR.. of a wave hold the same channel chunk: fold them, then one LDS atomic per channel
+    if (p.stats && !p.bn_z) {
+        // Forward statistics on the (otherwise ~90 % idle) matrix cores instead of the VALU: with F = the staged bf16 tile
+        // [32 pixels][16 channels] as an MFMA fragment (hardware transpose read), ones * F gives the per-channel sums and
+        // F^T F the Gram matrix whose diagonal is the per-channel sum of squares -- exact products of the STORED values,
+        // fp32 accumulation.  The VALU form (convert + add + fma per element) cost 30 % on the HBM-bound 1x1 layers.
+        // Rows past P and channels past Cout hold zeros (their operands were zero-filled).
+        constexpr int NCB = BC / 64;                       // 16-channel blocks per wave
+        union { s16x4 h[2]; bf16x8 v; } ones;
+        ones.h[0] = s16x4{0x3F80, 0x3F80, 0x3F80, 0x3F80};
+        ones.h[1] = ones.h[0];
+        const int trow = 8 * lg + (li >> 2);
 #pragma unroll
-        for (int off = CPR; off < 64; off <<= 1)
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int ch0 = (wave * NCB + cb) * 16;
+            f32x4 dsum = {0.f, 0.f, 0.f, 0.f}, dsq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                esum[i] += __shfl_xor(esum[i], off, 64);
-                esq[i] += __shfl_xor(esq[i], off, 64);
+            for (int ps = 0; ps < BP / 32; ++ps) {
+                const char* fp = smem + (ps * 32 + trow) * CROW + (ch0 + 4 * (li & 3)) * 2;
+                union { s16x4 h[2]; bf16x8 v; } f;
+                f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(fp));
+                f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(fp + 4 * CROW));
+                dsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, f.v, dsum, 0, 0, 0);
+                dsq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v, f.v, dsq, 0, 0, 0);
             }
-        if (lane < CPR && eco < p.Cout) {
+            // D rows = lg*4 + r, column = li: row 0 of dsum is held by lanes 0..15; the diagonal of dsq by lanes with li>>2 == lg
+            if (lg == 0) cs[ch0 + li] += dsum[0];
+            if ((li >> 2) == lg) {
+                const int r = li & 3;
+                cs[BC + ch0 + li] += r == 0 ? dsq[0] : r == 1 ? dsq[1] : r == 2 ? dsq[2] : dsq[3];
+            }
+        }
+    }
+    if (p.stats && p.bn_z) {
+        // Lanes l, l+CPR, l+2*CPR.. of a wave hold partial sums of the same channel chunk.  They are folded on the VALU
+        // with the gfx950 lane-swap instructions (v_permlane32_swap / v_permlane16_swap: "swap the upper half (odd rows)
+        // of a with the lower half (even rows) of b", so a' + b' folds TWO values at once and halves the register count
+        // per step) -- 24 VALU ops instead of 32-48 ds_bpermute, which had made this epilogue LDS-pipe-bound (-30 % on
+        // the HBM-bound 1x1 layers).  16 values -> 4 registers per lane, then 4 LDS adds per lane.
+        float v[16];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                atomicAdd(&cs[ech * 8 + i], esum[i]);
-                atomicAdd(&cs[BC + ech * 8 + i], esq[i]);
+        for (int i = 0; i < 8; ++i) { v[i] = esum[i]; v[8 + i] = esq[i]; }
+        if (CPR == 8) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)              // lanes l and l+8 of a 16-lane row: DPP row_ror:8
+                v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), 0x128, 0xf, 0xf, false));
+        }
+        float u[8], wv[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // (inline asm: with this toolchain the __builtin_amdgcn_permlane32_swap result pair is mis-compiled when both
+            // halves feed a float add -- verified on hardware, tools/scratch/fold.hip; s_nop covers the VALU->permlane hazard)
+            float a = v[2 * i], b = v[2 * i + 1];
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+            u[i] = a + b;                                   // rows 0,1: v[2i]; rows 2,3: v[2i+1]
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = u[2 * j], b = u[2 * j + 1];
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+            wv[j] = a + b;                                  // row r holds value 4j + {0,2,1,3}[r]
+        }
+        const int lrow = lane >> 4;
+        const int vsel = ((lrow & 1) << 1) | (lrow >> 1);
+        if (eco < p.Cout && (CPR >= 16 || !(lane & 8))) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int id = 4 * j + vsel;              // 0..7: sum of channel id; 8..15: second moment of channel id-8
+                atomicAdd(&cs[(id >> 3) * BC + ech * 8 + (id & 7)], wv[j]);
             }
         }
     }
