@@ -36,6 +36,8 @@ SIGNATURES = {
     "adamml_residual_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _P],
     "adamml_conv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _I, _P, _Z, _P],
     "adamml_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "adamml_pack_stem_weight": [_P, _P, _I, _I, _P],
+    "adamml_conv_stem_fwd": [_DESC, _P, _P, _P, _P, _P],
     "adamml_dwconv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "adamml_dwconv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
     "adamml_dwconv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _P, _Z, _P],
@@ -79,6 +81,8 @@ def load():
     lib.adamml_conv_bwd_weight_workspace.restype = c_size_t
     lib.adamml_dwconv_bwd_weight_workspace.argtypes = [_DESC]
     lib.adamml_dwconv_bwd_weight_workspace.restype = c_size_t
+    lib.adamml_conv_stem_supported.argtypes = [_DESC]
+    lib.adamml_conv_stem_supported.restype = c_int
     lib.adamml_version.restype = c_int
     lib.adamml_last_error_string.restype = c_char_p
     _lib = lib

@@ -148,6 +148,10 @@ class ConvState:
         self.cin = pad8(self.cin_true)
         self.w_fwd = None
         self.w_dgrad = None
+        self.w_stem = None
+        # ResNet stem (7x7/2 of an RGB-like image): LDS-patch kernel with its own weight pack (csrc/conv_stem.hip)
+        self.stem = (not depthwise and self.kh == 7 and self.kw == 7 and stride == 2 and pad == 3 and self.cout == 64
+                     and self.cin_true <= 4)
         self.version = -1
 
     def repack(self, need_dgrad):
@@ -160,6 +164,10 @@ class ConvState:
         if self.w_fwd is None:
             self.w_fwd = torch.empty(self.cout, self.kh * self.kw * self.cin, dtype=torch.bfloat16, device=w.device)
         call("adamml_pack_conv_weight", ptr(w), ptr(self.w_fwd), self.cout, self.cin_true, self.cin, self.kh, self.kw, 0)
+        if self.stem:
+            if self.w_stem is None:
+                self.w_stem = torch.empty(self.cout, 7 * 8 * 4, dtype=torch.bfloat16, device=w.device)
+            call("adamml_pack_stem_weight", ptr(w), ptr(self.w_stem), self.cout, self.cin_true)
         if need_dgrad:
             if self.w_dgrad is None:
                 self.w_dgrad = torch.empty(self.cin, self.kh * self.kw * self.cout, dtype=torch.bfloat16, device=w.device)
@@ -246,6 +254,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False):
     C = d.Cout
     count = d.N * d.OH * d.OW               # elements per channel per group
     fwd = "adamml_dwconv_fwd" if cs.depthwise else "adamml_conv_fwd"
+    stem = cs.stem and x.scale is None and hip.load().adamml_conv_stem_supported(byref(d))
     # algorithmic work of this layer (true input channels, each tensor touched once), for the roofline report
     macs = float(count) * G * C * cs.kh * cs.kw * (1 if cs.depthwise else cs.cin_true)
     in_b, out_b = 2.0 * G * d.N * d.H * d.W * cs.cin_true, 2.0 * G * count * C
@@ -253,11 +262,17 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False):
     hip.next_meta = (2 * macs, in_b + out_b + w_b)
     if rt.training:
         stats = rt.fwd_arena.take(G * 2 * C * STAT_SLOTS)
-        call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), ptr(stats))
+        if stem:
+            call("adamml_conv_stem_fwd", byref(d), ptr(x.data), ptr(cs.w_stem), ptr(y), ptr(stats))
+        else:
+            call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), ptr(stats))
         vec = _bn_vectors(rt, bn, stats, count, C, dev)
         rt.touched_bns.append(bn)
     else:
-        call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), None)
+        if stem:
+            call("adamml_conv_stem_fwd", byref(d), ptr(x.data), ptr(cs.w_stem), ptr(y), None)
+        else:
+            call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), None)
         vec = _bn_eval_vectors(bn, C, dev)
     if rt.training:
         out = Lazy(y, vec[0, 0], vec[0, 1], act, gs=4 * C)

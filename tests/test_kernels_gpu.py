@@ -537,3 +537,35 @@ def test_pools_groups_equal_separate_launches():
     for g in range(G):
         call("adamml_gap_fwd", ptr(_g(x, G)[g]), ptr(s[g]), ptr(t[g]), 0, 2, ptr(_g(f1, G)[g]), n, H * W, C, 1)
     assert torch.equal(f, f1)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,G", [(3, 64, 64, 3, 1), (2, 224, 224, 3, 2), (2, 30, 50, 1, 1), (1, 96, 96, 4, 3)])
+def test_conv_stem_fast_path(N, H, W, Cin, G):
+    """7x7/2 stem from an LDS-resident patch (csrc/conv_stem.hip) == torch conv on the same bf16 operands; statistics
+    of the stored outputs per BatchNorm group."""
+    torch.manual_seed(20)
+    x = torch.randn(G * N, Cin, H, W, device=DEV)
+    w = torch.randn(64, Cin, 7, 7, device=DEV) * (2.0 / (Cin * 49)) ** 0.5
+    ref = F.conv2d(rb(x), rb(w), stride=2, padding=3)
+    OH, OW = ref.shape[2:]
+    d = ConvDesc(N, H, W, 8, OH, OW, 64, 7, 7, 2, 3, 1, 0, 0, G, 0)
+    assert hip.load().adamml_conv_stem_supported(byref(d))
+    ws = torch.empty(64, 224, dtype=torch.bfloat16, device=DEV)
+    call("adamml_pack_stem_weight", ptr(w), ptr(ws), 64, Cin)
+    xh = nhwc(x)
+    y = torch.empty(G * N, OH, OW, 64, dtype=torch.bfloat16, device=DEV)
+    st = torch.zeros(G, STAT_SLOTS, 128, dtype=torch.float64, device=DEV)
+    call("adamml_conv_stem_fwd", byref(d), ptr(xh), ptr(ws), ptr(y), ptr(st))
+    close(nchw(y), ref, what="stem fwd")
+    yf = y.float().reshape(G, -1, 64).double()
+    assert torch.allclose(st.sum(1)[:, :64], yf.sum(1), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(st.sum(1)[:, 64:], (yf * yf).sum(1), rtol=1e-4, atol=1e-3)
+    # generic kernel on the same operands: same values up to fp32 summation order
+    y2 = torch.empty_like(y)
+    call("adamml_conv_fwd", byref(d), ptr(xh), ptr(pack(w, 8, 0)), None, None, ptr(y2), None)
+    close(y.float(), y2.float(), what="stem vs generic")
+    # unsupported shapes are refused, not mis-computed
+    bad = ConvDesc(N, H, W, 16, OH, OW, 64, 7, 7, 2, 3, 1, 0, 0)
+    assert not hip.load().adamml_conv_stem_supported(byref(bad))
+    with pytest.raises(RuntimeError):
+        call("adamml_conv_stem_fwd", byref(bad), ptr(xh), ptr(ws), ptr(y), None)

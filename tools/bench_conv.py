@@ -52,7 +52,12 @@ for name, N, H, Cin, Cout, k, s, p, lazy, cnt in L:
     ws = hip.wgrad_workspace(d, Cin, DEV)
     gb = (x.numel() * Cin / cp + y.numel()) * 2 / 1e9
     fl = 2.0 * y.numel() * Cin * k * k / 1e12
-    t1 = timeit(lambda: call("adamml_conv_fwd", byref(d), ptr(x), ptr(wf), sc, sh, ptr(y), ptr(st) if "nostats" not in sys.argv else None))
+    if name.startswith("stem") and hip.load().adamml_conv_stem_supported(byref(d)):
+        wst = torch.empty(Cout, 224, dtype=torch.bfloat16, device=DEV)
+        call("adamml_pack_stem_weight", ptr(w), ptr(wst), Cout, Cin)
+        t1 = timeit(lambda: call("adamml_conv_stem_fwd", byref(d), ptr(x), ptr(wst), ptr(y), ptr(st)))
+    else:
+        t1 = timeit(lambda: call("adamml_conv_fwd", byref(d), ptr(x), ptr(wf), sc, sh, ptr(y), ptr(st) if "nostats" not in sys.argv else None))
     if name.startswith("stem"):
         t2 = 0.0
     elif k == 3 or "c3" in name:   # sole-consumer data gradients carry the BatchNorm-backward reduction
