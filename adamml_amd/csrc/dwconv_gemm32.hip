@@ -30,19 +30,22 @@ struct DwP {
     bf16_t* y;
     double* stats;
     int N, H, W, C, OH, OW, stride, pad, act, accumulate, nseg, seglen;
+    int nrb, rows_per_thread;   // forward: row blocks per image / output rows walked by one thread
     size_t P, ppb;
     size_t gx, gy;        // element strides between BatchNorm groups of x / y (blockIdx.y = group)
     int in_gstride;
 };
 
-// "Row walker": one thread owns 4 channels of a short run of outputs in ONE output row and slides a 3x3 register
-// window along it, so every input element is loaded (and BatchNorm+ReLU6-transformed) ~once per output row instead
-// of nine times, with no per-pixel index arithmetic.  4 channels (8 B) per lane keeps the window + weights + sums at
-// ~100 VGPRs (4-5 waves/SIMD); adjacent lanes own adjacent channel groups -> contiguous 512 B per wave access.
+// "Column-strip walker": one thread owns 4 channels x SEGW adjacent output columns and walks DOWN `rows_per_thread`
+// output rows with a 3-row register window of BatchNorm+ReLU6-transformed inputs.  Every input row is loaded and
+// transformed once per strip (the earlier row-wise form re-transformed each element for the 3 output rows that use it:
+// 31 VALU ops per output element, VALU-bound at ~1 TB/s); the window rotates by compile-time index (rows are processed in
+// groups of 3), the next input row(s) are in flight while the current output row is computed, and the per-channel
+// statistics stay in registers for the whole walk (one LDS fold per thread, one global publication per workgroup).
 template <int S>
-__global__ __launch_bounds__(NT) void dwconv_fwd_kernel(DwP p) {
-    constexpr int SEG = S == 1 ? 8 : 4;                 // outputs per thread (compile-time: all loads issue up front)
-    constexpr int NCOL = (SEG - 1) * S + 3;             // input columns feeding them
+__global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
+    constexpr int SEGW = S == 1 ? 4 : 2;                // output columns per thread
+    constexpr int NCOL = (SEGW - 1) * S + 3;            // input columns feeding them
     __shared__ float smem[2 * MAXC];
     const unsigned lb = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const unsigned bx = lb % gridDim.x;
@@ -55,32 +58,19 @@ __global__ __launch_bounds__(NT) void dwconv_fwd_kernel(DwP p) {
     }
     const int nchunk = p.C >> 2;
     const int gid = bx * NT + threadIdx.x;
-    const int chunk = gid % nchunk, tsk = gid / nchunk;
-    const int seg = tsk % p.nseg, row = tsk / p.nseg;
-    const bool active = row < p.N * p.OH;
+    const int chunk = gid % nchunk;
+    int tsk = gid / nchunk;
+    const int seg = tsk % p.nseg;
+    tsk /= p.nseg;
+    const int rb = tsk % p.nrb, n = tsk / p.nrb;
+    const bool active = n < p.N;
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     if (active) {
         const int c = chunk * 4;
-        const int n = row / p.OH, oh = row - n * p.OH;
-        const int ow_b = seg * SEG;
+        const int ow_b = seg * SEGW;
         const int iw_b = ow_b * S - p.pad;
-        bf16x4 raw[3][NCOL];
-        bool vok[3][NCOL];
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int ih = oh * S - p.pad + kh;
-            const bool rok = ih >= 0 && ih < p.H;
-            const bf16_t* rp = p.x + (((size_t)n * p.H + (rok ? ih : 0)) * p.W) * p.C + c;
-#pragma unroll
-            for (int j = 0; j < NCOL; ++j) {
-                const int iw = iw_b + j;
-                const bool ok = rok && iw >= 0 && iw < p.W;
-                vok[kh][j] = ok;
-                bf16x4 v = {0, 0, 0, 0};
-                if (ok) v = *reinterpret_cast<const bf16x4*>(rp + (size_t)iw * p.C);
-                raw[kh][j] = v;
-            }
-        }
+        const int oh_b = rb * p.rows_per_thread;
+        const int oh_e = min(p.OH, oh_b + p.rows_per_thread);
         f32x4 wt[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(p.w + (size_t)t * p.C + c);
@@ -90,30 +80,93 @@ __global__ __launch_bounds__(NT) void dwconv_fwd_kernel(DwP p) {
             sc = *reinterpret_cast<const f32x4*>(p.in_scale + c);
             sh = *reinterpret_cast<const f32x4*>(p.in_shift + c);
         }
-        f32x4 win[3][NCOL];
+        bool cok[NCOL];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+        for (int j = 0; j < NCOL; ++j) cok[j] = (unsigned)(iw_b + j) < (unsigned)p.W;
+        const bf16_t* img = p.x + (size_t)n * p.H * p.W * p.C + c;
+        bf16_t* yimg = p.y + (size_t)n * p.OH * p.OW * p.C + c;
+
+        struct Raw { bf16x4 v[NCOL]; bool rok; };
+        auto load_row = [&](int ih, Raw& r) {
+            r.rok = (unsigned)ih < (unsigned)p.H;
+            const bf16_t* rp = img + ((size_t)(r.rok ? ih : 0) * p.W + iw_b) * p.C;
 #pragma unroll
             for (int j = 0; j < NCOL; ++j) {
-                f32x4 v = bf4_to_f32(raw[kh][j]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = vok[kh][j] ? clamp_act(fmaf(v[i], sc[i], sh[i]), lo, hi) : 0.f;
-                win[kh][j] = v;
+                bf16x4 v = {0, 0, 0, 0};
+                if (r.rok && cok[j]) v = *reinterpret_cast<const bf16x4*>(rp + (ptrdiff_t)j * p.C);
+                r.v[j] = v;
             }
-        bf16_t* yrow = p.y + (size_t)row * p.OW * p.C + c;
+        };
+        auto xform = [&](const Raw& r, f32x4 (&dst)[NCOL]) {
 #pragma unroll
-        for (int o = 0; o < SEG; ++o) {
-            if (ow_b + o < p.OW) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NCOL; ++j) {
+                f32x4 v = bf4_to_f32(r.v[j]);
+                const bool ok = r.rok && cok[j];
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
+                for (int i = 0; i < 4; ++i) v[i] = ok ? clamp_act(fmaf(v[i], sc[i], sh[i]), lo, hi) : 0.f;
+                dst[j] = v;
+            }
+        };
+        auto emit = [&](int oh, const f32x4 (&r0)[NCOL], const f32x4 (&r1)[NCOL], const f32x4 (&r2)[NCOL]) {
+            bf16_t* yrow = yimg + (size_t)oh * p.OW * p.C;
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) acc += win[kh][o * S + kw] * wt[kh * 3 + kw];
-                bf16x4 ob = f32_to_bf4(acc);
-                *reinterpret_cast<bf16x4*>(yrow + (size_t)(ow_b + o) * p.C) = ob;
-                f32x4 rv = bf4_to_f32(ob);
-                s += rv;
-                q += rv * rv;
+            for (int o = 0; o < SEGW; ++o) {
+                if (ow_b + o < p.OW) {
+                    f32x4 acc = r0[o * S] * wt[0];
+                    acc += r0[o * S + 1] * wt[1];
+                    acc += r0[o * S + 2] * wt[2];
+                    acc += r1[o * S] * wt[3];
+                    acc += r1[o * S + 1] * wt[4];
+                    acc += r1[o * S + 2] * wt[5];
+                    acc += r2[o * S] * wt[6];
+                    acc += r2[o * S + 1] * wt[7];
+                    acc += r2[o * S + 2] * wt[8];
+                    const bf16x4 ob = f32_to_bf4(acc);
+                    *reinterpret_cast<bf16x4*>(yrow + (size_t)(ow_b + o) * p.C) = ob;
+                    const f32x4 rv = bf4_to_f32(ob);
+                    s += rv;
+                    q += rv * rv;
+                }
+            }
+        };
+
+        f32x4 win[3][NCOL];
+        Raw nxt[S];                                          // rows in flight (S new input rows per output row)
+        if (S == 1) {
+            // rows ih = oh-1, oh, oh+1: window slot of input row ih is (ih - (oh_b - 1)) % 3
+            { Raw r; load_row(oh_b * S - p.pad, r); xform(r, win[0]); }
+            { Raw r; load_row(oh_b * S - p.pad + 1, r); xform(r, win[1]); }
+            load_row(oh_b - p.pad + 2, nxt[0]);
+            for (int oh = oh_b; oh < oh_e; oh += 3) {
+                xform(nxt[0], win[2]);
+                if (oh + 1 < oh_e) load_row(oh + 1 - p.pad + 2, nxt[0]);
+                emit(oh, win[0], win[1], win[2]);
+                if (oh + 1 >= oh_e) break;
+                xform(nxt[0], win[0]);
+                if (oh + 2 < oh_e) load_row(oh + 2 - p.pad + 2, nxt[0]);
+                emit(oh + 1, win[1], win[2], win[0]);
+                if (oh + 2 >= oh_e) break;
+                xform(nxt[0], win[1]);
+                if (oh + 3 < oh_e) load_row(oh + 3 - p.pad + 2, nxt[0]);
+                emit(oh + 2, win[2], win[0], win[1]);
+            }
+        } else {
+            // rows ih = 2oh-1, 2oh, 2oh+1; row 2oh+1 is kept as the top row of output row oh+1
+            { Raw r; load_row(oh_b * 2 - p.pad, r); xform(r, win[0]); }
+            load_row(oh_b * 2 - p.pad + 1, nxt[0]);
+            load_row(oh_b * 2 - p.pad + 2, nxt[1]);
+            for (int oh = oh_b; oh < oh_e; oh += 3) {
+                xform(nxt[0], win[1]); xform(nxt[1], win[2]);
+                if (oh + 1 < oh_e) { load_row((oh + 1) * 2 - p.pad + 1, nxt[0]); load_row((oh + 1) * 2 - p.pad + 2, nxt[1]); }
+                emit(oh, win[0], win[1], win[2]);
+                if (oh + 1 >= oh_e) break;
+                xform(nxt[0], win[0]); xform(nxt[1], win[1]);
+                if (oh + 2 < oh_e) { load_row((oh + 2) * 2 - p.pad + 1, nxt[0]); load_row((oh + 2) * 2 - p.pad + 2, nxt[1]); }
+                emit(oh + 1, win[2], win[0], win[1]);
+                if (oh + 2 >= oh_e) break;
+                xform(nxt[0], win[2]); xform(nxt[1], win[0]);
+                if (oh + 3 < oh_e) { load_row((oh + 3) * 2 - p.pad + 1, nxt[0]); load_row((oh + 3) * 2 - p.pad + 2, nxt[1]); }
+                emit(oh + 2, win[1], win[2], win[0]);
             }
         }
     }
@@ -373,9 +426,14 @@ extern "C" int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, con
     const int groups = d->groups < 1 ? 1 : d->groups;
     p.gx = (size_t)d->N * d->H * d->W * d->Cin; p.gy = p.P * d->Cin; p.in_gstride = d->in_gstride;
     p.ppb = 0;
-    p.seglen = d->stride == 1 ? 8 : 4;          // == SEG of dwconv_fwd_kernel<S>
+    p.seglen = d->stride == 1 ? 4 : 2;          // == SEGW of dwconv_fwd_kernel<S>
     p.nseg = (d->OW + p.seglen - 1) / p.seglen;
-    const long threads = (long)d->N * d->OH * p.nseg * (p.C / 4);
+    // rows walked per thread: long walks amortise the 2-row window prologue, but the grid must still fill the chip
+    p.rows_per_thread = 12;
+    while (p.rows_per_thread > 3 &&
+           (long)groups * d->N * ceil_div(d->OH, p.rows_per_thread) * p.nseg * (p.C / 4) < 4096L * NT) p.rows_per_thread -= 3;
+    p.nrb = ceil_div(d->OH, p.rows_per_thread);
+    const long threads = (long)d->N * p.nrb * p.nseg * (p.C / 4);
     const int nblk = (int)((threads + NT - 1) / NT);
     if (d->stride == 1) hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3(nblk, groups), dim3(NT), 0, stream, p);
     else hipLaunchKernelGGL(dwconv_fwd_kernel<2>, dim3(nblk, groups), dim3(NT), 0, stream, p);
