@@ -31,6 +31,7 @@ struct DwP {
     double* stats;
     int N, H, W, C, OH, OW, stride, pad, act, accumulate, nseg, seglen;
     int nrb, rows_per_thread;   // forward: row blocks per image / output rows walked by one thread
+    int flip;                   // forward kernel used as the stride-1 data gradient: taps read in reverse order
     size_t P, ppb;
     size_t gx, gy;        // element strides between BatchNorm groups of x / y (blockIdx.y = group)
     int in_gstride;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
         const int oh_e = min(p.OH, oh_b + p.rows_per_thread);
         f32x4 wt[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(p.w + (size_t)t * p.C + c);
+        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(p.w + (size_t)(p.flip ? 8 - t : t) * p.C + c);
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         const float lo = p.in_scale ? act_lo(p.act) : -INFINITY, hi = p.in_scale ? act_hi(p.act) : INFINITY;
         if (p.in_scale) {
@@ -233,15 +234,21 @@ struct DwWP {
     const float* in_scale;
     const float* in_shift;
     float* dw;            // [C][3][3] fp32
-    float* ws;            // optional [gridDim.x][9*C] partial buffer in dw layout
-    int N, H, W, C, OH, OW, stride, pad, act, rows_per_thread, nseg, seglen;
-    size_t P, ppb;
+    float* ws;            // optional [gridDim.y][gridDim.x][9*C] partial buffer in dw layout
+    int N, H, W, C, OH, OW, stride, pad, act, rows_per_thread, nseg, nrb;
     size_t gdz, gx;
     int in_gstride;
 };
 
+// Weight gradient with the forward kernel's column-strip walk: dw[c][kh][kw] = sum_p dz[p][c] * a[p@(kh,kw)][c] over a
+// 3-row register window of transformed inputs (each input row loaded and transformed once per strip), 36 register
+// accumulators per thread.  The grid is capped (thread count a multiple of every channel-group count of MobileNetV2) with
+// a task loop: a thread keeps its 4-channel group, publishes its accumulators once, and a workgroup writes ONE partial
+// [9*C] tile (plain stores into the workspace, summed by adamml_launch_split_reduce; fp32 atomics without a workspace).
 template <int S>
-__global__ __launch_bounds__(NT) void dwconv_bwd_weight_kernel(DwWP p) {
+__global__ __launch_bounds__(NT, 2) void dwconv_bwd_weight_kernel(DwWP p) {
+    constexpr int SEGW = S == 1 ? 4 : 2;
+    constexpr int NCOL = (SEGW - 1) * S + 3;
     extern __shared__ float dsm[];        // [9][C]
     p.dz += (size_t)blockIdx.y * p.gdz;
     p.x += (size_t)blockIdx.y * p.gx;
@@ -249,70 +256,122 @@ __global__ __launch_bounds__(NT) void dwconv_bwd_weight_kernel(DwWP p) {
     const int nchunk = p.C >> 2;
     for (int i = threadIdx.x; i < 9 * p.C; i += NT) dsm[i] = 0.f;
     __syncthreads();
-    // each thread walks a run of outputs in `rows_per_thread` consecutive rows of its 4-channel group
-    // capped grid (<= 540 workgroups, thread count a multiple of every channel-group count of MobileNetV2) with a
-    // task loop: a thread keeps its 4-channel group, so 36 register accumulators are published once per thread and
-    // the 9*C global atomics once per workgroup -- not thousands of workgroups hammering the same 9*C addresses
     const int gid = blockIdx.x * NT + threadIdx.x;
     const int nthreads = gridDim.x * NT;
     const int chunk = gid % nchunk;
-    const int total_rows = p.N * p.OH;
-    const long ntasks = (long)nchunk * p.nseg * ((total_rows + p.rows_per_thread - 1) / p.rows_per_thread);
+    const long ntasks = (long)nchunk * p.nseg * p.nrb * p.N;
     const int c = chunk * 4;
     f32x4 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    const float lo = p.in_scale ? act_lo(p.act) : -INFINITY, hi = p.in_scale ? act_hi(p.act) : INFINITY;
+    if (p.in_scale) {
+        sc = *reinterpret_cast<const f32x4*>(p.in_scale + c);
+        sh = *reinterpret_cast<const f32x4*>(p.in_shift + c);
+    }
     bool any = false;
     for (long task = gid; task < ntasks; task += nthreads) {
-        const int tsk = (int)(task / nchunk);
-        const int seg = tsk % p.nseg, rgrp = tsk / p.nseg;
-        const int r0 = rgrp * p.rows_per_thread;
-        const int ow_b = seg * p.seglen, ow_e = min(p.OW, ow_b + p.seglen);
+        int tsk = (int)(task / nchunk);
+        const int seg = tsk % p.nseg;
+        tsk /= p.nseg;
+        const int rb = tsk % p.nrb, n = tsk / p.nrb;
         any = true;
-        const int r1 = min(total_rows, r0 + p.rows_per_thread);
-        for (int row = r0; row < r1; ++row) {
-            const int n = row / p.OH, oh = row - n * p.OH;
-            const bf16_t* rowp[3];
-            bool rok[3];
+        const int ow_b = seg * SEGW;
+        const int iw_b = ow_b * S - p.pad;
+        const int oh_b = rb * p.rows_per_thread;
+        const int oh_e = min(p.OH, oh_b + p.rows_per_thread);
+        bool cok[NCOL], ook[SEGW];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int ih = oh * S - p.pad + kh;
-                rok[kh] = ih >= 0 && ih < p.H;
-                rowp[kh] = p.x + ((size_t)n * p.H + (rok[kh] ? ih : 0)) * p.W * p.C + c;
+        for (int j = 0; j < NCOL; ++j) cok[j] = (unsigned)(iw_b + j) < (unsigned)p.W;
+#pragma unroll
+        for (int o = 0; o < SEGW; ++o) ook[o] = ow_b + o < p.OW;
+        const bf16_t* img = p.x + (size_t)n * p.H * p.W * p.C + c;
+        const bf16_t* gimg = p.dz + ((size_t)n * p.OH * p.OW + ow_b) * p.C + c;
+
+        struct Raw { bf16x4 v[NCOL]; bool rok; };
+        struct GRow { bf16x4 v[SEGW]; };
+        auto load_row = [&](int ih, Raw& r) {
+            r.rok = (unsigned)ih < (unsigned)p.H;
+            const bf16_t* rp = img + ((size_t)(r.rok ? ih : 0) * p.W + iw_b) * p.C;
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                bf16x4 v = {0, 0, 0, 0};
+                if (r.rok && cok[j]) v = *reinterpret_cast<const bf16x4*>(rp + (ptrdiff_t)j * p.C);
+                r.v[j] = v;
             }
-            auto load_col = [&](int iw, f32x4 (&col)[3]) {
-                const bool cok = iw >= 0 && iw < p.W;
+        };
+        auto load_g = [&](int oh, GRow& gr) {
+            const bf16_t* rp = gimg + (size_t)oh * p.OW * p.C;
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (cok && rok[kh])
-                        v = transform4(*reinterpret_cast<const bf16x4*>(rowp[kh] + (size_t)iw * p.C), p.in_scale, p.in_shift, c, p.act);
-                    col[kh] = v;
+            for (int o = 0; o < SEGW; ++o) {
+                bf16x4 v = {0, 0, 0, 0};
+                if (ook[o]) v = *reinterpret_cast<const bf16x4*>(rp + (size_t)o * p.C);
+                gr.v[o] = v;
+            }
+        };
+        auto xform = [&](const Raw& r, f32x4 (&dst)[NCOL]) {
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) {
+                f32x4 v = bf4_to_f32(r.v[j]);
+                const bool ok = r.rok && cok[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = ok ? clamp_act(fmaf(v[i], sc[i], sh[i]), lo, hi) : 0.f;
+                dst[j] = v;
+            }
+        };
+        auto emit = [&](const GRow& gr, const f32x4 (&r0)[NCOL], const f32x4 (&r1)[NCOL], const f32x4 (&r2)[NCOL]) {
+#pragma unroll
+            for (int o = 0; o < SEGW; ++o) {
+                const f32x4 g = bf4_to_f32(gr.v[o]);            // zero for columns past OW
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    acc[kw] += g * r0[o * S + kw];
+                    acc[3 + kw] += g * r1[o * S + kw];
+                    acc[6 + kw] += g * r2[o * S + kw];
                 }
-            };
-            f32x4 w0[3], w1[3], w2[3];
-            load_col(ow_b * S - p.pad, w0);
-            load_col(ow_b * S + 1 - p.pad, w1);
-            const bf16_t* grow = p.dz + (size_t)row * p.OW * p.C + c;
-            for (int ow = ow_b; ow < ow_e; ++ow) {
-                load_col(ow * S + 2 - p.pad, w2);
-                f32x4 g = bf4_to_f32(*reinterpret_cast<const bf16x4*>(grow + (size_t)ow * p.C));
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    acc[kh * 3] += g * w0[kh];
-                    acc[kh * 3 + 1] += g * w1[kh];
-                    acc[kh * 3 + 2] += g * w2[kh];
-                }
-                if (S == 1) {
-#pragma unroll
-                    for (int kh = 0; kh < 3; ++kh) { w0[kh] = w1[kh]; w1[kh] = w2[kh]; }
-                } else {
-#pragma unroll
-                    for (int kh = 0; kh < 3; ++kh) w0[kh] = w2[kh];
-                    load_col((ow + 1) * S + 1 - p.pad, w1);
-                }
+            }
+        };
+        f32x4 win[3][NCOL];
+        Raw nxt[S];
+        GRow gcur, gnxt;
+        { Raw r; load_row(oh_b * S - p.pad, r); xform(r, win[0]); }
+        if (S == 1) {
+            { Raw r; load_row(oh_b - p.pad + 1, r); xform(r, win[1]); }
+            load_row(oh_b - p.pad + 2, nxt[0]);
+        } else {
+            load_row(oh_b * 2 - p.pad + 1, nxt[0]);
+            load_row(oh_b * 2 - p.pad + 2, nxt[1]);
+        }
+        load_g(oh_b, gnxt);
+        // window slot roles rotate with period 3 (compile-time indices): a = top row, then the S new rows
+#define DW_STEP(OHV, A, B, C2)                                                                                  \
+        {                                                                                                       \
+            if (S == 1) xform(nxt[0], win[C2]); else { xform(nxt[0], win[B]); xform(nxt[S - 1], win[C2]); }     \
+            gcur = gnxt;                                                                                        \
+            if ((OHV) + 1 < oh_e) {                                                                             \
+                if (S == 1) load_row((OHV) + 1 - p.pad + 2, nxt[0]);                                            \
+                else { load_row(((OHV) + 1) * 2 - p.pad + 1, nxt[0]); load_row(((OHV) + 1) * 2 - p.pad + 2, nxt[S - 1]); } \
+                load_g((OHV) + 1, gnxt);                                                                        \
+            }                                                                                                   \
+            emit(gcur, win[A], win[B], win[C2]);                                                                \
+        }
+        for (int oh = oh_b; oh < oh_e; oh += 3) {
+            if (S == 1) {
+                DW_STEP(oh, 0, 1, 2);
+                if (oh + 1 >= oh_e) break;
+                DW_STEP(oh + 1, 1, 2, 0);
+                if (oh + 2 >= oh_e) break;
+                DW_STEP(oh + 2, 2, 0, 1);
+            } else {
+                DW_STEP(oh, 0, 1, 2);
+                if (oh + 1 >= oh_e) break;
+                DW_STEP(oh + 1, 2, 0, 1);
+                if (oh + 2 >= oh_e) break;
+                DW_STEP(oh + 2, 1, 2, 0);
             }
         }
+#undef DW_STEP
     }
     if (any) {
 #pragma unroll
@@ -426,6 +485,7 @@ extern "C" int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, con
     const int groups = d->groups < 1 ? 1 : d->groups;
     p.gx = (size_t)d->N * d->H * d->W * d->Cin; p.gy = p.P * d->Cin; p.in_gstride = d->in_gstride;
     p.ppb = 0;
+    p.flip = 0;
     p.seglen = d->stride == 1 ? 4 : 2;          // == SEGW of dwconv_fwd_kernel<S>
     p.nseg = (d->OW + p.seglen - 1) / p.seglen;
     // rows walked per thread: long walks amortise the 2-row window prologue, but the grid must still fill the chip
@@ -447,33 +507,51 @@ extern "C" int adamml_dwconv_bwd_data(const adamml_conv_desc_t* d, const void* d
     DwP p;
     p.x = (const bf16_t*)dz; p.w = w; p.in_scale = nullptr; p.in_shift = nullptr; p.y = (bf16_t*)dx; p.stats = nullptr;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.pad = d->pad;
-    p.act = 0; p.accumulate = accumulate; p.nseg = 1; p.seglen = 0;
+    p.act = 0; p.accumulate = accumulate; p.nseg = 1; p.seglen = 0; p.flip = 0;
     p.P = (size_t)d->N * d->H * d->W;
     if (!p.P) return ADAMML_OK;
     const int groups = d->groups < 1 ? 1 : d->groups;
     p.gx = (size_t)d->N * d->OH * d->OW * d->Cin; p.gy = p.P * d->Cin; p.in_gstride = 0;
+    if (d->stride == 1 && !accumulate && d->pad == 1) {
+        // stride 1: the data gradient IS the forward walk over dz with the taps reversed (no transform, no statistics)
+        p.H = d->OH; p.W = d->OW; p.OH = d->H; p.OW = d->W; p.flip = 1;
+        p.seglen = 4;
+        p.nseg = (p.OW + 3) / 4;
+        p.rows_per_thread = 12;
+        while (p.rows_per_thread > 3 && (long)groups * p.N * ceil_div(p.OH, p.rows_per_thread) * p.nseg * (p.C / 4) < 4096L * NT) p.rows_per_thread -= 3;
+        p.nrb = ceil_div(p.OH, p.rows_per_thread);
+        const long threads = (long)p.N * p.nrb * p.nseg * (p.C / 4);
+        hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3((unsigned)((threads + NT - 1) / NT), groups), dim3(NT), 0, stream, p);
+        return adamml_check_launch("dwconv_bwd_data");
+    }
     int nblk = dw_blocks(p.P, p.C, &p.ppb);
     hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(nblk, groups), dim3(NT), 0, stream, p);
     return adamml_check_launch("dwconv_bwd_data");
 }
 
-static int dw_wgrad_blocks(const adamml_conv_desc_t* d, int* seglen, int* nseg) {
-    const long rows = (long)d->N * d->OH, nchunk = d->Cin / 4;
-    *seglen = d->OW >= 32 ? 16 : (d->OW >= 8 ? 8 : d->OW);
-    *nseg = (d->OW + *seglen - 1) / *seglen;
-    const long threads = rows * *nseg * nchunk;
+static int dw_wgrad_blocks(const adamml_conv_desc_t* d, int* rows_per_thread, int* nseg, int* nrb) {
+    const long nchunk = d->Cin / 4;
+    const int segw = d->stride == 1 ? 4 : 2;           // == SEGW of dwconv_bwd_weight_kernel<S>
+    *nseg = (d->OW + segw - 1) / segw;
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    int rpt = 12;
+    while (rpt > 3 && (long)groups * d->N * ceil_div(d->OH, rpt) * *nseg * nchunk < 2048L * NT) rpt -= 3;
+    *rows_per_thread = rpt;
+    *nrb = ceil_div(d->OH, rpt);
+    const long threads = (long)d->N * *nrb * *nseg * nchunk;
     long nb = (threads + NT - 1) / NT;
     // NT * nblk must be a multiple of nchunk (a thread keeps its channel group across tasks): 45 | nblk covers every
     // C/4 in {8,12,24,36,48,96,144,240}; otherwise fall back to a multiple of nchunk
-    int nblk = nb >= 540 ? 540 : (int)((nb + 44) / 45 * 45);
+    const long cap = 2160 / groups / 45 * 45 > 0 ? 2160 / groups / 45 * 45 : 45;
+    int nblk = nb >= cap ? (int)cap : (int)((nb + 44) / 45 * 45);
     if ((NT * (long)nblk) % nchunk != 0) nblk = (int)((nblk + nchunk - 1) / nchunk * nchunk);
     return nblk;
 }
 
 extern "C" size_t adamml_dwconv_bwd_weight_workspace(const adamml_conv_desc_t* d) {
     if (!d || d->Cin % 8) return 0;
-    int a, b;
-    return (size_t)(d->groups < 1 ? 1 : d->groups) * dw_wgrad_blocks(d, &a, &b) * 9 * d->Cin * sizeof(float);
+    int a, b, c;
+    return (size_t)(d->groups < 1 ? 1 : d->groups) * dw_wgrad_blocks(d, &a, &b, &c) * 9 * d->Cin * sizeof(float);
 }
 
 extern "C" int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
@@ -484,13 +562,11 @@ extern "C" int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void*
     DwWP p;
     p.dz = (const bf16_t*)dz; p.x = (const bf16_t*)x; p.in_scale = in_scale; p.in_shift = in_shift; p.dw = dw;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.pad = d->pad; p.act = d->act;
-    p.P = (size_t)d->N * d->OH * d->OW;
-    if (!p.P) return ADAMML_OK;
-    p.rows_per_thread = 1;
-    p.ppb = 0;
-    const int nblk = dw_wgrad_blocks(d, &p.seglen, &p.nseg);
+    const size_t P = (size_t)d->N * d->OH * d->OW;
+    if (!P) return ADAMML_OK;
+    const int nblk = dw_wgrad_blocks(d, &p.rows_per_thread, &p.nseg, &p.nrb);
     const int groups = d->groups < 1 ? 1 : d->groups;
-    p.gdz = p.P * d->Cin; p.gx = (size_t)d->N * d->H * d->W * d->Cin; p.in_gstride = d->in_gstride;
+    p.gdz = P * d->Cin; p.gx = (size_t)d->N * d->H * d->W * d->Cin; p.in_gstride = d->in_gstride;
     p.ws = (workspace && workspace_bytes >= (size_t)groups * nblk * 9 * p.C * sizeof(float)) ? (float*)workspace : nullptr;
     if (d->stride == 1) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<1>, dim3(nblk, groups), dim3(NT), 9 * p.C * sizeof(float), stream, p);
     else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<2>, dim3(nblk, groups), dim3(NT), 9 * p.C * sizeof(float), stream, p);
