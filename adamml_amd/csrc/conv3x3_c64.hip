@@ -1,0 +1,340 @@
+// 3x3 stride-1 pad-1 convolution with 64 input and 64 output channels (conv2 of the layer-1 bottlenecks,
+// models/resnet.py:84-86 at 56x56, and -- with the flipped weight pack -- its data gradient), gfx950.
+//
+// The generic implicit-GEMM kernel re-gathers the activation tile once per tap: 9x the input through the 64 B/clk vector
+// memory path of a CU, which bounds it at ~17 % of the MFMA peak.  Here a workgroup (8 waves, one per CU) keeps
+//   * the whole weight matrix [64][9*64] bf16 (74 KB) resident in LDS for all its tiles, and
+//   * the INPUT PATCH of a strip of R full output rows ((R+2) x (W+2) pixels x 64 ch, zero border, 144-byte pixel pitch)
+//     in LDS, loaded once per tile with 16-byte coalesced loads that already apply the producer's BatchNorm+ReLU
+//     (so the lazily normalised input is never materialised in HBM), the next tile's patch in flight in registers;
+// the 18 K-steps (tap, 32-channel half) read both MFMA operands straight from LDS with aligned, conflict-free
+// ds_read_b128 -- no per-tap staging, no gathers.  Output strips are contiguous in HBM (full rows), staged through the
+// dead patch buffer and stored 16 B per lane; forward statistics come from the matrix cores, the data-gradient variant
+// applies the activation mask and accumulates the BatchNorm-backward sums (conv_gemm.hip epilogue semantics).
+#include "common.h"
+#include "../../include/adamml_hip.h"
+
+namespace {
+
+constexpr int NT3 = 512;
+constexpr int C64 = 64;
+constexpr int KT3 = 9 * C64;             // 576
+constexpr int WROW3 = KT3 * 2 + 16;      // LDS bytes per weight row (+16 B skew): 1168
+constexpr int PPIX = C64 * 2 + 16;       // patch pixel pitch: 144 B
+constexpr int SROW3 = C64 * 2 + 8;       // staging row: 136 B
+constexpr int MAXPT = 4;                 // pixel tiles (16 px) per wave
+constexpr int MAXPX3 = 8 * MAXPT * 16;   // 512 output pixels per tile at most
+constexpr int MAXSLOT3 = 10;             // 16-byte patch slots per thread
+
+struct C3P {
+    const bf16_t* x;
+    const bf16_t* w;         // [64][9][64] bf16 (pack mode 0 forward / mode 1 data gradient)
+    const float* in_scale;
+    const float* in_shift;
+    bf16_t* y;
+    double* stats;           // [G][SLOTS][128] or null
+    const bf16_t* bn_z;      // data gradient fused with the BatchNorm backward of the tensor it flows into, or null
+    const float* bn_vec;     // [G][4][64]
+    int bn_act, act;
+    int N, H, W, R, tiles_per_img, tiles_per_group, total_tiles, tpb;
+    int PW, PR, npt;         // patch width / rows (pixels); pixel tiles per tile
+    int in_gstride;
+    size_t gxy;              // elements per group of x and y (same shape)
+};
+
+__device__ __forceinline__ void fold16_to_cs(const f32x8& esum, const f32x8& esq, float* cs, int lane, int ech) {
+    // lanes l, l+8, .., l+56 of a wave hold partial sums of channel chunk `ech` (8 channels): DPP + lane-swap fold
+    // (see conv_gemm.hip), then 4 LDS adds from the lanes with bit 3 clear
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = esum[i]; v[8 + i] = esq[i]; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), 0x128, 0xf, 0xf, false));
+    float u[8], wv[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float a = v[2 * i], b = v[2 * i + 1];
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        u[i] = a + b;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a = u[2 * j], b = u[2 * j + 1];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        wv[j] = a + b;
+    }
+    const int lrow = lane >> 4;
+    const int vsel = ((lrow & 1) << 1) | (lrow >> 1);
+    if (!(lane & 8)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int id = 4 * j + vsel;
+            atomicAdd(&cs[(id >> 3) * C64 + ech * 8 + (id & 7)], wv[j]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_w = smem;                                              // [64][WROW3]
+    float* cs = reinterpret_cast<float*>(smem + C64 * WROW3);      // [128]
+    char* s_patch = smem + C64 * WROW3 + 512;                      // patch, later the staging tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+
+    for (int e = tid; e < C64 * (KT3 / 8); e += NT3) {
+        const int co = e / (KT3 / 8), ch = e - co * (KT3 / 8);
+        *reinterpret_cast<bf16x8*>(s_w + co * WROW3 + ch * 16) = *reinterpret_cast<const bf16x8*>(p.w + (size_t)co * KT3 + ch * 8);
+    }
+    if (tid < 128) cs[tid] = 0.f;
+
+    // ---- patch slots: slot e -> (patch pixel e >> 3, 16-byte chunk e & 7 == tid & 7); tile-invariant --------------------
+    const int nslots = p.PR * p.PW * 8;
+    const int ech = tid & 7;
+    int s_rc[MAXSLOT3];                  // patch (row << 16 | column) of each slot; dead slots get row 0x7fff
+#pragma unroll
+    for (int l = 0; l < MAXSLOT3; ++l) {
+        const int e = tid + l * NT3;
+        const int ppix = e >> 3;
+        const int pr = ppix / p.PW;
+        s_rc[l] = ((e < nslots ? pr : 0x7fff) << 16) | (ppix - pr * p.PW);
+    }
+    bf16x8 rp[MAXSLOT3];
+    unsigned rok = 0;
+    auto load_patch = [&](int tile) {
+        const int g = tile / p.tiles_per_group, tg = tile - g * p.tiles_per_group;
+        const int n = tg / p.tiles_per_img, tr = tg - n * p.tiles_per_img;
+        const int ih0 = tr * p.R - 1;
+        const bf16_t* img = p.x + (size_t)g * p.gxy + (size_t)n * p.H * p.W * C64 + ech * 8;
+        rok = 0;
+#pragma unroll
+        for (int l = 0; l < MAXSLOT3; ++l) {
+            // UNCONDITIONAL loads from clamped (always valid) addresses, zeroed at the LDS write: a branch per slot makes
+            // the compiler wait for each load before the next one is issued (one HBM round trip per slot)
+            const int ih = ih0 + (s_rc[l] >> 16), iw = (s_rc[l] & 0xffff) - 1;
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            rok |= (ok ? 1u : 0u) << l;
+            const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
+            rp[l] = *reinterpret_cast<const bf16x8*>(img + ((size_t)ihc * p.W + iwc) * C64);
+        }
+    };
+    const int tile0 = blockIdx.x * p.tpb;
+    if (tile0 < p.total_tiles) load_patch(tile0);
+    int cur_group = -1;
+
+    for (int it = 0; it < p.tpb; ++it) {
+        const int tile = tile0 + it;
+        if (tile >= p.total_tiles) break;
+        const int g = tile / p.tiles_per_group, tg = tile - g * p.tiles_per_group;
+        const int n = tg / p.tiles_per_img, tr = tg - n * p.tiles_per_img;
+        const int oh0 = tr * p.R;
+        const int rows = min(p.R, p.H - oh0);
+        const int npx = rows * p.W;
+        if (g != cur_group) {
+            if (p.stats && cur_group >= 0) {       // publish the finished group's sums, restart the accumulators
+                __syncthreads();
+                double* slot = p.stats + ((size_t)cur_group * ADAMML_STAT_SLOTS + (blockIdx.x & (ADAMML_STAT_SLOTS - 1))) * 128;
+                if (tid < 128) { atomicAdd(&slot[tid], (double)cs[tid]); cs[tid] = 0.f; }
+            }
+            cur_group = g;
+        }
+        // ---- prefetched patch -> LDS (BatchNorm + activation of the producer applied here, once per element) ------------
+        {
+            const float lo = act_lo(p.act), hi = act_hi(p.act);
+            f32x8 sc, sh;                          // (re-read per tile from L1/L2: not held across the MFMA loop)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
+            if (p.in_scale) {
+                sc = load_f32x8(p.in_scale + (size_t)g * p.in_gstride + ech * 8);
+                sh = load_f32x8(p.in_shift + (size_t)g * p.in_gstride + ech * 8);
+            }
+#pragma unroll
+            for (int l = 0; l < MAXSLOT3; ++l) {
+                const int e = tid + l * NT3;
+                if (e < nslots) {
+                    bf16x8 v = rp[l];
+                    if (!((rok >> l) & 1u)) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    else if (p.in_scale) {
+                        f32x8 f = bf8_to_f32(v);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) f[i] = clamp_act(fmaf(f[i], sc[i], sh[i]), lo, hi);
+                        v = f32_to_bf8(f);
+                    }
+                    *reinterpret_cast<bf16x8*>(s_patch + (e >> 3) * PPIX + ech * 16) = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (it + 1 < p.tpb && tile + 1 < p.total_tiles) load_patch(tile + 1);
+
+        // ---- MFMA: wave w owns pixel tiles w, w+8, w+16, w+24 (16 consecutive output pixels, row-major over the strip) ---
+        f32x4 acc[4][MAXPT];
+        int pixoff[MAXPT];
+#pragma unroll
+        for (int j = 0; j < MAXPT; ++j) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int q = (wave + 8 * j) * 16 + li;
+            if (q >= npx) q = 0;
+            const int r = q / p.W, c = q - r * p.W;
+            pixoff[j] = (r * p.PW + c) * PPIX + lg * 16;
+        }
+        const char* wbase = s_w + li * WROW3 + lg * 16;
+#pragma unroll 1
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) {                 // (kw, 32-channel half)
+                const int ks = kh * 6 + kk;
+                const int aoff = (kh * p.PW + (kk >> 1)) * PPIX + (kk & 1) * 64;
+                bf16x8 fw[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) fw[ct] = *reinterpret_cast<const bf16x8*>(wbase + ct * 16 * WROW3 + ks * 64);
+#pragma unroll
+                for (int j = 0; j < MAXPT; ++j) {
+                    if ((wave + 8 * j) * 16 < npx) {         // wave-uniform
+                        const bf16x8 fa = *reinterpret_cast<const bf16x8*>(s_patch + pixoff[j] + aoff);
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct)
+                            acc[ct][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ct], fa, acc[ct][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                     // patch consumed: its LDS becomes the staging tile
+
+        // ---- stage [npt*16][64] bf16 (rows >= npx zero) ---------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < MAXPT; ++j) {
+            const int pt = wave + 8 * j;
+            if (pt < p.npt) {
+                const int q = pt * 16 + li;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    bf16x4 v = f32_to_bf4(acc[ct][j]);
+                    if (q >= npx) v = bf16x4{0, 0, 0, 0};
+                    *reinterpret_cast<bf16x4*>(s_patch + q * SROW3 + (ct * 16 + lg * 4) * 2) = v;
+                }
+            }
+        }
+        __syncthreads();
+        const size_t obase = (size_t)g * p.gxy + ((size_t)n * p.H + oh0) * p.W * C64;
+        if (!p.bn_z) {
+            for (int e = tid; e < npx * 8; e += NT3) {
+                const int q = e >> 3;
+                const s16x4 lo = *reinterpret_cast<const s16x4*>(s_patch + q * SROW3 + ech * 16);
+                const s16x4 hi = *reinterpret_cast<const s16x4*>(s_patch + q * SROW3 + ech * 16 + 8);
+                union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+                u.s.a = lo; u.s.b = hi;
+                *reinterpret_cast<bf16x8*>(p.y + obase + (size_t)q * C64 + ech * 8) = u.v;
+            }
+            if (p.stats) {
+                // waves w and w+4 share channel block w & 3 and split the 32-pixel steps; ones*F and diag(F^T F)
+                union { s16x4 h[2]; bf16x8 v; } ones;
+                ones.h[0] = s16x4{0x3F80, 0x3F80, 0x3F80, 0x3F80};
+                ones.h[1] = ones.h[0];
+                const int cb = wave & 3;
+                const int trow = 8 * lg + (li >> 2);
+                f32x4 dsum = {0.f, 0.f, 0.f, 0.f}, dsq = {0.f, 0.f, 0.f, 0.f};
+                const int nps = (npx + 31) >> 5;
+                for (int ps = wave >> 2; ps < nps; ps += 2) {
+                    const char* fp = s_patch + (ps * 32 + trow) * SROW3 + (cb * 16 + 4 * (li & 3)) * 2;
+                    union { s16x4 h[2]; bf16x8 v; } f;
+                    f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(fp));
+                    f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(fp + 4 * SROW3));
+                    dsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, f.v, dsum, 0, 0, 0);
+                    dsq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v, f.v, dsq, 0, 0, 0);
+                }
+                if (lg == 0) atomicAdd(&cs[cb * 16 + li], dsum[0]);
+                if ((li >> 2) == lg) {
+                    const int r = li & 3;
+                    atomicAdd(&cs[64 + cb * 16 + li], r == 0 ? dsq[0] : r == 1 ? dsq[1] : r == 2 ? dsq[2] : dsq[3]);
+                }
+            }
+        } else {
+            // data gradient w.r.t. a lazily normalised tensor: g' = g * act'(scale*z+shift); sums of g' and g'*zhat
+            const float* vec = p.bn_vec + (size_t)g * 4 * C64;
+            const f32x8 bsc = load_f32x8(vec + ech * 8), bsh = load_f32x8(vec + C64 + ech * 8);
+            const f32x8 mu = load_f32x8(vec + 2 * C64 + ech * 8), is = load_f32x8(vec + 3 * C64 + ech * 8);
+            f32x8 esum, esq;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) esum[i] = esq[i] = 0.f;
+            for (int e = tid; e < npx * 8; e += NT3) {
+                const int q = e >> 3;
+                const s16x4 lo = *reinterpret_cast<const s16x4*>(s_patch + q * SROW3 + ech * 16);
+                const s16x4 hi = *reinterpret_cast<const s16x4*>(s_patch + q * SROW3 + ech * 16 + 8);
+                union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+                u.s.a = lo; u.s.b = hi;
+                f32x8 f = bf8_to_f32(u.v);
+                const f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(p.bn_z + obase + (size_t)q * C64 + ech * 8));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] *= act_mask(fmaf(zv[i], bsc[i], bsh[i]), p.bn_act);
+                const bf16x8 v = f32_to_bf8(f);
+                *reinterpret_cast<bf16x8*>(p.y + obase + (size_t)q * C64 + ech * 8) = v;
+                f = bf8_to_f32(v);
+                esum += f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) esq[i] += f[i] * (zv[i] - mu[i]) * is[i];
+            }
+            if (p.stats) fold16_to_cs(esum, esq, cs, lane, ech);
+        }
+        __syncthreads();                                     // staging consumed before the next patch lands
+    }
+    if (p.stats && cur_group >= 0) {
+        __syncthreads();
+        double* slot = p.stats + ((size_t)cur_group * ADAMML_STAT_SLOTS + (blockIdx.x & (ADAMML_STAT_SLOTS - 1))) * 128;
+        if (tid < 128) atomicAdd(&slot[tid], (double)cs[tid]);
+    }
+}
+
+}  // namespace
+
+// d: the FORWARD-shaped descriptor of the conv that is executed (for a data gradient: H/W of dz == H/W of dx).
+bool adamml_conv3x3_c64_supported(const adamml_conv_desc_t* d) {
+    if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Cin != 64 || d->Cout != 64 || (d->up > 1)) return false;
+    if (d->OH != d->H || d->OW != d->W || d->accumulate) return false;
+    if (d->W < 8 || d->W > MAXPX3 / 2) return false;        // at least 2 rows per tile
+    int R = MAXPX3 / d->W;
+    if (R > d->H) R = d->H;
+    // prefer a row count that divides H (no ragged last strip)
+    for (int r = R; r >= R - 3 && r >= 2; --r)
+        if (d->H % r == 0) { R = r; break; }
+    const int PR = R + 2, PW = d->W + 2;
+    if (PR * PW * 8 > MAXSLOT3 * NT3) return false;
+    const size_t patch = (size_t)PR * PW * PPIX, stage = (size_t)((R * d->W + 31) / 32 * 32) * SROW3;
+    if ((R * d->W + 31) / 32 * 2 > 8 * MAXPT) return false;
+    return C64 * WROW3 + 512 + (patch > stage ? patch : stage) <= 160 * 1024;
+}
+
+int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
+                              const float* in_shift, void* y, double* stats, const void* bn_z, const float* bn_vec, int bn_act,
+                              hipStream_t stream) {
+    C3P p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.in_scale = in_scale; p.in_shift = in_shift; p.y = (bf16_t*)y;
+    p.stats = stats; p.bn_z = (const bf16_t*)bn_z; p.bn_vec = bn_vec; p.bn_act = bn_act; p.act = d->act;
+    p.N = d->N; p.H = d->H; p.W = d->W;
+    int R = MAXPX3 / d->W;
+    if (R > d->H) R = d->H;
+    for (int r = R; r >= R - 3 && r >= 2; --r)
+        if (d->H % r == 0) { R = r; break; }
+    p.R = R; p.PR = R + 2; p.PW = d->W + 2;
+    p.npt = (R * d->W + 31) / 32 * 2;            // staged rows cover whole 32-pixel statistic steps
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    p.tiles_per_img = ceil_div(d->H, R);
+    p.tiles_per_group = d->N * p.tiles_per_img;
+    p.total_tiles = groups * p.tiles_per_group;
+    if (p.total_tiles <= 0) return ADAMML_OK;
+    p.in_gstride = d->in_gstride;
+    p.gxy = (size_t)d->N * d->H * d->W * C64;
+    p.tpb = ceil_div(p.total_tiles, 1024);
+    const size_t patch = (size_t)p.PR * p.PW * PPIX, stage = (size_t)p.npt * 16 * SROW3;
+    const size_t lds = C64 * WROW3 + 512 + (patch > stage ? patch : stage);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv3x3_c64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(ceil_div(p.total_tiles, p.tpb)), dim3(NT3), lds, stream, p);
+    return adamml_check_launch("conv3x3_c64");
+}

@@ -844,6 +844,11 @@ int ilog2_exact(int v) {
 
 }  // namespace
 
+bool adamml_conv3x3_c64_supported(const adamml_conv_desc_t* d);
+int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
+                              const float* in_shift, void* y, double* stats, const void* bn_z, const float* bn_vec, int bn_act,
+                              hipStream_t stream);
+
 // one parity class (ph, pw) of the data gradient of a stride-2 conv (see conv_dgrad_stride2)
 struct DgradClass { int nt; unsigned code; int ph, pw, OHc, OWc; };
 
@@ -852,6 +857,8 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
                        hipStream_t stream, const DgradClass* cls = nullptr) {
     if (!d || !x || !w_packed || !y) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: null argument");
     if (d->Cin % 8 || d->Cout % 8) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: channels must be multiples of 8 (Cin=%d Cout=%d)", d->Cin, d->Cout);
+    if (!cls && adamml_conv3x3_c64_supported(d))
+        return adamml_conv3x3_c64_launch(d, x, w_packed, in_scale, in_shift, y, stats, bn_z, bn_vec, bn_act, stream);
     ConvP p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.in_scale = in_scale; p.in_shift = in_shift;
     p.y = (bf16_t*)y; p.stats = stats;
@@ -913,6 +920,10 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     }
 #undef LAUNCH_CONV
     return adamml_check_launch("conv_fwd");
+}
+
+extern "C" int adamml_conv_fused_input_supported(const adamml_conv_desc_t* d) {
+    return d && adamml_conv3x3_c64_supported(d) ? 1 : 0;
 }
 
 extern "C" int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,

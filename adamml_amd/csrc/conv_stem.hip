@@ -74,13 +74,14 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_kernel(StemP p) {
         const bf16_t* img = p.x + (size_t)n * p.H * p.W * p.xc;
 #pragma unroll
         for (int l = 0; l < MAXSLOT; ++l) {
+            // unconditional loads from clamped addresses + select: per-slot branches would serialise the HBM round trips
             const int ih = ih0 + s_ih[l], iw = s_iw[l];
-            s16x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-            if ((unsigned)ih < (unsigned)p.H) {
-                const bf16_t* row = img + (size_t)ih * p.W * p.xc;
-                if ((unsigned)iw < (unsigned)p.W) a = *reinterpret_cast<const s16x4*>(row + iw * p.xc);
-                if ((unsigned)(iw + 1) < (unsigned)p.W) b = *reinterpret_cast<const s16x4*>(row + (iw + 1) * p.xc);
-            }
+            const bool rok = (unsigned)ih < (unsigned)p.H;
+            const bf16_t* row = img + (size_t)min(max(ih, 0), p.H - 1) * p.W * p.xc;
+            s16x4 a = *reinterpret_cast<const s16x4*>(row + min(max(iw, 0), p.W - 1) * p.xc);
+            s16x4 b = *reinterpret_cast<const s16x4*>(row + min(max(iw + 1, 0), p.W - 1) * p.xc);
+            if (!(rok && (unsigned)iw < (unsigned)p.W)) a = s16x4{0, 0, 0, 0};
+            if (!(rok && (unsigned)(iw + 1) < (unsigned)p.W)) b = s16x4{0, 0, 0, 0};
             ra[l] = a; rb[l] = b;
         }
     };

@@ -90,13 +90,10 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
         struct Raw { bf16x4 v[NCOL]; bool rok; };
         auto load_row = [&](int ih, Raw& r) {
             r.rok = (unsigned)ih < (unsigned)p.H;
-            const bf16_t* rp = img + ((size_t)(r.rok ? ih : 0) * p.W + iw_b) * p.C;
+            const bf16_t* rp = img + (size_t)(r.rok ? ih : 0) * p.W * p.C;
 #pragma unroll
-            for (int j = 0; j < NCOL; ++j) {
-                bf16x4 v = {0, 0, 0, 0};
-                if (r.rok && cok[j]) v = *reinterpret_cast<const bf16x4*>(rp + (ptrdiff_t)j * p.C);
-                r.v[j] = v;
-            }
+            for (int j = 0; j < NCOL; ++j)          // unconditional loads from clamped addresses; xform() zeroes the invalid ones
+                r.v[j] = *reinterpret_cast<const bf16x4*>(rp + (size_t)(cok[j] ? iw_b + j : 0) * p.C);
         };
         auto xform = [&](const Raw& r, f32x4 (&dst)[NCOL]) {
 #pragma unroll
@@ -293,20 +290,17 @@ __global__ __launch_bounds__(NT, 2) void dwconv_bwd_weight_kernel(DwWP p) {
         struct GRow { bf16x4 v[SEGW]; };
         auto load_row = [&](int ih, Raw& r) {
             r.rok = (unsigned)ih < (unsigned)p.H;
-            const bf16_t* rp = img + ((size_t)(r.rok ? ih : 0) * p.W + iw_b) * p.C;
+            const bf16_t* rp = img + (size_t)(r.rok ? ih : 0) * p.W * p.C;
 #pragma unroll
-            for (int j = 0; j < NCOL; ++j) {
-                bf16x4 v = {0, 0, 0, 0};
-                if (r.rok && cok[j]) v = *reinterpret_cast<const bf16x4*>(rp + (ptrdiff_t)j * p.C);
-                r.v[j] = v;
-            }
+            for (int j = 0; j < NCOL; ++j)          // unconditional loads from clamped addresses; xform() zeroes the invalid ones
+                r.v[j] = *reinterpret_cast<const bf16x4*>(rp + (size_t)(cok[j] ? iw_b + j : 0) * p.C);
         };
         auto load_g = [&](int oh, GRow& gr) {
             const bf16_t* rp = gimg + (size_t)oh * p.OW * p.C;
 #pragma unroll
             for (int o = 0; o < SEGW; ++o) {
-                bf16x4 v = {0, 0, 0, 0};
-                if (ook[o]) v = *reinterpret_cast<const bf16x4*>(rp + (size_t)o * p.C);
+                bf16x4 v = *reinterpret_cast<const bf16x4*>(rp + (size_t)(ook[o] ? o : 0) * p.C);
+                if (!ook[o]) v = bf16x4{0, 0, 0, 0};
                 gr.v[o] = v;
             }
         };

@@ -81,6 +81,8 @@ def load():
     lib.adamml_conv_bwd_weight_workspace.restype = c_size_t
     lib.adamml_dwconv_bwd_weight_workspace.argtypes = [_DESC]
     lib.adamml_dwconv_bwd_weight_workspace.restype = c_size_t
+    lib.adamml_conv_fused_input_supported.argtypes = [_DESC]
+    lib.adamml_conv_fused_input_supported.restype = c_int
     lib.adamml_conv_stem_supported.argtypes = [_DESC]
     lib.adamml_conv_stem_supported.restype = c_int
     lib.adamml_version.restype = c_int

@@ -241,9 +241,10 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False):
     """conv (dense or depthwise) + train/eval BatchNorm + activation, as one lazy tensor.
     sole_consumer=True promises that this conv is the ONLY consumer of x: its data-gradient epilogue may then apply
     x's activation mask and accumulate x's BatchNorm-backward sums (no separate reduction pass over g and z)."""
-    if x.scale is not None and not cs.depthwise and cs.kh * cs.kw > 1:
-        x = materialize(rt, x)
     G = rt.groups
+    if x.scale is not None and not cs.depthwise and cs.kh * cs.kw > 1 and \
+            not hip.load().adamml_conv_fused_input_supported(byref(cs.desc(x.shape, x.act, G, x.gs))):
+        x = materialize(rt, x)
     d = cs.desc(x.shape, x.act, G, x.gs)
     if x.shape[3] != cs.cin:
         raise RuntimeError("conv_bn: input has %d channels, weight pack expects %d" % (x.shape[3], cs.cin))

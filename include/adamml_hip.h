@@ -55,6 +55,10 @@ const char* adamml_last_error_string(void);
  * train-mode BatchNorm. */
 int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
                     const float* in_shift, void* y, double* stats, hipStream_t stream);
+/* 1 when adamml_conv_fwd applies the lazy input transform of this KxK conv ONCE per element (LDS-resident input patch:
+ * 3x3 / stride 1 / pad 1 / 64 -> 64 channels), so the caller need not materialise the normalised input first; 0 when the
+ * implicit-GEMM loader would re-apply it once per tap. */
+int adamml_conv_fused_input_supported(const adamml_conv_desc_t* d);
 /* autograd of the above w.r.t. its input (d = forward descriptor; w packed with mode 1) */
 int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
                          int accumulate, hipStream_t stream);
