@@ -101,7 +101,9 @@ def ptr(t):
 
 class LaunchProfiler:
     """Optional per-launch HIP-event timing (bench.py roofline leg): every C-ABI launch is bracketed by events on the
-    stream it is enqueued on; `meta` = (algorithmic flops, algorithmic HBM bytes) supplied by the caller."""
+    stream it is enqueued on; `meta` = (algorithmic flops, algorithmic HBM bytes[, device kernel]) supplied by the caller:
+    launches are grouped by the device kernel when the caller names it (one C-ABI entry point may dispatch to several
+    kernels), by the entry point otherwise."""
 
     def __init__(self):
         self.records = []
@@ -110,6 +112,8 @@ class LaunchProfiler:
         torch.cuda.synchronize()
         agg = {}
         for name, s, e, meta in self.records:
+            if len(meta) > 2 and meta[2]:
+                name = meta[2]
             a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             a["launches"] += 1
             a["ms"] += s.elapsed_time(e)

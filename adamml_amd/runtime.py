@@ -260,7 +260,11 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False):
     macs = float(count) * G * C * cs.kh * cs.kw * (1 if cs.depthwise else cs.cin_true)
     in_b, out_b = 2.0 * G * d.N * d.H * d.W * cs.cin_true, 2.0 * G * count * C
     w_b = 2.0 * C * cs.kh * cs.kw * (1 if cs.depthwise else cs.cin_true)
-    hip.next_meta = (2 * macs, in_b + out_b + w_b)
+    # device kernel behind adamml_conv_fwd / adamml_conv_bwd_data[_bn] for this layer (bench.py groups launches by it)
+    kern = None
+    if not cs.depthwise:
+        kern = "conv3x3_c64_kernel" if hip.load().adamml_conv_fused_input_supported(byref(d)) else "conv_gemm_kernel"
+    hip.next_meta = (2 * macs, in_b + out_b + w_b, "conv_stem_kernel" if stem else kern)
     if rt.training:
         stats = rt.fwd_arena.take(G * 2 * C * STAT_SLOTS)
         if stem:
@@ -300,13 +304,13 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False):
                 if x.grad is None:
                     x.grad = torch.empty_like(x.data)
                     acc = 0
-                hip.next_meta = (2 * macs, in_b * (1 + acc) + out_b + w_b)
+                hip.next_meta = (2 * macs, in_b * (1 + acc) + out_b + w_b, kern)
                 tgt = x.src if x.src is not None else x
                 if cs.depthwise:
                     call("adamml_dwconv_bwd_data", byref(d), ptr(dz), ptr(cs.w_fwd), ptr(x.grad), acc)
                 elif sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None:
                     sums = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS)
-                    hip.next_meta = (2 * macs, 2 * in_b + out_b + w_b)
+                    hip.next_meta = (2 * macs, 2 * in_b + out_b + w_b, kern)
                     call("adamml_conv_bwd_data_bn", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), ptr(tgt.data), ptr(tgt.vec),
                          tgt.act, ptr(sums))
                     tgt.pre_sums = sums
