@@ -9,7 +9,8 @@ from ctypes import c_void_p, c_int, c_int32, c_int64, c_float, c_double, c_size_
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadamml_hip.so")
+# ADAMML_HIP_LIB: developer aid for A/B runs of two builds of the library in one session (tools/bench_*.py)
+LIB_PATH = os.environ.get("ADAMML_HIP_LIB") or os.path.join(_HERE, "libadamml_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 STAT_SLOTS = 32          # ADAMML_STAT_SLOTS in include/adamml_hip.h

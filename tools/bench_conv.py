@@ -63,7 +63,8 @@ for name, N, H, Cin, Cout, k, s, p, lazy, cnt in L:
     elif k == 3 or "c3" in name:   # sole-consumer data gradients carry the BatchNorm-backward reduction
         t2 = timeit(lambda: call("adamml_conv_bwd_data_bn", byref(d), ptr(dz), ptr(wd), ptr(dx), ptr(x), ptr(vec), 1, ptr(sm)))
     else:
-        t2 = timeit(lambda: call("adamml_conv_bwd_data", byref(d), ptr(dz), ptr(wd), ptr(dx), 0))
+        acc = 1 if (name.endswith(" c1") or name.endswith(" ds")) else 0      # as used in the net: accumulates into the identity-path gradient
+        t2 = timeit(lambda: call("adamml_conv_bwd_data", byref(d), ptr(dz), ptr(wd), ptr(dx), acc))
     t3 = timeit(lambda: call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x), sc, sh, ptr(dw), Cin, ptr(ws), ws.numel() * 4))
     tot[0] += t1 * cnt; tot[1] += t2 * cnt; tot[2] += t3 * cnt
     print("%-12s x%d N=%4d H=%3d %4d->%4d k%d s%d  %.2f GB %.2f TF | fwd %.3f ms %5.0f GB/s %4.0f TF/s | dgrad %.3f ms %5.0f GB/s | wgrad %.3f ms %5.0f GB/s %4.0f TF/s"
