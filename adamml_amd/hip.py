@@ -39,6 +39,7 @@ SIGNATURES = {
     "adamml_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "adamml_pack_stem_weight": [_P, _P, _I, _I, _P],
     "adamml_conv_stem_fwd": [_DESC, _P, _P, _P, _P, _P],
+    "adamml_conv_stem_bwd_weight": [_DESC, _P, _P, _P, _I, _P, _Z, _P],
     "adamml_dwconv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "adamml_dwconv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
     "adamml_dwconv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _P, _Z, _P],
@@ -80,6 +81,8 @@ def load():
         fn.restype = c_int
     lib.adamml_conv_bwd_weight_workspace.argtypes = [_DESC, _I]
     lib.adamml_conv_bwd_weight_workspace.restype = c_size_t
+    lib.adamml_conv_stem_bwd_weight_workspace.argtypes = [_DESC]
+    lib.adamml_conv_stem_bwd_weight_workspace.restype = c_size_t
     lib.adamml_dwconv_bwd_weight_workspace.argtypes = [_DESC]
     lib.adamml_dwconv_bwd_weight_workspace.restype = c_size_t
     lib.adamml_conv_fused_input_supported.argtypes = [_DESC]
@@ -146,9 +149,11 @@ def call(name, *args):
 _wgrad_ws = {}
 
 
-def wgrad_workspace(desc, cin_true, device, depthwise=False):
+def wgrad_workspace(desc, cin_true, device, depthwise=False, stem=False):
     """Persistent per-device scratch for the split weight-gradient partial tiles (grown on demand)."""
-    if depthwise:
+    if stem:
+        need = load().adamml_conv_stem_bwd_weight_workspace(ctypes.byref(desc))
+    elif depthwise:
         need = load().adamml_dwconv_bwd_weight_workspace(ctypes.byref(desc))
     else:
         need = load().adamml_conv_bwd_weight_workspace(ctypes.byref(desc), cin_true)

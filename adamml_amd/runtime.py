@@ -295,6 +295,10 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False):
                     ws = hip.wgrad_workspace(d, 0, dz.device, depthwise=True)
                     call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(cs.weight.grad),
                          ptr(ws), ws.numel() * 4)
+                elif stem:
+                    ws = hip.wgrad_workspace(d, cs.cin_true, dz.device, stem=True)
+                    call("adamml_conv_stem_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(cs.weight.grad), cs.cin_true, ptr(ws),
+                         ws.numel() * 4)
                 else:
                     ws = hip.wgrad_workspace(d, cs.cin_true, dz.device)
                     call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift),

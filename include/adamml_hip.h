@@ -85,11 +85,16 @@ int adamml_pack_conv_weight(const float* w, void* out, int cout, int cin_true, i
  * to 8) to 64 channels from an LDS-resident input patch, K = 7*8*4 = 224 instead of 49*8 = 392, with the statistics of
  * adamml_conv_fwd.  w_stem_packed = bf16 [64][7][8][4] from adamml_pack_stem_weight (fp32 OIHW master weight).  The plain
  * input only (no lazy BatchNorm transform); adamml_conv_stem_supported() tells whether a descriptor qualifies, otherwise
- * callers use adamml_conv_fwd.  The gradients use adamml_conv_bwd_weight (the stem has no data gradient). */
+ * callers use adamml_conv_fwd (the stem has no data gradient). */
 int adamml_conv_stem_supported(const adamml_conv_desc_t* d);
 int adamml_pack_stem_weight(const float* w, void* out, int cout, int cin_true, hipStream_t stream);
 int adamml_conv_stem_fwd(const adamml_conv_desc_t* d, const void* x, const void* w_stem_packed, void* y, double* stats,
                          hipStream_t stream);
+/* weight gradient of the same conv: dw (fp32 OIHW, cin_true channels) += dz^T * im2col(x), pixels as the MFMA reduction
+ * dimension, im2col fragments read transposed from the LDS input patch; workspace >= adamml_conv_stem_bwd_weight_workspace */
+size_t adamml_conv_stem_bwd_weight_workspace(const adamml_conv_desc_t* d);
+int adamml_conv_stem_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, float* dw, int cin_true,
+                                void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 /* depthwise 3x3 conv (groups == channels; sound_mobilenet_v2.py:58, policy_net.py:66,80) */
 int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, const float* w_tapmajor, const float* in_scale,

@@ -564,6 +564,17 @@ def test_conv_stem_fast_path(N, H, W, Cin, G):
     y2 = torch.empty_like(y)
     call("adamml_conv_fwd", byref(d), ptr(xh), ptr(pack(w, 8, 0)), None, None, ptr(y2), None)
     close(y.float(), y2.float(), what="stem vs generic")
+    # weight gradient from the same LDS patch (pixels = MFMA reduction dimension, transposed-read im2col fragments)
+    xr = rb(x).requires_grad_(True)
+    wr = rb(w).requires_grad_(True)
+    ref2 = F.conv2d(xr, wr, stride=2, padding=3)
+    gy = torch.randn_like(ref2)
+    ref2.backward(rb(gy))
+    dzh = nhwc(gy)
+    wsb = hip.wgrad_workspace(d, Cin, DEV, stem=True)
+    dw = torch.ones_like(w)                              # accumulate semantics: dw += ...
+    call("adamml_conv_stem_bwd_weight", byref(d), ptr(dzh), ptr(xh), ptr(dw), Cin, ptr(wsb), wsb.numel() * 4)
+    close(dw - 1, wr.grad, what="stem wgrad")
     # unsupported shapes are refused, not mis-computed
     bad = ConvDesc(N, H, W, 16, OH, OW, 64, 7, 7, 2, 3, 1, 0, 0)
     assert not hip.load().adamml_conv_stem_supported(byref(bad))

@@ -65,7 +65,11 @@ for name, N, H, Cin, Cout, k, s, p, lazy, cnt in L:
     else:
         acc = 1 if (name.endswith(" c1") or name.endswith(" ds")) else 0      # as used in the net: accumulates into the identity-path gradient
         t2 = timeit(lambda: call("adamml_conv_bwd_data", byref(d), ptr(dz), ptr(wd), ptr(dx), acc))
-    t3 = timeit(lambda: call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x), sc, sh, ptr(dw), Cin, ptr(ws), ws.numel() * 4))
+    if name.startswith("stem") and hip.load().adamml_conv_stem_supported(byref(d)):
+        wss = hip.wgrad_workspace(d, Cin, DEV, stem=True)
+        t3 = timeit(lambda: call("adamml_conv_stem_bwd_weight", byref(d), ptr(dz), ptr(x), ptr(dw), Cin, ptr(wss), wss.numel() * 4))
+    else:
+        t3 = timeit(lambda: call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x), sc, sh, ptr(dw), Cin, ptr(ws), ws.numel() * 4))
     tot[0] += t1 * cnt; tot[1] += t2 * cnt; tot[2] += t3 * cnt
     print("%-12s x%d N=%4d H=%3d %4d->%4d k%d s%d  %.2f GB %.2f TF | fwd %.3f ms %5.0f GB/s %4.0f TF/s | dgrad %.3f ms %5.0f GB/s | wgrad %.3f ms %5.0f GB/s %4.0f TF/s"
           % (name, cnt, N, H, Cin, Cout, k, s, gb, fl, t1, gb / t1 * 1e3, fl / t1 * 1e3, t2, gb / max(t2, 1e-9) * 1e3, t3, gb / t3 * 1e3, fl / t3 * 1e3))
