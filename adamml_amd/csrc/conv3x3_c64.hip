@@ -181,6 +181,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
             pixoff[j] = (r * p.PW + c) * PPIX + lg * 16;
         }
         const char* wbase = s_w + li * WROW3 + lg * 16;
+        const bool last_live = (wave + 24) * 16 < npx;
 #pragma unroll 1
         for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
@@ -190,14 +191,22 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
                 bf16x8 fw[4];
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) fw[ct] = *reinterpret_cast<const bf16x8*>(wbase + ct * 16 * WROW3 + ks * 64);
+                // pixel tiles 0..2 of a wave are computed unconditionally (dead ones of a short strip read valid patch addresses and
+                // are zeroed at staging; full strips have >= 24 live tiles); only the 4th is guarded, so the
+                // bulk is straight-line code whose ds_reads the compiler can run ahead of the MFMAs
+                bf16x8 fa[3];
 #pragma unroll
-                for (int j = 0; j < MAXPT; ++j) {
-                    if ((wave + 8 * j) * 16 < npx) {         // wave-uniform
-                        const bf16x8 fa = *reinterpret_cast<const bf16x8*>(s_patch + pixoff[j] + aoff);
+                for (int j = 0; j < 3; ++j) fa[j] = *reinterpret_cast<const bf16x8*>(s_patch + pixoff[j] + aoff);
 #pragma unroll
-                        for (int ct = 0; ct < 4; ++ct)
-                            acc[ct][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ct], fa, acc[ct][j], 0, 0, 0);
-                    }
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        acc[ct][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ct], fa[j], acc[ct][j], 0, 0, 0);
+                if (last_live) {                             // wave-uniform
+                    const bf16x8 f3 = *reinterpret_cast<const bf16x8*>(s_patch + pixoff[3] + aoff);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        acc[ct][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ct], f3, acc[ct][3], 0, 0, 0);
                 }
             }
         }
