@@ -296,6 +296,172 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same conv: dW[co][tap][ci] = sum_p dz[p][co] * a[p @ tap][ci], pixels as the MFMA reduction
+// dimension.  Same strips and the same (transformed, zero-bordered) LDS input patch as the forward; the dz strip is
+// staged next to it.  Both operands are pixel-major, so the fragments are hardware transpose reads with lane-supplied
+// addresses: A from the dz strip, B = 16 consecutive input channels of the patch pixel shifted by the tap.  36 N tiles
+// (9 taps x 4 channel blocks) are split over the 8 waves; accumulators live in registers over all strips of a workgroup,
+// one partial [64][9][64] fp32 per workgroup goes to the workspace (tap-major, summed and permuted by wgrad_reduce_kernel).
+struct C3WP {
+    const bf16_t* x;
+    const bf16_t* dz;
+    const float* in_scale;
+    const float* in_shift;
+    float* ws;
+    int act, N, H, W, R, tiles_per_img, tiles_per_group, total_tiles, tpb, PW, PR, in_gstride;
+    size_t gxy;
+};
+
+constexpr int MAXDZ3 = 8;                // 16-byte dz slots per thread (MAXPX3 px x 8 chunks / 512)
+
+__global__ __launch_bounds__(NT3, 1) void conv3x3_c64_wgrad_kernel(C3WP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_patch = smem;
+    char* s_dz = smem + p.PR * p.PW * PPIX;                          // [MAXPX3][SROW3]
+    int* s_poff = reinterpret_cast<int*>(s_dz + MAXPX3 * SROW3);     // patch byte offset of each strip pixel
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int ech = tid & 7;
+    const int nslots = p.PR * p.PW * 8;
+    for (int q = tid; q < MAXPX3; q += NT3) {
+        const int qq = q < p.R * p.W ? q : 0;
+        const int r = qq / p.W, c = qq - r * p.W;
+        s_poff[q] = (r * p.PW + c) * PPIX;
+    }
+    int s_rc[MAXSLOT3];
+#pragma unroll
+    for (int l = 0; l < MAXSLOT3; ++l) {
+        const int e = tid + l * NT3;
+        const int ppix = e >> 3;
+        const int pr = ppix / p.PW;
+        s_rc[l] = ((e < nslots ? pr : 0x7fff) << 16) | (ppix - pr * p.PW);
+    }
+    bf16x8 rp[MAXSLOT3], rz[MAXDZ3];
+    unsigned rok = 0;                    // bits 0..9: patch slots valid; bits 16..23: dz slots valid
+    auto load_tile = [&](int tile) {
+        const int g = tile / p.tiles_per_group, tg = tile - g * p.tiles_per_group;
+        const int n = tg / p.tiles_per_img, tr = tg - n * p.tiles_per_img;
+        const int ih0 = tr * p.R - 1;
+        const size_t ibase = (size_t)g * p.gxy + (size_t)n * p.H * p.W * C64;
+        const bf16_t* img = p.x + ibase + ech * 8;
+        rok = 0;
+#pragma unroll
+        for (int l = 0; l < MAXSLOT3; ++l) {
+            const int ih = ih0 + (s_rc[l] >> 16), iw = (s_rc[l] & 0xffff) - 1;
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            rok |= (ok ? 1u : 0u) << l;
+            const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
+            rp[l] = *reinterpret_cast<const bf16x8*>(img + ((size_t)ihc * p.W + iwc) * C64);
+        }
+        const int oh0 = tr * p.R;
+        const int npx = min(p.R, p.H - oh0) * p.W;
+        const bf16_t* zb = p.dz + ibase + (size_t)oh0 * p.W * C64;
+#pragma unroll
+        for (int l = 0; l < MAXDZ3; ++l) {
+            const int e = tid + l * NT3;
+            rz[l] = *reinterpret_cast<const bf16x8*>(zb + (size_t)(e < npx * 8 ? e : 0) * 8);
+            rok |= (e < npx * 8 ? 1u : 0u) << (16 + l);
+        }
+    };
+    f32x4 acc[4][5];                      // [cout tile][own N tile j]: N tile nt = wave + 8*j -> (tap nt >> 2, channel block nt & 3)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 5; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int noff[5];                          // patch byte offset of each own N tile: tap shift + channel block + this lane's 8-byte chunk
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int nt = min(wave + 8 * j, 35), t = nt >> 2, kh = t / 3, kw = t - kh * 3;
+        noff[j] = (kh * p.PW + kw) * PPIX + ((nt & 3) * 16 + 4 * (li & 3)) * 2;
+    }
+    const int tile0 = blockIdx.x * p.tpb;
+    if (tile0 < p.total_tiles) load_tile(tile0);
+    const int trow = 8 * lg + (li >> 2);
+
+    for (int it = 0; it < p.tpb; ++it) {
+        const int tile = tile0 + it;
+        if (tile >= p.total_tiles) break;
+        const int g = tile / p.tiles_per_group, tg = tile - g * p.tiles_per_group;
+        const int tr = tg % p.tiles_per_img;
+        const int npx = min(p.R, p.H - tr * p.R) * p.W;
+        {
+            const float lo = act_lo(p.act), hi = act_hi(p.act);
+            f32x8 sc, sh;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
+            if (p.in_scale) {
+                sc = load_f32x8(p.in_scale + (size_t)g * p.in_gstride + ech * 8);
+                sh = load_f32x8(p.in_shift + (size_t)g * p.in_gstride + ech * 8);
+            }
+#pragma unroll
+            for (int l = 0; l < MAXSLOT3; ++l) {
+                const int e = tid + l * NT3;
+                if (e < nslots) {
+                    bf16x8 v = rp[l];
+                    if (!((rok >> l) & 1u)) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    else if (p.in_scale) {
+                        f32x8 f = bf8_to_f32(v);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) f[i] = clamp_act(fmaf(f[i], sc[i], sh[i]), lo, hi);
+                        v = f32_to_bf8(f);
+                    }
+                    *reinterpret_cast<bf16x8*>(s_patch + (e >> 3) * PPIX + ech * 16) = v;
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < MAXDZ3; ++l) {
+                const int e = tid + l * NT3;
+                union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+                u.v = (rok >> (16 + l)) & 1u ? rz[l] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                char* dst = s_dz + (e >> 3) * SROW3 + ech * 16;
+                *reinterpret_cast<s16x4*>(dst) = u.s.a;
+                *reinterpret_cast<s16x4*>(dst + 8) = u.s.b;
+            }
+        }
+        __syncthreads();
+        if (it + 1 < p.tpb && tile + 1 < p.total_tiles) load_tile(tile + 1);
+        const int nks = (npx + 31) >> 5;
+        for (int ks = 0; ks < nks; ++ks) {
+            const int q0 = ks * 32 + trow;
+            const char* pb0 = s_patch + s_poff[q0];
+            const char* pb1 = s_patch + s_poff[q0 + 4];
+            const char* zb0 = s_dz + q0 * SROW3 + 4 * (li & 3) * 2;
+            bf16x8 fa[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                union { s16x4 h[2]; bf16x8 v; } f;
+                f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(zb0 + mt * 32));
+                f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(zb0 + mt * 32 + 4 * SROW3));
+                fa[mt] = f.v;
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                if (wave + 8 * j < 36) {                         // wave-uniform (only j == 4 can fail)
+                    union { s16x4 h[2]; bf16x8 v; } f;
+                    f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb0 + noff[j]));
+                    f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pb1 + noff[j]));
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], f.v, acc[mt][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = p.ws + (size_t)blockIdx.x * C64 * KT3;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int nt = wave + 8 * j;
+            if (nt < 36) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(size_t)(mt * 16 + lg * 4 + r) * KT3 + nt * 16 + li] = acc[mt][j][r];
+            }
+        }
+}
+
 }  // namespace
 
 // d: the FORWARD-shaped descriptor of the conv that is executed (for a data gradient: H/W of dz == H/W of dx).
@@ -346,4 +512,54 @@ int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const 
     }
     hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(ceil_div(p.total_tiles, p.tpb)), dim3(NT3), lds, stream, p);
     return adamml_check_launch("conv3x3_c64");
+}
+
+static int c3_geometry(const adamml_conv_desc_t* d, int* R_out) {
+    int R = MAXPX3 / d->W;
+    if (R > d->H) R = d->H;
+    for (int r = R; r >= R - 3 && r >= 2; --r)
+        if (d->H % r == 0) { R = r; break; }
+    *R_out = R;
+    return ceil_div(d->H, R);
+}
+
+bool adamml_conv3x3_c64_wgrad_supported(const adamml_conv_desc_t* d, int cin_true) {
+    if (cin_true != C64 || !adamml_conv3x3_c64_supported(d)) return false;
+    int R;
+    c3_geometry(d, &R);
+    const size_t lds = (size_t)(R + 2) * (d->W + 2) * PPIX + (size_t)MAXPX3 * SROW3 + MAXPX3 * sizeof(int);
+    return lds <= 160 * 1024;
+}
+
+int adamml_conv3x3_c64_wgrad_blocks(const adamml_conv_desc_t* d, int* tpb_out) {
+    int R;
+    const long total = (long)(d->groups < 1 ? 1 : d->groups) * d->N * c3_geometry(d, &R);
+    int tpb = (int)((total + 255) / 256);                  // one workgroup per CU
+    if (tpb < 1) tpb = 1;
+    if (tpb_out) *tpb_out = tpb;
+    return (int)((total + tpb - 1) / tpb);
+}
+
+int adamml_conv3x3_c64_wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
+                                    const float* in_shift, float* ws, hipStream_t stream) {
+    C3WP p;
+    p.x = (const bf16_t*)x; p.dz = (const bf16_t*)dz; p.in_scale = in_scale; p.in_shift = in_shift; p.ws = ws; p.act = d->act;
+    p.N = d->N; p.H = d->H; p.W = d->W;
+    p.tiles_per_img = c3_geometry(d, &p.R);
+    p.PR = p.R + 2; p.PW = d->W + 2;
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    p.tiles_per_group = d->N * p.tiles_per_img;
+    p.total_tiles = groups * p.tiles_per_group;
+    p.in_gstride = d->in_gstride;
+    p.gxy = (size_t)d->N * d->H * d->W * C64;
+    const int nblk = adamml_conv3x3_c64_wgrad_blocks(d, &p.tpb);
+    const size_t lds = (size_t)p.PR * p.PW * PPIX + (size_t)MAXPX3 * SROW3 + MAXPX3 * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv3x3_c64 wgrad: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_c64_wgrad_kernel, dim3(nblk), dim3(NT3), lds, stream, p);
+    return adamml_check_launch("conv3x3_c64 wgrad");
 }

@@ -849,6 +849,11 @@ int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const 
                               const float* in_shift, void* y, double* stats, const void* bn_z, const float* bn_vec, int bn_act,
                               hipStream_t stream);
 
+bool adamml_conv3x3_c64_wgrad_supported(const adamml_conv_desc_t* d, int cin_true);
+int adamml_conv3x3_c64_wgrad_blocks(const adamml_conv_desc_t* d, int* tpb_out);
+int adamml_conv3x3_c64_wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
+                                    const float* in_shift, float* ws, hipStream_t stream);
+
 // one parity class (ph, pw) of the data gradient of a stride-2 conv (see conv_dgrad_stride2)
 struct DgradClass { int nt; unsigned code; int ph, pw, OHc, OWc; };
 
@@ -1057,7 +1062,12 @@ extern "C" size_t adamml_conv_bwd_weight_workspace(const adamml_conv_desc_t* d, 
     WgradPlan pl;
     if (!d || wgrad_plan(d, cin_true, &pl)) return 0;
     const int groups = d->groups < 1 ? 1 : d->groups;
-    return (size_t)groups * pl.nsplit * d->Cout * cin_true * d->KH * d->KW * sizeof(float);
+    size_t need = (size_t)groups * pl.nsplit * d->Cout * cin_true * d->KH * d->KW * sizeof(float);
+    if (adamml_conv3x3_c64_wgrad_supported(d, cin_true)) {
+        const size_t n3 = (size_t)adamml_conv3x3_c64_wgrad_blocks(d, nullptr) * 64 * 576 * sizeof(float);
+        if (n3 > need) need = n3;
+    }
+    return need;
 }
 
 extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
@@ -1071,6 +1081,15 @@ extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* d
     if (rc) return rc;
     const size_t dw_numel = (size_t)d->Cout * cin_true * d->KH * d->KW;
     const int groups = d->groups < 1 ? 1 : d->groups;
+    if (workspace && adamml_conv3x3_c64_wgrad_supported(d, cin_true)) {
+        // 3x3 / 64 -> 64: LDS-patch kernel with one partial per workgroup (conv3x3_c64.hip)
+        const int nblk = adamml_conv3x3_c64_wgrad_blocks(d, nullptr);
+        if (workspace_bytes >= (size_t)nblk * dw_numel * sizeof(float)) {
+            rc = adamml_conv3x3_c64_wgrad_launch(d, dz, x, in_scale, in_shift, (float*)workspace, stream);
+            if (rc) return rc;
+            return adamml_launch_split_reduce((const float*)workspace, dw, dw_numel, nblk, stream, 9, cin_true);
+        }
+    }
     float* ws = nullptr;
     if (workspace && workspace_bytes >= (size_t)groups * pl.nsplit * dw_numel * sizeof(float)) ws = (float*)workspace;
     dim3 grid(pl.nsplit * pl.n_tiles * groups), block(NTHREADS);

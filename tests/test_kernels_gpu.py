@@ -621,6 +621,11 @@ def test_conv3x3_c64_patch_kernel(N, H, W, G, lazy):
     else:
         # xr.grad is w.r.t. the ACTIVATED input: same quantity the plain data gradient returns
         close(nchw(dx), xr.grad, what="conv3x3_c64 dgrad (activated input)")
+    # weight gradient from the same LDS patch (lazy input transform per group, sum over the groups)
+    ws = hip.wgrad_workspace(d, C, DEV)
+    dw = torch.ones_like(w)
+    call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(xh), ptr(scale), ptr(shift), ptr(dw), C, ptr(ws), ws.numel() * 4)
+    close(dw - 1, wr.grad, what="conv3x3_c64 wgrad")
     # BatchNorm-fused variant: g' = g * relu'(scale*z+shift), sums of g' and g'*zhat per group
     vec = torch.randn(G, 4, C, device=DEV)
     vec[:, 0] = vec[:, 0].abs() + 0.5
