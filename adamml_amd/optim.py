@@ -28,6 +28,14 @@ class FlatSGD:
         if self.fb.flat_grad is not None:
             self.fb.flat_grad.zero_()
 
+    def state_dict(self):
+        return {"flat": "sgd", "lr": self.lr, "steps": self.steps, "momentum_buffer": None if self.mom is None else self.mom.detach().cpu()}
+
+    def load_state_dict(self, sd):
+        self.lr, self.steps = sd.get("lr", self.lr), sd.get("steps", 0)
+        mb = sd.get("momentum_buffer")
+        self.mom = None if mb is None or self.fb.flat is None or mb.numel() != self.fb.flat.numel() else mb.to(self.fb.flat.device)
+
 
 class FlatAdam:
     def __init__(self, flat_buffers, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
@@ -50,6 +58,18 @@ class FlatAdam:
     def zero_grad(self):
         if self.fb.flat_grad is not None:
             self.fb.flat_grad.zero_()
+
+    def state_dict(self):
+        return {"flat": "adam", "lr": self.lr, "steps": self.steps, "exp_avg": None if self.m is None else self.m.detach().cpu(),
+                "exp_avg_sq": None if self.v is None else self.v.detach().cpu()}
+
+    def load_state_dict(self, sd):
+        self.lr, self.steps = sd.get("lr", self.lr), sd.get("steps", 0)
+        m, v = sd.get("exp_avg"), sd.get("exp_avg_sq")
+        ok = m is not None and v is not None and self.fb.flat is not None and m.numel() == self.fb.flat.numel()
+        self.m, self.v = (m.to(self.fb.flat.device), v.to(self.fb.flat.device)) if ok else (None, None)
+        if not ok:
+            self.steps = 0
 
 
 def _mark_dirty(module):

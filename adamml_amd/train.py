@@ -1,0 +1,420 @@
+"""Restated `train_adamml` launcher on the HIP hot path.
+
+Same command-line flags as the reference (opts.py:5-149, the model / optimisation / staging / checkpoint ones), the same
+three-stage schedule (train_adamml.py:340-626: warm-up of the main nets with the policy frozen -> alternating main / policy
+epochs with Gumbel-temperature decay -> fine-tuning of the main nets from the best checkpoint), two optimizers
+(SGD-momentum for the main nets, Adam for the policy: train_adamml.py:250-257) with the reference's learning-rate
+schedules, and the reference's checkpoint dictionary (`state_dict` with the DDP `module.` prefix, `stage`, `temperature`,
+`epoch`, `best_top1`, ...), so checkpoints interchange with the reference in both directions.
+
+The dataset / decoding / augmentation pipeline of the reference is out of scope of this repository (SURVEY.md section 8:
+CPU-side I/O): pass your own iterables of `(list_of_modal_tensors, target)` to `main(train_loader=..., val_loader=...)`,
+or use `--synthetic N` (N synthetic batches per epoch, adamml_amd.synth) to exercise the whole schedule.
+
+    python -m adamml_amd.train --backbone_net adamml -d 50 --groups 8 --num_segments 5 --modality rgb sound \\
+        --causality_modeling lstm --learnable_lf_weights -b 72 --epochs 20 --warmup_epochs 5 --finetune_epochs 10 \\
+        --cost_weights 1.0 0.05 --sync-bn --synthetic 100
+"""
+import argparse
+import math
+import os
+import shutil
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import synth
+from .distributed import HipDDP
+from .model_builder import build_model
+from .optim import FlatAdam, FlatSGD
+
+CHANNELS = {"rgb": 3, "flow": 10, "rgbdiff": 15, "sound": 1}
+
+
+def arg_parser():
+    p = argparse.ArgumentParser(description="AdaMML training on MI355X (restated reference launcher)")
+    # model definition (opts.py:8-35)
+    p.add_argument("--backbone_net", default="adamml", choices=["adamml", "resnet", "sound_mobilenet_v2"])
+    p.add_argument("-d", "--depth", default=50, type=int)
+    p.add_argument("--dropout", default=0.5, type=float)
+    p.add_argument("--groups", default=8, type=int, help="number of frames")
+    p.add_argument("--num_segments", default=5, type=int)
+    p.add_argument("--frames_per_group", default=1, type=int)
+    p.add_argument("--without_t_stride", action="store_true")
+    p.add_argument("--pooling_method", default="max", choices=["avg", "max"])
+    p.add_argument("--fusion_point", default="logits", type=str)
+    p.add_argument("--prefix", default="", type=str)
+    p.add_argument("--learnable_lf_weights", action="store_true")
+    p.add_argument("--causality_modeling", default=None, type=str, choices=[None, "lstm"])
+    p.add_argument("--cost_weights", default=None, type=float, nargs="+")
+    p.add_argument("--rng_policy", action="store_true")
+    p.add_argument("--rng_threshold", type=float, default=0.5)
+    p.add_argument("--gammas", default=10.0, type=float)
+    p.add_argument("--penalty_type", default="blockdrop", choices=["mean", "blockdrop"])
+    # training (opts.py:42-78)
+    p.add_argument("-b", "--batch-size", default=72, type=int, help="GLOBAL batch, split over the ranks (train_adamml.py:122)")
+    p.add_argument("--lr", "--learning-rate", default=0.01, type=float)
+    p.add_argument("--p_lr", "--p_learning-rate", default=0.01, type=float)
+    p.add_argument("--lr_scheduler", default="cosine", choices=["step", "multisteps", "cosine"])
+    p.add_argument("--lr_steps", default=[15, 30, 45], type=float, nargs="+")
+    p.add_argument("--momentum", default=0.9, type=float)
+    p.add_argument("--nesterov", action="store_true")
+    p.add_argument("--weight-decay", "--wd", default=1e-4, type=float)
+    p.add_argument("--epochs", default=50, type=int)
+    p.add_argument("--warmup_epochs", default=5, type=int)
+    p.add_argument("--finetune_epochs", default=10, type=int)
+    p.add_argument("--resume", default="", type=str)
+    p.add_argument("--auto_resume", action="store_true")
+    p.add_argument("--pretrained", type=str, default=None)
+    p.add_argument("--unimodality_pretrained", type=str, nargs="+", default=[])
+    p.add_argument("--start-epoch", default=0, type=int)
+    p.add_argument("--clip_gradient", "--cg", default=None, type=float)
+    p.add_argument("--curr_stage", type=str, default="warmup", choices=["warmup", "alternative_training", "finetune"])
+    # data / logging (the subset that reaches the model or the run name)
+    p.add_argument("--dataset", default="kinetics-sounds")
+    p.add_argument("--datadir", default=None)
+    p.add_argument("--num_classes", default=31, type=int)
+    p.add_argument("--input_size", default=224, type=int)
+    p.add_argument("--dense_sampling", action="store_true")
+    p.add_argument("--modality", default=["rgb", "sound"], type=str, nargs="+")
+    p.add_argument("--logdir", default="", type=str)
+    p.add_argument("--print-freq", default=100, type=int)
+    p.add_argument("-e", "--evaluate", action="store_true")
+    p.add_argument("--val_num_clips", default=10, type=int)
+    p.add_argument("--sync-bn", action="store_true")
+    p.add_argument("--synthetic", default=0, type=int, metavar="N", help="N synthetic batches per epoch instead of a dataset")
+    return p
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def compute_policy_loss(penalty_type, selection, cost_weights, gammas, cls_logits, cls_targets):
+    """utils/utils.py:166-184."""
+    num_modality = selection.shape[-1]
+    loss = torch.zeros((), dtype=selection.dtype, device=selection.device)
+    if penalty_type == "mean":
+        for w, pl in zip(cost_weights, selection.chunk(num_modality, dim=-1)):
+            loss = loss + w * pl.mean()
+    elif penalty_type == "blockdrop":
+        correct = (cls_logits.detach().argmax(-1) == cls_targets).type_as(cls_logits)
+        sel = selection.mean(dim=1) ** 2
+        for w, pl in zip(cost_weights, sel.chunk(num_modality, dim=-1)):
+            # pl is [N,1], correct is [N]: the product broadcasts to [N,N] exactly as in the reference (utils/utils.py:179)
+            loss = loss + w * (correct * pl).mean()
+        loss = loss + ((1.0 - correct) * gammas).mean()
+    return loss
+
+
+def accuracy(output, target, topk=(1, 5)):
+    maxk = min(max(topk), output.shape[1])
+    pred = output.topk(maxk, 1, True, True)[1].t()
+    correct = pred.eq(target.view(1, -1).expand_as(pred))
+    return [correct[:min(k, maxk)].reshape(-1).float().sum() * (100.0 / target.size(0)) for k in topk]
+
+
+class Meter:
+    def __init__(self):
+        self.sum, self.n = 0.0, 0
+
+    def update(self, v, n=1):
+        self.sum += float(v) * n
+        self.n += n
+
+    @property
+    def avg(self):
+        return self.sum / max(self.n, 1)
+
+
+class LRSchedule:
+    """StepLR / MultiStepLR / CosineAnnealingLR (train_adamml.py:259-270) for the flat optimizers; step(epoch) sets
+    the learning rate of epoch `epoch` in closed form, as the reference's schedulers do when stepped with an epoch."""
+
+    def __init__(self, opt, kind, base_lr, epochs, steps):
+        self.opt, self.kind, self.base, self.epochs, self.steps, self.last = opt, kind, base_lr, epochs, [int(s) for s in steps], 0
+
+    def step(self, epoch):
+        self.last = epoch
+        if self.kind == "step":
+            lr = self.base * 0.1 ** (epoch // self.steps[0])
+        elif self.kind == "multisteps":
+            lr = self.base * 0.1 ** sum(1 for s in self.steps if epoch >= s)
+        else:
+            lr = 0.5 * self.base * (1 + math.cos(math.pi * epoch / max(self.epochs, 1)))
+        self.opt.lr = lr
+
+    def state_dict(self):
+        return {"last_epoch": self.last, "base_lr": self.base}
+
+    def load_state_dict(self, sd):
+        self.step(sd.get("last_epoch", 0))
+
+
+def strip_module_prefix(sd):
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+
+
+def load_reference_checkpoint(model, path_or_dict, strict=True):
+    """Load a reference checkpoint (`{'state_dict': {'module.<name>': tensor}}`, a bare state_dict, with or without the
+    DDP prefix) into an adamml_amd model; returns the checkpoint dict.  (weights stay OIHW fp32
+    at this boundary, the bf16 GEMM packs are rebuilt on the next forward.)"""
+    ck = torch.load(path_or_dict, map_location="cpu") if isinstance(path_or_dict, (str, os.PathLike)) else path_or_dict
+    sd = ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck
+    target = model.module if hasattr(model, "module") else model
+    with torch.no_grad():
+        target.load_state_dict(strip_module_prefix(sd), strict=strict)
+    for m in target.modules():
+        if hasattr(m, "mark_weights_dirty"):
+            m.mark_weights_dirty()
+    if isinstance(ck, dict) and "temperature" in ck and hasattr(target, "policy_net"):
+        target.policy_net.set_temperature(ck["temperature"])
+    return ck if isinstance(ck, dict) else {"state_dict": sd}
+
+
+def reference_state_dict(model):
+    """state_dict with the `module.` prefix the reference's DDP-wrapped checkpoints carry (train_adamml.py:386)."""
+    target = model.module if hasattr(model, "module") else model
+    return {"module." + k: v.detach().cpu() for k, v in target.state_dict().items()}
+
+
+def save_checkpoint(state, is_best, filepath, epoch=None, suffix=""):
+    """utils/utils.py:89-96."""
+    cur = os.path.join(filepath, "checkpoint.pth.tar")
+    torch.save(state, cur)
+    if epoch:
+        shutil.copyfile(cur, os.path.join(filepath, "checkpoint{}_{:02d}.pth.tar".format(suffix, epoch)))
+    if is_best:
+        shutil.copyfile(cur, os.path.join(filepath, "model_best.pth.tar"))
+
+
+class SyntheticLoader:
+    """N deterministic synthetic batches per epoch (per-rank batch), already on the device."""
+
+    def __init__(self, args, n, batch, device, rank, segments=None):
+        self.args, self.n, self.batch, self.device, self.rank = args, n, batch, device, rank
+        self.segments = segments or args.num_segments
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        a = self.args
+        for i in range(self.n):
+            seed = 42 + i + 1000 * self.rank
+            xs = synth.synth_inputs(a.modality, self.batch, self.segments, a.groups, a.input_size, seed=seed)
+            y = synth.synth_labels(self.batch, a.num_classes, seed=seed)
+            yield [x.to(self.device) for x in xs], y.to(self.device)
+
+
+# ------------------------------------------------------------------------------------------------ one epoch
+def train_epoch(loader, ddp, opt, p_opt, epoch, args, cost_weights, rank=0, log=print):
+    """utils/utils.py:320-426."""
+    model = ddp.module
+    model.train()
+    opt.zero_grad()
+    p_opt.zero_grad()
+    device = next(model.parameters()).device
+    cw = torch.tensor(cost_weights if cost_weights is not None else [0.0] * len(args.modality), device=device)
+    gammas = torch.tensor(args.gammas, device=device)
+    meters = {k: Meter() for k in ("loss", "top1", "top5", "time")}
+    sel_meter = {m: Meter() for m in args.modality}
+    end = time.time()
+    for i, (images, target) in enumerate(loader):
+        images = [x.to(device, non_blocking=True) for x in images]
+        target = target.to(device, non_blocking=True)
+        output, selection = ddp(images)
+        loss = F.cross_entropy(output, target)
+        if model.update_policy_net:
+            loss = loss + compute_policy_loss(args.penalty_type, selection, cw, gammas, output, target)
+        prec1, prec5 = accuracy(output, target)
+        ratio = selection.detach().mean(0).mean(0)
+        if dist.is_initialized():
+            for t in (prec1, prec5, ratio):
+                dist.all_reduce(t)
+                t /= dist.get_world_size()
+        loss.backward()
+        ddp.reduce_gradients()
+        if args.clip_gradient is not None:
+            bufs = model.flat_grad_buffers()
+            total = torch.sqrt(sum((b.float() ** 2).sum() for b in bufs))
+            scale = (args.clip_gradient / (total + 1e-6)).clamp(max=1.0)
+            for b in bufs:
+                b.mul_(scale)
+        if model.update_policy_net:
+            p_opt.step()
+            p_opt.zero_grad()
+        if model.update_main_net:
+            opt.step()
+            opt.zero_grad()
+        meters["loss"].update(loss.item(), target.size(0))
+        meters["top1"].update(prec1.item(), target.size(0))
+        meters["top5"].update(prec5.item(), target.size(0))
+        for ii, m in enumerate(args.modality[:ratio.numel()]):
+            sel_meter[m].update(ratio[ii].item())
+        meters["time"].update(time.time() - end)
+        end = time.time()
+        if i % args.print_freq == 0 and rank == 0:
+            log("Epoch: [{}][{}/{}]\tTime {:.3f}\tLoss {:.4f}\tPrec@1 {:.3f}\tPrec@5 {:.3f}\t{}".format(
+                epoch, i, len(loader), meters["time"].avg, meters["loss"].avg, meters["top1"].avg, meters["top5"].avg,
+                " ".join("{}:{:.2f}".format(k, v.avg * 100) for k, v in sel_meter.items())))
+    return meters, sel_meter
+
+
+@torch.no_grad()
+def validate(loader, ddp, args, num_segments):
+    """utils/utils.py:427-507 (top-k on the concatenated outputs; mAP needs torchnet in the reference and is not restated)."""
+    model = ddp.module
+    model.eval()
+    device = next(model.parameters()).device
+    outs, labels, sels = [], [], []
+    loss_m = Meter()
+    for images, target in loader:
+        images = [x.to(device, non_blocking=True) for x in images]
+        target = target.to(device, non_blocking=True)
+        output, selection = model(images, num_segments)
+        loss_m.update(F.cross_entropy(output, target).item(), target.size(0))
+        outs.append(output)
+        labels.append(target)
+        sels.append(selection)
+    output, target, selection = torch.cat(outs), torch.cat(labels), torch.cat(sels)
+    if dist.is_initialized():
+        def gather(t):
+            lst = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+            dist.all_gather(lst, t.contiguous())
+            return torch.cat(lst)
+        output, target, selection = gather(output), gather(target), gather(selection)
+    top1, top5 = accuracy(output, target)
+    return top1.item(), top5.item(), loss_m.avg, selection
+
+
+# ------------------------------------------------------------------------------------------------ schedule
+def main(argv=None, train_loader=None, val_loader=None, log=print):
+    args = arg_parser().parse_args(argv)
+    args.input_channels = [CHANNELS[m] for m in args.modality]
+    args.imagenet_pretrained = False
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("adamml_amd.train needs an MI355X: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("ADAMML_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+    args.distributed = world > 1
+    per_rank_batch = max(1, args.batch_size // world)                       # train_adamml.py:122
+    if args.backbone_net != "adamml":
+        raise SystemExit("adamml_amd.train restates train_adamml.py; unimodal training is models.resnet / sound_mobilenet_v2 "
+                         "behind the same registry (build_model) with a plain loop")
+
+    model, arch_name = build_model(args)
+    model = model.to(device)
+    if args.pretrained:
+        load_reference_checkpoint(model, args.pretrained, strict=False)
+    ddp = HipDDP(model, sync_bn=(args.sync_bn and world > 1))
+    log_folder = os.path.join(args.logdir or "snapshots", arch_name)
+    if rank == 0:
+        os.makedirs(log_folder, exist_ok=True)
+
+    if train_loader is None:
+        if not args.synthetic:
+            raise SystemExit("no dataset pipeline in this repository: pass train_loader/val_loader to main() or use --synthetic N")
+        train_loader = SyntheticLoader(args, args.synthetic, per_rank_batch, device, rank)
+        val_loader = SyntheticLoader(args, max(1, args.synthetic // 4), per_rank_batch, device, rank + 7777, args.val_num_clips)
+
+    def make_optimizers():
+        o = FlatSGD(model._flat_main, args.lr, args.momentum, args.weight_decay, args.nesterov)
+        po = FlatAdam(model._flat_policy, args.p_lr, weight_decay=args.weight_decay)
+        return o, po, LRSchedule(o, args.lr_scheduler, args.lr, args.epochs, args.lr_steps), \
+            LRSchedule(po, args.lr_scheduler, args.p_lr, args.epochs, args.lr_steps)
+
+    # flat parameter buffers must exist before the optimizers look at them
+    model._flat_policy.ensure(device)
+    model._flat_main.ensure(device)
+    opt, p_opt, sched, p_sched = make_optimizers()
+    best_top1, stage = 0.0, args.curr_stage
+    if args.auto_resume and os.path.exists(os.path.join(log_folder, "checkpoint.pth.tar")):
+        args.resume = os.path.join(log_folder, "checkpoint.pth.tar")
+    if args.resume:
+        ck = load_reference_checkpoint(model, args.resume)
+        args.start_epoch, best_top1, stage = ck.get("epoch", 0), float(ck.get("best_top1", 0.0)), ck.get("stage", stage)
+        sched.load_state_dict(ck.get("scheduler", {}))
+        p_sched.load_state_dict(ck.get("p_scheduler", {}))
+        for o, key in ((opt, "optimizer"), (p_opt, "p_optimizer")):
+            if isinstance(ck.get(key), dict) and "flat" in ck[key]:
+                o.load_state_dict(ck[key])
+
+    def snapshot(epoch, st, is_best, suffix):
+        if rank != 0:
+            return
+        save_checkpoint({"epoch": epoch, "arch": arch_name, "state_dict": reference_state_dict(model), "best_top1": best_top1,
+                         "p_optimizer": p_opt.state_dict(), "optimizer": opt.state_dict(), "p_scheduler": p_sched.state_dict(),
+                         "scheduler": sched.state_dict(), "temperature": model.policy_net.temperature, "stage": st},
+                        is_best, log_folder, epoch, suffix)
+
+    zero_cost = [0.0] * len(args.modality)
+    if args.evaluate:
+        top1, top5, loss, _ = validate(val_loader, ddp, args, args.val_num_clips)
+        log("Val: Loss {:.4f}\tTop@1 {:.4f}\tTop@5 {:.4f}".format(loss, top1, top5))
+        return {"top1": top1, "top5": top5, "loss": loss}
+
+    history = []
+    if stage == "warmup":                                                   # train_adamml.py:340-392
+        if args.warmup_epochs > 0 and rank == 0:
+            log("Stage [Warming up]: Main network with {} epochs".format(args.warmup_epochs))
+        model.freeze_policy_net()
+        model.unfreeze_main_net()
+        for epoch in range(args.start_epoch, args.warmup_epochs):
+            m, _ = train_epoch(train_loader, ddp, opt, p_opt, epoch + 1, args, zero_cost, rank, log)
+            history.append(("warmup", epoch + 1, m["loss"].avg))
+            snapshot(epoch + 1, "warmup", False, "_warmup")
+        stage, args.start_epoch = "alternative_training", 0
+        opt, p_opt, sched, p_sched = make_optimizers()
+    if stage == "alternative_training":                                     # train_adamml.py:394-519
+        if rank == 0:
+            log("Stage [Alternative training]: {} epochs".format(args.epochs))
+        for epoch in range(args.start_epoch, args.epochs):
+            model.freeze_policy_net()
+            model.unfreeze_main_net()
+            m, _ = train_epoch(train_loader, ddp, opt, p_opt, epoch + 1, args, zero_cost, rank, log)
+            history.append(("main", epoch + 1, m["loss"].avg))
+            model.unfreeze_policy_net()
+            model.freeze_main_net()
+            m, _ = train_epoch(train_loader, ddp, opt, p_opt, epoch + 1, args, args.cost_weights, rank, log)
+            history.append(("policy", epoch + 1, m["loss"].avg))
+            top1, top5, vloss, _ = validate(val_loader, ddp, args, args.val_num_clips)
+            sched.step(epoch + 1)
+            p_sched.step(epoch + 1)
+            is_best = top1 > best_top1
+            best_top1 = max(top1, best_top1)
+            if rank == 0:
+                log("Val: [{:03d}/{:03d}]\tLoss {:.4f}\tTop@1 {:.4f}\tTop@5 {:.4f}".format(epoch + 1, args.epochs, vloss, top1, top5))
+            snapshot(epoch + 1, "alternative_training", is_best, "_main")
+            model.decay_temperature()
+        stage, args.start_epoch = "finetune", 0
+        opt, p_opt, sched, p_sched = make_optimizers()
+    if stage == "finetune" and args.finetune_epochs > 0:                    # train_adamml.py:521-620
+        if rank == 0:
+            log("Stage [Post finetuning]: Finetune the main network {} epochs".format(args.finetune_epochs))
+        best = os.path.join(log_folder, "model_best.pth.tar")
+        if args.start_epoch == 0 and os.path.exists(best):
+            load_reference_checkpoint(model, best)
+        model.freeze_policy_net()
+        model.unfreeze_main_net()
+        for epoch in range(args.start_epoch, args.finetune_epochs):
+            m, _ = train_epoch(train_loader, ddp, opt, p_opt, epoch + 1, args, zero_cost, rank, log)
+            history.append(("finetune", epoch + 1, m["loss"].avg))
+            top1, top5, vloss, _ = validate(val_loader, ddp, args, args.val_num_clips)
+            sched.step(epoch + 1)
+            p_sched.step(epoch + 1)
+            is_best = top1 > best_top1
+            best_top1 = max(top1, best_top1)
+            if rank == 0:
+                log("Val: [{:03d}/{:03d}]\tLoss {:.4f}\tTop@1 {:.4f}\tTop@5 {:.4f}".format(epoch + 1, args.finetune_epochs, vloss, top1, top5))
+            snapshot(epoch + 1, "finetune", is_best, "_finetune")
+    return {"history": history, "best_top1": best_top1, "log_folder": log_folder, "temperature": model.policy_net.temperature}
+
+
+if __name__ == "__main__":
+    main()

@@ -352,7 +352,10 @@ def policy_loss(penalty_type, selection, cost_weights, gammas, cls_logits, cls_t
         correct = (cls_logits.detach().argmax(-1) == cls_targets).to(cls_logits.dtype)
         usage = selection.mean(dim=1) ** 2
         for mi in range(M):
-            loss = loss + cost_weights[mi] * (correct * usage[:, mi]).mean()
+            # reference: `correctness * pl` with correctness [N] and pl = chunk(...) of shape [N,1] BROADCASTS to [N,N]
+            # (utils/utils.py:177-181), i.e. mean(correct) * mean(usage), not the per-video product -- mirrored as is
+            # (pinned by tests/golden/policy_loss_cases.npz)
+            loss = loss + cost_weights[mi] * (correct.unsqueeze(0) * usage[:, mi:mi + 1]).mean()
         loss = loss + ((1.0 - correct) * gammas).mean()
     return loss
 
