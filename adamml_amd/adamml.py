@@ -37,6 +37,10 @@ class AdaMML(nn.Module, MeanStdMixin):
         self.update_policy_net = True
         self.update_main_net = True
         self.use_side_stream = True
+        # inference only: run the main nets on the (segment, video) pairs the policy selected, instead of computing every
+        # backbone call and multiplying the skipped ones by zero (models/adamml.py:81-86)
+        self.skip_unselected = True
+        self.last_skip_stats = None
         self._side = None
         self._flat_policy = FlatBuffers(self.policy_net)
         self._flat_main = FlatBuffers(self.main_net)
@@ -78,6 +82,8 @@ class AdaMML(nn.Module, MeanStdMixin):
             self._flat_policy.ensure_grads()
             self._flat_main.ensure_grads()
         p_x, m_x, num_segments = self.data_layer(x, num_segments)
+        if self.skip_unselected and not self.training and not torch.is_grad_enabled():
+            return self._forward_skipping(x, p_x, m_x, num_segments, gumbel_exponential)
         # Two HIP streams: the ResNet(s) stay on the caller's stream; the MobileNetV2 policy nets and the sound main net
         # (hundreds of small launches) are enqueued on a side stream and overlap them.  The main nets never depend on the
         # decisions before the logit mask (models/adamml.py:81-86), so the policy runs concurrently with segment 0..S-1.
@@ -114,6 +120,37 @@ class AdaMML(nn.Module, MeanStdMixin):
         all_logits = [self.main_net.fuse(seg_logits[i], decisions[i]) for i in range(num_segments)]
         final_logits = torch.stack(all_logits, dim=1).mean(dim=1)
         return final_logits, decisions.permute((2, 0, 1))
+
+    def _forward_skipping(self, x, p_x, m_x, num_segments, gumbel_exponential):
+        """Eval-mode forward with decision-driven compaction: the decisions are taken first, then each main net only sees
+        the (segment, video) clips whose decision is 1 -- the compute saving AdaMML is about.  Exact: eval-mode BatchNorm is
+        a per-sample affine map, so a clip's logits do not depend on which other clips share the launch, and the skipped
+        clips' logits are multiplied by 0 in the reference (joint_resnet_mobilenetv2.py:94)."""
+        S, B, dev = num_segments, x[0].size(0), x[0].device
+        if not self.rng_policy:
+            decisions, decision_logits = self.policy_net.decide(self.policy_net.all_segment_features(p_x), gumbel_exponential)
+            self.last_policy_logits = decision_logits
+        else:
+            decisions = (torch.rand((S, self.num_modality, B), dtype=x[0].dtype, device=dev) > self.rng_threshold).float()
+        stacked, ran = [], []
+        for m_i in range(self.num_modality):
+            net = self.main_net.nets[m_i]
+            frames = m_x[m_i].flatten(0, 1)                                   # [S*B*F, H, W, C], clips contiguous
+            fpc = frames.shape[0] // (S * B)
+            idx = (decisions[:, m_i, :].reshape(-1) > 0.5).nonzero().flatten()      # host sync: the launch sizes depend on it
+            ncls = net.fc.out_features if hasattr(net, "fc") else net.classifier[1].out_features
+            out = torch.zeros(S * B, ncls, dtype=torch.float32, device=dev)
+            if idx.numel() == S * B:
+                out = net.forward_nhwc(frames, 1)
+            elif idx.numel() > 0:
+                sel = frames.view(S * B, fpc, *frames.shape[1:]).index_select(0, idx).flatten(0, 1)
+                out.index_copy_(0, idx, net.forward_nhwc(sel, 1))
+            stacked.append(out)
+            ran.append(int(idx.numel()))
+        self.last_skip_stats = {"clips": S * B, "executed_per_modality": ran}
+        seg_logits = [[l.view(S, B, -1)[i] for l in stacked] for i in range(S)]
+        all_logits = [self.main_net.fuse(seg_logits[i], decisions[i]) for i in range(S)]
+        return torch.stack(all_logits, dim=1).mean(dim=1), decisions.permute((2, 0, 1))
 
     def _side_stream(self, dev, idx=0):
         if self._side is None or self._side[0].device != dev:

@@ -273,3 +273,27 @@ def test_adamml(name):
         loss.backward()
         check_against_emulation(model, emu, ref, mode, logits.detach().cpu().numpy())
         check_against_golden(model, gold, emu, mode, logits.detach().cpu().numpy())
+
+
+def test_eval_skipping_equals_masking():
+    """Inference with decision-driven compaction (main nets only run the selected (segment, video) clips) returns exactly
+    the logits of the compute-everything-then-mask forward of the reference (models/adamml.py:81-86)."""
+    from adamml_amd import adamml
+    torch.manual_seed(0)
+    S, B = 3, 4
+    model = adamml(groups=8, modality=["rgb", "sound"], input_channels=[3, 1], num_segments=S, rng_policy=False, rng_threshold=0.5,
+                   causality_modeling="lstm", num_classes=31, depth=50, without_t_stride=False, dropout=0.5, pooling_method="max",
+                   fusion_point="logits", unimodality_pretrained=[], learnable_lf_weights=True).to(DEV).eval()
+    xs = [t.to(DEV) for t in synth.synth_inputs(["rgb", "sound"], B, S, 8, 64, seed=5)]
+    expo = synth.synth_gumbel_exponential(S, 2, B, seed=11).to(DEV)
+    with torch.no_grad():
+        model.skip_unselected = False
+        ref, dec_ref = model(xs, gumbel_exponential=expo)
+        model.skip_unselected = True
+        got, dec = model(xs, gumbel_exponential=expo)
+    assert torch.equal(dec, dec_ref)
+    st = model.last_skip_stats
+    assert st["clips"] == S * B and all(0 <= n <= S * B for n in st["executed_per_modality"])
+    assert st["executed_per_modality"] == [int(dec[:, :, m].sum().item()) for m in range(2)]
+    print("  executed clips per modality:", st["executed_per_modality"], "of", st["clips"])
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5), (got - ref).abs().max().item()
