@@ -116,6 +116,7 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
 // Row-walking elementwise kernels: a thread keeps ONE 8-channel chunk for all its pixels (ChanMap), so the per-channel
 // BatchNorm vectors are loaded into registers once per thread instead of once per 16 B of activation traffic (the
 // per-element form issued 14 cached vector loads per 2 streaming loads and ran at ~3.5 TB/s; this form streams at ~6).
+template <bool STREAM>
 __global__ __launch_bounds__(NT) void bn_act_add_kernel(const bf16_t* z, const float* scale, const float* shift, int z_gs, int act,
                                                         const bf16_t* idn, const float* id_scale, const float* id_shift, int id_gs,
                                                         bf16_t* out, size_t P, int C, size_t ppb) {
@@ -134,16 +135,19 @@ __global__ __launch_bounds__(NT) void bn_act_add_kernel(const bf16_t* z, const f
     const size_t pb = (size_t)blockIdx.x * ppb;
     const size_t pe = pb + ppb < P ? pb + ppb : P;
     for (size_t p = pb + m.rslot; p < pe; p += m.rows_per_pass) {
-        f32x8 v = bf8_to_f32(*reinterpret_cast<const bf16x8*>(z + p * C + c));
+        f32x8 v = bf8_to_f32(STREAM ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(z + p * C + c))
+                                    : *reinterpret_cast<const bf16x8*>(z + p * C + c));
         if (idn) {
-            const f32x8 w = bf8_to_f32(*reinterpret_cast<const bf16x8*>(idn + p * C + c));
+            const f32x8 w = bf8_to_f32(STREAM ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(idn + p * C + c))
+                                              : *reinterpret_cast<const bf16x8*>(idn + p * C + c));
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = clamp_act(fmaf(v[i], sc[i], sh[i]) + fmaf(w[i], isc[i], ish[i]), lo, hi);
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = clamp_act(fmaf(v[i], sc[i], sh[i]), lo, hi);
         }
-        *reinterpret_cast<bf16x8*>(out + p * C + c) = f32_to_bf8(v);
+        if (STREAM) __builtin_nontemporal_store(f32_to_bf8(v), reinterpret_cast<bf16x8*>(out + p * C + c));
+        else *reinterpret_cast<bf16x8*>(out + p * C + c) = f32_to_bf8(v);
     }
 }
 
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const bf16_t* g, cons
 // Residual-add backward (models/resnet.py:110-111 / sound_mobilenet_v2.py:67): g2 = g_out * act'(out), plus the
 // BatchNorm-backward sums of the one or two lazily normalised operands of the add (bn3 and, in the first block of a
 // stage, the downsample BN) in the same pass over g_out / out.
+template <bool STREAM>
 __global__ __launch_bounds__(NT) void residual_bwd_kernel(const bf16_t* g_out, const bf16_t* out, int act, bf16_t* g2,
                                                           const bf16_t* za, const float* veca, double* sumsa,
                                                           const bf16_t* zb, const float* vecb, double* sumsb,
@@ -216,20 +221,26 @@ __global__ __launch_bounds__(NT) void residual_bwd_kernel(const bf16_t* g_out, c
         if (zb) { mub = load_f32x8(vecb + 2 * C + c); isb = load_f32x8(vecb + 3 * C + c); }
         const float lo = act_lo(act), hi = act_hi(act);
         for (size_t p = pb + m.rslot; p < pe; p += m.rows_per_pass) {
-            f32x8 gv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(g_out + p * C + c));
-            const f32x8 ov = bf8_to_f32(*reinterpret_cast<const bf16x8*>(out + p * C + c));
+            auto ld = [](const bf16_t* q) {
+                return STREAM ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(q)) : *reinterpret_cast<const bf16x8*>(q);
+            };
+            f32x8 gv = bf8_to_f32(ld(g_out + p * C + c));
+            const f32x8 ov = bf8_to_f32(ld(out + p * C + c));
 #pragma unroll
             for (int i = 0; i < 8; ++i) gv[i] *= mask_act(ov[i], lo, hi);
             const bf16x8 gb = f32_to_bf8(gv);
-            if (g2 != g_out || act != ACT_NONE) *reinterpret_cast<bf16x8*>(g2 + p * C + c) = gb;
+            if (g2 != g_out || act != ACT_NONE) {
+                if (STREAM) __builtin_nontemporal_store(gb, reinterpret_cast<bf16x8*>(g2 + p * C + c));
+                else *reinterpret_cast<bf16x8*>(g2 + p * C + c) = gb;
+            }
             gv = bf8_to_f32(gb);
             if (za) {
-                const f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(za + p * C + c));
+                const f32x8 zv = bf8_to_f32(ld(za + p * C + c));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { sa[i] += gv[i]; qa[i] += gv[i] * (zv[i] - mua[i]) * isa[i]; }
             }
             if (zb) {
-                const f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(zb + p * C + c));
+                const f32x8 zv = bf8_to_f32(ld(zb + p * C + c));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { sb[i] += gv[i]; qb[i] += gv[i] * (zv[i] - mub[i]) * isb[i]; }
             }
@@ -647,8 +658,12 @@ extern "C" int adamml_bn_act_add(const void* z, const float* scale, const float*
     if (groups < 1) groups = 1;
     size_t ppb, nblk;
     rowwalk_grid(P, C, groups, 8192, &ppb, &nblk);
-    hipLaunchKernelGGL(bn_act_add_kernel, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)z, scale, shift, z_gstride, act,
-                       (const bf16_t*)idn, id_scale, id_shift, id_gstride, (bf16_t*)out, P, C, ppb);
+    if ((size_t)groups * P * C * 2 > ((size_t)256 << 20))
+        hipLaunchKernelGGL(bn_act_add_kernel<true>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)z, scale, shift, z_gstride,
+                           act, (const bf16_t*)idn, id_scale, id_shift, id_gstride, (bf16_t*)out, P, C, ppb);
+    else
+        hipLaunchKernelGGL(bn_act_add_kernel<false>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)z, scale, shift, z_gstride,
+                           act, (const bf16_t*)idn, id_scale, id_shift, id_gstride, (bf16_t*)out, P, C, ppb);
     return adamml_check_launch("bn_act_add");
 }
 
@@ -685,8 +700,12 @@ extern "C" int adamml_residual_bwd(const void* g_out, const void* out, int act, 
     if ((za && (!veca || !sumsa)) || (zb && (!vecb || !sumsb))) return adamml_set_error(ADAMML_EINVAL, "residual_bwd: null BN operands");
     size_t ppb, nblk;
     reduce_grid(P, C, groups, &ppb, &nblk);
-    hipLaunchKernelGGL(residual_bwd_kernel, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g_out, (const bf16_t*)out, act,
-                       (bf16_t*)g2, (const bf16_t*)za, veca, sumsa, (const bf16_t*)zb, vecb, sumsb, P, C, ppb);
+    if ((size_t)groups * P * C * 2 > ((size_t)256 << 20))
+        hipLaunchKernelGGL(residual_bwd_kernel<true>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g_out, (const bf16_t*)out,
+                           act, (bf16_t*)g2, (const bf16_t*)za, veca, sumsa, (const bf16_t*)zb, vecb, sumsb, P, C, ppb);
+    else
+        hipLaunchKernelGGL(residual_bwd_kernel<false>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g_out, (const bf16_t*)out,
+                           act, (bf16_t*)g2, (const bf16_t*)za, veca, sumsa, (const bf16_t*)zb, vecb, sumsb, P, C, ppb);
     return adamml_check_launch("residual_bwd");
 }
 
