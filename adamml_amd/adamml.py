@@ -100,7 +100,6 @@ class AdaMML(nn.Module, MeanStdMixin):
         S = num_segments
         B = x[0].size(0)
         stacked = self.main_net.backbone_logits([m_x[m_i].flatten(0, 1) for m_i in range(self.num_modality)], side, groups=S)
-        seg_logits = [[l.view(S, B, -1)[i] for l in stacked] for i in range(S)]
         if not self.rng_policy:
             if side is not None:
                 with torch.cuda.stream(pside):
@@ -117,8 +116,7 @@ class AdaMML(nn.Module, MeanStdMixin):
             main.wait_stream(pside)
             for t in [decisions] + list(stacked):
                 t.record_stream(main)
-        all_logits = [self.main_net.fuse(seg_logits[i], decisions[i]) for i in range(num_segments)]
-        final_logits = torch.stack(all_logits, dim=1).mean(dim=1)
+        final_logits = self.main_net.fuse_segments(stacked, decisions, num_segments)
         return final_logits, decisions.permute((2, 0, 1))
 
     def _forward_skipping(self, x, p_x, m_x, num_segments, gumbel_exponential):
@@ -148,9 +146,7 @@ class AdaMML(nn.Module, MeanStdMixin):
             stacked.append(out)
             ran.append(int(idx.numel()))
         self.last_skip_stats = {"clips": S * B, "executed_per_modality": ran}
-        seg_logits = [[l.view(S, B, -1)[i] for l in stacked] for i in range(S)]
-        all_logits = [self.main_net.fuse(seg_logits[i], decisions[i]) for i in range(S)]
-        return torch.stack(all_logits, dim=1).mean(dim=1), decisions.permute((2, 0, 1))
+        return self.main_net.fuse_segments(stacked, decisions, S), decisions.permute((2, 0, 1))
 
     def _side_stream(self, dev, idx=0):
         if self._side is None or self._side[0].device != dev:

@@ -61,6 +61,12 @@ SIGNATURES = {
     "adamml_gemm_f32": [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _I, _I, _P],
     "adamml_sgd_step": [_P, _P, _P, _Z, _F, _F, _F, _I, _I, _P],
     "adamml_adam_step": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _P],
+    "adamml_policy_head_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "adamml_policy_head_bwd": [_P, _P, _P, _I, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "adamml_gumbel_gate_fwd": [_P, _P, _F, _P, _P, _I, _P],
+    "adamml_gumbel_gate_bwd": [_P, _P, _F, _P, _I, _P],
+    "adamml_fusion_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "adamml_fusion_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
 }
 
 _lib = None
@@ -163,6 +169,11 @@ def wgrad_workspace(desc, cin_true, device, depthwise=False, stem=False):
         buf = torch.empty(max(need // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
         _wgrad_ws[key] = buf
     return buf
+
+
+def ptr_array(tensors):
+    """HOST array of device pointers (const float* const* arguments); None entries become NULL."""
+    return (c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
 
 def require_gpu(t):

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from .common import MeanStdMixin
+from .functional import fuse_segments
 from .resnet import ResNet
 from .sound_mobilenet_v2 import MobileNetV2
 
@@ -67,18 +68,15 @@ class JointResNetMobileNetV2(nn.Module, MeanStdMixin):
                 out.append(net.forward_nhwc(x, groups))          # [G*B, classes] fp32
         return out
 
+    def fuse_segments(self, logits, decisions, num_segments):
+        """logits: list over modality of [S*B, classes] (segment-major); decisions [S,M,B] or None -> [B, classes]:
+        decision mask (:94), late fusion with cat(lf_weights, 1 - sum) or the plain mean (:112-127) and the mean over the
+        segments (models/adamml.py:88), one adamml_fusion_fwd launch."""
+        return fuse_segments(list(logits), decisions, self.lf_weights, num_segments)
+
     def fuse(self, logits, decisions=None):
-        out = []
-        for i, tmp in enumerate(logits):
-            if decisions is not None:
-                tmp = tmp * decisions[i].view((tmp.size(0), 1))  # :94
-            out.append(tmp)
-        out = torch.stack(out, dim=0)                            # M x B x C
-        if self.lf_weights is not None:
-            comple = torch.ones(1, dtype=self.lf_weights.dtype, device=self.lf_weights.device) - torch.sum(self.lf_weights, dim=0)
-            weights = torch.cat((self.lf_weights, comple), dim=0).view(-1, 1, 1)
-            return torch.sum(out * weights, dim=0)
-        return torch.mean(out, dim=0)
+        """One segment: logits list of [B, classes], decisions [M,B] or None."""
+        return self.fuse_segments(logits, decisions.reshape(1, len(logits), -1) if decisions is not None else None, 1)
 
     def forward(self, multi_modalities, decisions=None):
         """multi_modalities: list of NHWC bf16 frame tensors of ONE segment; decisions [M, B] or None."""

@@ -4,11 +4,10 @@ Mirrors models/policy_net.py:54-387 (MobileNetV2, JointMobileNetV2, PolicyNet, p
 import math
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .backbone import HipBackbone
 from .common import MeanStdMixin
-from .functional import hip_linear
+from .functional import hip_linear, policy_head, gumbel_gate
 from .mobilenet_common import BlockPlan, run_blocks
 from .runtime import Lazy, conv_bn, gap, ACT_NONE, ACT_RELU, ACT_RELU6
 
@@ -139,17 +138,6 @@ class JointMobileNetV2(nn.Module):
         return hip_linear(out, self.joint[2].weight, self.joint[2].bias, ACT_RELU)
 
 
-def gumbel_hard_last(logits, tau, expo=None):
-    """F.gumbel_softmax(logits, tau, hard=True)[:, -1] (models/policy_net.py:283-290); `expo` supplies the
-    Exponential(1) draw for reproducible parity runs, otherwise it is drawn on the device."""
-    if expo is None:
-        expo = torch.empty_like(logits).exponential_()
-    y_soft = F.softmax((logits - expo.log()) / tau, dim=-1)
-    index = y_soft.max(-1, keepdim=True)[1]
-    y_hard = torch.zeros_like(logits).scatter_(-1, index, 1.0)
-    return (y_hard - y_soft.detach() + y_soft)[:, -1]
-
-
 class PolicyNet(nn.Module):
     """models/policy_net.py:261-379."""
 
@@ -169,7 +157,9 @@ class PolicyNet(nn.Module):
             self.fcs = nn.ModuleList([nn.Linear(feature_dim, 2) for _ in range(self.num_modality)])
 
     def wrapper_gumbel_softmax(self, logits, expo=None):
-        return gumbel_hard_last(logits, self.temperature, expo)
+        if expo is None:
+            expo = torch.empty_like(logits).exponential_()
+        return gumbel_gate(logits, expo, self.temperature)
 
     def set_temperature(self, temperature):
         self.temperature = temperature
@@ -178,12 +168,6 @@ class PolicyNet(nn.Module):
         if decay_ratio:
             self.temperature *= decay_ratio
         print("Current temperature: {}".format(self.temperature), flush=True)
-
-    def _lstm_cell(self, x, h, c):
-        gates = hip_linear(x, self.lstm.weight_ih, self.lstm.bias_ih) + hip_linear(h, self.lstm.weight_hh, self.lstm.bias_hh)
-        gi, gf, gg, go = gates.chunk(4, dim=1)
-        c = torch.sigmoid(gf) * c + torch.sigmoid(gi) * torch.tanh(gg)
-        return torch.sigmoid(go) * torch.tanh(c), c
 
     def segment_features(self, x, i):
         """Joint feature [B, 2048] of segment i (models/policy_net.py:323-326); lets the caller interleave the policy
@@ -202,32 +186,23 @@ class PolicyNet(nn.Module):
         return self.decide(self.all_segment_features(x), gumbel_exponential)
 
     def decide(self, outs, gumbel_exponential=None):
-        """LSTM causality head + hard Gumbel-softmax over the per-segment features (models/policy_net.py:329-373)."""
+        """Causality head + hard Gumbel-softmax over the per-segment features (models/policy_net.py:329-373) on the HIP
+        head kernels: `lstm` = one adamml_policy_head_fwd launch for all S segments (the per-video recurrence runs inside
+        the kernel); None = FC heads on adamml_gemm_f32 + adamml_gumbel_gate_fwd.  gumbel_exponential: optional
+        Exponential(1) draw, [S, M*B, 2] (lstm) / [M*S*B, 2] (None) -- the reference's row order -- for parity runs."""
         M = self.num_modality
-        S = len(outs)
-        B = outs[0].shape[0]
+        feats = torch.stack(list(outs), 0) if not torch.is_tensor(outs) else outs        # [S, B, F]
+        S, B = feats.shape[0], feats.shape[1]
+        if gumbel_exponential is None:
+            gumbel_exponential = torch.empty(S * M * B, 2, dtype=torch.float32, device=feats.device).exponential_()
         if self.causality_modeling is None:
-            o = torch.stack(outs, 0).view(S * B, -1)
+            o = feats.reshape(S * B, -1)
             logits = torch.cat([hip_linear(o, fc.weight, fc.bias) for fc in self.fcs], dim=0)      # (MSB) x 2
-            expo = gumbel_exponential.reshape(M * S * B, 2) if gumbel_exponential is not None else None
-            decisions = self.wrapper_gumbel_softmax(logits, expo).view(M, S, -1).transpose(0, 1)
-            return decisions, logits.view(M, S, -1, 2).transpose(0, 1)
+            decisions = gumbel_gate(logits, gumbel_exponential.reshape(M * S * B, 2), self.temperature)
+            return decisions.view(M, S, -1).transpose(0, 1), logits.view(M, S, -1, 2).transpose(0, 1)
         if self.causality_modeling != 'lstm':
             raise ValueError("unknown mode")
-        all_logits, decisions = [], []
-        h = c = logits = None
-        for i in range(S):
-            if i == 0:
-                prev = outs[i].new_zeros(B, 2 * M)
-                h, c = outs[i].new_zeros(B, 256), outs[i].new_zeros(B, 256)
-            else:
-                prev = logits.view(M, -1, 2).permute(1, 0, 2).contiguous().view(-1, 2 * M)
-            h, c = self._lstm_cell(torch.cat((outs[i], prev), dim=-1), h, c)
-            logits = torch.cat([hip_linear(h, fc.weight, fc.bias) for fc in self.fcs], dim=0)       # MB x 2
-            all_logits.append(logits.view(M, -1, 2))
-            decisions.append(self.wrapper_gumbel_softmax(
-                logits, gumbel_exponential[i] if gumbel_exponential is not None else None))
-        return torch.stack(decisions, 0).view(S, M, -1), torch.stack(all_logits, 0)
+        return policy_head(feats, self.lstm, self.fcs, self.temperature, gumbel_exponential.reshape(S, M, B, 2))
 
     @property
     def network_name(self):

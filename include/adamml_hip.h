@@ -178,6 +178,45 @@ int adamml_sgd_step(float* p, const float* g, float* mom, size_t n, float lr, fl
 int adamml_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, hipStream_t stream);
 
+/* ---- policy causality head and late fusion -------------------------------------------------------------------------
+ * PolicyNet.forward, causality_modeling='lstm' (models/policy_net.py:341-370): nn.LSTMCell over the S segments with the
+ * previous segment's logits fed back, one nn.Linear(256, 2) head per modality, F.gumbel_softmax(tau, hard=True)[:, -1]
+ * (:283-290).  The recurrence is per video, so one workgroup runs one video through all S steps (one launch, no
+ * per-segment launches).  The caller first computes the feature half of the gates for ALL segments with
+ * adamml_gemm_f32: gates_x[S,B,4H] = feat[S*B,F] @ W_ih[:, :F]^T + b_ih;  this entry point adds b_hh, W_hh h and
+ * W_ih[:, F:] prev (w_prev = W_ih + F, ld_ih = F + 2M).  `expo` [S,M,B,2] is the Exponential(1) draw behind the Gumbel
+ * noise (torch.empty_like(logits).exponential_() in the reference), supplied by the caller so runs are reproducible.
+ * fc_w / fc_b are HOST arrays of M device pointers (fcs[m].weight [2,H], fcs[m].bias [2]); M <= 4; hidden must be 256.
+ * Outputs: decisions [S,M,B], logits [S,M,B,2]; saved for the backward pass: h_all / c_all [S+1,B,H] (slot 0 = the zero
+ * initial state), gate_act [S,B,4H] (post-nonlinearity i,f,g,o), prev_all [S,B,2M], ysoft [S,M,B,2]. */
+int adamml_policy_head_fwd(const float* gates_x, const float* w_prev, int ld_ih, const float* w_hh, const float* b_hh,
+                           const float* const* fc_w, const float* const* fc_b, const float* expo, float tau,
+                           float* decisions, float* logits, float* h_all, float* c_all, float* gate_act, float* prev_all,
+                           float* ysoft, int S, int B, int M, int hidden, hipStream_t stream);
+/* Reverse recurrence: d_decisions [S,M,B] (straight-through: the gradient flows through y_soft), d_logits_in [S,M,B,2]
+ * or NULL.  Writes d_gates [S,B,4H] (gradient of the pre-activation gates) and d_logits [S,M,B,2] (total gradient of each
+ * step's logits); the weight / bias / feature gradients are GEMMs over those two (adamml_gemm_f32), issued by the caller. */
+int adamml_policy_head_bwd(const float* d_decisions, const float* d_logits_in, const float* w_prev, int ld_ih,
+                           const float* w_hh, const float* const* fc_w, float tau, const float* c_all,
+                           const float* gate_act, const float* ysoft, float* d_gates, float* d_logits, int S, int B, int M,
+                           int hidden, hipStream_t stream);
+/* The gate alone, for the head without causality modelling (policy_net.py:330-340): rows of 2 logits. */
+int adamml_gumbel_gate_fwd(const float* logits, const float* expo, float tau, float* decisions, float* ysoft, int rows,
+                           hipStream_t stream);
+int adamml_gumbel_gate_bwd(const float* d_decisions, const float* ysoft, float tau, float* d_logits, int rows,
+                           hipStream_t stream);
+
+/* Decision-gated late fusion and segment mean (models/joint_resnet_mobilenetv2.py:94,112-127; models/adamml.py:86-88):
+ *   out[b,c] = 1/S sum_s sum_m w_m * (decisions[s,m,b] * x[m][s*B+b, c]),  w = cat(lf_weights, 1 - sum(lf_weights)) when
+ * lf_weights != NULL ([M-1], learnable), else 1/M.  x / d_x: HOST arrays of M device pointers to [S*B, C] fp32 logits;
+ * decisions may be NULL (no gating).  Backward: d_x[m] (entries may be NULL), d_decisions [S,M,B] or NULL, and
+ * d_lf_part [S*B, M] or NULL = per-row d out / d w_m (the caller folds rows and applies d w / d lf_weights). */
+int adamml_fusion_fwd(const float* const* x, const float* decisions, const float* lf_weights, float* out, int S, int B,
+                      int C, int M, hipStream_t stream);
+int adamml_fusion_bwd(const float* const* x, const float* decisions, const float* lf_weights, const float* g_out,
+                      float* const* d_x, float* d_decisions, float* d_lf_part, int S, int B, int C, int M,
+                      hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

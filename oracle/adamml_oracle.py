@@ -244,6 +244,13 @@ def policy_forward(sd, p, p_x, modality, num_frames, temperature, expo, causalit
         f = F.relu(F.linear(f, sd[p + "joint_net.joint.0.weight"], sd[p + "joint_net.joint.0.bias"]))
         f = F.relu(F.linear(f, sd[p + "joint_net.joint.2.weight"], sd[p + "joint_net.joint.2.bias"]))
         feats.append(f)
+    return policy_head(sd, p, feats, M, temperature, expo, causality)
+
+
+def policy_head(sd, p, feats, M, temperature, expo, causality="lstm"):
+    """Causality head of PolicyNet.forward (models/policy_net.py:329-373) on the per-segment joint features
+    (list of S tensors [B, 2048]): FC heads or LSTMCell with the previous logits fed back, then the hard Gumbel gate."""
+    S = len(feats)
     B = feats[0].shape[0]
     all_logits, decisions = [], []
     if causality is None:

@@ -1,0 +1,177 @@
+"""Parity of the policy causality head (LSTMCell recurrence + FC heads + hard Gumbel-softmax gate) and of the
+decision-gated late fusion: HIP kernels (adamml_policy_head_fwd/_bwd, adamml_gumbel_gate_*, adamml_fusion_*) against the
+oracle's restatement of models/policy_net.py:329-373 and models/joint_resnet_mobilenetv2.py:94,112-127 on identical fp32
+inputs.  fp32 end to end: outputs rtol 1e-4 / atol 1e-5 (expf / tanhf / reduction-order differences), gradients
+rtol 1e-3 relative to the gradient scale; hard decisions must be identical."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+from adamml_amd.functional import policy_head, gumbel_gate, fuse_segments, hip_linear  # noqa: E402
+from oracle import adamml_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def _head_modules(M, F, lstm, seed):
+    g = torch.Generator().manual_seed(seed)
+    mods = {}
+    if lstm:
+        cell = nn.LSTMCell(F + 2 * M, 256)
+        for p in cell.parameters():
+            p.data = (torch.rand(p.shape, generator=g) - 0.5) * 0.12
+        mods["lstm"] = cell
+    fcs = nn.ModuleList([nn.Linear(256 if lstm else F, 2) for _ in range(M)])
+    for p in fcs.parameters():
+        p.data = (torch.rand(p.shape, generator=g) - 0.5) * 0.5
+    mods["fcs"] = fcs
+    return mods
+
+
+def _sd(mods, dev):
+    sd = {}
+    if "lstm" in mods:
+        for k, v in mods["lstm"].named_parameters():
+            sd["p.lstm." + k] = v.detach().to(dev).clone().requires_grad_(True)
+    for i, fc in enumerate(mods["fcs"]):
+        sd["p.fcs.%d.weight" % i] = fc.weight.detach().to(dev).clone().requires_grad_(True)
+        sd["p.fcs.%d.bias" % i] = fc.bias.detach().to(dev).clone().requires_grad_(True)
+    return sd
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-20)
+
+
+@pytest.mark.parametrize("S,B,M", [(5, 6, 2), (5, 72, 2), (3, 5, 3), (1, 4, 1), (10, 9, 3)])
+def test_policy_head_lstm_matches_oracle(S, B, M):
+    F_ = 2048
+    mods = _head_modules(M, F_, True, seed=S * 100 + B)
+    g = torch.Generator().manual_seed(7)
+    feats = torch.rand(S, B, F_, generator=g) * 0.5
+    expo = torch.empty(S, M * B, 2).exponential_(generator=g)
+    r_dec, r_log = torch.randn(S, M, B, generator=g), torch.randn(S, M, B, 2, generator=g)
+    tau = 5.0 * 0.965 ** 3
+    # oracle (CPU fp32)
+    sd = _sd(mods, "cpu")
+    fo = feats.clone().requires_grad_(True)
+    d_o, l_o = O.policy_head(sd, "p.", list(fo.unbind(0)), M, tau, expo, "lstm")
+    ((d_o * r_dec).sum() + (l_o * r_log).sum()).backward()
+    # HIP
+    cell = mods["lstm"].to(DEV)
+    fcs = mods["fcs"].to(DEV)
+    fh = feats.to(DEV).requires_grad_(True)
+    d_h, l_h = policy_head(fh, cell, fcs, tau, expo.to(DEV).view(S, M, B, 2))
+    ((d_h * r_dec.to(DEV)).sum() + (l_h * r_log.to(DEV)).sum()).backward()
+    assert torch.allclose(l_h.cpu(), l_o, rtol=1e-4, atol=1e-5), _rel(l_h.cpu(), l_o)
+    assert torch.equal(d_h.detach().cpu().round(), d_o.detach().round())
+    assert torch.allclose(d_h.detach().cpu(), d_o.detach(), rtol=0, atol=3e-7)       # 1 or 0 up to one rounding of y_soft
+    assert _rel(fh.grad.cpu(), fo.grad) < 1e-3
+    for k, ref in (("weight_ih", "p.lstm.weight_ih"), ("weight_hh", "p.lstm.weight_hh"), ("bias_ih", "p.lstm.bias_ih"),
+                   ("bias_hh", "p.lstm.bias_hh")):
+        assert _rel(getattr(cell, k).grad.cpu(), sd[ref].grad) < 1e-3, k
+    for i, fc in enumerate(fcs):
+        assert _rel(fc.weight.grad.cpu(), sd["p.fcs.%d.weight" % i].grad) < 1e-3
+        assert _rel(fc.bias.grad.cpu(), sd["p.fcs.%d.bias" % i].grad) < 1e-3
+
+
+def test_policy_head_matches_stock_lstmcell():
+    """Same head against torch's own nn.LSTMCell / F.gumbel_softmax-shaped arithmetic on the GPU (not the oracle):
+    guards the gate order i,f,g,o and the [m0 j0, m0 j1, m1 j0, ...] feedback layout of policy_net.py:353."""
+    S, B, M, F_ = 4, 8, 2, 2048
+    mods = _head_modules(M, F_, True, seed=3)
+    cell, fcs = mods["lstm"].to(DEV), mods["fcs"].to(DEV)
+    feats = torch.rand(S, B, F_, device=DEV)
+    expo = torch.empty(S, M, B, 2, device=DEV).exponential_()
+    d_h, l_h = policy_head(feats, cell, fcs, 5.0, expo)
+    h = c = None
+    logits = None
+    for s in range(S):
+        prev = torch.zeros(B, 2 * M, device=DEV) if s == 0 else logits.view(M, -1, 2).permute(1, 0, 2).contiguous().view(-1, 2 * M)
+        h, c = cell(torch.cat((feats[s], prev), -1), None if s == 0 else (h, c))
+        logits = torch.cat([fc(h) for fc in fcs], 0)
+        assert torch.allclose(l_h[s].reshape(M * B, 2), logits, rtol=1e-4, atol=1e-5)
+        y = torch.softmax((logits - expo[s].reshape(M * B, 2).log()) / 5.0, -1)
+        assert torch.equal(d_h[s].reshape(-1).round(), (y[:, 1] > y[:, 0]).float())
+
+
+@pytest.mark.parametrize("R", [1, 37, 4096])
+def test_gumbel_gate_matches_oracle(R):
+    g = torch.Generator().manual_seed(R)
+    logits = torch.randn(R, 2, generator=g)
+    expo = torch.empty(R, 2).exponential_(generator=g)
+    r = torch.randn(R, generator=g)
+    lo = logits.clone().requires_grad_(True)
+    d_o = O.gumbel_hard_select(lo, 2.5, expo)
+    (d_o * r).sum().backward()
+    lh = logits.to(DEV).requires_grad_(True)
+    d_h = gumbel_gate(lh, expo.to(DEV), 2.5)
+    (d_h * r.to(DEV)).sum().backward()
+    assert torch.equal(d_h.detach().cpu().round(), d_o.detach().round())
+    assert torch.allclose(d_h.detach().cpu(), d_o.detach(), rtol=0, atol=3e-7)
+    assert torch.allclose(lh.grad.cpu(), lo.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_policy_head_without_causality_matches_oracle():
+    S, B, M, F_ = 5, 6, 3, 2048
+    mods = _head_modules(M, F_, False, seed=11)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.rand(S, B, F_, generator=g) * 0.5
+    expo = torch.empty(M * S * B, 2).exponential_(generator=g)
+    sd = _sd(mods, "cpu")
+    d_o, l_o = O.policy_head(sd, "p.", list(feats.unbind(0)), M, 5.0, expo, None)
+    fcs = mods["fcs"].to(DEV)
+    o = feats.to(DEV).reshape(S * B, -1)
+    logits = torch.cat([hip_linear(o, fc.weight, fc.bias) for fc in fcs], 0)
+    d_h = gumbel_gate(logits, expo.to(DEV), 5.0).view(M, S, B).transpose(0, 1)
+    assert torch.allclose(logits.view(M, S, B, 2).transpose(0, 1).cpu(), l_o, rtol=1e-4, atol=1e-5)
+    assert torch.equal(d_h.detach().cpu().round(), d_o.detach().round())
+
+
+@pytest.mark.parametrize("M,learnable,gated", [(2, True, True), (2, False, True), (3, True, True), (2, True, False), (1, False, True)])
+def test_fusion_matches_reference_formula(M, learnable, gated):
+    """out = mean_s( sum_m w_m * (x_m[s] * dec[s,m]) ), w = cat(lf, 1 - sum lf) or 1/M
+    (models/joint_resnet_mobilenetv2.py:94,112-127 per segment, models/adamml.py:88 over segments)."""
+    S, B, C = 5, 7, 31
+    g = torch.Generator().manual_seed(M * 10 + learnable)
+    xs = [torch.randn(S * B, C, generator=g) for _ in range(M)]
+    dec = (torch.rand(S, M, B, generator=g) > 0.4).float() + 1e-3 * torch.randn(S, M, B, generator=g)
+    lf = torch.rand(M - 1, generator=g) * 0.5 if learnable and M > 1 else None
+    r = torch.randn(B, C, generator=g)
+
+    def ref(xs, dec, lf):
+        outs = []
+        for s in range(S):
+            o = []
+            for m in range(M):
+                t = xs[m].view(S, B, C)[s]
+                if dec is not None:
+                    t = t * dec[s, m].view(B, 1)
+                o.append(t)
+            o = torch.stack(o, 0)
+            if lf is not None:
+                w = torch.cat((lf, torch.ones(1) - lf.sum(0, keepdim=True)), 0).view(-1, 1, 1)
+                outs.append((o * w).sum(0))
+            else:
+                outs.append(o.mean(0))
+        return torch.stack(outs, 1).mean(1)
+
+    xo = [x.clone().requires_grad_(True) for x in xs]
+    do = dec.clone().requires_grad_(True) if gated else None
+    lo = lf.clone().requires_grad_(True) if lf is not None else None
+    out_o = ref(xo, do, lo)
+    (out_o * r).sum().backward()
+    xh = [x.to(DEV).requires_grad_(True) for x in xs]
+    dh = dec.to(DEV).requires_grad_(True) if gated else None
+    lh = lf.to(DEV).requires_grad_(True) if lf is not None else None
+    out_h = fuse_segments(xh, dh, lh, S)
+    (out_h * r.to(DEV)).sum().backward()
+    assert torch.allclose(out_h.detach().cpu(), out_o.detach(), rtol=1e-5, atol=1e-6)
+    for a, b in zip(xh, xo):
+        assert torch.allclose(a.grad.cpu(), b.grad, rtol=1e-5, atol=1e-7)
+    if gated:
+        assert torch.allclose(dh.grad.cpu(), do.grad, rtol=1e-4, atol=1e-6)
+    if lf is not None:
+        assert torch.allclose(lh.grad.cpu(), lo.grad, rtol=1e-4, atol=1e-5)
