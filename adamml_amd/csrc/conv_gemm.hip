@@ -33,6 +33,15 @@ struct ConvP {
     const bf16_t* bn_z;          // raw conv output that produced the consumer's input (same shape as y), or null
     const float* bn_vec;         // [4][Cout']: scale, shift, mean, invstd of that BatchNorm
     int bn_act;
+    // residual form of that epilogue (RES kernels; the gradient flows into the OUTPUT of a residual add,
+    // out = act(bn(z) [+ bn2(z2)] + ..)): the activation mask comes from the stored block output, `accumulate` adds the
+    // identity-path gradient already in y, and the sums of a second BatchNorm feeding the same add (downsample branch)
+    // are accumulated alongside
+    const bf16_t* res_out;       // block output [same shape as y]
+    int res_act;
+    const bf16_t* bn_z2;         // raw output of the second BatchNorm'd operand of the add, or null
+    const float* bn_vec2;
+    double* stats2;
     // MODE 3 (one parity class of the data gradient of a stride-2 conv, see conv_dgrad_stride2)
     int wK;                      // weight row stride in elements (== K except in MODE 3, where K covers the class taps only)
     int cls_nt;                  // taps of this class (0..4)
@@ -61,14 +70,18 @@ __device__ __forceinline__ void static_for(F&& f) {
 // PD = register prefetch depth (K steps of global loads in flight).  PD 1 keeps 3-4 workgroups per CU (latency hidden by
 // occupancy: best for the big, short-K layers); PD 3 is for small grids with long K loops (layer3/4), where a CU holds a
 // single workgroup and only explicit look-ahead hides the HBM round trip.
-template <int BC, int MODE, int PD>
-__global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
+// RES: residual form of the BatchNorm-fused data-gradient epilogue (MODE 0 only).  Its epilogue keeps four 16-byte streams
+// per row in flight and two sets of per-channel vectors, so it is compiled for 2 workgroups per CU (256 VGPRs) as its own
+// instantiation -- inside the shared kernel it pushed every MODE 0 instance into scratch spills.
+template <int BC, int MODE, int PD, bool RES = false>
+__global__ __launch_bounds__(NTHREADS, RES ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
     constexpr int WROWS = BC / 64;          // weight rows staged per thread
     constexpr int TILE_BYTES = (BP + BC) * 64;
     constexpr int EPI_BYTES = BP * (BC * 2 + 16);
     constexpr int STAGE_BYTES = (2 * TILE_BYTES) > EPI_BYTES ? (2 * TILE_BYTES) : EPI_BYTES;
-    constexpr int SMEM_BYTES = STAGE_BYTES + 2 * BC * 4 + 256 + (MODE == 3 ? BP * 4 + 16 : 0);   // + per-channel sums + tap-offset table (+ MODE 3: output row table, weight tap table)
+    constexpr int CS2_OFF = STAGE_BYTES + 2 * BC * 4 + 256 + (MODE == 3 ? BP * 4 + 16 : 0);     // second sum set (RES)
+    constexpr int SMEM_BYTES = CS2_OFF + (RES ? 2 * BC * 4 : 0);   // + per-channel sums + tap-offset table (+ MODE 3: output row table, weight tap table)
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
 
     {   // BatchNorm group of this workgroup: one launch covers the S per-segment calls of the reference
@@ -78,6 +91,10 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
         if (p.stats) p.stats += (size_t)g * ADAMML_STAT_SLOTS * 2 * p.Cout;
         if (p.in_scale) { p.in_scale += (size_t)g * p.in_gstride; p.in_shift += (size_t)g * p.in_gstride; }
         if (p.bn_z) { p.bn_z += (size_t)g * p.gy; p.bn_vec += (size_t)g * 4 * p.Cout; }
+        if (RES) {
+            p.res_out += (size_t)g * p.gy;
+            if (p.bn_z2) { p.bn_z2 += (size_t)g * p.gy; p.bn_vec2 += (size_t)g * 4 * p.Cout; p.stats2 += (size_t)g * ADAMML_STAT_SLOTS * 2 * p.Cout; }
+        }
     }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -128,8 +145,12 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
     constexpr int CROW = BC * 2 + 16;                  // LDS row stride (bytes): +16 B skews the banks
     static_assert(BP * CROW <= STAGE_BYTES, "epilogue tile must fit the staging buffers");
     float* cs = reinterpret_cast<float*>(smem + STAGE_BYTES);          // [2*BC] channel sums, live across the tile loop
+    float* cs2 = reinterpret_cast<float*>(smem + CS2_OFF);             // [2*BC] sums of the second BatchNorm (RES only)
+    const bool second = RES && p.bn_z2 != nullptr;
     if (p.stats) {
         for (int i = tid; i < 2 * BC; i += NTHREADS) cs[i] = 0.f;
+        if (second)
+            for (int i = tid; i < 2 * BC; i += NTHREADS) cs2[i] = 0.f;
     }
     constexpr int CPR = BC / 8;                        // 16-byte chunks per tile row
     constexpr int RSTEP = NTHREADS / CPR;              // rows covered per pass
@@ -308,9 +329,9 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
     // ---- epilogue: stage the bf16 tile through LDS, store 16 B per lane fully coalesced, and accumulate the
     //      per-channel sum / sum-of-squares of the stored (rounded) values on the way out -------------------
     // (the last K step ended with __syncthreads(): every wave is done reading the operand tiles)
-    f32x8 esum, esq;
+    f32x8 esum, esq, esq2;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) esum[i] = esq[i] = 0.f;
+    for (int i = 0; i < 8; ++i) esum[i] = esq[i] = esq2[i] = 0.f;
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
@@ -320,7 +341,59 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
             *reinterpret_cast<bf16x4*>(smem + prow * CROW + ccol * 2) = f32_to_bf4(acc[ct][pt]);
         }
     __syncthreads();
-    if (eco < p.Cout && p.bn_z) {
+    if (RES) {
+        // Residual form: y already holds the identity-path gradient (accumulate), the mask is act'(block output), and a
+        // second BatchNorm operand of the add (downsample branch) gets its sum(g' * zhat2) in the same pass.  Rows are
+        // processed in batches of EB: ALL global loads of a batch (z, identity-path gradient, block output, second z) are
+        // issued before the first store.  Loads and stores retire in order through vmcnt on this ISA, so a row-at-a-time
+        // loop (load, mask, store, next row) exposes one HBM round trip per row, and this epilogue is the whole kernel
+        // (K = 64..512: a few MFMA steps per tile).
+        if (eco < p.Cout) {
+        const f32x8 mu = load_f32x8(p.bn_vec + 2 * p.Cout + eco), is = load_f32x8(p.bn_vec + 3 * p.Cout + eco);
+        f32x8 mu2, is2;
+        if (second) { mu2 = load_f32x8(p.bn_vec2 + 2 * p.Cout + eco); is2 = load_f32x8(p.bn_vec2 + 3 * p.Cout + eco); }
+        const float rlo = act_lo(p.res_act), rhi = act_hi(p.res_act);
+        constexpr int NR = BP / RSTEP, EB = NR < 4 ? NR : 4;
+#pragma unroll
+        for (int b0 = 0; b0 < NR; b0 += EB) {
+            bf16x8 zr[EB], dr[EB], orr[EB], z2r[EB];
+            size_t pr[EB];
+            bool ok[EB];
+#pragma unroll
+            for (int j = 0; j < EB; ++j) {
+                const int r = erow0 + (b0 + j) * RSTEP;
+                ok[j] = p0 + r < p.P;
+                pr[j] = (size_t)(ok[j] ? p0 + r : p0) * p.Cout + eco;       // clamped: out-of-range rows re-read row p0, never stored
+                zr[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.bn_z + pr[j]));
+                if (p.accumulate) dr[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.y + pr[j]));
+                orr[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.res_out + pr[j]));
+                if (second) z2r[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.bn_z2 + pr[j]));
+            }
+#pragma unroll
+            for (int j = 0; j < EB; ++j) {
+                const int r = erow0 + (b0 + j) * RSTEP;
+                f32x8 f = bf8_to_f32(*reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16));
+                const f32x8 zv = bf8_to_f32(zr[j]);
+                if (p.accumulate) f += bf8_to_f32(dr[j]);
+                const f32x8 ov = bf8_to_f32(orr[j]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] *= mask_act(ov[i], rlo, rhi);
+                const bf16x8 v = f32_to_bf8(f);
+                if (ok[j]) *reinterpret_cast<bf16x8*>(p.y + pr[j]) = v;
+                const float keep = ok[j] ? 1.f : 0.f;
+                f = bf8_to_f32(v) * keep;
+                esum += f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) esq[i] += f[i] * (zv[i] - mu[i]) * is[i];
+                if (second) {
+                    const f32x8 z2 = bf8_to_f32(z2r[j]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) esq2[i] += f[i] * (z2[i] - mu2[i]) * is2[i];
+                }
+            }
+        }
+        }
+    } else if (eco < p.Cout && p.bn_z) {
         // data gradient w.r.t. a lazily normalised tensor: apply the activation mask here, store g' and accumulate
         // sum(g') and sum(g' * zhat) -- the BatchNorm-backward reduction pass never has to re-read g and z
         const f32x8 sc = load_f32x8(p.bn_vec + eco), sh = load_f32x8(p.bn_vec + p.Cout + eco);
@@ -394,38 +467,42 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
         // of a with the lower half (even rows) of b", so a' + b' folds TWO values at once and halves the register count
         // per step) -- 24 VALU ops instead of 32-48 ds_bpermute, which had made this epilogue LDS-pipe-bound (-30 % on
         // the HBM-bound 1x1 layers).  16 values -> 4 registers per lane, then 4 LDS adds per lane.
-        float v[16];
+        auto fold = [&](const f32x8& s1, const f32x8& s2, float* dst) {
+            float v[16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { v[i] = esum[i]; v[8 + i] = esq[i]; }
-        if (CPR == 8) {
+            for (int i = 0; i < 8; ++i) { v[i] = s1[i]; v[8 + i] = s2[i]; }
+            if (CPR == 8) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i)              // lanes l and l+8 of a 16-lane row: DPP row_ror:8
-                v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), 0x128, 0xf, 0xf, false));
-        }
-        float u[8], wv[4];
+                for (int i = 0; i < 16; ++i)              // lanes l and l+8 of a 16-lane row: DPP row_ror:8
+                    v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), 0x128, 0xf, 0xf, false));
+            }
+            float u[8], wv[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            // (inline asm: with this toolchain the __builtin_amdgcn_permlane32_swap result pair is mis-compiled when both
-            // halves feed a float add -- verified on hardware, tools/scratch/fold.hip; s_nop covers the VALU->permlane hazard)
-            float a = v[2 * i], b = v[2 * i + 1];
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-            u[i] = a + b;                                   // rows 0,1: v[2i]; rows 2,3: v[2i+1]
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float a = u[2 * j], b = u[2 * j + 1];
-            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-            wv[j] = a + b;                                  // row r holds value 4j + {0,2,1,3}[r]
-        }
-        const int lrow = lane >> 4;
-        const int vsel = ((lrow & 1) << 1) | (lrow >> 1);
-        if (eco < p.Cout && (CPR >= 16 || !(lane & 8))) {
+            for (int i = 0; i < 8; ++i) {
+                // (inline asm: with this toolchain the __builtin_amdgcn_permlane32_swap result pair is mis-compiled when both
+                // halves feed a float add -- verified on hardware, tools/scratch/fold.hip; s_nop covers the VALU->permlane hazard)
+                float a = v[2 * i], b = v[2 * i + 1];
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+                u[i] = a + b;                                   // rows 0,1: v[2i]; rows 2,3: v[2i+1]
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int id = 4 * j + vsel;              // 0..7: sum of channel id; 8..15: second moment of channel id-8
-                atomicAdd(&cs[(id >> 3) * BC + ech * 8 + (id & 7)], wv[j]);
+                float a = u[2 * j], b = u[2 * j + 1];
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+                wv[j] = a + b;                                  // row r holds value 4j + {0,2,1,3}[r]
             }
-        }
+            const int lrow = lane >> 4;
+            const int vsel = ((lrow & 1) << 1) | (lrow >> 1);
+            if (eco < p.Cout && (CPR >= 16 || !(lane & 8))) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int id = 4 * j + vsel;              // 0..7: sum of channel id; 8..15: second moment of channel id-8
+                    atomicAdd(&dst[(id >> 3) * BC + ech * 8 + (id & 7)], wv[j]);
+                }
+            }
+        };
+        fold(esum, esq, cs);
+        if (second) fold(esum, esq2, cs2);
     }
     __syncthreads();                                   // staging tile consumed before the next tile's operands land
     }   // tile loop
@@ -436,6 +513,15 @@ __global__ __launch_bounds__(NTHREADS, (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 1
             if (c0 + i < p.Cout) {
                 atomicAdd(&slot[c0 + i], (double)cs[i]);
                 atomicAdd(&slot[p.Cout + c0 + i], (double)cs[BC + i]);
+            }
+        }
+        if (second) {
+            double* slot2 = p.stats2 + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * p.Cout;
+            for (int i = tid; i < BC; i += NTHREADS) {
+                if (c0 + i < p.Cout) {
+                    atomicAdd(&slot2[c0 + i], (double)cs2[i]);
+                    atomicAdd(&slot2[p.Cout + c0 + i], (double)cs2[BC + i]);
+                }
             }
         }
     }
@@ -856,10 +942,12 @@ int adamml_conv3x3_c64_wgrad_launch(const adamml_conv_desc_t* d, const void* dz,
 
 // one parity class (ph, pw) of the data gradient of a stride-2 conv (see conv_dgrad_stride2)
 struct DgradClass { int nt; unsigned code; int ph, pw, OHc, OWc; };
+// residual form of the BatchNorm-fused data-gradient epilogue (ConvP::res_out ..)
+struct ResEpi { const void* res_out; int res_act; const void* bn_z2; const float* bn_vec2; double* stats2; };
 
 static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
                        const float* in_shift, void* y, double* stats, const void* bn_z, const float* bn_vec, int bn_act,
-                       hipStream_t stream, const DgradClass* cls = nullptr) {
+                       hipStream_t stream, const DgradClass* cls = nullptr, const ResEpi* res = nullptr) {
     if (!d || !x || !w_packed || !y) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: null argument");
     if (d->Cin % 8 || d->Cout % 8) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: channels must be multiples of 8 (Cin=%d Cout=%d)", d->Cin, d->Cout);
     if (!cls && adamml_conv3x3_c64_supported(d))
@@ -868,6 +956,8 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.in_scale = in_scale; p.in_shift = in_shift;
     p.y = (bf16_t*)y; p.stats = stats;
     p.bn_z = (const bf16_t*)bn_z; p.bn_vec = bn_vec; p.bn_act = bn_act;
+    p.res_out = res ? (const bf16_t*)res->res_out : nullptr; p.res_act = res ? res->res_act : 0;
+    p.bn_z2 = res ? (const bf16_t*)res->bn_z2 : nullptr; p.bn_vec2 = res ? res->bn_vec2 : nullptr; p.stats2 = res ? res->stats2 : nullptr;
     const int groups = d->groups < 1 ? 1 : d->groups;
     p.gx = (size_t)d->N * d->H * d->W * d->Cin;
     p.gy = (size_t)d->N * d->OH * d->OW * d->Cout;
@@ -911,6 +1001,12 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     if (mode == 2 && !multitap) { p.cin_shift = 30; }      // 1x1 strided dgrad: tap = k >> 30 = 0, ci = k
     const int nk = ceil_div(p.K, BK);
     const bool deep = (long)grid.x * grid.y <= 768 && nk >= 8;        // < 1 wave of workgroups per CU slot and a long K loop
+    if (res) {
+        if (mode != 0) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res: only 1x1 / stride-1 convs");
+        if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, true>), grid, block, 0, stream, p);
+        return adamml_check_launch("conv_bwd_data_res");
+    }
 #define LAUNCH_CONV(BCV, MODEV)                                                                             \
     do {                                                                                                    \
         if (deep) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 3>), grid, block, 0, stream, p);          \
@@ -989,6 +1085,27 @@ extern "C" int adamml_conv_bwd_data_bn(const adamml_conv_desc_t* d, const void* 
     g.stride = 1; g.up = d->stride; g.pad = d->KH - 1 - d->pad;
     g.act = ACT_NONE; g.accumulate = 0; g.in_gstride = 0;
     return conv_launch(&g, dz, w_dgrad_packed, nullptr, nullptr, dx, sums, z_in, bn_vec, act, stream);
+}
+
+extern "C" int adamml_conv_bwd_data_res_supported(const adamml_conv_desc_t* d) {
+    return d && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cin % 8 == 0 && d->Cout % 8 == 0 ? 1 : 0;
+}
+
+extern "C" int adamml_conv_bwd_data_res(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
+                                        int accumulate, const void* res_out, int res_act, const void* z_a, const float* vec_a,
+                                        double* sums_a, const void* z_b, const float* vec_b, double* sums_b,
+                                        hipStream_t stream) {
+    if (!d || !res_out || !z_a || !vec_a || !sums_a) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_res: null argument");
+    if ((z_b != nullptr) != (vec_b != nullptr) || (z_b != nullptr) != (sums_b != nullptr))
+        return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_res: incomplete second BatchNorm operand");
+    if (!adamml_conv_bwd_data_res_supported(d)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res: only 1x1 / stride-1 convs");
+    adamml_conv_desc_t g = *d;
+    g.N = d->N; g.H = d->OH; g.W = d->OW; g.Cin = d->Cout;
+    g.OH = d->H; g.OW = d->W; g.Cout = d->Cin;
+    g.stride = 1; g.up = 1; g.pad = 0;
+    g.act = ACT_NONE; g.accumulate = accumulate ? 1 : 0; g.in_gstride = 0;
+    ResEpi r{res_out, res_act, z_b, vec_b, sums_b};
+    return conv_launch(&g, dz, w_dgrad_packed, nullptr, nullptr, dx, sums_a, z_a, vec_a, ACT_NONE, stream, nullptr, &r);
 }
 
 extern "C" int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,

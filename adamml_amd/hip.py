@@ -34,6 +34,7 @@ SIGNATURES = {
     "adamml_conv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "adamml_conv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
     "adamml_conv_bwd_data_bn": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
+    "adamml_conv_bwd_data_res": [_DESC, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "adamml_residual_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _P],
     "adamml_conv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _I, _P, _Z, _P],
     "adamml_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -93,6 +94,8 @@ def load():
     lib.adamml_dwconv_bwd_weight_workspace.restype = c_size_t
     lib.adamml_conv_fused_input_supported.argtypes = [_DESC]
     lib.adamml_conv_fused_input_supported.restype = c_int
+    lib.adamml_conv_bwd_data_res_supported.argtypes = [_DESC]
+    lib.adamml_conv_bwd_data_res_supported.restype = c_int
     lib.adamml_conv_stem_supported.argtypes = [_DESC]
     lib.adamml_conv_stem_supported.restype = c_int
     lib.adamml_version.restype = c_int

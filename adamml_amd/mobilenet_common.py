@@ -18,7 +18,8 @@ def run_blocks(rt, h, plans):
             x = temporal_pool(rt, x, bp.tpool, "max")
         y = x
         if bp.pw is not None:
-            y = conv_bn(rt, y, bp.pw[0], bp.pw[1], ACT_RELU6)
+            # the expansion conv is recorded before the block's own residual add, so it is reversed after it: last consumer
+            y = conv_bn(rt, y, bp.pw[0], bp.pw[1], ACT_RELU6, last_consumer=True)
         y = conv_bn(rt, y, bp.dw[0], bp.dw[1], ACT_RELU6)
         y = conv_bn(rt, y, bp.pwl[0], bp.pwl[1], ACT_NONE, sole_consumer=True)      # the dw output feeds only this conv
         h = add_act(rt, y, x, ACT_NONE) if bp.residual else y

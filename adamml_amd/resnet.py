@@ -97,7 +97,9 @@ class ResNet(HipBackbone, MeanStdMixin):
                 # the downsample branch is issued FIRST so that its data gradient runs LAST in the reversed tape: it then
                 # accumulates into the gradient conv1 already wrote, and a stride-2 1x1 only touches a quarter of the pixels
                 idn = conv_bn(rt, h, b._csd, b.downsample[1], ACT_NONE) if b._csd is not None else h
-                o = conv_bn(rt, h, b._cs1, b.bn1, ACT_RELU)
+                # without a downsample branch conv1 is the last consumer of h in the reversed tape (the identity path of
+                # the add is reversed first): its data-gradient epilogue finishes the previous block's residual backward
+                o = conv_bn(rt, h, b._cs1, b.bn1, ACT_RELU, last_consumer=b._csd is None)
                 o = conv_bn(rt, o, b._cs2, b.bn2, ACT_RELU, sole_consumer=True)
                 o = conv_bn(rt, o, b._cs3, b.bn3, ACT_NONE, sole_consumer=True)
                 h = add_act(rt, o, idn, ACT_RELU, idn_sole=b._csd is not None)

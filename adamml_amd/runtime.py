@@ -25,7 +25,7 @@ def pad8(c):
 class Lazy:
     """Activation tensor [G*N,H,W,C] bf16 (G BatchNorm groups, group-major) whose value is act(scale*data + shift)
     (scale None -> data); group g uses scale + g*gs, shift + g*gs (gs == 0: one pair for all groups)."""
-    __slots__ = ("data", "scale", "shift", "gs", "act", "grad", "requires_grad", "vec", "src", "pre_sums")
+    __slots__ = ("data", "scale", "shift", "gs", "act", "grad", "requires_grad", "vec", "src", "pre_sums", "res", "res_done")
 
     def __init__(self, data, scale=None, shift=None, act=ACT_NONE, requires_grad=True, gs=0):
         self.data, self.scale, self.shift, self.act, self.gs = data, scale, shift, act, gs
@@ -34,6 +34,8 @@ class Lazy:
         self.vec = None             # train-mode BatchNorm vectors [G,4,C] (scale, shift, mean, invstd) of a lazy tensor
         self.src = None             # lazy tensor this plain tensor is the materialisation of
         self.pre_sums = None        # BatchNorm-backward sums already accumulated by the producer of .grad
+        self.res = None             # (z, idn, act, idn_sole) of the residual add that produced this tensor
+        self.res_done = False       # .grad is already act-masked and the add's BatchNorm-backward sums are in place
 
     @property
     def shape(self):
@@ -237,10 +239,16 @@ def materialize(rt, x):
     return a
 
 
-def conv_bn(rt, x, cs, bn, act, sole_consumer=False):
+def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
     """conv (dense or depthwise) + train/eval BatchNorm + activation, as one lazy tensor.
     sole_consumer=True promises that this conv is the ONLY consumer of x: its data-gradient epilogue may then apply
-    x's activation mask and accumulate x's BatchNorm-backward sums (no separate reduction pass over g and z)."""
+    x's activation mask and accumulate x's BatchNorm-backward sums (no separate reduction pass over g and z).
+    last_consumer=True promises that every other consumer of x has already contributed to x.grad when this conv's
+    backward runs (conv1 of a bottleneck: the identity path of the residual add is recorded later, hence reversed
+    earlier).  If x is the output of a residual add, the data-gradient epilogue then finishes that add's backward too:
+    it adds the identity-path gradient, applies the add's activation mask and accumulates the BatchNorm-backward sums
+    of the add's operands (adamml_conv_bwd_data_res) -- the gradient of the block output is written once, already
+    masked, instead of being written, re-read, masked and written again by adamml_residual_bwd."""
     G = rt.groups
     if x.scale is not None and not cs.depthwise and cs.kh * cs.kw > 1 and \
             not hip.load().adamml_conv_fused_input_supported(byref(cs.desc(x.shape, x.act, G, x.gs))):
@@ -312,6 +320,18 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False):
                 tgt = x.src if x.src is not None else x
                 if cs.depthwise:
                     call("adamml_dwconv_bwd_data", byref(d), ptr(dz), ptr(cs.w_fwd), ptr(x.grad), acc)
+                elif last_consumer and _residual_fusable(x, d):
+                    z, idn, ract, idn_sole = x.res
+                    fb = idn is not None and idn_sole and idn.requires_grad and idn.vec is not None and idn.grad is None
+                    sa = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS)
+                    sb = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS) if fb else None
+                    hip.next_meta = (2 * macs, in_b * (3 + acc + (1 if fb else 0)) + out_b + w_b, kern)
+                    call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc, ptr(x.data), ract,
+                         ptr(z.data), ptr(z.vec), ptr(sa), ptr(idn.data) if fb else None, ptr(idn.vec) if fb else None, ptr(sb))
+                    z.pre_sums = sa
+                    if fb:
+                        idn.pre_sums = sb
+                    x.res_done = True
                 elif sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None:
                     sums = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS)
                     hip.next_meta = (2 * macs, 2 * in_b + out_b + w_b, kern)
@@ -322,6 +342,17 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False):
                     call("adamml_conv_bwd_data", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc)
         rt.tape.record(bwd)
     return out
+
+
+def _residual_fusable(x, d):
+    """x is the output of a residual add whose backward (mask + BatchNorm-backward sums of its BatchNorm'd operand) can
+    be finished by the data-gradient epilogue of the conv described by d."""
+    if x.res is None or x.res_done or x.src is not None:
+        return False
+    z = x.res[0]
+    if not (z.requires_grad and z.vec is not None and z.grad is None and z.pre_sums is None):
+        return False
+    return bool(hip.load().adamml_conv_bwd_data_res_supported(byref(d)))
 
 
 def _accum_grad(t, g):
@@ -347,6 +378,7 @@ def add_act(rt, z, idn, act, idn_sole=False):
          ptr(idn.scale) if idn is not None else None, ptr(idn.shift) if idn is not None else None,
          idn.gs if idn is not None else 0, ptr(out_t), P, C, G)
     out = Lazy(out_t)
+    out.res = (z, idn, act, idn_sole)
     if rt.tape.need_grad:
         def bwd():
             g = out.grad
@@ -355,6 +387,13 @@ def add_act(rt, z, idn, act, idn_sole=False):
                 return
             fa = z.requires_grad and z.vec is not None and z.grad is None
             fb = idn is not None and idn_sole and idn.requires_grad and idn.vec is not None and idn.grad is None
+            if out.res_done:
+                # the last consumer's data-gradient epilogue already masked g and accumulated the sums (conv_bn)
+                out.res_done = False
+                _accum_grad(z, g)
+                if idn is not None:
+                    _accum_grad(idn, g)
+                return
             g2 = torch.empty_like(g) if act != ACT_NONE else g
             if fa or fb:
                 sa = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS) if fa else None

@@ -68,6 +68,18 @@ int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const void
  * then skipped. */
 int adamml_conv_bwd_data_bn(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx, const void* z_in,
                             const float* bn_vec, int act, double* sums, hipStream_t stream);
+
+/* Data gradient of a 1x1 / stride-1 conv whose INPUT is the output of a residual add  out = act(bn_a(z_a) + idn)
+ * (models/resnet.py:110-111; sound_mobilenet_v2.py:67), finishing that add's backward in the epilogue:
+ *   g' = (W^T dz [+ dx, when accumulate: the identity-path gradient already stored there]) * act'(res_out)
+ * is written to dx, and sum(g'), sum(g' * zhat_a) go to sums_a ([groups][SLOTS][2*Cin], caller zeroes); when the add's
+ * other operand is BatchNorm'd too (downsample branch) z_b / vec_b / sums_b receive the same for it (else all NULL).
+ * Replaces adamml_conv_bwd_data(accumulate) + adamml_residual_bwd: the block-output gradient is written once. */
+int adamml_conv_bwd_data_res_supported(const adamml_conv_desc_t* d);
+int adamml_conv_bwd_data_res(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
+                             int accumulate, const void* res_out, int res_act, const void* z_a, const float* vec_a,
+                             double* sums_a, const void* z_b, const float* vec_b, double* sums_b, hipStream_t stream);
+
 /* autograd w.r.t. the weight: dw (fp32 OIHW, cin_true input channels) += dz^T * im2col(act(x)).  The pixel axis is
  * split over workgroups; with a workspace of adamml_conv_bwd_weight_workspace() bytes the partial tiles are written
  * with plain stores and summed by a second launch (device-scope fp32 atomics run at ~20 G/s on MI355X and would

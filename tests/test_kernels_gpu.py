@@ -641,3 +641,58 @@ def test_conv3x3_c64_patch_kernel(N, H, W, G, lazy):
     zh = (zf.double() - vec[:, 2].view(G, 1, C).double()) * vec[:, 3].view(G, 1, C).double()
     assert torch.allclose(sums.sum(1)[:, :C], gpd.sum(1), rtol=1e-3, atol=1e-2)
     assert torch.allclose(sums.sum(1)[:, C:], (gpd * zh).sum(1), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,G,second,acc,act", [(4, 28, 256, 64, 1, False, 1, 1), (6, 14, 256, 64, 3, True, 1, 1),
+                                                             (4, 20, 512, 128, 2, True, 0, 1), (2, 16, 24, 144, 1, False, 1, 0),
+                                                             (5, 7, 2048, 512, 5, False, 1, 1)])
+def test_conv_bwd_data_res_equals_dgrad_then_residual_bwd(N, H, Cin, Cout, G, second, acc, act):
+    """adamml_conv_bwd_data_res (1x1 data gradient finishing the residual add's backward in its epilogue) against the
+    unfused sequence adamml_conv_bwd_data(accumulate) + adamml_residual_bwd, and against fp32 torch arithmetic.
+    The fused form rounds the block-output gradient once instead of twice: 1 bf16 ulp of slack on g', sums rtol 2e-3."""
+    torch.manual_seed(N * 7 + H)
+    P = N * H * H                       # pixels per group
+    w = torch.randn(Cout, Cin, 1, 1, device=DEV) * (2.0 / Cout) ** 0.5
+    dz = torch.randn(G * N, H, H, Cout, device=DEV).to(torch.bfloat16)
+    g_idn = torch.randn(G * N, H, H, Cin, device=DEV).to(torch.bfloat16)          # identity-path gradient already in dx
+    out = torch.randn(G * N, H, H, Cin, device=DEV).clamp_min(0).to(torch.bfloat16) if act else \
+        torch.randn(G * N, H, H, Cin, device=DEV).to(torch.bfloat16)
+    za = torch.randn(G * N, H, H, Cin, device=DEV).to(torch.bfloat16)
+    zb = torch.randn(G * N, H, H, Cin, device=DEV).to(torch.bfloat16)
+    veca, vecb = torch.rand(G, 4, Cin, device=DEV) + 0.5, torch.rand(G, 4, Cin, device=DEV) + 0.5
+    d = ConvDesc(N, H, H, Cin, H, H, Cout, 1, 1, 1, 0, 1, 0, 0, G, 0)
+    assert hip.load().adamml_conv_bwd_data_res_supported(byref(d)) == 1
+    wd = pack(w, Cin, 1)
+    # unfused reference on the device
+    dx_ref = g_idn.clone() if acc else torch.empty_like(g_idn)
+    call("adamml_conv_bwd_data", byref(d), ptr(dz), ptr(wd), ptr(dx_ref), acc)
+    g2 = torch.empty_like(dx_ref)
+    sa_ref = torch.zeros(G, STAT_SLOTS, 2 * Cin, dtype=torch.float64, device=DEV)
+    sb_ref = torch.zeros(G, STAT_SLOTS, 2 * Cin, dtype=torch.float64, device=DEV)
+    call("adamml_residual_bwd", ptr(dx_ref), ptr(out), act, ptr(g2), ptr(za), ptr(veca), ptr(sa_ref), ptr(zb) if second else None,
+         ptr(vecb) if second else None, ptr(sb_ref) if second else None, P, Cin, G)
+    # fused
+    dx = g_idn.clone() if acc else torch.empty_like(g_idn)
+    sa = torch.zeros_like(sa_ref)
+    sb = torch.zeros_like(sb_ref)
+    call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(wd), ptr(dx), acc, ptr(out), act, ptr(za), ptr(veca), ptr(sa),
+         ptr(zb) if second else None, ptr(vecb) if second else None, ptr(sb) if second else None)
+    # fp32 torch arithmetic
+    full = torch.einsum("nhwo,oc->nhwc", dz.float(), rb(w).view(Cout, Cin))
+    if acc:
+        full = full + g_idn.float()
+    if act:
+        full = full * (out.float() > 0)
+    scale = full.abs().max().item()
+    assert (dx.float() - full).abs().max().item() <= 1e-2 * scale
+    assert (dx.float() - g2.float()).abs().max().item() <= 1.6e-2 * scale      # double vs single rounding
+    gq = dx.float().view(G, P, Cin).double()
+    for s_got, s_ref, z, vec in ((sa, sa_ref, za, veca),) + (((sb, sb_ref, zb, vecb),) if second else ()):
+        got = s_got.sum(1)
+        zhat = (z.float().view(G, P, Cin) - vec[:, 2].view(G, 1, Cin)) * vec[:, 3].view(G, 1, Cin)
+        exp = torch.cat([gq.sum(1), (gq * zhat.double()).sum(1)], dim=1)        # from the values the kernel stored
+        tol = 2e-3 * exp.abs().max().item() + 1e-3
+        assert (got - exp).abs().max().item() <= tol
+        assert (got - s_ref.sum(1)).abs().max().item() <= 2e-2 * s_ref.sum(1).abs().max().item() + 1e-2
+    if not second:
+        assert sb.abs().max().item() == 0.0
