@@ -480,6 +480,90 @@ __global__ void temporal_pool_bwd_kernel(const bf16_t* gy, const bf16_t* x, cons
     }
 }
 
+// Temporal max-pool backward fused with the residual-add backward of the block that produced the pool's input
+// (models/common.py:28-33 after models/resnet.py:110-111): the pool is the only consumer of the block output `out`, so
+// its input gradient IS the block-output gradient.  One thread walks the T frames of one (clip, pixel, 8-channel chunk)
+// column: window arg-maxes from `out` (first maximum in scan order 2to-1, 2to, 2to+1, as the forward kernel), routed
+// gradient, activation mask act'(out), store g', and the BatchNorm-backward sums of the add's BatchNorm'd operand z.
+// Replaces temporal_pool_bwd (write gx) + residual_bwd (re-read gx, out): 6.5 -> 3.5 tensor passes.
+template <int T>
+__global__ __launch_bounds__(NT) void temporal_pool_residual_bwd_kernel(const bf16_t* gy, const bf16_t* out, int act, bf16_t* g2,
+                                                                        const bf16_t* za, const float* veca, double* sumsa,
+                                                                        size_t NBHW, int HW, int C, size_t cpb) {
+    constexpr int To = (T - 1) / 2 + 1;
+    __shared__ float smem[2 * MAXC];
+    const int NB = (int)(NBHW / HW);
+    {
+        const size_t goff = (size_t)blockIdx.y * NB * T * HW * C;
+        gy += (size_t)blockIdx.y * NB * To * HW * C;
+        out += goff; g2 += goff; za += goff;
+        veca += (size_t)blockIdx.y * 4 * C;
+        sumsa += (size_t)blockIdx.y * ADAMML_STAT_SLOTS * 2 * C;
+    }
+    ChanMap m(C, threadIdx.x);
+    float sa[8], qa[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sa[i] = qa[i] = 0.f;
+    const size_t cb = (size_t)blockIdx.x * cpb;
+    const size_t ce = cb + cpb < NBHW ? cb + cpb : NBHW;
+    if (m.active) {
+        const int c = m.chunk * 8;
+        const f32x8 mua = load_f32x8(veca + 2 * C + c), isa = load_f32x8(veca + 3 * C + c);
+        const float lo = act_lo(act), hi = act_hi(act);
+        const size_t fstride = (size_t)HW * C;                    // elements between consecutive frames of a clip
+        for (size_t col = cb + m.rslot; col < ce; col += m.rows_per_pass) {
+            const size_t nb = col / HW, hw = col - nb * HW;
+            const size_t base = (nb * T * HW + hw) * C + c, gbase = (nb * To * HW + hw) * C + c;
+            bf16x8 ov[T], zv[T], gv[To];
+#pragma unroll
+            for (int t = 0; t < T; ++t) ov[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(out + base + t * fstride));
+#pragma unroll
+            for (int t = 0; t < To; ++t) gv[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(gy + gbase + t * fstride));
+#pragma unroll
+            for (int t = 0; t < T; ++t) zv[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(za + base + t * fstride));
+            int bt[To][8];
+#pragma unroll
+            for (int to = 0; to < To; ++to) {
+                f32x8 best;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bt[to][i] = -1; }
+#pragma unroll
+                for (int k = -1; k <= 1; ++k) {
+                    const int tt = 2 * to + k;
+                    if (tt < 0 || tt >= T) continue;
+                    const f32x8 v = bf8_to_f32(ov[tt]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (v[i] > best[i]) { best[i] = v[i]; bt[to][i] = tt; }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const f32x8 o = bf8_to_f32(ov[t]);
+                f32x8 acc;
+                const f32x8 g0 = bf8_to_f32(gv[t >> 1]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = bt[t >> 1][i] == t ? g0[i] : 0.f;
+                if ((t & 1) && ((t + 1) >> 1) < To) {
+                    const f32x8 g1 = bf8_to_f32(gv[((t + 1) >> 1) < To ? ((t + 1) >> 1) : 0]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += bt[((t + 1) >> 1) < To ? ((t + 1) >> 1) : 0][i] == t ? g1[i] : 0.f;
+                }
+                // (the unfused path rounds the routed gradient to bf16 before masking: same here)
+                acc = bf8_to_f32(f32_to_bf8(acc));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] *= mask_act(o[i], lo, hi);
+                const bf16x8 gb = f32_to_bf8(acc);
+                __builtin_nontemporal_store(gb, reinterpret_cast<bf16x8*>(g2 + base + t * fstride));
+                const f32x8 gq = bf8_to_f32(gb), z = bf8_to_f32(zv[t]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { sa[i] += gq[i]; qa[i] += gq[i] * (z[i] - mua[i]) * isa[i]; }
+            }
+        }
+    }
+    block_channel_publish(sa, qa, m, smem, C, sumsa);
+}
+
 __global__ void gap_fwd_kernel(const bf16_t* x, const float* scale, const float* shift, int gs, int act, float* out, int N, int HW,
                                int C) {
     x += (size_t)blockIdx.y * N * HW * C;
@@ -778,6 +862,28 @@ extern "C" int adamml_temporal_pool_bwd(const void* g_y, const void* x, const fl
     hipLaunchKernelGGL(temporal_pool_bwd_kernel, dim3(grid_for(n, NT, 4096 / groups + 1), groups), dim3(NT), 0, stream, (const bf16_t*)g_y,
                        (const bf16_t*)x, scale, shift, gstride, act, (bf16_t*)g_x, NB, T, To, HWC / 8, C, mode);
     return adamml_check_launch("temporal_pool_bwd");
+}
+
+extern "C" int adamml_temporal_pool_bwd_res_supported(int T, int C, int mode) {
+    return (T == 2 || T == 4 || T == 8) && mode == 0 && C % 8 == 0 && C <= MAXC ? 1 : 0;
+}
+
+extern "C" int adamml_temporal_pool_bwd_res(const void* g_y, const void* out, int act, void* g2, const void* z_a, const float* vec_a,
+                                            double* sums_a, int NB, int T, int HW, int C, int groups, hipStream_t stream) {
+    CHECK_C(C, "temporal_pool_bwd_res");
+    if (!adamml_temporal_pool_bwd_res_supported(T, C, 0)) return adamml_set_error(ADAMML_EUNSUPPORTED, "temporal_pool_bwd_res: T=%d C=%d", T, C);
+    if (!g_y || !out || !g2 || !z_a || !vec_a || !sums_a) return adamml_set_error(ADAMML_EINVAL, "temporal_pool_bwd_res: null argument");
+    const size_t cols = (size_t)NB * HW;
+    if (!cols) return ADAMML_OK;
+    if (groups < 1) groups = 1;
+    size_t cpb, nblk;
+    reduce_grid(cols, C, groups, &cpb, &nblk);
+#define LAUNCH_TPR(TV)                                                                                                              \
+    hipLaunchKernelGGL(temporal_pool_residual_bwd_kernel<TV>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g_y, \
+                       (const bf16_t*)out, act, (bf16_t*)g2, (const bf16_t*)z_a, vec_a, sums_a, cols, HW, C, cpb)
+    if (T == 8) LAUNCH_TPR(8); else if (T == 4) LAUNCH_TPR(4); else LAUNCH_TPR(2);
+#undef LAUNCH_TPR
+    return adamml_check_launch("temporal_pool_bwd_res");
 }
 
 extern "C" int adamml_gap_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, float* out, int N, int HW,

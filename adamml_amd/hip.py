@@ -56,6 +56,7 @@ SIGNATURES = {
     "adamml_maxpool2d_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "adamml_temporal_pool_fwd": [_P, _P, _P, _I, _I, _P, _I, _I, _Z, _I, _I, _I, _P],
     "adamml_temporal_pool_bwd": [_P, _P, _P, _P, _I, _I, _P, _I, _I, _Z, _I, _I, _I, _P],
+    "adamml_temporal_pool_bwd_res": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "adamml_gap_fwd": [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P],
     "adamml_gap_bwd": [_P, _P, _I, _I, _I, _P],
     "adamml_clip_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -96,6 +97,8 @@ def load():
     lib.adamml_conv_fused_input_supported.restype = c_int
     lib.adamml_conv_bwd_data_res_supported.argtypes = [_DESC]
     lib.adamml_conv_bwd_data_res_supported.restype = c_int
+    lib.adamml_temporal_pool_bwd_res_supported.argtypes = [_I, _I, _I]
+    lib.adamml_temporal_pool_bwd_res_supported.restype = c_int
     lib.adamml_conv_stem_supported.argtypes = [_DESC]
     lib.adamml_conv_stem_supported.restype = c_int
     lib.adamml_version.restype = c_int

@@ -15,7 +15,7 @@ def run_blocks(rt, h, plans):
     for bp in plans:
         x = h
         if bp.tpool:
-            x = temporal_pool(rt, x, bp.tpool, "max")
+            x = temporal_pool(rt, x, bp.tpool, "max", sole_consumer=True)
         y = x
         if bp.pw is not None:
             # the expansion conv is recorded before the block's own residual add, so it is reversed after it: last consumer

@@ -104,7 +104,7 @@ class ResNet(HipBackbone, MeanStdMixin):
                 o = conv_bn(rt, o, b._cs3, b.bn3, ACT_NONE, sole_consumer=True)
                 h = add_act(rt, o, idn, ACT_RELU, idn_sole=b._csd is not None)
             if li < 3 and not self.without_t_stride:
-                h = temporal_pool(rt, h, frames, self.pooling_method)
+                h = temporal_pool(rt, h, frames, self.pooling_method, sole_consumer=True)
                 frames = max(1, frames // 2)
         feat, push = gap(rt, h)                       # [N*T', 2048] fp32
         mask = None

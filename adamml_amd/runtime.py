@@ -437,8 +437,10 @@ def maxpool3x3s2(rt, x):
     return out
 
 
-def temporal_pool(rt, x, frames, mode):
-    """models/common.py:4-33 on [G*N*T,H,W,C]; mode 'max' | 'avg'."""
+def temporal_pool(rt, x, frames, mode, sole_consumer=False):
+    """models/common.py:4-33 on [G*N*T,H,W,C]; mode 'max' | 'avg'.  sole_consumer=True promises that the pool is the only
+    consumer of x: when x is the output of a residual add, the pool's backward then finishes that add's backward in the
+    same pass (adamml_temporal_pool_bwd_res)."""
     nt, h, w, C = x.shape
     G = rt.groups
     nb = nt // frames                       # clips over all groups
@@ -456,6 +458,18 @@ def temporal_pool(rt, x, frames, mode):
             if g is None or not x.requires_grad:
                 return
             gx = torch.empty_like(x.data)
+            if sole_consumer and x.grad is None and x.scale is None and x.res is not None and not x.res_done and \
+                    hip.load().adamml_temporal_pool_bwd_res_supported(frames, C, m):
+                z, idn, ract, idn_sole = x.res
+                fb = idn is not None and idn_sole and idn.requires_grad and idn.vec is not None and idn.grad is None
+                if z.requires_grad and z.vec is not None and z.grad is None and z.pre_sums is None and not fb:
+                    sa = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS)
+                    call("adamml_temporal_pool_bwd_res", ptr(g), ptr(x.data), ract, ptr(gx), ptr(z.data), ptr(z.vec), ptr(sa),
+                         nb // G, frames, h * w, C, G)
+                    z.pre_sums = sa
+                    x.res_done = True
+                    x.grad = gx
+                    return
             call("adamml_temporal_pool_bwd", ptr(g), ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(gx), nb // G, frames,
                  h * w * C, C, m, G)
             _accum_grad(x, gx)

@@ -168,6 +168,15 @@ int adamml_temporal_pool_fwd(const void* x, const float* scale, const float* shi
                              int T, size_t HWC, int C, int mode, int groups, hipStream_t stream);
 int adamml_temporal_pool_bwd(const void* g_y, const void* x, const float* scale, const float* shift, int gstride, int act,
                              void* g_x, int NB, int T, size_t HWC, int C, int mode, int groups, hipStream_t stream);
+/* Temporal MAX-pool backward fused with the residual-add backward of the block that produced the pool's input
+ * (models/common.py:28-33 directly after models/resnet.py:110-111; the pool is that block output's only consumer):
+ *   g2[n,t] = route(g_y)[n,t] * act'(out[n,t]),  sums_a += (sum g2, sum g2 * zhat_a)   per channel and group.
+ * out / g2 / z_a: [groups*NB*T, HW, C]; g_y: [groups*NB*To, HW, C]; T in {2,4,8}.  Replaces adamml_temporal_pool_bwd +
+ * adamml_residual_bwd (6.5 -> 3.5 passes over the block-output tensor). */
+int adamml_temporal_pool_bwd_res_supported(int T, int C, int mode);
+int adamml_temporal_pool_bwd_res(const void* g_y, const void* out, int act, void* g2, const void* z_a, const float* vec_a,
+                                 double* sums_a, int NB, int T, int HW, int C, int groups, hipStream_t stream);
+
 /* AdaptiveAvgPool2d(1) on a lazy input -> fp32 [groups*N,C] (resnet.py:212, sound_mobilenet_v2.py:157, policy_net.py:147) */
 int adamml_gap_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, float* out, int N, int HW,
                    int C, int groups, hipStream_t stream);

@@ -696,3 +696,33 @@ def test_conv_bwd_data_res_equals_dgrad_then_residual_bwd(N, H, Cin, Cout, G, se
         assert (got - s_ref.sum(1)).abs().max().item() <= 2e-2 * s_ref.sum(1).abs().max().item() + 1e-2
     if not second:
         assert sb.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("T,NB,HW,C,G,act", [(8, 3, 49, 256, 1, 1), (4, 2, 30, 512, 3, 1), (2, 5, 16, 1024, 2, 1), (4, 3, 25, 64, 1, 0)])
+def test_temporal_pool_bwd_res_equals_pool_bwd_then_residual_bwd(T, NB, HW, C, G, act):
+    """adamml_temporal_pool_bwd_res against the unfused adamml_temporal_pool_bwd + adamml_residual_bwd: the routed, masked
+    gradient must be bit-identical (same arg-max rule, same rounding points) and the sums equal up to summation order."""
+    torch.manual_seed(T * 31 + C)
+    To = (T - 1) // 2 + 1
+    out = torch.randn(G * NB * T, HW, C, device=DEV)
+    out = (out.clamp_min(0) if act else out).to(torch.bfloat16)
+    out[::3] = out[1::3][: out[::3].shape[0]]                      # exact ties between neighbouring frames
+    gy = torch.randn(G * NB * To, HW, C, device=DEV).to(torch.bfloat16)
+    z = torch.randn(G * NB * T, HW, C, device=DEV).to(torch.bfloat16)
+    vec = torch.rand(G, 4, C, device=DEV) + 0.5
+    gx = torch.empty_like(out)
+    call("adamml_temporal_pool_bwd", ptr(gy), ptr(out), None, None, 0, 0, ptr(gx), NB, T, HW * C, C, 0, G)
+    g2_ref = torch.empty_like(out)
+    s_ref = torch.zeros(G, STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
+    call("adamml_residual_bwd", ptr(gx), ptr(out), act, ptr(g2_ref), ptr(z), ptr(vec), ptr(s_ref), None, None, None, NB * T * HW, C, G)
+    if not act:
+        g2_ref = gx
+    g2 = torch.empty_like(out)
+    s = torch.zeros_like(s_ref)
+    assert hip.load().adamml_temporal_pool_bwd_res_supported(T, C, 0) == 1
+    call("adamml_temporal_pool_bwd_res", ptr(gy), ptr(out), act, ptr(g2), ptr(z), ptr(vec), ptr(s), NB, T, HW, C, G)
+    assert torch.equal(g2, g2_ref)
+    a, b = s.sum(1), s_ref.sum(1)
+    assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-6
+    assert hip.load().adamml_temporal_pool_bwd_res_supported(3, C, 0) == 0
+    assert hip.load().adamml_temporal_pool_bwd_res_supported(4, C, 1) == 0
