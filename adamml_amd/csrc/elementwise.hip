@@ -402,6 +402,115 @@ __global__ void maxpool_bwd_kernel(const bf16_t* gy, const uint8_t* idx, bf16_t*
     }
 }
 
+// MaxPool2d(3, 2, 1) backward fused with the BatchNorm backward of the tensor the pool reads (the ResNet stem:
+// models/resnet.py:199-202 conv1 -> bn1 -> relu -> maxpool, the pool being the stem output's only consumer).  The routed
+// gradient g[n,ih,iw,c] = sum over the <= 4 windows whose recorded arg-max is this pixel is cheap to recompute from the
+// pooled gradient and the 1-byte indices (1/4 of the pixels), so it is never written: pass 1 (APPLY = false) accumulates
+// sum(g') and sum(g' zhat), pass 2 (APPLY = true) writes dz = k0 (g' - k1 - zhat k2) -- instead of maxpool_bwd (write g),
+// bn_bwd_reduce (read g, z) and bn_bwd_apply (read g, z, write dz): 29 -> 17 GB at the benchmark shape.
+// A thread owns one 8-channel chunk of a 2x2 input quad (rows 2k, 2k+1; columns 2j, 2j+1): the quad is covered by exactly
+// the four windows (k+a, j+b), a, b in {0, 1}, and pixel (dy, dx) belongs to window (a, b) iff a <= dy and b <= dx, at tap
+// (dy - 2a + 1) * 3 + (dx - 2b + 1) -- four (index, gradient) loads per four pixels instead of 2.25 per pixel.
+template <bool APPLY>
+__global__ __launch_bounds__(NT) void maxpool_bwd_bn_kernel(const bf16_t* gy, const uint8_t* idx, const bf16_t* z, const float* vec, int act,
+                                                            double* sums, const float* coef, bf16_t* dz, int N, int H, int W, int C,
+                                                            int OH, int OW, size_t qpb) {
+    __shared__ float smem[APPLY ? 1 : 2 * MAXC];
+    const size_t P = (size_t)N * H * W;
+    const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;
+    const size_t Q = (size_t)N * QH * QW;
+    {
+        const size_t po = (size_t)blockIdx.y * N * OH * OW * C;
+        gy += po; idx += po;
+        z += (size_t)blockIdx.y * P * C;
+        vec += (size_t)blockIdx.y * 4 * C;
+        if (APPLY) { dz += (size_t)blockIdx.y * P * C; coef += (size_t)blockIdx.y * 3 * C; }
+        else sums += (size_t)blockIdx.y * ADAMML_STAT_SLOTS * 2 * C;
+    }
+    ChanMap m(C, threadIdx.x);
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+    const size_t qb = (size_t)blockIdx.x * qpb;
+    const size_t qe = qb + qpb < Q ? qb + qpb : Q;
+    if (m.active) {
+        const int c = m.chunk * 8;
+        const f32x8 sc = load_f32x8(vec + c), sh = load_f32x8(vec + C + c), mu = load_f32x8(vec + 2 * C + c), is = load_f32x8(vec + 3 * C + c);
+        f32x8 k0, k1, k2;
+        if (APPLY) { k0 = load_f32x8(coef + c); k1 = load_f32x8(coef + C + c); k2 = load_f32x8(coef + 2 * C + c); }
+        const float lo = act_lo(act), hi = act_hi(act);
+        for (size_t qi = qb + m.rslot; qi < qe; qi += m.rows_per_pass) {
+            const int n = (int)(qi / ((size_t)QH * QW));
+            const int rem = (int)(qi - (size_t)n * QH * QW);
+            const int k = rem / QW, j = rem - k * QW;
+            // the four windows of the quad
+            uint64_t wi[2][2];
+            bf16x8 wg[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const bool ok = k + a < OH && j + b < OW;
+                    const size_t o = (((size_t)n * OH + (ok ? k + a : 0)) * OW + (ok ? j + b : 0)) * C + c;
+                    wi[a][b] = ok ? *reinterpret_cast<const uint64_t*>(idx + o) : ~0ull;        // 0xff never equals a tap
+                    wg[a][b] = *reinterpret_cast<const bf16x8*>(gy + o);
+                }
+            bf16x8 zr[2][2];
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const bool ok = 2 * k + dy < H && 2 * j + dx < W;
+                    const size_t pp = ((size_t)n * H + (ok ? 2 * k + dy : 0)) * W + (ok ? 2 * j + dx : 0);
+                    zr[dy][dx] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(z + pp * C + c));
+                }
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const bool ok = 2 * k + dy < H && 2 * j + dx < W;
+                    f32x8 acc;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+                    for (int a = 0; a <= dy; ++a)
+#pragma unroll
+                        for (int b = 0; b <= dx; ++b) {
+                            const unsigned tap = (unsigned)((dy - 2 * a + 1) * 3 + (dx - 2 * b + 1));
+                            const f32x8 g = bf8_to_f32(wg[a][b]);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i)
+                                if ((unsigned)((wi[a][b] >> (8 * i)) & 0xff) == tap) acc[i] += g[i];
+                        }
+                    const f32x8 gv = bf8_to_f32(f32_to_bf8(acc));      // the unfused path stores the routed gradient in bf16
+                    const f32x8 zv = bf8_to_f32(zr[dy][dx]);
+                    if (APPLY) {
+                        f32x8 o;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float gp = gv[i] * mask_act(fmaf(zv[i], sc[i], sh[i]), lo, hi);
+                            const float zh = (zv[i] - mu[i]) * is[i];
+                            o[i] = k0[i] * (gp - k1[i] - zh * k2[i]);
+                        }
+                        if (ok) {
+                            const size_t pp = ((size_t)n * H + 2 * k + dy) * W + 2 * j + dx;
+                            __builtin_nontemporal_store(f32_to_bf8(o), reinterpret_cast<bf16x8*>(dz + pp * C + c));
+                        }
+                    } else {
+                        const float keep = ok ? 1.f : 0.f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float gp = keep * gv[i] * mask_act(fmaf(zv[i], sc[i], sh[i]), lo, hi);
+                            s[i] += gp;
+                            q[i] += gp * (zv[i] - mu[i]) * is[i];
+                        }
+                    }
+                }
+        }
+    }
+    if (!APPLY) block_channel_publish(s, q, m, smem, C, sums);
+}
+
 // x: [NB, T, HWC] -> y: [NB, To, HWC], To = (T-1)/2+1
 __global__ void temporal_pool_fwd_kernel(const bf16_t* x, const float* scale, const float* shift, int gs, int act, bf16_t* y,
                                          int NB, int T, int To, size_t hwc8, int C, int mode) {
@@ -836,6 +945,34 @@ extern "C" int adamml_maxpool2d_bwd(const void* g_y, const uint8_t* idx, void* g
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, (const bf16_t*)g_y, idx, (bf16_t*)g_x, N, H, W, C,
                        OH, OW, accumulate);
     return adamml_check_launch("maxpool2d_bwd");
+}
+
+extern "C" int adamml_maxpool2d_bwd_bn_reduce(const void* g_y, const uint8_t* idx, const void* z, const float* vec, int act, double* sums,
+                                              int N, int H, int W, int C, int OH, int OW, int groups, hipStream_t stream) {
+    CHECK_C(C, "maxpool2d_bwd_bn_reduce");
+    if (!g_y || !idx || !z || !vec || !sums) return adamml_set_error(ADAMML_EINVAL, "maxpool2d_bwd_bn_reduce: null argument");
+    const size_t P = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2);          // 2x2 input quads
+    if (!P) return ADAMML_OK;
+    if (groups < 1) groups = 1;
+    size_t ppb, nblk;
+    reduce_grid(P, C, groups, &ppb, &nblk);
+    hipLaunchKernelGGL(maxpool_bwd_bn_kernel<false>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g_y, idx,
+                       (const bf16_t*)z, vec, act, sums, (const float*)nullptr, (bf16_t*)nullptr, N, H, W, C, OH, OW, ppb);
+    return adamml_check_launch("maxpool2d_bwd_bn_reduce");
+}
+
+extern "C" int adamml_maxpool2d_bwd_bn_apply(const void* g_y, const uint8_t* idx, const void* z, const float* vec, int act, const float* coef,
+                                             void* dz, int N, int H, int W, int C, int OH, int OW, int groups, hipStream_t stream) {
+    CHECK_C(C, "maxpool2d_bwd_bn_apply");
+    if (!g_y || !idx || !z || !vec || !coef || !dz) return adamml_set_error(ADAMML_EINVAL, "maxpool2d_bwd_bn_apply: null argument");
+    const size_t P = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2);          // 2x2 input quads
+    if (!P) return ADAMML_OK;
+    if (groups < 1) groups = 1;
+    size_t ppb, nblk;
+    rowwalk_grid(P, C, groups, 8192, &ppb, &nblk);
+    hipLaunchKernelGGL(maxpool_bwd_bn_kernel<true>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g_y, idx,
+                       (const bf16_t*)z, vec, act, (double*)nullptr, coef, (bf16_t*)dz, N, H, W, C, OH, OW, ppb);
+    return adamml_check_launch("maxpool2d_bwd_bn_apply");
 }
 
 extern "C" int adamml_temporal_pool_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, void* y, int NB,

@@ -54,6 +54,8 @@ SIGNATURES = {
     "adamml_bn_bwd_apply": [_P, _P, _P, _I, _P, _P, _Z, _I, _I, _P],
     "adamml_maxpool2d_fwd": [_P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "adamml_maxpool2d_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adamml_maxpool2d_bwd_bn_reduce": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adamml_maxpool2d_bwd_bn_apply": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "adamml_temporal_pool_fwd": [_P, _P, _P, _I, _I, _P, _I, _I, _Z, _I, _I, _I, _P],
     "adamml_temporal_pool_bwd": [_P, _P, _P, _P, _I, _I, _P, _I, _I, _Z, _I, _I, _I, _P],
     "adamml_temporal_pool_bwd_res": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

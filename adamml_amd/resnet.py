@@ -91,7 +91,7 @@ class ResNet(HipBackbone, MeanStdMixin):
         n = nt // frames                              # clips over all groups
         h = Lazy(x, requires_grad=False)
         h = conv_bn(rt, h, self._stem, self.bn1, ACT_RELU)
-        h = maxpool3x3s2(rt, h)
+        h = maxpool3x3s2(rt, h, sole_consumer=True)
         for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
             for b in layer:
                 # the downsample branch is issued FIRST so that its data gradient runs LAST in the reversed tape: it then

@@ -25,7 +25,7 @@ def pad8(c):
 class Lazy:
     """Activation tensor [G*N,H,W,C] bf16 (G BatchNorm groups, group-major) whose value is act(scale*data + shift)
     (scale None -> data); group g uses scale + g*gs, shift + g*gs (gs == 0: one pair for all groups)."""
-    __slots__ = ("data", "scale", "shift", "gs", "act", "grad", "requires_grad", "vec", "src", "pre_sums", "res", "res_done")
+    __slots__ = ("data", "scale", "shift", "gs", "act", "grad", "requires_grad", "vec", "src", "pre_sums", "res", "res_done", "pool_grad")
 
     def __init__(self, data, scale=None, shift=None, act=ACT_NONE, requires_grad=True, gs=0):
         self.data, self.scale, self.shift, self.act, self.gs = data, scale, shift, act, gs
@@ -34,6 +34,7 @@ class Lazy:
         self.vec = None             # train-mode BatchNorm vectors [G,4,C] (scale, shift, mean, invstd) of a lazy tensor
         self.src = None             # lazy tensor this plain tensor is the materialisation of
         self.pre_sums = None        # BatchNorm-backward sums already accumulated by the producer of .grad
+        self.pool_grad = None       # (g_y, idx, OH, OW): .grad = routed max-pool gradient, recomputed by the BatchNorm backward
         self.res = None             # (z, idn, act, idn_sole) of the residual add that produced this tensor
         self.res_done = False       # .grad is already act-masked and the add's BatchNorm-backward sums are in place
 
@@ -206,6 +207,21 @@ def _bn_backward(rt, out, y, vec, bn, act, count):
     n, oh, ow, C = y.shape
     G = rt.groups
     P = n // G * oh * ow                    # pixels per group
+    if out.pool_grad is not None:
+        # the only consumer was a 3x3/2 max-pool: its routed gradient is recomputed from the pooled gradient and the
+        # arg-max indices inside both BatchNorm-backward passes instead of being written and re-read twice
+        gy, idx, poh, pow_ = out.pool_grad
+        out.pool_grad = None
+        sums = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS)
+        call("adamml_maxpool2d_bwd_bn_reduce", ptr(gy), ptr(idx), ptr(y), ptr(vec), act, ptr(sums), n // G, oh, ow, C, poh, pow_, G)
+        sums, nslots = rt.sync.reduce(sums, C, G)
+        coef = torch.empty(G, 3, C, dtype=torch.float32, device=y.device)
+        train_bn = bn.weight.requires_grad
+        call("adamml_bn_bwd_finalize", ptr(sums), nslots, G, float(count * rt.sync.world), ptr(bn.weight), ptr(vec),
+             ptr(bn.weight.grad) if train_bn else None, ptr(bn.bias.grad) if train_bn else None, ptr(coef), C)
+        dz = torch.empty_like(y)
+        call("adamml_maxpool2d_bwd_bn_apply", ptr(gy), ptr(idx), ptr(y), ptr(vec), act, ptr(coef), ptr(dz), n // G, oh, ow, C, poh, pow_, G)
+        return dz
     if out.pre_sums is not None:            # reduction fused into the kernel that produced g (already activation-masked)
         sums, out.pre_sums = out.pre_sums, None
     else:
@@ -294,7 +310,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
         out = Lazy(y, vec[0], vec[1], act)
     if rt.tape.need_grad:
         def bwd():
-            if out.grad is None:
+            if out.grad is None and out.pool_grad is None:
                 return
             dz = _bn_backward(rt, out, y, vec, bn, act, count)
             if cs.weight.requires_grad:
@@ -414,7 +430,9 @@ def add_act(rt, z, idn, act, idn_sole=False):
     return out
 
 
-def maxpool3x3s2(rt, x):
+def maxpool3x3s2(rt, x, sole_consumer=False):
+    """nn.MaxPool2d(3, 2, 1) on a lazy input.  sole_consumer=True promises the pool is the only consumer of x: for a
+    train-mode BatchNorm'd x the backward then hands (g_y, idx) to x's BatchNorm backward instead of materialising x.grad."""
     n, h, w, C = x.shape
     oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
     y = torch.empty(n, oh, ow, C, dtype=torch.bfloat16, device=x.data.device)
@@ -427,6 +445,9 @@ def maxpool3x3s2(rt, x):
             g = out.grad
             out.grad = None
             if g is None or not x.requires_grad:
+                return
+            if sole_consumer and x.grad is None and x.vec is not None and x.pre_sums is None:
+                x.pool_grad = (g, idx, oh, ow)
                 return
             acc = 1
             if x.grad is None:

@@ -168,6 +168,15 @@ int adamml_temporal_pool_fwd(const void* x, const float* scale, const float* shi
                              int T, size_t HWC, int C, int mode, int groups, hipStream_t stream);
 int adamml_temporal_pool_bwd(const void* g_y, const void* x, const float* scale, const float* shift, int gstride, int act,
                              void* g_x, int NB, int T, size_t HWC, int C, int mode, int groups, hipStream_t stream);
+/* MaxPool2d(3,2,1) backward fused with the BatchNorm backward of the pool's (lazily normalised) input -- the ResNet stem
+ * (models/resnet.py:199-202), whose only consumer is the pool.  The routed gradient is recomputed from g_y / idx in both
+ * passes and never stored: _reduce accumulates sum(g'), sum(g' zhat) into sums [groups][SLOTS][2C]; _apply (after
+ * adamml_bn_bwd_finalize produced coef) writes dz.  N = images per group; g_y / idx: [groups*N, OH, OW, C]. */
+int adamml_maxpool2d_bwd_bn_reduce(const void* g_y, const uint8_t* idx, const void* z, const float* vec, int act, double* sums,
+                                   int N, int H, int W, int C, int OH, int OW, int groups, hipStream_t stream);
+int adamml_maxpool2d_bwd_bn_apply(const void* g_y, const uint8_t* idx, const void* z, const float* vec, int act, const float* coef,
+                                  void* dz, int N, int H, int W, int C, int OH, int OW, int groups, hipStream_t stream);
+
 /* Temporal MAX-pool backward fused with the residual-add backward of the block that produced the pool's input
  * (models/common.py:28-33 directly after models/resnet.py:110-111; the pool is that block output's only consumer):
  *   g2[n,t] = route(g_y)[n,t] * act'(out[n,t]),  sums_a += (sum g2, sum g2 * zhat_a)   per channel and group.

@@ -726,3 +726,36 @@ def test_temporal_pool_bwd_res_equals_pool_bwd_then_residual_bwd(T, NB, HW, C, G
     assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-6
     assert hip.load().adamml_temporal_pool_bwd_res_supported(3, C, 0) == 0
     assert hip.load().adamml_temporal_pool_bwd_res_supported(4, C, 1) == 0
+
+
+@pytest.mark.parametrize("N,H,W,C,G", [(3, 30, 30, 64, 1), (2, 29, 31, 64, 3), (1, 16, 16, 128, 2)])
+def test_maxpool_bwd_bn_fused_equals_unfused_sequence(N, H, W, C, G):
+    """adamml_maxpool2d_bwd_bn_reduce / _apply (routed gradient recomputed inside the BatchNorm backward, never stored)
+    against adamml_maxpool2d_bwd + adamml_bn_bwd_reduce + adamml_bn_bwd_apply: dz bit-identical given the same
+    coefficients, sums equal up to summation order."""
+    torch.manual_seed(N + H)
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    z = torch.randn(G * N, H, W, C, device=DEV).to(torch.bfloat16)
+    vec = torch.rand(G, 4, C, device=DEV) + 0.5
+    vec[:, 1] -= 1.0                                                   # shift: a good share of ReLU-masked pixels
+    y = torch.empty(G * N, OH, OW, C, dtype=torch.bfloat16, device=DEV)
+    idx = torch.empty(G * N, OH, OW, C, dtype=torch.uint8, device=DEV)
+    call("adamml_maxpool2d_fwd", ptr(z), ptr(vec[0, 0]), ptr(vec[0, 1]), 4 * C, 1, ptr(y), ptr(idx), N, H, W, C, OH, OW, G)
+    gy = torch.randn(G * N, OH, OW, C, device=DEV).to(torch.bfloat16)
+    P = N * H * W
+    # unfused
+    gx = torch.empty_like(z)
+    call("adamml_maxpool2d_bwd", ptr(gy), ptr(idx), ptr(gx), G * N, H, W, C, OH, OW, 0)
+    s_ref = torch.zeros(G, STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
+    call("adamml_bn_bwd_reduce", ptr(gx), ptr(z), ptr(vec), 1, ptr(s_ref), P, C, G)
+    coef = torch.rand(G, 3, C, device=DEV) - 0.5
+    dz_ref = torch.empty_like(z)
+    call("adamml_bn_bwd_apply", ptr(gx), ptr(z), ptr(vec), 1, ptr(coef), ptr(dz_ref), P, C, G)
+    # fused
+    s = torch.zeros_like(s_ref)
+    call("adamml_maxpool2d_bwd_bn_reduce", ptr(gy), ptr(idx), ptr(z), ptr(vec), 1, ptr(s), N, H, W, C, OH, OW, G)
+    dz = torch.empty_like(z)
+    call("adamml_maxpool2d_bwd_bn_apply", ptr(gy), ptr(idx), ptr(z), ptr(vec), 1, ptr(coef), ptr(dz), N, H, W, C, OH, OW, G)
+    assert torch.equal(dz, dz_ref)
+    a, b = s.sum(1), s_ref.sum(1)
+    assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-6
