@@ -96,6 +96,7 @@ class HipBackbone(nn.Module):
         self._anchor = None
         self._packed_version = None
         self.flat_owner = None       # FlatBuffers managing this net's parameters (self or the enclosing sub-network)
+        self.grad_hook = None        # HipDDP: callable(params) fired in backward once the gradients of `params` are final
 
     # -- weight packs ------------------------------------------------------------------------------
     def _register_conv(self, conv, depthwise=False):
@@ -113,6 +114,16 @@ class HipBackbone(nn.Module):
         for cs in self._conv_states:
             cs.repack(need_dgrad)
         self._packed_version = ver
+
+    def _mark_grads_ready_after(self, tape, modules):
+        """Record a tape marker BEFORE the forward ops of `modules`: in the reversed tape it fires right after their last
+        backward closure, i.e. when every weight gradient of those modules has been enqueued -- the data-parallel wrapper
+        starts their all-reduce there, overlapping it with the rest of the backward pass."""
+        if not tape.need_grad or self.grad_hook is None:
+            return
+        params = [p for m in modules for p in m.parameters() if p.requires_grad]
+        if params:
+            tape.record(lambda: self.grad_hook(params) if self.grad_hook is not None else None)
 
     def _trainable(self):
         return any(p.requires_grad for p in self.parameters())

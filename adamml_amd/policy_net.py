@@ -97,6 +97,7 @@ class MobileNetV2(HipBackbone, MeanStdMixin):
         rt = self.rt
         tape = rt.begin_forward(x.device, self.training, need_grad, groups)
         self._repack(need_grad)
+        self._mark_grads_ready_after(tape, [self])        # one gradient bucket: exchanged as soon as this net's backward is enqueued
         h = conv_bn(rt, Lazy(x, requires_grad=False), self._stem[0], self._stem[1], ACT_RELU6)
         h = run_blocks(rt, h, self._plans)
         h = conv_bn(rt, h, self._last[0], self._last[1], ACT_RELU6)

@@ -90,9 +90,16 @@ class ResNet(HipBackbone, MeanStdMixin):
         nt = x.shape[0]
         n = nt // frames                              # clips over all groups
         h = Lazy(x, requires_grad=False)
+        # gradient buckets for the data-parallel exchange (parameter order == flat-buffer order): [stem, layer1, layer2],
+        # [layer3], [layer4, fc]; each marker fires when its bucket's last weight gradient has been enqueued
+        self._mark_grads_ready_after(tape, [self.conv1, self.bn1, self.layer1, self.layer2])
         h = conv_bn(rt, h, self._stem, self.bn1, ACT_RELU)
         h = maxpool3x3s2(rt, h, sole_consumer=True)
         for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
+            if li == 2:
+                self._mark_grads_ready_after(tape, [self.layer3])
+            elif li == 3:
+                self._mark_grads_ready_after(tape, [self.layer4, self.fc])
             for b in layer:
                 # the downsample branch is issued FIRST so that its data gradient runs LAST in the reversed tape: it then
                 # accumulates into the gradient conv1 already wrote, and a stride-2 1x1 only touches a quarter of the pixels

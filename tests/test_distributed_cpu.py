@@ -86,6 +86,60 @@ def test_flat_gradient_allreduce_matches_full_batch():
     assert torch.allclose(g0, ref, atol=1e-6)
 
 
+def _bucketed_overlap(rank, world):
+    """HipDDP's overlapped exchange: a backbone announces a contiguous slice of the flat buffer from inside backward
+    (async all-reduce), reduce_gradients() finishes the gaps; the result must equal the one-shot average."""
+    from adamml_amd.backbone import FlatBuffers
+    from adamml_amd.distributed import HipDDP, shard_batch
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(4, 3)
+            self.b = torch.nn.Linear(3, 5)
+            self.c = torch.nn.Linear(5, 2)
+            self.fb = FlatBuffers(self)
+            self.grad_hook = None
+
+        def backbones(self):
+            return [self]
+
+        def flat_grad_buffers(self):
+            return [self.fb.flat_grad]
+
+        def forward(self, x):
+            return self.c(torch.tanh(self.b(torch.tanh(self.a(x)))))
+
+    torch.manual_seed(0)
+    m = Net()
+    m.fb.ensure(torch.device("cpu"))
+    m.fb.ensure_grads()
+    x = torch.arange(32, dtype=torch.float32).reshape(8, 4) / 10
+    (xs,) = shard_batch([x], rank, world)
+    ddp = HipDDP(m)
+    assert m.grad_hook is not None
+    ddp.broadcast_parameters()
+    ddp(xs).pow(2).mean().backward()
+    m.grad_hook(list(m.b.parameters()))                        # middle slice first (as layer4 would be), then the tail
+    m.grad_hook(list(m.c.parameters()))
+    m.grad_hook([m.a.weight, m.c.bias])                        # not contiguous: must be left to reduce_gradients()
+    assert len(ddp._pending) == 2
+    ddp.reduce_gradients()
+    assert not ddp._pending
+    return m.fb.flat_grad.clone()
+
+
+def test_bucketed_async_allreduce_matches_full_batch():
+    g0, g1 = _run(_bucketed_overlap)
+    assert torch.allclose(g0, g1)
+    torch.manual_seed(0)
+    a, b, c = torch.nn.Linear(4, 3), torch.nn.Linear(3, 5), torch.nn.Linear(5, 2)
+    x = torch.arange(32, dtype=torch.float32).reshape(8, 4) / 10
+    c(torch.tanh(b(torch.tanh(a(x))))).pow(2).mean().backward()
+    ref = torch.cat([p.grad.reshape(-1) for m in (a, b, c) for p in m.parameters()])
+    assert torch.allclose(g0, ref, atol=1e-6)
+
+
 def _syncbn_stats(rank, world):
     """What SyncCtx.reduce does with the per-rank [sum, sumsq] vectors, on gloo."""
     torch.manual_seed(1)
