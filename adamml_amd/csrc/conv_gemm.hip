@@ -42,6 +42,12 @@ struct ConvP {
     const bf16_t* bn_z2;         // raw output of the second BatchNorm'd operand of the add, or null
     const float* bn_vec2;
     double* stats2;
+    // DUAL kernels (1x1 data gradient whose input dz is the BatchNorm backward of (g, z)): the loader reads g (= x) and z
+    // (= x2) and forms dz = A[c] g + B[c] z + C[c] on the way into LDS (aff = [3][K] per group); `side` (optional) receives
+    // dz for the weight-gradient kernel, written by the workgroups of cout tile 0 -- adamml_bn_bwd_apply never runs
+    const bf16_t* x2;
+    const float* aff;
+    bf16_t* side;
     // MODE 3 (one parity class of the data gradient of a stride-2 conv, see conv_dgrad_stride2)
     int wK;                      // weight row stride in elements (== K except in MODE 3, where K covers the class taps only)
     int cls_nt;                  // taps of this class (0..4)
@@ -73,15 +79,22 @@ __device__ __forceinline__ void static_for(F&& f) {
 // RES: residual form of the BatchNorm-fused data-gradient epilogue (MODE 0 only).  Its epilogue keeps four 16-byte streams
 // per row in flight and two sets of per-channel vectors, so it is compiled for 2 workgroups per CU (256 VGPRs) as its own
 // instantiation -- inside the shared kernel it pushed every MODE 0 instance into scratch spills.
-template <int BC, int MODE, int PD, bool RES = false>
-__global__ __launch_bounds__(NTHREADS, RES ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
+// DUAL: the BatchNorm-backward affine of two source tensors is applied by the MODE 0 loader (own instantiation as well:
+// a second register ring for z, 2 workgroups per CU, deep prefetch).
+template <int BC, int MODE, int PD, bool RES = false, bool DUAL = false>
+__global__ __launch_bounds__(NTHREADS, (RES || DUAL) ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
     constexpr int WROWS = BC / 64;          // weight rows staged per thread
     constexpr int TILE_BYTES = (BP + BC) * 64;
     constexpr int EPI_BYTES = BP * (BC * 2 + 16);
     constexpr int STAGE_BYTES = (2 * TILE_BYTES) > EPI_BYTES ? (2 * TILE_BYTES) : EPI_BYTES;
     constexpr int CS2_OFF = STAGE_BYTES + 2 * BC * 4 + 256 + (MODE == 3 ? BP * 4 + 16 : 0);     // second sum set (RES)
-    constexpr int SMEM_BYTES = CS2_OFF + (RES ? 2 * BC * 4 : 0);   // + per-channel sums + tap-offset table (+ MODE 3: output row table, weight tap table)
+    // MODE 0: the per-input-channel vectors of the loader transform (lazy BatchNorm scale / shift, or the three DUAL affine
+    // vectors) are staged in LDS once per workgroup when K <= VEC_MAXK: read from global inside store_tile they were an
+    // exposed L1/L2 round trip in every K step (the loads can only be issued when the tile registers are consumed)
+    constexpr int VEC_MAXK = 1024;
+    constexpr int VEC_OFF = CS2_OFF + (RES ? 2 * BC * 4 : 0);
+    constexpr int SMEM_BYTES = VEC_OFF + (MODE == 0 ? (DUAL ? 3 : 2) * VEC_MAXK * 4 : 0);   // + per-channel sums + tap-offset table (+ MODE 3: output row table, weight tap table)
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
 
     {   // BatchNorm group of this workgroup: one launch covers the S per-segment calls of the reference
@@ -91,12 +104,27 @@ __global__ __launch_bounds__(NTHREADS, RES ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) 
         if (p.stats) p.stats += (size_t)g * ADAMML_STAT_SLOTS * 2 * p.Cout;
         if (p.in_scale) { p.in_scale += (size_t)g * p.in_gstride; p.in_shift += (size_t)g * p.in_gstride; }
         if (p.bn_z) { p.bn_z += (size_t)g * p.gy; p.bn_vec += (size_t)g * 4 * p.Cout; }
+        if (DUAL) {
+            p.x2 += (size_t)g * p.gx;
+            p.aff += (size_t)g * 3 * p.K;
+            if (p.side) p.side += (size_t)g * p.gx;
+        }
         if (RES) {
             p.res_out += (size_t)g * p.gy;
             if (p.bn_z2) { p.bn_z2 += (size_t)g * p.gy; p.bn_vec2 += (size_t)g * 4 * p.Cout; p.stats2 += (size_t)g * ADAMML_STAT_SLOTS * 2 * p.Cout; }
         }
     }
     const int tid = threadIdx.x;
+    float* s_vec = reinterpret_cast<float*>(smem + (MODE == 0 ? VEC_OFF : 0));
+    const bool vec_lds = MODE == 0 && p.K <= VEC_MAXK && (DUAL || p.in_scale != nullptr);
+    if (vec_lds) {
+        if (DUAL) {
+            for (int i = tid; i < 3 * p.K; i += NTHREADS) s_vec[i] = p.aff[i];
+        } else {
+            for (int i = tid; i < p.K; i += NTHREADS) { s_vec[i] = p.in_scale[i]; s_vec[p.K + i] = p.in_shift[i]; }
+        }
+        __syncthreads();
+    }
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wp = wave & 1;                // pixel half
@@ -213,6 +241,7 @@ __global__ __launch_bounds__(NTHREADS, RES ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) 
     // register prefetch ring of depth PD: global loads run PD K-steps ahead of the MFMAs.  One K step of compute is
     // ~0.15 us but an HBM round trip is 1-2 us, so a one-step look-ahead left the kernel latency-bound.
     bf16x8 ra[PD][2], rw[PD][WROWS];
+    bf16x8 ra2[DUAL ? PD : 1][2];
     int rci[PD];
     bool rav[PD][2];
 #pragma unroll
@@ -232,6 +261,11 @@ __global__ __launch_bounds__(NTHREADS, RES ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) 
                 bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + (size_t)(unsigned)(a_base[r] + k));
                 ra[SL][r] = v;
+                if (DUAL) {
+                    bf16x8 v2 = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ok) v2 = *reinterpret_cast<const bf16x8*>(p.x2 + (size_t)(unsigned)(a_base[r] + k));
+                    ra2[DUAL ? SL : 0][r] = v2;
+                }
             }
         } else if (MODE == 1 || MODE == 3) {
             const int tap = kok ? (k >> p.cin_shift) : 0;
@@ -279,7 +313,28 @@ __global__ __launch_bounds__(NTHREADS, RES ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) 
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             bf16x8 v = ra[SL][r];
-            if (p.in_scale && rav[SL][r]) v = f32_to_bf8(transform8(v, p.in_scale, p.in_shift, rci[SL], p.act));
+            if (DUAL) {
+                if (rav[SL][r]) {
+                    const f32x8 gv = bf8_to_f32(v), zv = bf8_to_f32(ra2[DUAL ? SL : 0][r]);
+                    f32x8 ca, cb, cc;
+                    if (vec_lds) { ca = load_f32x8(s_vec + rci[SL]); cb = load_f32x8(s_vec + p.K + rci[SL]); cc = load_f32x8(s_vec + 2 * p.K + rci[SL]); }
+                    else { ca = load_f32x8(p.aff + rci[SL]); cb = load_f32x8(p.aff + p.K + rci[SL]); cc = load_f32x8(p.aff + 2 * p.K + rci[SL]); }
+                    f32x8 o;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = fmaf(ca[i], gv[i], fmaf(cb[i], zv[i], cc[i]));
+                    v = f32_to_bf8(o);
+                    if (p.side && ctile == 0) *reinterpret_cast<bf16x8*>(p.side + (size_t)(unsigned)(a_base[r] + rci[SL])) = v;
+                }
+            } else if (p.in_scale && rav[SL][r]) {
+                if (vec_lds) {
+                    const f32x8 sc = load_f32x8(s_vec + rci[SL]), sh = load_f32x8(s_vec + p.K + rci[SL]);
+                    const float lo = act_lo(p.act), hi = act_hi(p.act);
+                    f32x8 f = bf8_to_f32(v);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) f[i] = clamp_act(fmaf(f[i], sc[i], sh[i]), lo, hi);
+                    v = f32_to_bf8(f);
+                } else v = f32_to_bf8(transform8(v, p.in_scale, p.in_shift, rci[SL], p.act));
+            }
             *reinterpret_cast<bf16x8*>(base + lds_off(row_a + r * 64, chunk)) = v;
         }
 #pragma unroll
@@ -944,10 +999,12 @@ int adamml_conv3x3_c64_wgrad_launch(const adamml_conv_desc_t* d, const void* dz,
 struct DgradClass { int nt; unsigned code; int ph, pw, OHc, OWc; };
 // residual form of the BatchNorm-fused data-gradient epilogue (ConvP::res_out ..)
 struct ResEpi { const void* res_out; int res_act; const void* bn_z2; const float* bn_vec2; double* stats2; };
+// dual-source input of a 1x1 data gradient (ConvP::x2 ..)
+struct DualIn { const void* z; const float* aff; void* side; };
 
 static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
                        const float* in_shift, void* y, double* stats, const void* bn_z, const float* bn_vec, int bn_act,
-                       hipStream_t stream, const DgradClass* cls = nullptr, const ResEpi* res = nullptr) {
+                       hipStream_t stream, const DgradClass* cls = nullptr, const ResEpi* res = nullptr, const DualIn* dual = nullptr) {
     if (!d || !x || !w_packed || !y) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: null argument");
     if (d->Cin % 8 || d->Cout % 8) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: channels must be multiples of 8 (Cin=%d Cout=%d)", d->Cin, d->Cout);
     if (!cls && adamml_conv3x3_c64_supported(d))
@@ -958,6 +1015,7 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     p.bn_z = (const bf16_t*)bn_z; p.bn_vec = bn_vec; p.bn_act = bn_act;
     p.res_out = res ? (const bf16_t*)res->res_out : nullptr; p.res_act = res ? res->res_act : 0;
     p.bn_z2 = res ? (const bf16_t*)res->bn_z2 : nullptr; p.bn_vec2 = res ? res->bn_vec2 : nullptr; p.stats2 = res ? res->stats2 : nullptr;
+    p.x2 = dual ? (const bf16_t*)dual->z : nullptr; p.aff = dual ? dual->aff : nullptr; p.side = dual ? (bf16_t*)dual->side : nullptr;
     const int groups = d->groups < 1 ? 1 : d->groups;
     p.gx = (size_t)d->N * d->H * d->W * d->Cin;
     p.gy = (size_t)d->N * d->OH * d->OW * d->Cout;
@@ -1006,6 +1064,12 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
         if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, true>), grid, block, 0, stream, p);
         return adamml_check_launch("conv_bwd_data_res");
+    }
+    if (dual) {
+        if (mode != 0 || res) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_dual: only 1x1 / stride-1 convs");
+        if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 3, false, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 3, false, true>), grid, block, 0, stream, p);
+        return adamml_check_launch("conv_bwd_data_dual");
     }
 #define LAUNCH_CONV(BCV, MODEV)                                                                             \
     do {                                                                                                    \
@@ -1085,6 +1149,24 @@ extern "C" int adamml_conv_bwd_data_bn(const adamml_conv_desc_t* d, const void* 
     g.stride = 1; g.up = d->stride; g.pad = d->KH - 1 - d->pad;
     g.act = ACT_NONE; g.accumulate = 0; g.in_gstride = 0;
     return conv_launch(&g, dz, w_dgrad_packed, nullptr, nullptr, dx, sums, z_in, bn_vec, act, stream);
+}
+
+extern "C" int adamml_conv_bwd_data_dual(const adamml_conv_desc_t* d, const void* g, const void* z, const float* aff, void* dz_side,
+                                         const void* w_dgrad_packed, void* dx, int accumulate, const void* z_in, const float* bn_vec,
+                                         int act, double* sums, hipStream_t stream) {
+    if (!d || !g || !z || !aff) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_dual: null argument");
+    if (!(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0))
+        return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_dual: only 1x1 / stride-1 convs");
+    if ((z_in != nullptr) != (bn_vec != nullptr) || (z_in != nullptr) != (sums != nullptr))
+        return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_dual: incomplete BatchNorm epilogue operands");
+    if (z_in && accumulate) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_dual: the BatchNorm epilogue does not accumulate");
+    adamml_conv_desc_t gd = *d;
+    gd.N = d->N; gd.H = d->OH; gd.W = d->OW; gd.Cin = d->Cout;
+    gd.OH = d->H; gd.OW = d->W; gd.Cout = d->Cin;
+    gd.stride = 1; gd.up = 1; gd.pad = 0;
+    gd.act = ACT_NONE; gd.accumulate = accumulate ? 1 : 0; gd.in_gstride = 0;
+    DualIn di{z, aff, dz_side};
+    return conv_launch(&gd, g, w_dgrad_packed, nullptr, nullptr, dx, sums, z_in, bn_vec, act, stream, nullptr, nullptr, &di);
 }
 
 extern "C" int adamml_conv_bwd_data_res_supported(const adamml_conv_desc_t* d) {

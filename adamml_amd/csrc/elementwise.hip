@@ -275,6 +275,21 @@ __global__ void bn_bwd_finalize_kernel(const double* sums, int nslots, int group
     }
 }
 
+// dz = k0 (g' - k1 - zhat k2), zhat = (z - mu) invstd  ==  A g' + B z + C  per channel: the form the dual-source loader of
+// the 1x1 data gradient applies (adamml_conv_bwd_data_dual).  coef [G][3][C], vec [G][4][C] -> aff [G][3][C].
+__global__ void bn_bwd_affine_kernel(const float* coef, const float* vec, float* aff, int C, int groups) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * groups) return;
+    const int g = i / C, c = i - g * C;
+    const float* cf = coef + (size_t)g * 3 * C;
+    const float* v = vec + (size_t)g * 4 * C;
+    const float k0 = cf[c], k1 = cf[C + c], k2 = cf[2 * C + c], mu = v[2 * C + c], is = v[3 * C + c];
+    float* a = aff + (size_t)g * 3 * C;
+    a[c] = k0;
+    a[C + c] = -k0 * k2 * is;
+    a[2 * C + c] = k0 * (k2 * mu * is - k1);
+}
+
 // STREAM: the tensors are larger than the 256 MB Infinity Cache -> non-temporal accesses (nothing is re-used from cache);
 // smaller tensors keep default caching so that the consumers of dz (data / weight gradient) still find it in L2 / MALL.
 template <bool STREAM>
@@ -908,6 +923,12 @@ extern "C" int adamml_bn_bwd_finalize(const double* sums, int nslots, int groups
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, stream, sums, nslots, groups, count, gamma, vec, dgamma,
                        dbeta, coef, C);
     return adamml_check_launch("bn_bwd_finalize");
+}
+
+extern "C" int adamml_bn_bwd_affine(const float* coef, const float* vec, float* aff, int C, int groups, hipStream_t stream) {
+    if (!coef || !vec || !aff || C < 1 || groups < 1) return adamml_set_error(ADAMML_EINVAL, "bn_bwd_affine: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_affine_kernel, dim3(ceil_div(C * groups, 256)), dim3(256), 0, stream, coef, vec, aff, C, groups);
+    return adamml_check_launch("bn_bwd_affine");
 }
 
 extern "C" int adamml_bn_bwd_apply(const void* g, const void* z, const float* vec, int act, const float* coef, void* dz, size_t P, int C,

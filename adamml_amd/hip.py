@@ -34,6 +34,8 @@ SIGNATURES = {
     "adamml_conv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "adamml_conv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
     "adamml_conv_bwd_data_bn": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
+    "adamml_bn_bwd_affine": [_P, _P, _P, _I, _I, _P],
+    "adamml_conv_bwd_data_dual": [_DESC, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
     "adamml_conv_bwd_data_res": [_DESC, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "adamml_residual_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _P],
     "adamml_conv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _I, _P, _Z, _P],

@@ -200,8 +200,10 @@ def _bn_eval_vectors(bn, C, device):
     return vec
 
 
-def _bn_backward(rt, out, y, vec, bn, act, count):
-    """Turns out.grad (w.r.t. the activated value) into dz (w.r.t. the raw conv output); accumulates dgamma/dbeta."""
+def _bn_backward(rt, out, y, vec, bn, act, count, defer_apply=False):
+    """Turns out.grad (w.r.t. the activated value) into dz (w.r.t. the raw conv output); accumulates dgamma/dbeta.
+    defer_apply=True stops after the finalize step and returns (g, coef): the caller's data-gradient kernel applies
+    dz = k0 (g - k1 - zhat k2) in its loader (adamml_conv_bwd_data_dual) instead of a separate pass over g and z."""
     g = out.grad
     out.grad = None
     n, oh, ow, C = y.shape
@@ -232,6 +234,8 @@ def _bn_backward(rt, out, y, vec, bn, act, count):
     train_bn = bn.weight.requires_grad
     call("adamml_bn_bwd_finalize", ptr(sums), nslots, G, float(count * rt.sync.world), ptr(bn.weight), ptr(vec),
          ptr(bn.weight.grad) if train_bn else None, ptr(bn.bias.grad) if train_bn else None, ptr(coef), C)
+    if defer_apply:
+        return g, coef
     dz = torch.empty_like(y)
     call("adamml_bn_bwd_apply", ptr(g), ptr(y), ptr(vec), act, ptr(coef), ptr(dz), P, C, G)
     return dz
@@ -312,6 +316,10 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
         def bwd():
             if out.grad is None and out.pool_grad is None:
                 return
+            if DUAL_DGRAD and act == ACT_NONE and not cs.depthwise and not stem and cs.kh == 1 and cs.kw == 1 and cs.stride == 1 \
+                    and cs.pad == 0 and out.pool_grad is None and x.requires_grad and rt.training:
+                _conv1x1_backward_dual(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern)
+                return
             dz = _bn_backward(rt, out, y, vec, bn, act, count)
             if cs.weight.requires_grad:
                 hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b)
@@ -358,6 +366,43 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                     call("adamml_conv_bwd_data", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc)
         rt.tape.record(bwd)
     return out
+
+
+DUAL_DGRAD = True     # 1x1 / linear-BatchNorm layers: BatchNorm-backward apply folded into the data-gradient loader
+
+
+def _conv1x1_backward_dual(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern):
+    """Backward of a 1x1 / stride-1 conv followed by a linear (no activation) train-mode BatchNorm -- bn3 and the stride-1
+    downsample BN of a bottleneck, the projection conv of an inverted residual.  After the BatchNorm-backward sums are
+    finalised, the data-gradient kernel reads (g, z) directly and forms dz = A g + B z + C in its loader; dz is written
+    once, as a side output, for the weight-gradient kernel.  Saves one full pass over the layer's largest tensor."""
+    G = rt.groups
+    C = d.Cout
+    g, coef = _bn_backward(rt, out, y, vec, bn, ACT_NONE, count, defer_apply=True)
+    aff = torch.empty(G, 3, C, dtype=torch.float32, device=y.device)
+    call("adamml_bn_bwd_affine", ptr(coef), ptr(vec), ptr(aff), C, G)
+    need_w = cs.weight.requires_grad
+    dz = torch.empty_like(y) if need_w else None
+    acc = 1
+    if x.grad is None:
+        x.grad = torch.empty_like(x.data)
+        acc = 0
+    tgt = x.src if x.src is not None else x
+    if sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None:
+        sums = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS)
+        hip.next_meta = (2 * macs, 2 * in_b + (3 if need_w else 2) * out_b + w_b, kern)
+        call("adamml_conv_bwd_data_dual", byref(d), ptr(g), ptr(y), ptr(aff), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), 0, ptr(tgt.data),
+             ptr(tgt.vec), tgt.act, ptr(sums))
+        tgt.pre_sums = sums
+    else:
+        hip.next_meta = (2 * macs, in_b * (1 + acc) + (3 if need_w else 2) * out_b + w_b, kern)
+        call("adamml_conv_bwd_data_dual", byref(d), ptr(g), ptr(y), ptr(aff), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc, None, None, 0,
+             None)
+    if need_w:
+        hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b)
+        ws = hip.wgrad_workspace(d, cs.cin_true, dz.device)
+        call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(cs.weight.grad), cs.cin_true,
+             ptr(ws), ws.numel() * 4)
 
 
 def _residual_fusable(x, d):

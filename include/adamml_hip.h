@@ -69,6 +69,17 @@ int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const void
 int adamml_conv_bwd_data_bn(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx, const void* z_in,
                             const float* bn_vec, int act, double* sums, hipStream_t stream);
 
+/* Data gradient of a 1x1 / stride-1 conv fused with the BatchNorm backward "apply" pass of its own output's BatchNorm
+ * (activation NONE: bn3 / downsample BN of a bottleneck, the linear bottleneck of MobileNetV2): the loader reads the
+ * masked gradient g and the raw conv output z and forms dz = A g + B z + C per channel (aff [groups][3][Cout] from
+ * adamml_bn_bwd_affine) on the way into LDS, so adamml_bn_bwd_apply (read g, z; write dz) never runs for this layer;
+ * dz_side (optional, same shape as g) receives dz once for adamml_conv_bwd_weight.  z_in / bn_vec / act / sums (all or none):
+ * the BatchNorm-fused epilogue of adamml_conv_bwd_data_bn. */
+int adamml_bn_bwd_affine(const float* coef, const float* vec, float* aff, int C, int groups, hipStream_t stream);
+int adamml_conv_bwd_data_dual(const adamml_conv_desc_t* d, const void* g, const void* z, const float* aff, void* dz_side,
+                              const void* w_dgrad_packed, void* dx, int accumulate, const void* z_in, const float* bn_vec, int act,
+                              double* sums, hipStream_t stream);
+
 /* Data gradient of a 1x1 / stride-1 conv whose INPUT is the output of a residual add  out = act(bn_a(z_a) + idn)
  * (models/resnet.py:110-111; sound_mobilenet_v2.py:67), finishing that add's backward in the epilogue:
  *   g' = (W^T dz [+ dx, when accumulate: the identity-path gradient already stored there]) * act'(res_out)

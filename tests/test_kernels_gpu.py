@@ -759,3 +759,59 @@ def test_maxpool_bwd_bn_fused_equals_unfused_sequence(N, H, W, C, G):
     assert torch.equal(dz, dz_ref)
     a, b = s.sum(1), s_ref.sum(1)
     assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,G,mode", [(4, 28, 64, 256, 1, "plain"), (6, 14, 128, 512, 3, "bn"), (4, 20, 64, 256, 2, "acc"),
+                                                  (2, 16, 144, 24, 1, "bn"), (5, 7, 512, 2048, 5, "bn"), (3, 14, 256, 1024, 1, "plain")])
+def test_conv_bwd_data_dual_equals_apply_then_dgrad(N, H, Cin, Cout, G, mode):
+    """adamml_conv_bwd_data_dual (BatchNorm-backward apply folded into the loader of the 1x1 data gradient, dz as a side
+    output) against adamml_bn_bwd_apply + adamml_conv_bwd_data[_bn].  The affine form A g + B z + C rounds differently
+    from k0 (g - k1 - zhat k2) in the last fp32 bit: dz within 1 bf16 ulp, dx within 1e-2 of its scale."""
+    torch.manual_seed(N * 3 + H)
+    P = N * H * H
+    w = torch.randn(Cout, Cin, 1, 1, device=DEV) * (2.0 / Cout) ** 0.5
+    g = torch.randn(G * N, H, H, Cout, device=DEV).to(torch.bfloat16)
+    z = torch.randn(G * N, H, H, Cout, device=DEV).to(torch.bfloat16)
+    vec = torch.rand(G, 4, Cout, device=DEV) + 0.5
+    coef = torch.rand(G, 3, Cout, device=DEV) * 0.5 + 0.25
+    coef[:, 1:] -= 0.5
+    d = ConvDesc(N, H, H, Cin, H, H, Cout, 1, 1, 1, 0, 1, 0, 0, G, 0)
+    wd = pack(w, Cin, 1)
+    zin = torch.randn(G * N, H, H, Cin, device=DEV).to(torch.bfloat16)
+    vin = torch.rand(G, 4, Cin, device=DEV) + 0.5
+    vin[:, 1] -= 1.0
+    base = torch.randn(G * N, H, H, Cin, device=DEV).to(torch.bfloat16)
+    # unfused
+    dz_ref = torch.empty_like(g)
+    call("adamml_bn_bwd_apply", ptr(g), ptr(z), ptr(vec), 0, ptr(coef), ptr(dz_ref), P, Cout, G)
+    dx_ref = base.clone()
+    s_ref = torch.zeros(G, STAT_SLOTS, 2 * Cin, dtype=torch.float64, device=DEV)
+    if mode == "bn":
+        call("adamml_conv_bwd_data_bn", byref(d), ptr(dz_ref), ptr(wd), ptr(dx_ref), ptr(zin), ptr(vin), 1, ptr(s_ref))
+    else:
+        call("adamml_conv_bwd_data", byref(d), ptr(dz_ref), ptr(wd), ptr(dx_ref), 1 if mode == "acc" else 0)
+    # fused
+    aff = torch.empty(G, 3, Cout, device=DEV)
+    call("adamml_bn_bwd_affine", ptr(coef), ptr(vec), ptr(aff), Cout, G)
+    dz = torch.zeros_like(g)
+    dx = base.clone()
+    s = torch.zeros_like(s_ref)
+    if mode == "bn":
+        call("adamml_conv_bwd_data_dual", byref(d), ptr(g), ptr(z), ptr(aff), ptr(dz), ptr(wd), ptr(dx), 0, ptr(zin), ptr(vin), 1, ptr(s))
+    else:
+        call("adamml_conv_bwd_data_dual", byref(d), ptr(g), ptr(z), ptr(aff), ptr(dz), ptr(wd), ptr(dx), 1 if mode == "acc" else 0,
+             None, None, 0, None)
+    scale = dz_ref.float().abs().max().item()
+    assert (dz.float() - dz_ref.float()).abs().max().item() <= 2 ** -7 * scale
+    assert (dz != dz_ref).float().mean().item() < 0.05                       # the odd last-bit rounding difference only
+    sx = dx_ref.float().abs().max().item()
+    assert (dx.float() - dx_ref.float()).abs().max().item() <= 1e-2 * sx
+    if mode == "bn":
+        a, b = s.sum(1), s_ref.sum(1)
+        assert (a - b).abs().max().item() <= 1e-2 * b.abs().max().item() + 1e-2
+    # without the side output the data gradient is unchanged
+    dx2 = base.clone()
+    if mode != "bn":
+        call("adamml_conv_bwd_data_dual", byref(d), ptr(g), ptr(z), ptr(aff), None, ptr(wd), ptr(dx2), 1 if mode == "acc" else 0,
+             None, None, 0, None)
+        assert torch.equal(dx2, dx)
