@@ -609,7 +609,7 @@ __device__ __forceinline__ int tr_swz(int row) {
     return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 2;               // 128-byte rows: parity picks the bank half
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WPD = 1>
 __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
     constexpr int AROW = BM * 2;            // bytes per LDS row (one pixel)
     constexpr int BROW = BN * 2;
@@ -636,8 +636,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
 
     constexpr int ACH = BM / 8, BCH = BN / 8;                 // 16-byte chunks per row
     constexpr int AL = (32 * ACH) / NTHREADS, BL = (32 * BCH) / NTHREADS;
-    bf16x8 ra[AL], rb[BL];
-    bool rbv[BL];
+    // register prefetch ring: global loads run WPD K steps (of 32 pixels) ahead of the MFMAs.  One K step is ~0.1 us of
+    // matrix work but an HBM round trip is 1-2 us: with a one-step look-ahead the layer2-4 problems (3-4 workgroups per CU)
+    // sat at 250-450 TFLOP/s and ~2.4 TB/s -- neither roof.  WPD = 4 costs 40 VGPRs (5 -> 3 waves per SIMD), which loses
+    // on the HBM-bound layer-1 shapes and on grids with > 4 workgroups per CU, so the launcher picks per problem.
+    bf16x8 ra[WPD][AL], rb[WPD][BL];
+    bool rbv[WPD][BL];
     int b_kh[BL], b_kw[BL], b_ci[BL], b_n[BL], b_oh[BL], b_ow[BL];
     bool b_ok[BL];
 #pragma unroll
@@ -657,7 +661,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
         b_ow[l] = rem - b_oh[l] * p.OW;
     }
 
-    auto issue_loads = [&](int pbase) {
+    auto issue_loads = [&](auto slot_c, int pbase) {
+        constexpr int SL = decltype(slot_c)::value;
 #pragma unroll
         for (int l = 0; l < AL; ++l) {
             int e = tid + l * NTHREADS;
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
             int pp = pbase + row, co = co0 + ch * 8;
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (pp < pe && co < p.Cout) v = *reinterpret_cast<const bf16x8*>(p.dz + (size_t)pp * p.Cout + co);
-            ra[l] = v;
+            ra[SL][l] = v;
         }
 #pragma unroll
         for (int l = 0; l < BL; ++l) {
@@ -675,28 +680,29 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
             int ih = b_oh[l] * p.stride + b_kh[l], iw = b_ow[l] * p.stride + b_kw[l];
             bool ok = (pbase + row < pe) && b_ok[l] && ih >= 0 && iw >= 0 && ih < p.H && iw < p.W;
             if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + ((size_t)(b_n[l] * p.H + ih) * p.W + iw) * p.Cin + b_ci[l]);
-            rbv[l] = ok;
-            rb[l] = v;
+            rbv[SL][l] = ok;
+            rb[SL][l] = v;
             // advance this chunk's pixel by one K step (32 output pixels)
             b_ow[l] += 32;
             while (b_ow[l] >= p.OW) { b_ow[l] -= p.OW; ++b_oh[l]; }
             while (b_oh[l] >= p.OH) { b_oh[l] -= p.OH; ++b_n[l]; }
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](auto slot_c, int buf) {
+        constexpr int SL = decltype(slot_c)::value;
         char* base = smem + buf * TILE_BYTES;
 #pragma unroll
         for (int l = 0; l < AL; ++l) {
             int e = tid + l * NTHREADS;
             int row = e / ACH, ch = e - row * ACH;
-            *reinterpret_cast<bf16x8*>(base + row * AROW + ((ch ^ (tr_swz<BM>(row) >> 1)) << 4)) = ra[l];
+            *reinterpret_cast<bf16x8*>(base + row * AROW + ((ch ^ (tr_swz<BM>(row) >> 1)) << 4)) = ra[SL][l];
         }
 #pragma unroll
         for (int l = 0; l < BL; ++l) {
             int e = tid + l * NTHREADS;
             int row = e / BCH, ch = e - row * BCH;
-            bf16x8 v = rb[l];
-            if (p.in_scale && rbv[l]) v = f32_to_bf8(transform8(v, p.in_scale, p.in_shift, b_ci[l], p.act));
+            bf16x8 v = rb[SL][l];
+            if (p.in_scale && rbv[SL][l]) v = f32_to_bf8(transform8(v, p.in_scale, p.in_shift, b_ci[l], p.act));
             *reinterpret_cast<bf16x8*>(base + 32 * AROW + row * BROW + ((ch ^ (tr_swz<BN>(row) >> 1)) << 4)) = v;
         }
     };
@@ -708,20 +714,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
         for (int jn = 0; jn < NT; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = pe > ps ? (pe - ps + 31) / 32 : 0;
-    if (nk > 0) {
-        issue_loads(ps);
-        store_tile(0);
-    }
-    __syncthreads();
     const int li = lane & 15, lg = lane >> 4;
     // transpose-read addressing: lane li of a 16-lane group supplies the 8-byte unit
     // [pixel row 8*lg + (li>>2) (+4)][channels 4*(li&3) ..+3]; it receives channel li of rows 0..3.
     const int trow = 8 * lg + (li >> 2), tq = li & 3;
     const int a_lo = trow * AROW, a_hi = (trow + 4) * AROW, b_lo = trow * BROW, b_hi = (trow + 4) * BROW;
     const int ax_lo = tr_swz<BM>(trow), ax_hi = tr_swz<BM>(trow + 4), bx_lo = tr_swz<BN>(trow), bx_hi = tr_swz<BN>(trow + 4);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) issue_loads(ps + (kt + 1) * 32);
+    auto compute = [&](int buf) {
         const char* base = smem + buf * TILE_BYTES;
         bf16x8 fa[MT], fb[NT];
 #pragma unroll
@@ -747,8 +746,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
+    };
+    static_for<WPD>([&](auto sc) {
+        if ((int)decltype(sc)::value < nk) issue_loads(sc, ps + (int)decltype(sc)::value * 32);
+    });
+    for (int kt0 = 0; kt0 < nk; kt0 += WPD) {
+        static_for<WPD>([&](auto sc) {
+            const int kt = kt0 + (int)decltype(sc)::value;
+            if (kt < nk) {                               // uniform
+                store_tile(sc, kt & 1);                  // waits (counted vmcnt) only for this slot's loads
+                if (kt + WPD < nk) issue_loads(sc, ps + (kt + WPD) * 32);
+                __syncthreads();                         // tile kt visible; everyone is past compute(kt-1)
+                compute(kt & 1);
+            }
+        });
     }
     const int taps = p.KH * p.KW;
 #pragma unroll
@@ -1316,6 +1327,7 @@ extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* d
         if (pl.BM == 64 && pl.BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, stream, p);
         else if (pl.BM == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, block, 0, stream, p);
         else if (pl.BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, block, 0, stream, p);
+        else if ((long)grid.x * grid.y <= 1100) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, stream, p);
     }
     rc = adamml_check_launch("conv_bwd_weight");
