@@ -1327,7 +1327,7 @@ extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* d
         if (pl.BM == 64 && pl.BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, stream, p);
         else if (pl.BM == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, block, 0, stream, p);
         else if (pl.BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, block, 0, stream, p);
-        else if ((long)grid.x * grid.y <= 1100) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 4>), grid, block, 0, stream, p);
+        else if ((long)grid.x * grid.y <= 1100) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 6>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, stream, p);
     }
     rc = adamml_check_launch("conv_bwd_weight");
