@@ -1162,12 +1162,19 @@ extern "C" int adamml_conv_bwd_data_bn(const adamml_conv_desc_t* d, const void* 
     return conv_launch(&g, dz, w_dgrad_packed, nullptr, nullptr, dx, sums, z_in, bn_vec, act, stream);
 }
 
+// Measured on MI355X (tools/bench_fused.py, B = 72): against apply + data gradient the dual loader wins for K = Cout <= 512
+// (layer 1: 3.8 vs 4.2 ms, layer 2: 1.01 vs 1.05 ms) and loses beyond (layer 3: 0.33 vs 0.30 ms; layer 4: every one of
+// the 4 cout tiles repeats the affine and the vectors no longer fit the LDS table).
+extern "C" int adamml_conv_bwd_data_dual_supported(const adamml_conv_desc_t* d) {
+    return d && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cout <= 512 && d->Cin % 8 == 0 && d->Cout % 8 == 0 ? 1 : 0;
+}
+
 extern "C" int adamml_conv_bwd_data_dual(const adamml_conv_desc_t* d, const void* g, const void* z, const float* aff, void* dz_side,
                                          const void* w_dgrad_packed, void* dx, int accumulate, const void* z_in, const float* bn_vec,
                                          int act, double* sums, hipStream_t stream) {
     if (!d || !g || !z || !aff) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_dual: null argument");
-    if (!(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0))
-        return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_dual: only 1x1 / stride-1 convs");
+    if (!adamml_conv_bwd_data_dual_supported(d))
+        return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_dual: only 1x1 / stride-1 convs with Cout <= 512");
     if ((z_in != nullptr) != (bn_vec != nullptr) || (z_in != nullptr) != (sums != nullptr))
         return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_dual: incomplete BatchNorm epilogue operands");
     if (z_in && accumulate) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_dual: the BatchNorm epilogue does not accumulate");

@@ -99,6 +99,8 @@ def load():
     lib.adamml_dwconv_bwd_weight_workspace.restype = c_size_t
     lib.adamml_conv_fused_input_supported.argtypes = [_DESC]
     lib.adamml_conv_fused_input_supported.restype = c_int
+    lib.adamml_conv_bwd_data_dual_supported.argtypes = [_DESC]
+    lib.adamml_conv_bwd_data_dual_supported.restype = c_int
     lib.adamml_conv_bwd_data_res_supported.argtypes = [_DESC]
     lib.adamml_conv_bwd_data_res_supported.restype = c_int
     lib.adamml_temporal_pool_bwd_res_supported.argtypes = [_I, _I, _I]

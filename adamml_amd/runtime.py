@@ -316,8 +316,8 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
         def bwd():
             if out.grad is None and out.pool_grad is None:
                 return
-            if DUAL_DGRAD and act == ACT_NONE and not cs.depthwise and not stem and cs.kh == 1 and cs.kw == 1 and cs.stride == 1 \
-                    and cs.pad == 0 and out.pool_grad is None and x.requires_grad and rt.training:
+            if DUAL_DGRAD and act == ACT_NONE and not cs.depthwise and not stem and out.pool_grad is None and x.requires_grad \
+                    and rt.training and hip.load().adamml_conv_bwd_data_dual_supported(byref(d)):
                 _conv1x1_backward_dual(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern)
                 return
             dz = _bn_backward(rt, out, y, vec, bn, act, count)

@@ -75,6 +75,7 @@ int adamml_conv_bwd_data_bn(const adamml_conv_desc_t* d, const void* dz, const v
  * adamml_bn_bwd_affine) on the way into LDS, so adamml_bn_bwd_apply (read g, z; write dz) never runs for this layer;
  * dz_side (optional, same shape as g) receives dz once for adamml_conv_bwd_weight.  z_in / bn_vec / act / sums (all or none):
  * the BatchNorm-fused epilogue of adamml_conv_bwd_data_bn. */
+int adamml_conv_bwd_data_dual_supported(const adamml_conv_desc_t* d);   /* 1x1, stride 1, Cout <= 512 (where it pays) */
 int adamml_bn_bwd_affine(const float* coef, const float* vec, float* aff, int C, int groups, hipStream_t stream);
 int adamml_conv_bwd_data_dual(const adamml_conv_desc_t* d, const void* g, const void* z, const float* aff, void* dz_side,
                               const void* w_dgrad_packed, void* dx, int accumulate, const void* z_in, const float* bn_vec, int act,

@@ -762,7 +762,7 @@ def test_maxpool_bwd_bn_fused_equals_unfused_sequence(N, H, W, C, G):
 
 
 @pytest.mark.parametrize("N,H,Cin,Cout,G,mode", [(4, 28, 64, 256, 1, "plain"), (6, 14, 128, 512, 3, "bn"), (4, 20, 64, 256, 2, "acc"),
-                                                  (2, 16, 144, 24, 1, "bn"), (5, 7, 512, 2048, 5, "bn"), (3, 14, 256, 1024, 1, "plain")])
+                                                  (2, 16, 144, 24, 1, "bn"), (5, 7, 128, 512, 5, "bn"), (3, 14, 256, 384, 1, "plain")])
 def test_conv_bwd_data_dual_equals_apply_then_dgrad(N, H, Cin, Cout, G, mode):
     """adamml_conv_bwd_data_dual (BatchNorm-backward apply folded into the loader of the 1x1 data gradient, dz as a side
     output) against adamml_bn_bwd_apply + adamml_conv_bwd_data[_bn].  The affine form A g + B z + C rounds differently
@@ -776,6 +776,7 @@ def test_conv_bwd_data_dual_equals_apply_then_dgrad(N, H, Cin, Cout, G, mode):
     coef = torch.rand(G, 3, Cout, device=DEV) * 0.5 + 0.25
     coef[:, 1:] -= 0.5
     d = ConvDesc(N, H, H, Cin, H, H, Cout, 1, 1, 1, 0, 1, 0, 0, G, 0)
+    assert hip.load().adamml_conv_bwd_data_dual_supported(byref(d)) == 1
     wd = pack(w, Cin, 1)
     zin = torch.randn(G * N, H, H, Cin, device=DEV).to(torch.bfloat16)
     vin = torch.rand(G, 4, Cin, device=DEV) + 0.5
