@@ -38,6 +38,7 @@ struct ConvP {
     // identity-path gradient already in y, and the sums of a second BatchNorm feeding the same add (downsample branch)
     // are accumulated alongside
     const bf16_t* res_out;       // block output [same shape as y]
+    const uint8_t* res_mask;     // or: 1 bit per element, act'(block output) != 0 (adamml_bn_act_add_mask) -- 1/16 of the bytes
     int res_act;
     const bf16_t* bn_z2;         // raw output of the second BatchNorm'd operand of the add, or null
     const float* bn_vec2;
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL) ? 2 : (PD == 1 ? (BC == 128
         }
         if (RES) {
             p.res_out += (size_t)g * p.gy;
+            if (p.res_mask) p.res_mask += ((size_t)g * p.gy) >> 3;
             if (p.bn_z2) { p.bn_z2 += (size_t)g * p.gy; p.bn_vec2 += (size_t)g * 4 * p.Cout; p.stats2 += (size_t)g * ADAMML_STAT_SLOTS * 2 * p.Cout; }
         }
     }
@@ -412,6 +414,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL) ? 2 : (PD == 1 ? (BC == 128
 #pragma unroll
         for (int b0 = 0; b0 < NR; b0 += EB) {
             bf16x8 zr[EB], dr[EB], orr[EB], z2r[EB];
+            unsigned mbits[EB];
             size_t pr[EB];
             bool ok[EB];
 #pragma unroll
@@ -421,7 +424,8 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL) ? 2 : (PD == 1 ? (BC == 128
                 pr[j] = (size_t)(ok[j] ? p0 + r : p0) * p.Cout + eco;       // clamped: out-of-range rows re-read row p0, never stored
                 zr[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.bn_z + pr[j]));
                 if (p.accumulate) dr[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.y + pr[j]));
-                orr[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.res_out + pr[j]));
+                if (p.res_mask) mbits[j] = p.res_mask[pr[j] >> 3];
+                else orr[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.res_out + pr[j]));
                 if (second) z2r[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.bn_z2 + pr[j]));
             }
 #pragma unroll
@@ -430,9 +434,14 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL) ? 2 : (PD == 1 ? (BC == 128
                 f32x8 f = bf8_to_f32(*reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16));
                 const f32x8 zv = bf8_to_f32(zr[j]);
                 if (p.accumulate) f += bf8_to_f32(dr[j]);
-                const f32x8 ov = bf8_to_f32(orr[j]);
+                if (p.res_mask) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) f[i] *= mask_act(ov[i], rlo, rhi);
+                    for (int i = 0; i < 8; ++i) f[i] = (mbits[j] >> i) & 1u ? f[i] : 0.f;
+                } else {
+                    const f32x8 ov = bf8_to_f32(orr[j]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) f[i] *= mask_act(ov[i], rlo, rhi);
+                }
                 const bf16x8 v = f32_to_bf8(f);
                 if (ok[j]) *reinterpret_cast<bf16x8*>(p.y + pr[j]) = v;
                 const float keep = ok[j] ? 1.f : 0.f;
@@ -1009,7 +1018,7 @@ int adamml_conv3x3_c64_wgrad_launch(const adamml_conv_desc_t* d, const void* dz,
 // one parity class (ph, pw) of the data gradient of a stride-2 conv (see conv_dgrad_stride2)
 struct DgradClass { int nt; unsigned code; int ph, pw, OHc, OWc; };
 // residual form of the BatchNorm-fused data-gradient epilogue (ConvP::res_out ..)
-struct ResEpi { const void* res_out; int res_act; const void* bn_z2; const float* bn_vec2; double* stats2; };
+struct ResEpi { const void* res_out; const uint8_t* res_mask; int res_act; const void* bn_z2; const float* bn_vec2; double* stats2; };
 // dual-source input of a 1x1 data gradient (ConvP::x2 ..)
 struct DualIn { const void* z; const float* aff; void* side; };
 
@@ -1025,6 +1034,7 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     p.y = (bf16_t*)y; p.stats = stats;
     p.bn_z = (const bf16_t*)bn_z; p.bn_vec = bn_vec; p.bn_act = bn_act;
     p.res_out = res ? (const bf16_t*)res->res_out : nullptr; p.res_act = res ? res->res_act : 0;
+    p.res_mask = res ? res->res_mask : nullptr;
     p.bn_z2 = res ? (const bf16_t*)res->bn_z2 : nullptr; p.bn_vec2 = res ? res->bn_vec2 : nullptr; p.stats2 = res ? res->stats2 : nullptr;
     p.x2 = dual ? (const bf16_t*)dual->z : nullptr; p.aff = dual ? dual->aff : nullptr; p.side = dual ? (bf16_t*)dual->side : nullptr;
     const int groups = d->groups < 1 ? 1 : d->groups;
@@ -1192,7 +1202,7 @@ extern "C" int adamml_conv_bwd_data_res_supported(const adamml_conv_desc_t* d) {
 }
 
 extern "C" int adamml_conv_bwd_data_res(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
-                                        int accumulate, const void* res_out, int res_act, const void* z_a, const float* vec_a,
+                                        int accumulate, const void* res_out, const uint8_t* res_mask, int res_act, const void* z_a, const float* vec_a,
                                         double* sums_a, const void* z_b, const float* vec_b, double* sums_b,
                                         hipStream_t stream) {
     if (!d || !res_out || !z_a || !vec_a || !sums_a) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_res: null argument");
@@ -1204,7 +1214,7 @@ extern "C" int adamml_conv_bwd_data_res(const adamml_conv_desc_t* d, const void*
     g.OH = d->H; g.OW = d->W; g.Cout = d->Cin;
     g.stride = 1; g.up = 1; g.pad = 0;
     g.act = ACT_NONE; g.accumulate = accumulate ? 1 : 0; g.in_gstride = 0;
-    ResEpi r{res_out, res_act, z_b, vec_b, sums_b};
+    ResEpi r{res_out, res_mask, res_act, z_b, vec_b, sums_b};
     return conv_launch(&g, dz, w_dgrad_packed, nullptr, nullptr, dx, sums_a, z_a, vec_a, ACT_NONE, stream, nullptr, &r);
 }
 

@@ -119,10 +119,11 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, con
 template <bool STREAM>
 __global__ __launch_bounds__(NT) void bn_act_add_kernel(const bf16_t* z, const float* scale, const float* shift, int z_gs, int act,
                                                         const bf16_t* idn, const float* id_scale, const float* id_shift, int id_gs,
-                                                        bf16_t* out, size_t P, int C, size_t ppb) {
+                                                        bf16_t* out, uint8_t* mask_out, size_t P, int C, size_t ppb) {
     const size_t goff = (size_t)blockIdx.y * P * C;
     z += goff; out += goff;
     if (idn) idn += goff;
+    if (mask_out) mask_out += goff >> 3;
     ChanMap m(C, threadIdx.x);
     if (!m.active) return;
     const int c = m.chunk * 8;
@@ -148,6 +149,15 @@ __global__ __launch_bounds__(NT) void bn_act_add_kernel(const bf16_t* z, const f
         }
         if (STREAM) __builtin_nontemporal_store(f32_to_bf8(v), reinterpret_cast<bf16x8*>(out + p * C + c));
         else *reinterpret_cast<bf16x8*>(out + p * C + c) = f32_to_bf8(v);
+        if (mask_out) {
+            // act'(out) of the STORED value, one bit per element: the residual backward (adamml_conv_bwd_data_res) reads
+            // 1/16 of the bytes it would read from `out`
+            const f32x8 r = bf8_to_f32(f32_to_bf8(v));
+            unsigned bits = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bits |= (r[i] > lo && r[i] < hi) ? (1u << i) : 0u;
+            mask_out[(p * C + c) >> 3] = (uint8_t)bits;
+        }
     }
 }
 
@@ -858,8 +868,8 @@ static void rowwalk_grid(size_t P, int C, int groups, int cap_total, size_t* ppb
     *nblk_out = nblk;
 }
 
-extern "C" int adamml_bn_act_add(const void* z, const float* scale, const float* shift, int z_gstride, int act, const void* idn,
-                                 const float* id_scale, const float* id_shift, int id_gstride, void* out, size_t P, int C, int groups,
+static int bn_act_add_launch(const void* z, const float* scale, const float* shift, int z_gstride, int act, const void* idn,
+                                 const float* id_scale, const float* id_shift, int id_gstride, void* out, uint8_t* mask_out, size_t P, int C, int groups,
                                  hipStream_t stream) {
     CHECK_C(C, "bn_act_add");
     if (!P) return ADAMML_OK;
@@ -868,11 +878,23 @@ extern "C" int adamml_bn_act_add(const void* z, const float* scale, const float*
     rowwalk_grid(P, C, groups, 8192, &ppb, &nblk);
     if ((size_t)groups * P * C * 2 > ((size_t)256 << 20))
         hipLaunchKernelGGL(bn_act_add_kernel<true>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)z, scale, shift, z_gstride,
-                           act, (const bf16_t*)idn, id_scale, id_shift, id_gstride, (bf16_t*)out, P, C, ppb);
+                           act, (const bf16_t*)idn, id_scale, id_shift, id_gstride, (bf16_t*)out, mask_out, P, C, ppb);
     else
         hipLaunchKernelGGL(bn_act_add_kernel<false>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)z, scale, shift, z_gstride,
-                           act, (const bf16_t*)idn, id_scale, id_shift, id_gstride, (bf16_t*)out, P, C, ppb);
+                           act, (const bf16_t*)idn, id_scale, id_shift, id_gstride, (bf16_t*)out, mask_out, P, C, ppb);
     return adamml_check_launch("bn_act_add");
+}
+
+extern "C" int adamml_bn_act_add(const void* z, const float* scale, const float* shift, int z_gstride, int act, const void* idn,
+                                 const float* id_scale, const float* id_shift, int id_gstride, void* out, size_t P, int C, int groups,
+                                 hipStream_t stream) {
+    return bn_act_add_launch(z, scale, shift, z_gstride, act, idn, id_scale, id_shift, id_gstride, out, nullptr, P, C, groups, stream);
+}
+
+extern "C" int adamml_bn_act_add_mask(const void* z, const float* scale, const float* shift, int z_gstride, int act, const void* idn,
+                                      const float* id_scale, const float* id_shift, int id_gstride, void* out, uint8_t* mask_out,
+                                      size_t P, int C, int groups, hipStream_t stream) {
+    return bn_act_add_launch(z, scale, shift, z_gstride, act, idn, id_scale, id_shift, id_gstride, out, mask_out, P, C, groups, stream);
 }
 
 extern "C" int adamml_act_bwd_from_output(const void* g_out, const void* out, int act, void* g, size_t n, hipStream_t stream) {

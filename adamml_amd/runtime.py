@@ -345,12 +345,12 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                 if cs.depthwise:
                     call("adamml_dwconv_bwd_data", byref(d), ptr(dz), ptr(cs.w_fwd), ptr(x.grad), acc)
                 elif last_consumer and _residual_fusable(x, d):
-                    z, idn, ract, idn_sole = x.res
+                    z, idn, ract, idn_sole, rmask = x.res
                     fb = idn is not None and idn_sole and idn.requires_grad and idn.vec is not None and idn.grad is None
                     sa = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS)
                     sb = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS) if fb else None
-                    hip.next_meta = (2 * macs, in_b * (3 + acc + (1 if fb else 0)) + out_b + w_b, kern)
-                    call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc, ptr(x.data), ract,
+                    hip.next_meta = (2 * macs, in_b * ((2.0625 if rmask is not None else 3) + acc + (1 if fb else 0)) + out_b + w_b, kern)
+                    call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc, ptr(x.data), ptr(rmask), ract,
                          ptr(z.data), ptr(z.vec), ptr(sa), ptr(idn.data) if fb else None, ptr(idn.vec) if fb else None, ptr(sb))
                     z.pre_sums = sa
                     if fb:
@@ -435,11 +435,13 @@ def add_act(rt, z, idn, act, idn_sole=False):
     out_t = torch.empty_like(z.data)
     G = rt.groups
     P = n // G * h * w
-    call("adamml_bn_act_add", ptr(z.data), ptr(z.scale), ptr(z.shift), z.gs, act, ptr(idn.data) if idn is not None else None,
+    # 1 bit per element of act'(out): what the fused residual backward needs of `out` (None when nothing will be masked)
+    mask_t = torch.empty(n, h, w, C // 8, dtype=torch.uint8, device=out_t.device) if (rt.tape.need_grad and act != ACT_NONE) else None
+    call("adamml_bn_act_add_mask", ptr(z.data), ptr(z.scale), ptr(z.shift), z.gs, act, ptr(idn.data) if idn is not None else None,
          ptr(idn.scale) if idn is not None else None, ptr(idn.shift) if idn is not None else None,
-         idn.gs if idn is not None else 0, ptr(out_t), P, C, G)
+         idn.gs if idn is not None else 0, ptr(out_t), ptr(mask_t), P, C, G)
     out = Lazy(out_t)
-    out.res = (z, idn, act, idn_sole)
+    out.res = (z, idn, act, idn_sole, mask_t)
     if rt.tape.need_grad:
         def bwd():
             g = out.grad
@@ -526,7 +528,7 @@ def temporal_pool(rt, x, frames, mode, sole_consumer=False):
             gx = torch.empty_like(x.data)
             if sole_consumer and x.grad is None and x.scale is None and x.res is not None and not x.res_done and \
                     hip.load().adamml_temporal_pool_bwd_res_supported(frames, C, m):
-                z, idn, ract, idn_sole = x.res
+                z, idn, ract, idn_sole, _ = x.res
                 fb = idn is not None and idn_sole and idn.requires_grad and idn.vec is not None and idn.grad is None
                 if z.requires_grad and z.vec is not None and z.grad is None and z.pre_sums is None and not fb:
                     sa = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS)

@@ -86,10 +86,12 @@ int adamml_conv_bwd_data_dual(const adamml_conv_desc_t* d, const void* g, const 
  *   g' = (W^T dz [+ dx, when accumulate: the identity-path gradient already stored there]) * act'(res_out)
  * is written to dx, and sum(g'), sum(g' * zhat_a) go to sums_a ([groups][SLOTS][2*Cin], caller zeroes); when the add's
  * other operand is BatchNorm'd too (downsample branch) z_b / vec_b / sums_b receive the same for it (else all NULL).
+ * res_mask (optional): the 1-bit-per-element act'(res_out) != 0 mask written by adamml_bn_act_add_mask; when given it is read
+ * instead of res_out (1/16 of the bytes).
  * Replaces adamml_conv_bwd_data(accumulate) + adamml_residual_bwd: the block-output gradient is written once. */
 int adamml_conv_bwd_data_res_supported(const adamml_conv_desc_t* d);
 int adamml_conv_bwd_data_res(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
-                             int accumulate, const void* res_out, int res_act, const void* z_a, const float* vec_a,
+                             int accumulate, const void* res_out, const uint8_t* res_mask, int res_act, const void* z_a, const float* vec_a,
                              double* sums_a, const void* z_b, const float* vec_b, double* sums_b, hipStream_t stream);
 
 /* autograd w.r.t. the weight: dw (fp32 OIHW, cin_true input channels) += dz^T * im2col(act(x)).  The pixel axis is
@@ -151,6 +153,10 @@ int adamml_bn_eval_affine(const float* gamma, const float* beta, const float* ru
 int adamml_bn_act_add(const void* z, const float* scale, const float* shift, int z_gstride, int act, const void* idn,
                       const float* id_scale, const float* id_shift, int id_gstride, void* out, size_t P, int C, int groups,
                       hipStream_t stream);
+/* same, additionally writing mask_out[(p*C + c) / 8] bit (c % 8) = act'(stored out) != 0 for the residual backward */
+int adamml_bn_act_add_mask(const void* z, const float* scale, const float* shift, int z_gstride, int act, const void* idn,
+                           const float* id_scale, const float* id_shift, int id_gstride, void* out, uint8_t* mask_out, size_t P,
+                           int C, int groups, hipStream_t stream);
 /* g = g_out * act'(out) evaluated from the stored block output */
 int adamml_act_bwd_from_output(const void* g_out, const void* out, int act, void* g, size_t n, hipStream_t stream);
 /* residual-add backward: g2 = g_out * act'(out) fused with the BatchNorm-backward sums of up to two lazily normalised

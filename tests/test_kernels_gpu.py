@@ -675,7 +675,7 @@ def test_conv_bwd_data_res_equals_dgrad_then_residual_bwd(N, H, Cin, Cout, G, se
     dx = g_idn.clone() if acc else torch.empty_like(g_idn)
     sa = torch.zeros_like(sa_ref)
     sb = torch.zeros_like(sb_ref)
-    call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(wd), ptr(dx), acc, ptr(out), act, ptr(za), ptr(veca), ptr(sa),
+    call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(wd), ptr(dx), acc, ptr(out), None, act, ptr(za), ptr(veca), ptr(sa),
          ptr(zb) if second else None, ptr(vecb) if second else None, ptr(sb) if second else None)
     # fp32 torch arithmetic
     full = torch.einsum("nhwo,oc->nhwc", dz.float(), rb(w).view(Cout, Cin))
@@ -696,6 +696,34 @@ def test_conv_bwd_data_res_equals_dgrad_then_residual_bwd(N, H, Cin, Cout, G, se
         assert (got - s_ref.sum(1)).abs().max().item() <= 2e-2 * s_ref.sum(1).abs().max().item() + 1e-2
     if not second:
         assert sb.abs().max().item() == 0.0
+    # the 1-bit mask form (what adamml_bn_act_add_mask writes) must give the identical result
+    lo_hi = (out.float() > 0) if act else torch.ones_like(out, dtype=torch.bool)
+    w8 = (2 ** torch.arange(8, device=DEV)).to(torch.int32)
+    mask = (lo_hi.view(G * N, H, H, Cin // 8, 8).to(torch.int32) * w8).sum(-1).to(torch.uint8).contiguous()
+    dx_m = g_idn.clone() if acc else torch.empty_like(g_idn)
+    sa_m, sb_m = torch.zeros_like(sa_ref), torch.zeros_like(sb_ref)
+    call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(wd), ptr(dx_m), acc, ptr(out), ptr(mask), act, ptr(za), ptr(veca), ptr(sa_m),
+         ptr(zb) if second else None, ptr(vecb) if second else None, ptr(sb_m) if second else None)
+    assert torch.equal(dx_m, dx)
+
+
+def test_bn_act_add_mask_bits():
+    torch.manual_seed(5)
+    P, C, G = 333, 64, 2
+    z, idn = torch.randn(G * P, C, device=DEV).to(torch.bfloat16), torch.randn(G * P, C, device=DEV).to(torch.bfloat16)
+    vec = torch.rand(G, 4, C, device=DEV) + 0.5
+    for act in (1, 2):
+        out = torch.empty_like(z)
+        mask = torch.zeros(G * P, C // 8, dtype=torch.uint8, device=DEV)
+        call("adamml_bn_act_add_mask", ptr(z), ptr(vec[0, 0]), ptr(vec[0, 1]), 4 * C, act, ptr(idn), None, None, 0, ptr(out), ptr(mask), P, C, G)
+        ref = torch.empty_like(z)
+        call("adamml_bn_act_add", ptr(z), ptr(vec[0, 0]), ptr(vec[0, 1]), 4 * C, act, ptr(idn), None, None, 0, ptr(ref), P, C, G)
+        assert torch.equal(out, ref)
+        o = out.float()
+        on = (o > 0) & ((o < 6) if act == 2 else torch.ones_like(o, dtype=torch.bool))
+        w8 = (2 ** torch.arange(8, device=DEV)).to(torch.int32)
+        exp = (on.view(G * P, C // 8, 8).to(torch.int32) * w8).sum(-1).to(torch.uint8)
+        assert torch.equal(mask, exp)
 
 
 @pytest.mark.parametrize("T,NB,HW,C,G,act", [(8, 3, 49, 256, 1, 1), (4, 2, 30, 512, 3, 1), (2, 5, 16, 1024, 2, 1), (4, 3, 25, 64, 1, 0)])

@@ -38,7 +38,7 @@ for name, N, H, Cm, Cb in [("layer1", B * 8, 56, 64, 256), ("layer2", B * 4, 28,
     dz1, gid, out, z3 = mid(), big(), big().clamp_min(0), big()
     vec = torch.rand(G, 4, Cb, device=DEV) + 0.5
     sa = torch.zeros(G, STAT_SLOTS, 2 * Cb, dtype=torch.float64, device=DEV)
-    t_res = timeit(lambda: call("adamml_conv_bwd_data_res", byref(d1), ptr(dz1), ptr(wd1), ptr(gid), 1, ptr(out), 1, ptr(z3), ptr(vec), ptr(sa),
+    t_res = timeit(lambda: call("adamml_conv_bwd_data_res", byref(d1), ptr(dz1), ptr(wd1), ptr(gid), 1, ptr(out), None, 1, ptr(z3), ptr(vec), ptr(sa),
                                 None, None, None))
     t_acc = timeit(lambda: call("adamml_conv_bwd_data", byref(d1), ptr(dz1), ptr(wd1), ptr(gid), 1))
     g2 = torch.empty_like(gid)
