@@ -111,8 +111,21 @@ class HipBackbone(nn.Module):
         ver = tuple(cs.weight._version for cs in self._conv_states[:4]) + (self._conv_states[0].weight.data_ptr(), need_dgrad)
         if self._packed_version == ver:
             return
+        # one launch refreshes every bf16 GEMM pack of this backbone (table rebuilt only when a buffer moved)
+        rows = [r for cs in self._conv_states for r in cs.pack_rows(need_dgrad)]
+        key = tuple((r[0].data_ptr(), r[1].data_ptr()) for r in rows)
+        if getattr(self, "_pack_key", None) != key:
+            epb = hip.load().adamml_pack_block_elems()
+            tab, blk = [], 0
+            for w, out, cout, cin_true, cin_pad, kh, kw, mode, n in rows:
+                tab.append([w.data_ptr(), out.data_ptr(), cout | (cin_true << 32), cin_pad | (kh << 32), kw | (mode << 32), blk])
+                blk += (n + epb - 1) // epb
+            self._pack_table = torch.tensor(tab, dtype=torch.int64).to(rows[0][0].device)
+            self._pack_blocks = blk
+            self._pack_key = key
+        hip.call("adamml_pack_conv_weights_batched", hip.ptr(self._pack_table), len(rows), self._pack_blocks)
         for cs in self._conv_states:
-            cs.repack(need_dgrad)
+            cs.repack_stem()
         self._packed_version = ver
 
     def _mark_grads_ready_after(self, tape, modules):

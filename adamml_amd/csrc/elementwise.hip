@@ -779,27 +779,53 @@ __global__ void clip_to_nhwc_kernel(const float* x, bf16_t* y, int B, int S, int
 }
 
 // ------------------------------------------------------------------------------------------------ weights
+__device__ __forceinline__ void pack_one(const float* w, void* out, int cout, int cin_true, int cin_pad, int taps, int mode, size_t e) {
+    if (mode == 0) {            // [co][tap][ci]
+        const int ci = (int)(e % cin_pad);
+        const int tap = (int)((e / cin_pad) % taps);
+        const int co = (int)(e / ((size_t)cin_pad * taps));
+        float v = ci < cin_true ? w[((size_t)co * cin_true + ci) * taps + tap] : 0.f;
+        reinterpret_cast<__bf16*>(out)[e] = (__bf16)v;
+    } else if (mode == 1) {     // [ci][tap flipped][co]
+        const int co = (int)(e % cout);
+        const int tap = (int)((e / cout) % taps);
+        const int ci = (int)(e / ((size_t)cout * taps));
+        float v = ci < cin_true ? w[((size_t)co * cin_true + ci) * taps + (taps - 1 - tap)] : 0.f;
+        reinterpret_cast<__bf16*>(out)[e] = (__bf16)v;
+    } else {                    // depthwise [tap][c] fp32
+        const int c = (int)(e % cout);
+        const int tap = (int)(e / cout);
+        reinterpret_cast<float*>(out)[e] = w[(size_t)c * taps + tap];
+    }
+}
+
+// All weight packs of a backbone in ONE launch (they were ~190 launches of ~5 us at the head of every training step, on the
+// critical path of each stream).  table: n rows of 6 x int64 {w, out, cout | cin_true << 32, cin_pad | kh << 32,
+// kw | mode << 32, first block}; a block of PACK_EPB elements finds its row by binary search over the first-block column.
+constexpr int PACK_EPB = 2048;
+__global__ __launch_bounds__(NT) void pack_conv_weights_batched_kernel(const long long* table, int n) {
+    int lo = 0, hi = n - 1;
+    const long long b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(size_t)mid * 6 + 5] <= b) lo = mid; else hi = mid - 1;
+    }
+    const long long* row = table + (size_t)lo * 6;
+    const float* w = reinterpret_cast<const float*>(row[0]);
+    void* out = reinterpret_cast<void*>(row[1]);
+    const int cout = (int)(row[2] & 0xffffffff), cin_true = (int)(row[2] >> 32), cin_pad = (int)(row[3] & 0xffffffff), kh = (int)(row[3] >> 32),
+              kw = (int)(row[4] & 0xffffffff), mode = (int)(row[4] >> 32);
+    const int taps = kh * kw;
+    const size_t total = mode == 2 ? (size_t)taps * cout : (size_t)cout * taps * cin_pad;
+    const size_t e0 = (size_t)(b - row[5]) * PACK_EPB;
+    for (size_t e = e0 + threadIdx.x; e < e0 + PACK_EPB && e < total; e += NT) pack_one(w, out, cout, cin_true, cin_pad, taps, mode, e);
+}
+
 __global__ void pack_conv_weight_kernel(const float* w, void* out, int cout, int cin_true, int cin_pad, int kh, int kw, int mode) {
     const int taps = kh * kw;
     const size_t total = mode == 2 ? (size_t)taps * cout : (size_t)cout * taps * cin_pad;
     for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
-        if (mode == 0) {            // [co][tap][ci]
-            const int ci = (int)(e % cin_pad);
-            const int tap = (int)((e / cin_pad) % taps);
-            const int co = (int)(e / ((size_t)cin_pad * taps));
-            float v = ci < cin_true ? w[((size_t)co * cin_true + ci) * taps + tap] : 0.f;
-            reinterpret_cast<__bf16*>(out)[e] = (__bf16)v;
-        } else if (mode == 1) {     // [ci][tap flipped][co]
-            const int co = (int)(e % cout);
-            const int tap = (int)((e / cout) % taps);
-            const int ci = (int)(e / ((size_t)cout * taps));
-            float v = ci < cin_true ? w[((size_t)co * cin_true + ci) * taps + (taps - 1 - tap)] : 0.f;
-            reinterpret_cast<__bf16*>(out)[e] = (__bf16)v;
-        } else {                    // depthwise [tap][c] fp32
-            const int c = (int)(e % cout);
-            const int tap = (int)(e / cout);
-            reinterpret_cast<float*>(out)[e] = w[(size_t)c * taps + tap];
-        }
+        pack_one(w, out, cout, cin_true, cin_pad, taps, mode, e);
     }
 }
 
@@ -1104,6 +1130,14 @@ extern "C" int adamml_pack_conv_weight(const float* w, void* out, int cout, int 
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, w, out, cout, cin_true, cin_pad, kh, kw, mode);
     return adamml_check_launch("pack_conv_weight");
 }
+
+extern "C" int adamml_pack_conv_weights_batched(const int64_t* table, int n, int64_t total_blocks, hipStream_t stream) {
+    if (!table || n < 1 || total_blocks < 1) return adamml_set_error(ADAMML_EINVAL, "pack_conv_weights_batched: bad arguments");
+    hipLaunchKernelGGL(pack_conv_weights_batched_kernel, dim3((unsigned)total_blocks), dim3(NT), 0, stream, (const long long*)table, n);
+    return adamml_check_launch("pack_conv_weights_batched");
+}
+
+extern "C" int adamml_pack_block_elems(void) { return PACK_EPB; }
 
 extern "C" int adamml_sgd_step(float* p, const float* g, float* mom, size_t n, float lr, float momentum, float weight_decay,
                                int nesterov, int first_step, hipStream_t stream) {

@@ -41,6 +41,7 @@ SIGNATURES = {
     "adamml_residual_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _P],
     "adamml_conv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _I, _P, _Z, _P],
     "adamml_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "adamml_pack_conv_weights_batched": [_P, _I, _L, _P],
     "adamml_pack_stem_weight": [_P, _P, _I, _I, _P],
     "adamml_conv_stem_fwd": [_DESC, _P, _P, _P, _P, _P],
     "adamml_conv_stem_bwd_weight": [_DESC, _P, _P, _P, _I, _P, _Z, _P],
@@ -108,6 +109,7 @@ def load():
     lib.adamml_temporal_pool_bwd_res_supported.restype = c_int
     lib.adamml_conv_stem_supported.argtypes = [_DESC]
     lib.adamml_conv_stem_supported.restype = c_int
+    lib.adamml_pack_block_elems.restype = c_int
     lib.adamml_version.restype = c_int
     lib.adamml_last_error_string.restype = c_char_p
     _lib = lib

@@ -157,6 +157,32 @@ class ConvState:
                      and self.cin_true <= 4)
         self.version = -1
 
+    def pack_rows(self, need_dgrad):
+        """(w, out, cout, cin_true, cin_pad, kh, kw, mode, n_out_elements) of every pack adamml_pack_conv_weights_batched
+        has to refresh for this conv (allocates the pack buffers on first use); the stem's own pack is not in the table."""
+        w = self.weight
+        rows = []
+        if self.depthwise:
+            if self.w_fwd is None:
+                self.w_fwd = torch.empty(self.kh * self.kw, self.cout, dtype=torch.float32, device=w.device)
+            return [(w, self.w_fwd, self.cout, 1, 1, self.kh, self.kw, 2, self.kh * self.kw * self.cout)]
+        n = self.cout * self.kh * self.kw * self.cin
+        if self.w_fwd is None:
+            self.w_fwd = torch.empty(self.cout, self.kh * self.kw * self.cin, dtype=torch.bfloat16, device=w.device)
+        rows.append((w, self.w_fwd, self.cout, self.cin_true, self.cin, self.kh, self.kw, 0, n))
+        if need_dgrad:
+            if self.w_dgrad is None:
+                self.w_dgrad = torch.empty(self.cin, self.kh * self.kw * self.cout, dtype=torch.bfloat16, device=w.device)
+            rows.append((w, self.w_dgrad, self.cout, self.cin_true, self.cin, self.kh, self.kw, 1, n))
+        return rows
+
+    def repack_stem(self):
+        if self.stem:
+            w = self.weight
+            if self.w_stem is None:
+                self.w_stem = torch.empty(self.cout, 7 * 8 * 4, dtype=torch.bfloat16, device=w.device)
+            call("adamml_pack_stem_weight", ptr(w), ptr(self.w_stem), self.cout, self.cin_true)
+
     def repack(self, need_dgrad):
         w = self.weight
         if self.depthwise:

@@ -25,6 +25,7 @@ import torch.nn.functional as F  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0          # HBM3E spec peak, same table
 CLIP_GFLOP_MAIN_STAGE = 86.7   # algorithmic GFLOP per clip, main-net stage
+CHANNELS = {"rgb": 3, "sound": 1, "flow": 10, "rgbdiff": 15}      # per frame (train_adamml.py:86-95)
 
 
 def parse():
@@ -38,6 +39,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sync-bn", action="store_true")
+    ap.add_argument("--modalities", nargs="+", default=["rgb", "sound"], choices=["rgb", "sound", "flow", "rgbdiff"],
+                    help="non-default: BASELINE.json configs[3] (rgb flow rgbdiff) / configs[4] (rgb sound flow rgbdiff)")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: no side streams, so per-kernel durations "
                     "in a rocprofv3 trace are not inflated by concurrently running kernels")
     return ap.parse_args()
@@ -45,8 +48,8 @@ def parse():
 
 def build(args, device):
     from adamml_amd import adamml, synth
-    mod = ["rgb", "sound"]
-    model = adamml(groups=8, modality=mod, input_channels=[3, 1], num_segments=args.segments, rng_policy=False,
+    mod = list(args.modalities)
+    model = adamml(groups=8, modality=mod, input_channels=[CHANNELS[m] for m in mod], num_segments=args.segments, rng_policy=False,
                    rng_threshold=0.5, causality_modeling="lstm", num_classes=31, depth=50, without_t_stride=False,
                    dropout=0.5, pooling_method="max", fusion_point="logits", unimodality_pretrained=[],
                    learnable_lf_weights=True)
@@ -61,10 +64,14 @@ def synth_batch(args, device, rank):
     b, s = args.batch, args.segments
     # generated on the device in chunks (a [72,120,224,224] fp32 clip tensor is 1.7 GB)
     torch.manual_seed(42 + rank)
-    rgb = torch.randn(b, s * 8 * 3, 224, 224, device=device)
-    snd = torch.randn(b, s, 256, 256, device=device) * 3.0 - 5.0
+    xs = []
+    for m in args.modalities:
+        if m == "sound":
+            xs.append(torch.randn(b, s, 256, 256, device=device) * 3.0 - 5.0)
+        else:
+            xs.append(torch.randn(b, s * 8 * CHANNELS[m], 224, 224, device=device))
     tgt = torch.randint(0, 31, (b,), generator=g).to(device)
-    return [rgb, snd], tgt
+    return xs, tgt
 
 
 def cpu_baseline(args):
@@ -223,7 +230,7 @@ def main():
                      "avg_launch_us": round(per_launch_ms * 1e3, 2), "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4),
                      "share_of_device_time": round(a["ms"] / tot_ms, 3)})
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.modalities == ["rgb", "sound"]:
         cpu = cpu_baseline(args)
 
     if rank == 0:
@@ -231,14 +238,17 @@ def main():
             "metric": "clips/sec (train fwd+bwd) RGB+Audio AdaMML @224^2, 5 seg", "value": round(value, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "AdaMML RGB+Audio (ResNet-50 + Sound-MobileNetV2 + MobileNetV2/LSTM policy), %s-net "
-                                   "stage train step, %d segments x 8 frames, 224^2 / 256^2 spectrogram" % (args.stage, args.segments),
+            "config": {"workload": ("AdaMML RGB+Audio (ResNet-50 + Sound-MobileNetV2 + MobileNetV2/LSTM policy), %s-net "
+                                    "stage train step, %d segments x 8 frames, 224^2 / 256^2 spectrogram" % (args.stage, args.segments))
+                       if args.modalities == ["rgb", "sound"] else
+                       ("AdaMML %s (non-headline config), %s-net stage train step, %d segments x 8 frames" % ("+".join(args.modalities), args.stage, args.segments)),
                        "videos_per_gpu": args.batch, "clips_per_step": clips, "segments": args.segments,
                        "parallelism": "dp%d%s" % (world, "+syncbn" if (world > 1 and not args.no_sync_bn) else ""),
                        "optimizer": "fused flat SGD(momentum 0.9, wd 5e-4)"},
             "videos_per_s": round(value / args.segments, 2),
-            "model_tflops": round(value * CLIP_GFLOP_MAIN_STAGE / 1e3, 1) if args.stage == "main" else None,
-            "model_mfma_frac": round(value * CLIP_GFLOP_MAIN_STAGE / 1e3 / (PEAK_BF16_TFLOPS * world), 4) if args.stage == "main" else None,
+            "model_tflops": round(value * CLIP_GFLOP_MAIN_STAGE / 1e3, 1) if (args.stage == "main" and args.modalities == ["rgb", "sound"]) else None,
+            "model_mfma_frac": round(value * CLIP_GFLOP_MAIN_STAGE / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
+            if (args.stage == "main" and args.modalities == ["rgb", "sound"]) else None,
             "peak_mem_gib": round(peak_mem, 1), "loss": round(float(loss.item()), 4),
             "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
         }

@@ -220,6 +220,12 @@ int adamml_gemm_f32(const float* a, int64_t a_sm, int64_t a_sk, const float* b, 
                     int64_t c_sm, int64_t c_sn, const float* bias, int act, int accumulate, int M, int N, int K,
                     hipStream_t stream);
 
+/* All weight packs of a backbone in one launch.  table (device): n rows of 6 x int64 {w (fp32 OIHW), out, cout | cin_true << 32,
+ * cin_pad | kh << 32, kw | mode << 32, first block}; row i owns blocks [first_i, first_{i+1}) of adamml_pack_block_elems()
+ * output elements each (modes as adamml_pack_conv_weight); total_blocks = first block past the last row. */
+int adamml_pack_block_elems(void);
+int adamml_pack_conv_weights_batched(const int64_t* table, int n, int64_t total_blocks, hipStream_t stream);
+
 /* flat fused optimizer steps (train_adamml.py:251-257 SGD-momentum / Adam with weight decay) */
 int adamml_sgd_step(float* p, const float* g, float* mom, size_t n, float lr, float momentum, float weight_decay,
                     int nesterov, int first_step, hipStream_t stream);

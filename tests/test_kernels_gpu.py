@@ -844,3 +844,25 @@ def test_conv_bwd_data_dual_equals_apply_then_dgrad(N, H, Cin, Cout, G, mode):
         call("adamml_conv_bwd_data_dual", byref(d), ptr(g), ptr(z), ptr(aff), None, ptr(wd), ptr(dx2), 1 if mode == "acc" else 0,
              None, None, 0, None)
         assert torch.equal(dx2, dx)
+
+
+def test_batched_weight_pack_equals_single_packs():
+    """adamml_pack_conv_weights_batched (one launch for all packs of a backbone) == adamml_pack_conv_weight per tensor."""
+    torch.manual_seed(9)
+    epb = hip.load().adamml_pack_block_elems()
+    specs = [(64, 3, 7, 7, 0), (64, 64, 1, 1, 0), (64, 64, 1, 1, 1), (128, 128, 3, 3, 0), (128, 128, 3, 3, 1), (96, 1, 3, 3, 2),
+             (24, 144, 1, 1, 0), (24, 144, 1, 1, 1), (2048, 512, 1, 1, 0)]
+    ws, outs, refs, tab, blk = [], [], [], [], 0
+    for cout, cin, kh, kw, mode in specs:
+        w = torch.randn(cout, cin, kh, kw, device=DEV)
+        cp = pad8(cin)
+        ref = pack(w, cp, mode)
+        out = torch.zeros_like(ref)
+        n = out.numel()
+        tab.append([w.data_ptr(), out.data_ptr(), cout | ((1 if mode == 2 else cin) << 32), (1 if mode == 2 else cp) | (kh << 32), kw | (mode << 32), blk])
+        blk += (n + epb - 1) // epb
+        ws.append(w); outs.append(out); refs.append(ref)
+    table = torch.tensor(tab, dtype=torch.int64).to(DEV)
+    call("adamml_pack_conv_weights_batched", ptr(table), len(specs), blk)
+    for o, r in zip(outs, refs):
+        assert torch.equal(o, r)
