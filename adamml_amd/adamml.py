@@ -37,6 +37,7 @@ class AdaMML(nn.Module, MeanStdMixin):
         self.update_policy_net = True
         self.update_main_net = True
         self.use_side_stream = True
+        self.use_wgrad_stream = True
         # inference only: run the main nets on the (segment, video) pairs the policy selected, instead of computing every
         # backbone call and multiplying the skipped ones by zero (models/adamml.py:81-86)
         self.skip_unselected = True
@@ -99,6 +100,13 @@ class AdaMML(nn.Module, MeanStdMixin):
         # work queued from the first microseconds of the step), then the policy nets on their own stream.
         S = num_segments
         B = x[0].size(0)
+        for net in self.main_net.nets:
+            # ResNets: weight gradients on their own stream, concurrent with the data-gradient chain (runtime._on_wgrad_stream)
+            if self.use_side_stream and self.use_wgrad_stream and not hasattr(net, "classifier"):
+                if net.rt.wgrad_stream is None:
+                    net.rt.wgrad_stream = torch.cuda.Stream(device=dev)
+            else:
+                net.rt.wgrad_stream = None
         stacked = self.main_net.backbone_logits([m_x[m_i].flatten(0, 1) for m_i in range(self.num_modality)], side, groups=S)
         if not self.rng_policy:
             if side is not None:

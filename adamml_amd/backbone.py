@@ -74,6 +74,8 @@ class _NetCall(torch.autograd.Function):
         ctx.tape.grad_out = g.contiguous()
         ctx.tape.backward()
         side = torch.cuda.current_stream()
+        if net.rt.wgrad_stream is not None:
+            side.wait_stream(net.rt.wgrad_stream)      # the weight gradients are complete before anyone reads .grad
         if side != torch.cuda.default_stream(g.device) and not getattr(net, "_join_queued", False):
             # the HIP weight-gradient kernels wrote .grad on a side stream without going through AccumulateGrad: make
             # the default stream wait for them once, when the whole backward pass has been enqueued
@@ -136,7 +138,13 @@ class HipBackbone(nn.Module):
             return
         params = [p for m in modules for p in m.parameters() if p.requires_grad]
         if params:
-            tape.record(lambda: self.grad_hook(params) if self.grad_hook is not None else None)
+            def fire():
+                if self.grad_hook is None:
+                    return
+                if self.rt.wgrad_stream is not None:       # this bucket's weight gradients run on the side stream
+                    torch.cuda.current_stream().wait_stream(self.rt.wgrad_stream)
+                self.grad_hook(params)
+            tape.record(fire)
 
     def _trainable(self):
         return any(p.requires_grad for p in self.parameters())

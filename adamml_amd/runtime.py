@@ -117,6 +117,7 @@ class NetRT:
         self.training = False
         self.groups = 1
         self.tape = Tape(False)
+        self.wgrad_stream = None     # optional side stream for the weight-gradient kernels (_on_wgrad_stream)
 
     def begin_forward(self, device, training, need_grad, groups=1):
         """groups = number of independent BatchNorm groups batched in this call: the S per-segment module calls of the
@@ -348,19 +349,20 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                 return
             dz = _bn_backward(rt, out, y, vec, bn, act, count)
             if cs.weight.requires_grad:
-                hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b)
-                if cs.depthwise:
-                    ws = hip.wgrad_workspace(d, 0, dz.device, depthwise=True)
-                    call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(cs.weight.grad),
-                         ptr(ws), ws.numel() * 4)
-                elif stem:
-                    ws = hip.wgrad_workspace(d, cs.cin_true, dz.device, stem=True)
-                    call("adamml_conv_stem_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(cs.weight.grad), cs.cin_true, ptr(ws),
-                         ws.numel() * 4)
-                else:
-                    ws = hip.wgrad_workspace(d, cs.cin_true, dz.device)
-                    call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift),
-                         ptr(cs.weight.grad), cs.cin_true, ptr(ws), ws.numel() * 4)
+                with _on_wgrad_stream(rt, (dz, x.data, x.scale)):
+                    hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b)
+                    if cs.depthwise:
+                        ws = hip.wgrad_workspace(d, 0, dz.device, depthwise=True)
+                        call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(cs.weight.grad),
+                             ptr(ws), ws.numel() * 4)
+                    elif stem:
+                        ws = hip.wgrad_workspace(d, cs.cin_true, dz.device, stem=True)
+                        call("adamml_conv_stem_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(cs.weight.grad), cs.cin_true, ptr(ws),
+                             ws.numel() * 4)
+                    else:
+                        ws = hip.wgrad_workspace(d, cs.cin_true, dz.device)
+                        call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift),
+                             ptr(cs.weight.grad), cs.cin_true, ptr(ws), ws.numel() * 4)
             if x.requires_grad:
                 acc = 1
                 if x.grad is None:
@@ -394,6 +396,34 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
     return out
 
 
+class _on_wgrad_stream:
+    """Weight gradients are leaves of the backward dataflow: nothing downstream of a conv's backward needs dW, only dz.
+    With rt.wgrad_stream set they are enqueued on that stream (after the kernels that produced their operands) and run
+    concurrently with the data-gradient chain, which on layers 2-4 is a sequence of latency-bound kernels that leave
+    most of the machine idle.  The tensors they read are pinned against reuse by the caching allocator (record_stream);
+    the backbone joins the stream before its gradients are consumed (backbone._NetCall.backward, HipDDP bucket hooks)."""
+
+    def __init__(self, rt, tensors):
+        self.ws = rt.wgrad_stream
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        if self.ws is not None:
+            self.ws.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(self.ws)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            for t in self.tensors:
+                if t is not None:
+                    t.record_stream(self.ws)
+        return False
+
+
 DUAL_DGRAD = True     # 1x1 / linear-BatchNorm layers: BatchNorm-backward apply folded into the data-gradient loader
 
 
@@ -425,10 +455,11 @@ def _conv1x1_backward_dual(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, 
         call("adamml_conv_bwd_data_dual", byref(d), ptr(g), ptr(y), ptr(aff), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc, None, None, 0,
              None)
     if need_w:
-        hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b)
-        ws = hip.wgrad_workspace(d, cs.cin_true, dz.device)
-        call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(cs.weight.grad), cs.cin_true,
-             ptr(ws), ws.numel() * 4)
+        with _on_wgrad_stream(rt, (dz, x.data, x.scale)):
+            hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b)
+            ws = hip.wgrad_workspace(d, cs.cin_true, dz.device)
+            call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(cs.weight.grad), cs.cin_true,
+                 ptr(ws), ws.numel() * 4)
 
 
 def _residual_fusable(x, d):
