@@ -1,5 +1,7 @@
 """Top-level AdaMML module on libadamml_hip: input re-layout, policy net, gated main net over segments.
 Mirrors models/adamml.py:12-171 (class AdaMML, factory adamml(); same state_dict, same caller-visible surface)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -37,7 +39,7 @@ class AdaMML(nn.Module, MeanStdMixin):
         self.update_policy_net = True
         self.update_main_net = True
         self.use_side_stream = True
-        self.use_wgrad_stream = True
+        self.use_wgrad_stream = os.environ.get("ADAMML_WGRAD_STREAM", "all")     # "0" | "resnet" | "all" (A/B aid)
         # inference only: run the main nets on the (segment, video) pairs the policy selected, instead of computing every
         # backbone call and multiplying the skipped ones by zero (models/adamml.py:81-86)
         self.skip_unselected = True
@@ -102,7 +104,8 @@ class AdaMML(nn.Module, MeanStdMixin):
         B = x[0].size(0)
         for net in self.main_net.nets:
             # ResNets: weight gradients on their own stream, concurrent with the data-gradient chain (runtime._on_wgrad_stream)
-            if self.use_side_stream and self.use_wgrad_stream and not hasattr(net, "classifier"):
+            if self.use_side_stream and (self.use_wgrad_stream == "all" or
+                                         (self.use_wgrad_stream == "resnet" and not hasattr(net, "classifier"))):
                 if net.rt.wgrad_stream is None:
                     net.rt.wgrad_stream = torch.cuda.Stream(device=dev)
             else:

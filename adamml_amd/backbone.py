@@ -76,6 +76,7 @@ class _NetCall(torch.autograd.Function):
         side = torch.cuda.current_stream()
         if net.rt.wgrad_stream is not None:
             side.wait_stream(net.rt.wgrad_stream)      # the weight gradients are complete before anyone reads .grad
+            net.rt.wgrad_pending.clear()               # later allocations on this stream are ordered behind that wait
         if side != torch.cuda.default_stream(g.device) and not getattr(net, "_join_queued", False):
             # the HIP weight-gradient kernels wrote .grad on a side stream without going through AccumulateGrad: make
             # the default stream wait for them once, when the whole backward pass has been enqueued

@@ -6,6 +6,7 @@ RAW output once and accumulates the per-channel sum / sum-of-squares in its epil
 the producer's BatchNorm scale/shift (+ReLU/ReLU6) while staging its input, so normalised activations are
 never materialised except at residual adds.  BatchNorm statistics, scale/shift and master weights are fp32.
 """
+import collections
 import math
 import torch
 import torch.distributed as dist
@@ -118,6 +119,7 @@ class NetRT:
         self.groups = 1
         self.tape = Tape(False)
         self.wgrad_stream = None     # optional side stream for the weight-gradient kernels (_on_wgrad_stream)
+        self.wgrad_pending = collections.deque()      # (event, operand tensors) of weight-gradient launches still in flight
 
     def begin_forward(self, device, training, need_grad, groups=1):
         """groups = number of independent BatchNorm groups batched in this call: the S per-segment module calls of the
@@ -400,10 +402,14 @@ class _on_wgrad_stream:
     """Weight gradients are leaves of the backward dataflow: nothing downstream of a conv's backward needs dW, only dz.
     With rt.wgrad_stream set they are enqueued on that stream (after the kernels that produced their operands) and run
     concurrently with the data-gradient chain, which on layers 2-4 is a sequence of latency-bound kernels that leave
-    most of the machine idle.  The tensors they read are pinned against reuse by the caching allocator (record_stream);
-    the backbone joins the stream before its gradients are consumed (backbone._NetCall.backward, HipDDP bucket hooks)."""
+    most of the machine idle.  The tensors they read are kept alive by rt.wgrad_pending until an event recorded behind
+    the kernel has completed (or the stream has been joined) -- NOT by Tensor.record_stream: with ~70 multi-GB blocks per
+    step parked in the caching allocator's cross-stream list the step time degraded from 152 ms to over a second within
+    eight steps (measured).  The backbone joins the stream before its gradients are consumed (backbone._NetCall.backward,
+    HipDDP bucket hooks)."""
 
     def __init__(self, rt, tensors):
+        self.rt = rt
         self.ws = rt.wgrad_stream
         self.tensors = tensors
         self.ctx = None
@@ -417,10 +423,13 @@ class _on_wgrad_stream:
 
     def __exit__(self, *exc):
         if self.ctx is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.ws)
             self.ctx.__exit__(*exc)
-            for t in self.tensors:
-                if t is not None:
-                    t.record_stream(self.ws)
+            pend = self.rt.wgrad_pending
+            pend.append((ev, self.tensors))
+            while pend and pend[0][0].query():          # drop the references of the launches that have finished
+                pend.popleft()
         return False
 
 

@@ -31,8 +31,8 @@ CHANNELS = {"rgb": 3, "sound": 1, "flow": 10, "rgbdiff": 15}      # per frame (t
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("ADAMML_BENCH_BATCH", 72)), help="videos per GPU")
     ap.add_argument("--segments", type=int, default=5)
     ap.add_argument("--stage", default="main", choices=["main", "policy"])
