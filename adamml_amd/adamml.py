@@ -10,7 +10,7 @@ from .backbone import FlatBuffers
 from .common import MeanStdMixin
 from .joint_resnet_mobilenetv2 import joint_resnet_mobilenetv2
 from .policy_net import p_joint_mobilenet
-from .runtime import clip_to_nhwc, SyncCtx
+from .runtime import clip_to_nhwc, clip_u8_to_nhwc, SyncCtx
 
 __all__ = ['adamml']
 
@@ -67,6 +67,15 @@ class AdaMML(nn.Module, MeanStdMixin):
                 p_x.append(t)
                 m_x.append(t)
                 continue
+            if x_.dtype == torch.uint8:
+                # MI355X extension: decoded frames [N, H, W, S*F*C] uint8 straight from `Stack` (video_transforms.py:302-318);
+                # ToTorchFormatTensor + GroupNormalize (mean / std of models/adamml.py:93-99) run inside the re-layout launch
+                c = x_.size(3) // (num_segments * f)
+                if idx in self.p_data_idx:
+                    p_x.append(clip_u8_to_nhwc(x_, num_segments, f, c, self.mean(m), self.std(m), out_hw=p_rgb_size, frame_step=2))
+                if idx in self.m_data_idx:
+                    m_x.append(clip_u8_to_nhwc(x_, num_segments, f, c, self.mean(m), self.std(m)))
+                continue
             c = x_.size(1) // (num_segments * f)
             if idx in self.p_data_idx:
                 p_x.append(clip_to_nhwc(x_, num_segments, f, c, out_hw=p_rgb_size, frame_step=2))
@@ -120,7 +129,7 @@ class AdaMML(nn.Module, MeanStdMixin):
                 decisions, decision_logits = self.policy_net.decide(self.policy_net.all_segment_features(p_x), gumbel_exponential)
             self.last_policy_logits = decision_logits
         else:
-            decisions = (torch.rand((num_segments, self.num_modality, x[0].size(0)), dtype=x[0].dtype, device=dev)
+            decisions = (torch.rand((num_segments, self.num_modality, x[0].size(0)), dtype=torch.float32, device=dev)
                          > self.rng_threshold).float()
         if side is not None:
             main.wait_stream(side)
@@ -140,7 +149,7 @@ class AdaMML(nn.Module, MeanStdMixin):
             decisions, decision_logits = self.policy_net.decide(self.policy_net.all_segment_features(p_x), gumbel_exponential)
             self.last_policy_logits = decision_logits
         else:
-            decisions = (torch.rand((S, self.num_modality, B), dtype=x[0].dtype, device=dev) > self.rng_threshold).float()
+            decisions = (torch.rand((S, self.num_modality, B), dtype=torch.float32, device=dev) > self.rng_threshold).float()
         stacked, ran = [], []
         for m_i in range(self.num_modality):
             net = self.main_net.nets[m_i]

@@ -778,6 +778,63 @@ __global__ void clip_to_nhwc_kernel(const float* x, bf16_t* y, int B, int S, int
     }
 }
 
+// Decoded-frame input path (utils/video_transforms.py:302-343 Stack -> ToTorchFormatTensor -> GroupNormalize, then
+// models/adamml.py:42-67): x [B][H][W][S*F*C] uint8 -- the HW(FC) array `Stack` produces, one byte per value instead of the
+// four of the normalised fp32 tensor -- to y [S][B*Fk][OH][OW][c_pad] bf16 with value ((u8 / 255) - mean[c % nm]) / std[c % nm]
+// in fp32 exactly as the reference evaluates it, bilinear (align_corners = False) when OH != H.  A thread owns one output
+// pixel for every (segment, frame): it reads the 1..4 source pixels' contiguous S*F*C bytes and writes S*Fk chunks.
+struct NormVec { float mean[4], std[4]; int n; };
+__global__ void clip_u8_to_nhwc_kernel(const uint8_t* x, bf16_t* y, int B, int S, int F, int C, int H, int W, int OH, int OW,
+                                       int frame_step, int Fk, int c_pad, NormVec nv, int div255) {
+    const size_t total = (size_t)B * OH * OW;
+    const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+    const bool resize = (OH != H) || (OW != W);
+    const int SFC = S * F * C;
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+        size_t r = e;
+        const int ow = (int)(r % OW); r /= OW;
+        const int oh = (int)(r % OH);
+        const int b = (int)(r / OH);
+        int h0 = oh, h1 = oh, w0 = ow, w1 = ow;
+        float lh1 = 0.f, lw1 = 0.f;
+        if (resize) {
+            float fh = fmaxf(sh * (oh + 0.5f) - 0.5f, 0.f), fw = fmaxf(sw * (ow + 0.5f) - 0.5f, 0.f);
+            h0 = (int)fh; w0 = (int)fw;
+            h1 = h0 + (h0 < H - 1 ? 1 : 0); w1 = w0 + (w0 < W - 1 ? 1 : 0);
+            lh1 = fh - h0; lw1 = fw - w0;
+        }
+        const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+        const uint8_t* p00 = x + (((size_t)b * H + h0) * W + w0) * SFC;
+        const uint8_t* p01 = x + (((size_t)b * H + h0) * W + w1) * SFC;
+        const uint8_t* p10 = x + (((size_t)b * H + h1) * W + w0) * SFC;
+        const uint8_t* p11 = x + (((size_t)b * H + h1) * W + w1) * SFC;
+        for (int s = 0; s < S; ++s)
+            for (int fk = 0; fk < Fk; ++fk) {
+                const int off = (s * F + fk * frame_step) * C;
+                bf16_t* dst = y + (((((size_t)s * B + b) * Fk + fk) * OH + oh) * OW + ow) * c_pad;
+                for (int c8 = 0; c8 < c_pad; c8 += 8) {
+                    f32x8 v;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int c = c8 + i;
+                        float val = 0.f;
+                        if (c < C) {
+                            const float m = nv.mean[c % nv.n], sd = nv.std[c % nv.n];
+                            auto nrm = [&](const uint8_t* q) {
+                                float t = (float)q[off + c];
+                                if (div255) t = t / 255.f;
+                                return (t - m) / sd;
+                            };
+                            val = resize ? lh0 * (lw0 * nrm(p00) + lw1 * nrm(p01)) + lh1 * (lw0 * nrm(p10) + lw1 * nrm(p11)) : nrm(p00);
+                        }
+                        v[i] = val;
+                    }
+                    *reinterpret_cast<bf16x8*>(dst + c8) = f32_to_bf8(v);
+                }
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weights
 __device__ __forceinline__ void pack_one(const float* w, void* out, int cout, int cin_true, int cin_pad, int taps, int mode, size_t e) {
     if (mode == 0) {            // [co][tap][ci]
@@ -1120,6 +1177,22 @@ extern "C" int adamml_clip_to_nhwc(const float* x, void* y, int B, int S, int F,
     hipLaunchKernelGGL(clip_to_nhwc_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, x, (bf16_t*)y, B, S, F, C, H, W, OH, OW,
                        frame_step, Fk, c_pad);
     return adamml_check_launch("clip_to_nhwc");
+}
+
+extern "C" int adamml_clip_u8_to_nhwc(const uint8_t* x, void* y, int B, int S, int F, int C, int H, int W, int OH, int OW, int frame_step,
+                                      int c_pad, const float* mean, const float* std, int n_mean, int div255, hipStream_t stream) {
+    if (!x || !y || !mean || !std) return adamml_set_error(ADAMML_EINVAL, "clip_u8_to_nhwc: null argument");
+    if (c_pad % 8 || c_pad < C || frame_step < 1) return adamml_set_error(ADAMML_EINVAL, "clip_u8_to_nhwc: bad c_pad/frame_step");
+    if (n_mean < 1 || n_mean > 4 || C % n_mean) return adamml_set_error(ADAMML_EINVAL, "clip_u8_to_nhwc: %d mean/std values for %d channels", n_mean, C);
+    const int Fk = (F + frame_step - 1) / frame_step;
+    const size_t n = (size_t)B * OH * OW;
+    if (!n || !S || !Fk) return ADAMML_OK;
+    NormVec nv;
+    nv.n = n_mean;
+    for (int i = 0; i < 4; ++i) { nv.mean[i] = i < n_mean ? mean[i] : 0.f; nv.std[i] = i < n_mean ? std[i] : 1.f; }
+    hipLaunchKernelGGL(clip_u8_to_nhwc_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, x, (bf16_t*)y, B, S, F, C, H, W, OH, OW, frame_step,
+                       Fk, c_pad, nv, div255);
+    return adamml_check_launch("clip_u8_to_nhwc");
 }
 
 extern "C" int adamml_pack_conv_weight(const float* w, void* out, int cout, int cin_true, int cin_pad, int kh, int kw, int mode,

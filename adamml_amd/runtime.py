@@ -666,3 +666,24 @@ def clip_to_nhwc(x, num_segments, frames, channels, out_hw=None, frame_step=1):
     y = torch.empty(num_segments, b * fk, oh, ow, cp, dtype=torch.bfloat16, device=x.device)
     call("adamml_clip_to_nhwc", ptr(x), ptr(y), b, num_segments, frames, channels, h, w, oh, ow, frame_step, cp)
     return y
+
+
+def clip_u8_to_nhwc(x, num_segments, frames, channels, mean, std, out_hw=None, frame_step=1, div255=True):
+    """Decoded uint8 frames [B, H, W, S*F*C] (the HW(FC) array of utils/video_transforms.py:302-318 `Stack`, batched) ->
+    [S, B*Fk, OH, OW, pad8(C)] bf16, normalised as ToTorchFormatTensor + GroupNormalize do (video_transforms.py:62-84,321-343)."""
+    hip.require_gpu(x)
+    if x.dtype != torch.uint8:
+        raise RuntimeError("clip_u8_to_nhwc: expected uint8 frames, got %s" % x.dtype)
+    b, h, w, sfc = x.shape
+    if sfc != num_segments * frames * channels:
+        raise RuntimeError("clip_u8_to_nhwc: last dim %d != S*F*C = %d*%d*%d" % (sfc, num_segments, frames, channels))
+    oh, ow = out_hw if out_hw else (h, w)
+    fk = (frames + frame_step - 1) // frame_step
+    cp = pad8(channels)
+    x = x.contiguous()
+    y = torch.empty(num_segments, b * fk, oh, ow, cp, dtype=torch.bfloat16, device=x.device)
+    import ctypes
+    mean, std = [float(v) for v in mean], [float(v) for v in std]
+    call("adamml_clip_u8_to_nhwc", ptr(x), ptr(y), b, num_segments, frames, channels, h, w, oh, ow, frame_step, cp,
+         (ctypes.c_float * len(mean))(*mean), (ctypes.c_float * len(std))(*std), len(mean), 1 if div255 else 0)
+    return y

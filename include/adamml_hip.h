@@ -214,6 +214,14 @@ int adamml_gap_bwd(const float* g, void* g_x, int N, int HW, int C, hipStream_t 
 int adamml_clip_to_nhwc(const float* x, void* y, int B, int S, int F, int C, int H, int W, int OH, int OW,
                         int frame_step, int c_pad, hipStream_t stream);
 
+/* Decoded-frame input path: what utils/video_transforms.py:302-343 (Stack -> ToTorchFormatTensor(div) -> GroupNormalize) and
+ * AdaMML.data_layer do between the decoder and the first conv, in one launch from the uint8 frames.  x: [B][H][W][S*F*C]
+ * uint8 (Stack's HW(FC) array per video); value = ((u8 / 255 if div255) - mean[c % n_mean]) / std[c % n_mean] in fp32, then the
+ * same re-layout / bilinear resize / frame stride as adamml_clip_to_nhwc.  mean / std: HOST arrays of n_mean <= 4 floats
+ * (models/adamml.py:93-99). */
+int adamml_clip_u8_to_nhwc(const uint8_t* x, void* y, int B, int S, int F, int C, int H, int W, int OH, int OW, int frame_step,
+                           int c_pad, const float* mean, const float* std, int n_mean, int div255, hipStream_t stream);
+
 /* y[M,N] = act(x[M,K] @ w[N,K]^T + bias) in fp32 with arbitrary strides (nn.Linear / LSTMCell gates and their
  * gradients: policy_net.py:228-231,278-279,351-362; resnet.py:215; sound_mobilenet_v2.py:158) */
 int adamml_gemm_f32(const float* a, int64_t a_sm, int64_t a_sk, const float* b, int64_t b_sn, int64_t b_sk, float* c,

@@ -86,3 +86,55 @@ def test_single_video():
         if float(sel.sum()) > 0:
             return
     raise AssertionError("no noise seed selected any modality")
+
+
+def test_uint8_frame_input_path_matches_reference_pipeline():
+    """Decoded uint8 frames -> (ToTorchFormatTensor(div) + GroupNormalize + data_layer) in one launch
+    (adamml_clip_u8_to_nhwc) against the reference arithmetic: x = (u8 / 255 - mean[c]) / std[c] (utils/video_transforms.py:
+    62-84,321-343), then models/adamml.py:42-67.  bf16 output: exact for the full-resolution main-net input, <= 1 bf16 ulp for
+    the bilinear 160x160 policy input (fp32 rounding order of the four-tap blend)."""
+    from adamml_amd.runtime import clip_u8_to_nhwc, clip_to_nhwc
+    from adamml_amd.common import MeanStdMixin
+    ms = MeanStdMixin()
+    torch.manual_seed(1)
+    B, S, Fr, H, W = 2, 3, 8, 64, 48
+    for m, C in (("rgb", 3), ("rgbdiff", 15), ("flow", 10)):
+        u8 = torch.randint(0, 256, (B, H, W, S * Fr * C), dtype=torch.uint8)
+        mean, std = ms.mean(m), ms.std(m)
+        x = u8.permute(0, 3, 1, 2).float().div(255)                          # ToTorchFormatTensor, per video
+        rep = (S * Fr * C) // len(mean)
+        mt = torch.tensor(mean * rep).view(1, -1, 1, 1)
+        st = torch.tensor(std * rep).view(1, -1, 1, 1)
+        x = (x - mt) / st                                                    # GroupNormalize
+        for out_hw, step in ((None, 1), ((40, 40), 2)):
+            got = clip_u8_to_nhwc(u8.to(DEV), S, Fr, C, mean, std, out_hw=out_hw, frame_step=step)
+            ref = clip_to_nhwc(x.to(DEV), S, Fr, C, out_hw=out_hw, frame_step=step)      # validated against the oracle's data_layer
+            assert got.shape == ref.shape
+            if out_hw is None:
+                assert torch.equal(got, ref), m
+            else:
+                d = (got.float() - ref.float()).abs()
+                assert (d <= ref.float().abs() * 2 ** -7 + 1e-6).all(), (m, d.max().item())
+                assert (got != ref).float().mean().item() < 0.02
+
+
+def test_adamml_accepts_uint8_frames():
+    """End to end: the model fed with uint8 frames returns the logits of the same model fed with the normalised fp32 tensor."""
+    torch.manual_seed(2)
+    B, S = 2, 2
+    model = adamml(groups=8, modality=["rgb", "sound"], input_channels=[3, 1], num_segments=S, rng_policy=False, rng_threshold=0.5,
+                   causality_modeling="lstm", num_classes=31, depth=50, without_t_stride=False, dropout=0.0, pooling_method="max",
+                   fusion_point="logits", unimodality_pretrained=[], learnable_lf_weights=True)
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), seed=1234))
+    model.to(DEV).eval()
+    u8 = torch.randint(0, 256, (B, 64, 64, S * 8 * 3), dtype=torch.uint8)
+    snd = torch.randn(B, S, 64, 64) * 3 - 5
+    mean, std = model.mean("rgb"), model.std("rgb")
+    x = u8.permute(0, 3, 1, 2).float().div(255)
+    x = (x - torch.tensor(mean * (S * 8)).view(1, -1, 1, 1)) / torch.tensor(std * (S * 8)).view(1, -1, 1, 1)
+    expo = synth.synth_gumbel_exponential(S, 2, B, seed=11).to(DEV)
+    with torch.no_grad():
+        a, da = model([u8.to(DEV), snd.to(DEV)], gumbel_exponential=expo)
+        b, db = model([x.to(DEV), snd.to(DEV)], gumbel_exponential=expo)
+    assert torch.equal(da, db)
+    assert torch.allclose(a, b, rtol=2e-2, atol=2e-2 * float(b.abs().max()) + 1e-6)
