@@ -35,7 +35,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("ADAMML_BENCH_BATCH", 72)), help="videos per GPU")
     ap.add_argument("--segments", type=int, default=5)
-    ap.add_argument("--stage", default="main", choices=["main", "policy"])
+    ap.add_argument("--stage", default="main", choices=["main", "policy", "infer"],
+                    help="main (headline metric) | policy: the other training stage | infer: eval-mode forward with the main nets "
+                         "run only on the clips the policy selected (non-headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-sync-bn", action="store_true")
@@ -140,6 +142,9 @@ def main():
     else:
         model.freeze_main_net()
     model.train()
+    if args.stage == "infer":
+        model.freeze_policy_net()
+        model.eval()
     if args.single_stream:
         model.use_side_stream = False
     images, target = synth_batch(args, device, rank)
@@ -147,6 +152,10 @@ def main():
 
     def step():
         nonlocal opt, p_opt
+        if args.stage == "infer":
+            with torch.no_grad():
+                out, sel = ddp(images)
+            return out.sum()
         out, sel = ddp(images)
         loss = F.cross_entropy(out, target)
         if model.update_policy_net:
@@ -189,7 +198,7 @@ def main():
 
     roof = None
     breakdown = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and args.stage != "infer":
         # per-launch HIP-event timing of one more step, single stream (concurrent streams would inflate each launch)
         model.use_side_stream = False
         step()
@@ -235,16 +244,20 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "clips/sec (train fwd+bwd) RGB+Audio AdaMML @224^2, 5 seg", "value": round(value, 2), "unit": "clips/s",
+            "metric": "clips/sec (train fwd+bwd) RGB+Audio AdaMML @224^2, 5 seg" if args.stage != "infer" else
+                      "clips/sec (inference fwd, policy-gated) AdaMML @224^2, 5 seg", "value": round(value, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("AdaMML RGB+Audio (ResNet-50 + Sound-MobileNetV2 + MobileNetV2/LSTM policy), %s-net "
-                                    "stage train step, %d segments x 8 frames, 224^2 / 256^2 spectrogram" % (args.stage, args.segments))
+            "config": {"workload": ("AdaMML %s (non-headline), eval-mode forward with decision-driven skipping of the main nets, "
+                                    "%d segments x 8 frames" % ("+".join(args.modalities), args.segments)) if args.stage == "infer" else
+                       ("AdaMML RGB+Audio (ResNet-50 + Sound-MobileNetV2 + MobileNetV2/LSTM policy), %s-net "
+                        "stage train step, %d segments x 8 frames, 224^2 / 256^2 spectrogram" % (args.stage, args.segments))
                        if args.modalities == ["rgb", "sound"] else
                        ("AdaMML %s (non-headline config), %s-net stage train step, %d segments x 8 frames" % ("+".join(args.modalities), args.stage, args.segments)),
                        "videos_per_gpu": args.batch, "clips_per_step": clips, "segments": args.segments,
                        "parallelism": "dp%d%s" % (world, "+syncbn" if (world > 1 and not args.no_sync_bn) else ""),
-                       "optimizer": "fused flat SGD(momentum 0.9, wd 5e-4)"},
+                       "optimizer": "fused flat SGD(momentum 0.9, wd 5e-4)" if args.stage != "infer" else None,
+                       "executed_clips_per_modality": getattr(model, "last_skip_stats", None)},
             "videos_per_s": round(value / args.segments, 2),
             "model_tflops": round(value * CLIP_GFLOP_MAIN_STAGE / 1e3, 1) if (args.stage == "main" and args.modalities == ["rgb", "sound"]) else None,
             "model_mfma_frac": round(value * CLIP_GFLOP_MAIN_STAGE / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
