@@ -232,9 +232,11 @@ def main():
         if os.path.exists(tfile) and name.startswith("conv_gemm_kernel"):
             t = json.load(open(tfile)).get("conv_gemm_kernel")
             if t:
-                traffic = round(t["per_launch_bytes"] * a["launches"] / 1e9, 2)     # GB per step, same launch set
+                traffic = round(t["per_launch_bytes"] / 1e9, 4)                     # GB per launch (average), as `achieved` is
                 tsrc = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 gfx950 correction), profiles/r01_pmc_hbm_traffic.json"
-        roof.update({"traffic": traffic, "traffic_unit": "GB per step (all launches of this kernel)", "traffic_source": tsrc,
+        roof.update({"traffic": traffic, "traffic_unit": "GB of HBM traffic per launch (PMC, average over this kernel's launches)",
+                     "traffic_source": tsrc, "algorithmic_gb_per_launch": round(a["bytes"] / a["launches"] / 1e9, 4),
+                     "traffic_gb_per_step": round(traffic * a["launches"], 2) if traffic is not None else None,
                      "algorithmic_gb_per_step": round(a["bytes"] / 1e9, 2), "kernel": name, "launches_per_step": a["launches"],
                      "avg_launch_us": round(per_launch_ms * 1e3, 2), "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4),
                      "share_of_device_time": round(a["ms"] / tot_ms, 3)})

@@ -38,6 +38,7 @@ out.append("HBM traffic (`r01_pmc_hbm_traffic.json`, `tools/gpu_pmc.sh`: two `--
 out.append("FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md): conv_gemm_kernel %.1f MB per launch = %.1f GB per step measured vs %.1f GB algorithmic (%.2fx)."
            % (t["per_launch_bytes"] / 1e6, t["per_launch_bytes"] * rf["launches_per_step"] / 1e9, rf["algorithmic_gb_per_step"],
               t["per_launch_bytes"] * rf["launches_per_step"] / 1e9 / rf["algorithmic_gb_per_step"]))
+out.append("(`roofline.achieved` = algorithmic bytes per launch / average launch duration; `roofline.traffic` = PMC bytes per launch.)")
 out.append("\nPer-layer micro-benchmarks behind DESIGN.md section 4: `tools/bench_conv.py`, `tools/bench_fused.py`, `tools/bench_dw.py`, `tools/bench_elementwise.py`.")
 open("profiles/README.md", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
