@@ -5,7 +5,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import hip
+from . import hip, interleave
 from .backbone import FlatBuffers
 from .common import MeanStdMixin
 from .joint_resnet_mobilenetv2 import joint_resnet_mobilenetv2
@@ -119,6 +119,29 @@ class AdaMML(nn.Module, MeanStdMixin):
                     net.rt.wgrad_stream = torch.cuda.Stream(device=dev)
             else:
                 net.rt.wgrad_stream = None
+        if side is not None and interleave.ENABLED and any(n.rt.sync.enabled for n in self.backbones()):
+            # SyncBatchNorm on one communicator: issue the backbones round-robin, one statistics exchange per turn, so that the
+            # side-stream nets' exchanges do not queue behind all of the ResNet's (interleave.py)
+            jobs = []
+            for m_i in range(self.num_modality):
+                net, xin = self.main_net.nets[m_i], m_x[m_i].flatten(0, 1)
+                jobs.append(((lambda net=net, xin=xin: net.forward_nhwc(xin, S)), side if self.main_net.modality[m_i] == 'sound' else main))
+            if not self.rng_policy:
+                jobs.append(((lambda: self.policy_net.decide(self.policy_net.all_segment_features(p_x), gumbel_exponential)), pside))
+            res = interleave.run_interleaved(jobs, dev)
+            stacked = res[:self.num_modality]
+            if not self.rng_policy:
+                decisions, decision_logits = res[-1]
+                self.last_policy_logits = decision_logits
+            else:
+                decisions = (torch.rand((num_segments, self.num_modality, x[0].size(0)), dtype=torch.float32, device=dev)
+                             > self.rng_threshold).float()
+            main.wait_stream(side)
+            main.wait_stream(pside)
+            for t in [decisions] + list(stacked):
+                t.record_stream(main)
+            final_logits = self.main_net.fuse_segments(stacked, decisions, num_segments)
+            return final_logits, decisions.permute((2, 0, 1))
         stacked = self.main_net.backbone_logits([m_x[m_i].flatten(0, 1) for m_i in range(self.num_modality)], side, groups=S)
         if not self.rng_policy:
             if side is not None:

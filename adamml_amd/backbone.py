@@ -4,7 +4,7 @@ call as a single node (forward = fused HIP launches, backward = the recorded tap
 import torch
 import torch.nn as nn
 
-from . import hip
+from . import hip, interleave
 from .runtime import NetRT, ConvState, Tape
 
 
@@ -70,9 +70,21 @@ class _NetCall(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         net = ctx.net
+        if net.rt.sync.enabled and interleave.ENABLED:
+            # SyncBatchNorm: the backward passes of the backbones are issued round-robin (interleave.py) once autograd has
+            # handed every backbone its output gradient -- nothing upstream waits for a backbone's input gradient
+            _deferred.append((ctx.tape, g.contiguous(), net, torch.cuda.current_stream()))
+            if len(_deferred) == 1:
+                torch.autograd.Variable._execution_engine.queue_callback(_run_deferred)
+            return None, None, None, None
+        _NetCall.run_tape(ctx.tape, g, net)
+        return None, None, None, None
+
+    @staticmethod
+    def run_tape(tape, g, net):
         net.rt.bwd_arena.reset(g.device)
-        ctx.tape.grad_out = g.contiguous()
-        ctx.tape.backward()
+        tape.grad_out = g.contiguous()
+        tape.backward()
         side = torch.cuda.current_stream()
         if net.rt.wgrad_stream is not None:
             side.wait_stream(net.rt.wgrad_stream)      # the weight gradients are complete before anyone reads .grad
@@ -85,8 +97,29 @@ class _NetCall(torch.autograd.Function):
             def _join():
                 net._join_queued = False
                 torch.cuda.default_stream(g.device).wait_stream(side)
-            torch.autograd.Variable._execution_engine.queue_callback(_join)
-        return None, None, None, None
+            if _in_deferred_run[0]:
+                _join()                     # already past the engine's callbacks: join right away
+            else:
+                torch.autograd.Variable._execution_engine.queue_callback(_join)
+
+
+_deferred = []
+_in_deferred_run = [False]
+
+
+def _run_deferred():
+    """End-of-backward callback under SyncBatchNorm: run the recorded tapes of all backbones interleaved."""
+    pend = list(_deferred)
+    del _deferred[:]
+    if not pend:
+        return
+    dev = pend[0][1].device
+    _in_deferred_run[0] = True
+    try:
+        jobs = [((lambda t=t, g=g, n=n: _NetCall.run_tape(t, g, n)), s) for (t, g, n, s) in pend]
+        interleave.run_interleaved(jobs, dev)
+    finally:
+        _in_deferred_run[0] = False
 
 
 class HipBackbone(nn.Module):

@@ -11,7 +11,7 @@ import math
 import torch
 import torch.distributed as dist
 
-from . import hip
+from . import hip, interleave
 from .hip import ConvDesc, ACT_NONE, ACT_RELU, ACT_RELU6, STAT_SLOTS, call, ptr
 from ctypes import byref
 
@@ -105,6 +105,7 @@ class SyncCtx:
         out = torch.empty(groups * 2 * C, dtype=torch.float64, device=t.device)
         call("adamml_stats_collapse", ptr(t), ptr(out), C, groups)
         dist.all_reduce(out, group=self.group)
+        interleave.yield_point()            # round-robin host issue of the backbones (interleave.py); no-op otherwise
         return out, 1
 
 

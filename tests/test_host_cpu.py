@@ -154,3 +154,32 @@ def test_unsupported_options_raise_like_the_reference():
     from adamml_amd.runtime import temporal_pool, NetRT, Lazy
     with pytest.raises(ValueError, match="only support avg or max"):
         temporal_pool(NetRT(), Lazy(torch.zeros(8, 1, 1, 8, dtype=torch.bfloat16)), 8, "median")
+
+
+def test_interleaver_is_deterministic_round_robin_and_propagates_errors():
+    """adamml_amd.interleave: jobs advance one yield point per turn in fixed order (the property that keeps the collective
+    sequence identical on every rank), results come back in job order, grad mode is inherited, exceptions are re-raised."""
+    import torch
+    from adamml_amd import interleave
+    log = []
+
+    def job(name, n):
+        def f():
+            for i in range(n):
+                log.append((name, i, torch.is_grad_enabled()))
+                interleave.yield_point()
+            return name * 2
+        return f
+
+    with torch.no_grad():
+        res = interleave.run_interleaved([(job("a", 3), None), (job("b", 1), None), (job("c", 2), None)], None)
+    assert res == ["aa", "bb", "cc"]
+    assert [(n, i) for n, i, _ in log] == [("a", 0), ("b", 0), ("c", 0), ("a", 1), ("c", 1), ("a", 2)]
+    assert not any(g for _, _, g in log)
+    interleave.yield_point()                     # a no-op outside a job
+
+    def boom():
+        interleave.yield_point()
+        raise ValueError("boom")
+    with pytest.raises(ValueError):
+        interleave.run_interleaved([(job("x", 2), None), (boom, None)], None)
