@@ -49,6 +49,14 @@ struct ConvP {
     const bf16_t* x2;
     const float* aff;
     bf16_t* side;
+    // K-concatenated second input (MODE 0): K steps k >= K1 read xb [pixels][C2] (with the lazy in_scale / in_shift transform,
+    // which then applies to xb ONLY) instead of x [pixels][K1]; weights are per group (gw elements apart); epi_add [Cout] per
+    // group is added to every output row before the epilogue's mask / store.  Used by the algebraic BatchNorm backward
+    // (adamml_conv_bwd_data_alg): dx = (W^T diag(A)) g' + (W^T diag(B) W) a + W^T C without ever forming dz.
+    const bf16_t* xb;
+    int K1, C2;
+    size_t gw;
+    const float* epi_add;
     // MODE 3 (one parity class of the data gradient of a stride-2 conv, see conv_dgrad_stride2)
     int wK;                      // weight row stride in elements (== K except in MODE 3, where K covers the class taps only)
     int cls_nt;                  // taps of this class (0..4)
@@ -82,8 +90,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 // instantiation -- inside the shared kernel it pushed every MODE 0 instance into scratch spills.
 // DUAL: the BatchNorm-backward affine of two source tensors is applied by the MODE 0 loader (own instantiation as well:
 // a second register ring for z, 2 workgroups per CU, deep prefetch).
-template <int BC, int MODE, int PD, bool RES = false, bool DUAL = false>
-__global__ __launch_bounds__(NTHREADS, (RES || DUAL) ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
+// CAT: K-concatenated second input + per-group weights + epilogue constant (algebraic BatchNorm backward); own instantiation
+// for the same reason.
+template <int BC, int MODE, int PD, bool RES = false, bool DUAL = false, bool CAT = false>
+__global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
     constexpr int WROWS = BC / 64;          // weight rows staged per thread
     constexpr int TILE_BYTES = (BP + BC) * 64;
@@ -105,6 +115,11 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL) ? 2 : (PD == 1 ? (BC == 128
         if (p.stats) p.stats += (size_t)g * ADAMML_STAT_SLOTS * 2 * p.Cout;
         if (p.in_scale) { p.in_scale += (size_t)g * p.in_gstride; p.in_shift += (size_t)g * p.in_gstride; }
         if (p.bn_z) { p.bn_z += (size_t)g * p.gy; p.bn_vec += (size_t)g * 4 * p.Cout; }
+        if (CAT) {
+            p.xb += (size_t)g * (p.gx / p.K1) * p.C2;
+            p.w += (size_t)g * p.gw;
+            p.epi_add += (size_t)g * p.Cout;
+        }
         if (DUAL) {
             p.x2 += (size_t)g * p.gx;
             p.aff += (size_t)g * 3 * p.K;
@@ -118,12 +133,13 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL) ? 2 : (PD == 1 ? (BC == 128
     }
     const int tid = threadIdx.x;
     float* s_vec = reinterpret_cast<float*>(smem + (MODE == 0 ? VEC_OFF : 0));
-    const bool vec_lds = MODE == 0 && p.K <= VEC_MAXK && (DUAL || p.in_scale != nullptr);
+    const int nvec = CAT ? p.C2 : p.K;                            // entries of the loader's per-channel vectors
+    const bool vec_lds = MODE == 0 && nvec <= VEC_MAXK && (DUAL || p.in_scale != nullptr);
     if (vec_lds) {
         if (DUAL) {
             for (int i = tid; i < 3 * p.K; i += NTHREADS) s_vec[i] = p.aff[i];
         } else {
-            for (int i = tid; i < p.K; i += NTHREADS) { s_vec[i] = p.in_scale[i]; s_vec[p.K + i] = p.in_shift[i]; }
+            for (int i = tid; i < nvec; i += NTHREADS) { s_vec[i] = p.in_scale[i]; s_vec[nvec + i] = p.in_shift[i]; }
         }
         __syncthreads();
     }
@@ -255,13 +271,16 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL) ? 2 : (PD == 1 ? (BC == 128
         const bool kok = k < p.K;
         int kw_off = k;                                  // offset of this K chunk in a weight row
         if (MODE == 0) {
-            rci[SL] = k;
+            const bool from_b = CAT && kt * BK >= p.K1;                 // wave-uniform: a K step lies in one source (K1 % BK == 0)
+            rci[SL] = from_b ? k - p.K1 : (CAT ? -1 : k);               // < 0: no lazy transform for this step
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const bool ok = a_ok[r] && kok;
                 rav[SL][r] = ok;
                 bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + (size_t)(unsigned)(a_base[r] + k));
+                if (CAT && from_b) {
+                    if (ok) v = *reinterpret_cast<const bf16x8*>(p.xb + (size_t)(unsigned)(a_base[r] / p.K1) * p.C2 + (k - p.K1));
+                } else if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + (size_t)(unsigned)(a_base[r] + k));
                 ra[SL][r] = v;
                 if (DUAL) {
                     bf16x8 v2 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -327,9 +346,9 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL) ? 2 : (PD == 1 ? (BC == 128
                     v = f32_to_bf8(o);
                     if (p.side && ctile == 0) *reinterpret_cast<bf16x8*>(p.side + (size_t)(unsigned)(a_base[r] + rci[SL])) = v;
                 }
-            } else if (p.in_scale && rav[SL][r]) {
+            } else if (p.in_scale && rav[SL][r] && (!CAT || rci[SL] >= 0)) {
                 if (vec_lds) {
-                    const f32x8 sc = load_f32x8(s_vec + rci[SL]), sh = load_f32x8(s_vec + p.K + rci[SL]);
+                    const f32x8 sc = load_f32x8(s_vec + rci[SL]), sh = load_f32x8(s_vec + nvec + rci[SL]);
                     const float lo = act_lo(p.act), hi = act_hi(p.act);
                     f32x8 f = bf8_to_f32(v);
 #pragma unroll
@@ -462,11 +481,15 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL) ? 2 : (PD == 1 ? (BC == 128
         // sum(g') and sum(g' * zhat) -- the BatchNorm-backward reduction pass never has to re-read g and z
         const f32x8 sc = load_f32x8(p.bn_vec + eco), sh = load_f32x8(p.bn_vec + p.Cout + eco);
         const f32x8 mu = load_f32x8(p.bn_vec + 2 * p.Cout + eco), is = load_f32x8(p.bn_vec + 3 * p.Cout + eco);
+        f32x8 cadd;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cadd[i] = 0.f;
+        if (CAT) cadd = load_f32x8(p.epi_add + eco);
 #pragma unroll
         for (int r = erow0; r < BP; r += RSTEP) {
             if (p0 + r >= p.P) break;
             const size_t pp = MODE == 3 ? (size_t)s_orow[r] : (size_t)(p0 + r);
-            f32x8 f = bf8_to_f32(*reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16));
+            f32x8 f = bf8_to_f32(*reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16)) + cadd;
             const f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(p.bn_z + pp * p.Cout + eco));
 #pragma unroll
             for (int i = 0; i < 8; ++i) f[i] *= act_mask(fmaf(zv[i], sc[i], sh[i]), p.bn_act);
@@ -485,6 +508,10 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL) ? 2 : (PD == 1 ? (BC == 128
             bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16);
             bf16_t* dst = p.y + pp * p.Cout + eco;
             f32x8 f = bf8_to_f32(v);
+            if (CAT) {
+                f += load_f32x8(p.epi_add + eco);
+                v = f32_to_bf8(f);
+            }
             if (p.accumulate) {
                 f += bf8_to_f32(*reinterpret_cast<const bf16x8*>(dst));
                 v = f32_to_bf8(f);
@@ -608,6 +635,10 @@ struct WgradP {
     int P, pix_per_block, n_cotiles, n_tiles, cin_shift, NK;   // NK = KH*KW*Cin: flattened (tap, ci) GEMM-N extent
     size_t gdz, gx;        // element strides between BatchNorm groups (blockIdx.y = group)
     int in_gstride;
+    // LZ kernels: lazy transform of the dz operand as well (Gram matrix a^T a of a lazily normalised activation)
+    const float* dz_scale;
+    const float* dz_shift;
+    int dz_act, dz_gstride;
 };
 
 // LDS image of one K step: [32 pixels][CH channels] bf16, row-major, 8-byte units XOR-swizzled so that the
@@ -618,7 +649,7 @@ __device__ __forceinline__ int tr_swz(int row) {
     return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 2;               // 128-byte rows: parity picks the bank half
 }
 
-template <int BM, int BN, int WPD = 1>
+template <int BM, int BN, int WPD = 1, bool LZ = false>
 __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
     constexpr int AROW = BM * 2;            // bytes per LDS row (one pixel)
     constexpr int BROW = BN * 2;
@@ -636,6 +667,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
     p.dz += (size_t)grp * p.gdz;
     p.x += (size_t)grp * p.gx;
     if (p.in_scale) { p.in_scale += (size_t)grp * p.in_gstride; p.in_shift += (size_t)grp * p.in_gstride; }
+    if (LZ && p.dz_scale) { p.dz_scale += (size_t)grp * p.dz_gstride; p.dz_shift += (size_t)grp * p.dz_gstride; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int co0 = (tile % p.n_cotiles) * BM;
@@ -651,6 +683,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
     // on the HBM-bound layer-1 shapes and on grids with > 4 workgroups per CU, so the launcher picks per problem.
     bf16x8 ra[WPD][AL], rb[WPD][BL];
     bool rbv[WPD][BL];
+    bool rav_a[LZ ? WPD : 1][AL];
     int b_kh[BL], b_kw[BL], b_ci[BL], b_n[BL], b_oh[BL], b_ow[BL];
     bool b_ok[BL];
 #pragma unroll
@@ -680,6 +713,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (pp < pe && co < p.Cout) v = *reinterpret_cast<const bf16x8*>(p.dz + (size_t)pp * p.Cout + co);
             ra[SL][l] = v;
+            if (LZ) rav_a[LZ ? SL : 0][l] = pp < pe && co < p.Cout;
         }
 #pragma unroll
         for (int l = 0; l < BL; ++l) {
@@ -704,7 +738,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
         for (int l = 0; l < AL; ++l) {
             int e = tid + l * NTHREADS;
             int row = e / ACH, ch = e - row * ACH;
-            *reinterpret_cast<bf16x8*>(base + row * AROW + ((ch ^ (tr_swz<BM>(row) >> 1)) << 4)) = ra[SL][l];
+            bf16x8 va = ra[SL][l];
+            if (LZ && p.dz_scale && rav_a[LZ ? SL : 0][l]) va = f32_to_bf8(transform8(va, p.dz_scale, p.dz_shift, co0 + ch * 8, p.dz_act));
+            *reinterpret_cast<bf16x8*>(base + row * AROW + ((ch ^ (tr_swz<BM>(row) >> 1)) << 4)) = va;
         }
 #pragma unroll
         for (int l = 0; l < BL; ++l) {
@@ -1021,10 +1057,13 @@ struct DgradClass { int nt; unsigned code; int ph, pw, OHc, OWc; };
 struct ResEpi { const void* res_out; const uint8_t* res_mask; int res_act; const void* bn_z2; const float* bn_vec2; double* stats2; };
 // dual-source input of a 1x1 data gradient (ConvP::x2 ..)
 struct DualIn { const void* z; const float* aff; void* side; };
+// K-concatenated second input, per-group weights, epilogue constant (ConvP::xb ..)
+struct CatIn { const void* xb; int C2; size_t gw; const float* epi_add; };
 
 static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
                        const float* in_shift, void* y, double* stats, const void* bn_z, const float* bn_vec, int bn_act,
-                       hipStream_t stream, const DgradClass* cls = nullptr, const ResEpi* res = nullptr, const DualIn* dual = nullptr) {
+                       hipStream_t stream, const DgradClass* cls = nullptr, const ResEpi* res = nullptr, const DualIn* dual = nullptr,
+                       const CatIn* cat = nullptr) {
     if (!d || !x || !w_packed || !y) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: null argument");
     if (d->Cin % 8 || d->Cout % 8) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: channels must be multiples of 8 (Cin=%d Cout=%d)", d->Cin, d->Cout);
     if (!cls && adamml_conv3x3_c64_supported(d))
@@ -1037,6 +1076,8 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     p.res_mask = res ? res->res_mask : nullptr;
     p.bn_z2 = res ? (const bf16_t*)res->bn_z2 : nullptr; p.bn_vec2 = res ? res->bn_vec2 : nullptr; p.stats2 = res ? res->stats2 : nullptr;
     p.x2 = dual ? (const bf16_t*)dual->z : nullptr; p.aff = dual ? dual->aff : nullptr; p.side = dual ? (bf16_t*)dual->side : nullptr;
+    p.xb = cat ? (const bf16_t*)cat->xb : nullptr; p.K1 = d->Cin; p.C2 = cat ? cat->C2 : 0; p.gw = cat ? cat->gw : 0;
+    p.epi_add = cat ? cat->epi_add : nullptr;
     const int groups = d->groups < 1 ? 1 : d->groups;
     p.gx = (size_t)d->N * d->H * d->W * d->Cin;
     p.gy = (size_t)d->N * d->OH * d->OW * d->Cout;
@@ -1047,6 +1088,11 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     if (p.up_shift < 0) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd: up=%d is not a power of two", p.up);
     p.act = d->act; p.accumulate = d->accumulate;
     p.P = d->N * d->OH * d->OW; p.K = d->KH * d->KW * d->Cin;
+    if (cat) {
+        if (d->KH * d->KW != 1 || d->stride != 1 || (d->up > 1) || d->Cin % BK || cat->C2 % 8 || cls || res || dual)
+            return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_alg: 1x1 / stride-1 convs with Cout %% 32 == 0 only");
+        p.K = d->Cin + cat->C2;
+    }
     p.wK = p.K;
     p.cls_nt = 0; p.cls_code = 0; p.oH = d->OH; p.oW = d->OW; p.o_ph = p.o_pw = 0;
     if (cls) {
@@ -1085,6 +1131,12 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
         if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, true>), grid, block, 0, stream, p);
         return adamml_check_launch("conv_bwd_data_res");
+    }
+    if (cat) {
+        if (mode != 0) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_alg: only 1x1 / stride-1 convs");
+        if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 3, false, false, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 3, false, false, true>), grid, block, 0, stream, p);
+        return adamml_check_launch("conv_bwd_data_alg");
     }
     if (dual) {
         if (mode != 0 || res) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_dual: only 1x1 / stride-1 convs");
@@ -1197,6 +1249,88 @@ extern "C" int adamml_conv_bwd_data_dual(const adamml_conv_desc_t* d, const void
     return conv_launch(&gd, g, w_dgrad_packed, nullptr, nullptr, dx, sums, z_in, bn_vec, act, stream, nullptr, nullptr, &di);
 }
 
+// ---- algebraic BatchNorm backward through a 1x1 conv z = W a followed by a linear BatchNorm (dz = A g' + B z + C per channel):
+//   dx = (W^T diag(A)) g' + (W^T diag(B) W) a + W^T C,   dW = A (.) (g'^T a) + B (.) (W G) + C (x) s,  G = a^T a, s = sum_p a
+// -- neither z nor dz is read or written.  Per BatchNorm group g the data gradient is ONE GEMM over the concatenated input
+// [g' | a] with the weight pack [Cin][Cout + Cin] built here, plus a constant per output channel.
+__global__ void alg_pack_kernel(const float* w, const float* aff, bf16_t* wp, float* cadd, int Cout, int Cin, int groups) {
+    // one thread per (group, ci, k): k < Cout -> W[k][ci] * A[k]; else M[ci][k - Cout] = sum_co W[co][ci] B[co] W[co][k - Cout]
+    const int K = Cout + Cin;
+    const size_t total = (size_t)groups * Cin * K;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(e % K);
+        const int ci = (int)((e / K) % Cin);
+        const int g = (int)(e / ((size_t)K * Cin));
+        const float* A = aff + (size_t)g * 3 * Cout;
+        const float* B = A + Cout;
+        float v;
+        if (k < Cout) v = w[(size_t)k * Cin + ci] * A[k];
+        else {
+            const int cj = k - Cout;
+            float acc = 0.f;
+            for (int co = 0; co < Cout; ++co) acc = fmaf(w[(size_t)co * Cin + ci] * B[co], w[(size_t)co * Cin + cj], acc);
+            v = acc;
+        }
+        wp[e] = __builtin_bit_cast(bf16_t, (__bf16)v);
+        if (k == 0) {
+            const float* Cc = A + 2 * Cout;
+            float acc = 0.f;
+            for (int co = 0; co < Cout; ++co) acc = fmaf(w[(size_t)co * Cin + ci], Cc[co], acc);
+            cadd[(size_t)g * Cin + ci] = acc;
+        }
+    }
+}
+
+// dW[co][ci] += sum_g  A_g[co] P_g[co][ci] + B_g[co] sum_cj W[co][cj] G_g[cj][ci] + C_g[co] s_g[ci]
+__global__ void alg_wgrad_combine_kernel(const float* w, const float* aff, const float* P, const float* G, const float* s, float* dw,
+                                         int Cout, int Cin, int groups) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Cout * Cin) return;
+    const int co = e / Cin, ci = e - co * Cin;
+    float acc = 0.f;
+    for (int g = 0; g < groups; ++g) {
+        const float* A = aff + (size_t)g * 3 * Cout;
+        const float* Gg = G + (size_t)g * Cin * Cin;
+        float wg = 0.f;
+        for (int cj = 0; cj < Cin; ++cj) wg = fmaf(w[(size_t)co * Cin + cj], Gg[(size_t)cj * Cin + ci], wg);
+        acc += A[co] * P[((size_t)g * Cout + co) * Cin + ci] + A[Cout + co] * wg + A[2 * Cout + co] * s[(size_t)g * Cin + ci];
+    }
+    dw[e] += acc;
+}
+
+extern "C" int adamml_alg_pack(const float* w, const float* aff, void* w_alg, float* epi_add, int Cout, int Cin, int groups,
+                               hipStream_t stream) {
+    if (!w || !aff || !w_alg || !epi_add || Cout < 1 || Cin < 1 || groups < 1) return adamml_set_error(ADAMML_EINVAL, "alg_pack: bad arguments");
+    const size_t total = (size_t)groups * Cin * (Cout + Cin);
+    hipLaunchKernelGGL(alg_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, aff, (bf16_t*)w_alg, epi_add, Cout, Cin, groups);
+    return adamml_check_launch("alg_pack");
+}
+
+extern "C" int adamml_alg_wgrad_combine(const float* w, const float* aff, const float* P, const float* G, const float* s, float* dw,
+                                        int Cout, int Cin, int groups, hipStream_t stream) {
+    if (!w || !aff || !P || !G || !s || !dw) return adamml_set_error(ADAMML_EINVAL, "alg_wgrad_combine: null argument");
+    hipLaunchKernelGGL(alg_wgrad_combine_kernel, dim3(ceil_div(Cout * Cin, 256)), dim3(256), 0, stream, w, aff, P, G, s, dw, Cout, Cin, groups);
+    return adamml_check_launch("alg_wgrad_combine");
+}
+
+extern "C" int adamml_conv_bwd_data_alg(const adamml_conv_desc_t* d, const void* g, const void* a, const float* a_scale, const float* a_shift,
+                                        const void* w_alg, const float* epi_add, void* dx, int accumulate, const void* z_in,
+                                        const float* bn_vec, int act, double* sums, hipStream_t stream) {
+    // d describes the FORWARD conv (1x1, stride 1); d->act / d->in_gstride describe the lazy transform of its input a
+    if (!d || !g || !a || !w_alg || !epi_add || !dx) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_alg: null argument");
+    if (!(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_alg: only 1x1 / stride-1 convs");
+    if ((z_in != nullptr) != (bn_vec != nullptr) || (z_in != nullptr) != (sums != nullptr))
+        return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_alg: incomplete BatchNorm epilogue operands");
+    if (z_in && accumulate) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_alg: the BatchNorm epilogue does not accumulate");
+    adamml_conv_desc_t gd = *d;
+    gd.N = d->N; gd.H = d->OH; gd.W = d->OW; gd.Cin = d->Cout;
+    gd.OH = d->H; gd.OW = d->W; gd.Cout = d->Cin;
+    gd.stride = 1; gd.up = 1; gd.pad = 0;
+    gd.act = d->act; gd.accumulate = accumulate ? 1 : 0; gd.in_gstride = d->in_gstride;
+    CatIn c{a, d->Cin, (size_t)d->Cin * (d->Cout + d->Cin), epi_add};
+    return conv_launch(&gd, g, w_alg, a_scale, a_shift, dx, sums, z_in, bn_vec, act, stream, nullptr, nullptr, nullptr, &c);
+}
+
 extern "C" int adamml_conv_bwd_data_res_supported(const adamml_conv_desc_t* d) {
     return d && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cin % 8 == 0 && d->Cout % 8 == 0 ? 1 : 0;
 }
@@ -1297,9 +1431,30 @@ extern "C" size_t adamml_conv_bwd_weight_workspace(const adamml_conv_desc_t* d, 
     return need;
 }
 
+struct WgradExtra { const float* dz_scale; const float* dz_shift; int dz_act, dz_gstride; bool per_group; };
+
+static int wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale, const float* in_shift, float* dw,
+                        int cin_true, void* workspace, size_t workspace_bytes, hipStream_t stream, const WgradExtra* ex);
+
 extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
                                       const float* in_shift, float* dw, int cin_true, void* workspace, size_t workspace_bytes,
                                       hipStream_t stream) {
+    return wgrad_launch(d, dz, x, in_scale, in_shift, dw, cin_true, workspace, workspace_bytes, stream, nullptr);
+}
+
+// Per-group products for the algebraic BatchNorm backward: out[g] = dz_g^T x_g ([groups][Cout][cin_true], OVERWRITTEN), with an
+// optional lazy transform of the dz operand too (Gram matrix a^T a: dz = x = the raw tensor, both transformed).  1x1 convs.
+extern "C" int adamml_conv_bwd_weight_grouped(const adamml_conv_desc_t* d, const void* dz, const float* dz_scale, const float* dz_shift,
+                                              int dz_act, int dz_gstride, const void* x, const float* in_scale, const float* in_shift,
+                                              float* out, int cin_true, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!d || d->KH * d->KW != 1) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_weight_grouped: 1x1 convs only");
+    if (!workspace) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_weight_grouped: needs the split workspace");
+    WgradExtra ex{dz_scale, dz_shift, dz_act, dz_gstride, true};
+    return wgrad_launch(d, dz, x, in_scale, in_shift, out, cin_true, workspace, workspace_bytes, stream, &ex);
+}
+
+static int wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale, const float* in_shift, float* dw,
+                        int cin_true, void* workspace, size_t workspace_bytes, hipStream_t stream, const WgradExtra* ex) {
     if (!d || !dz || !x || !dw) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_weight: null argument");
     if (d->Cin % 8 || d->Cout % 8) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_weight: channels must be multiples of 8");
     if ((long)d->N * d->OH * d->OW <= 0) return ADAMML_OK;
@@ -1308,7 +1463,9 @@ extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* d
     if (rc) return rc;
     const size_t dw_numel = (size_t)d->Cout * cin_true * d->KH * d->KW;
     const int groups = d->groups < 1 ? 1 : d->groups;
-    if (workspace && adamml_conv3x3_c64_wgrad_supported(d, cin_true)) {
+    if (ex && ex->per_group && !(workspace && workspace_bytes >= (size_t)groups * pl.nsplit * dw_numel * sizeof(float)))
+        return adamml_set_error(ADAMML_EINVAL, "conv_bwd_weight_grouped: workspace too small");
+    if (!ex && workspace && adamml_conv3x3_c64_wgrad_supported(d, cin_true)) {
         // 3x3 / 64 -> 64: LDS-patch kernel with one partial per workgroup (conv3x3_c64.hip)
         const int nblk = adamml_conv3x3_c64_wgrad_blocks(d, nullptr);
         if (workspace_bytes >= (size_t)nblk * dw_numel * sizeof(float)) {
@@ -1341,6 +1498,13 @@ extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* d
         p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.act = d->act; p.cin_true = cin_true;
         p.P = d->N * d->OH * d->OW; p.NK = pl.NK; p.cin_shift = pl.cin_shift; p.n_cotiles = pl.n_cotiles; p.n_tiles = pl.n_tiles;
         p.pix_per_block = pl.per_block;
+        p.dz_scale = ex ? ex->dz_scale : nullptr; p.dz_shift = ex ? ex->dz_shift : nullptr;
+        p.dz_act = ex ? ex->dz_act : 0; p.dz_gstride = ex ? ex->dz_gstride : 0;
+        if (ex && ex->dz_scale) {
+            if (pl.BM == 64 && pl.BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, true>), grid, block, 0, stream, p);
+            else if (pl.BM == 128 && pl.BN == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 1, true>), grid, block, 0, stream, p);
+            else return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_weight_grouped: lazy dz needs Cout == Cin in {64, >= 128}");
+        } else
         if (pl.BM == 64 && pl.BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, stream, p);
         else if (pl.BM == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, block, 0, stream, p);
         else if (pl.BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, block, 0, stream, p);
@@ -1349,5 +1513,13 @@ extern "C" int adamml_conv_bwd_weight(const adamml_conv_desc_t* d, const void* d
     }
     rc = adamml_check_launch("conv_bwd_weight");
     if (rc || !ws) return rc;
+    if (ex && ex->per_group) {
+        hipMemsetAsync(dw, 0, (size_t)groups * dw_numel * sizeof(float), stream);
+        for (int g = 0; g < groups; ++g) {
+            rc = adamml_launch_split_reduce(ws + (size_t)g * pl.nsplit * dw_numel, dw + (size_t)g * dw_numel, dw_numel, pl.nsplit, stream, 1, cin_true);
+            if (rc) return rc;
+        }
+        return ADAMML_OK;
+    }
     return adamml_launch_split_reduce(ws, dw, dw_numel, groups * pl.nsplit, stream, d->KH * d->KW, cin_true);
 }

@@ -300,6 +300,33 @@ __global__ void bn_bwd_affine_kernel(const float* coef, const float* vec, float*
     a[2 * C + c] = k0 * (k2 * mu * is - k1);
 }
 
+// s[g][c] = sum over the pixels of group g of act(scale x + shift)  (column sums of a lazily normalised activation: the
+// C (x) s term of the algebraic BatchNorm backward).  Row walker; fp32 atomics of per-workgroup partials (s zeroed here).
+__global__ __launch_bounds__(NT) void lazy_colsum_kernel(const bf16_t* x, const float* scale, const float* shift, int gs, int act, float* s,
+                                                         size_t P, int C, size_t ppb) {
+    __shared__ float smem[MAXC];
+    x += (size_t)blockIdx.y * P * C;
+    s += (size_t)blockIdx.y * C;
+    if (scale) { scale += (size_t)blockIdx.y * gs; shift += (size_t)blockIdx.y * gs; }
+    ChanMap m(C, threadIdx.x);
+    for (int i = threadIdx.x; i < C; i += NT) smem[i] = 0.f;
+    __syncthreads();
+    if (m.active) {
+        const int c = m.chunk * 8;
+        f32x8 acc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        const size_t pb = (size_t)blockIdx.x * ppb;
+        const size_t pe = pb + ppb < P ? pb + ppb : P;
+        for (size_t p = pb + m.rslot; p < pe; p += m.rows_per_pass)
+            acc += transform8(*reinterpret_cast<const bf16x8*>(x + p * C + c), scale, shift, c, act);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&smem[c + i], acc[i]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += NT) atomicAdd(&s[i], smem[i]);
+}
+
 // STREAM: the tensors are larger than the 256 MB Infinity Cache -> non-temporal accesses (nothing is re-used from cache);
 // smaller tensors keep default caching so that the consumers of dz (data / weight gradient) still find it in L2 / MALL.
 template <bool STREAM>
@@ -1028,6 +1055,19 @@ extern "C" int adamml_bn_bwd_finalize(const double* sums, int nslots, int groups
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, stream, sums, nslots, groups, count, gamma, vec, dgamma,
                        dbeta, coef, C);
     return adamml_check_launch("bn_bwd_finalize");
+}
+
+extern "C" int adamml_lazy_colsum(const void* x, const float* scale, const float* shift, int gstride, int act, float* s, size_t P, int C,
+                                  int groups, hipStream_t stream) {
+    CHECK_C(C, "lazy_colsum");
+    if (!x || !s) return adamml_set_error(ADAMML_EINVAL, "lazy_colsum: null argument");
+    if (groups < 1) groups = 1;
+    hipMemsetAsync(s, 0, (size_t)groups * C * sizeof(float), stream);
+    if (!P) return ADAMML_OK;
+    size_t ppb, nblk;
+    reduce_grid(P, C, groups, &ppb, &nblk);
+    hipLaunchKernelGGL(lazy_colsum_kernel, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)x, scale, shift, gstride, act, s, P, C, ppb);
+    return adamml_check_launch("lazy_colsum");
 }
 
 extern "C" int adamml_bn_bwd_affine(const float* coef, const float* vec, float* aff, int C, int groups, hipStream_t stream) {

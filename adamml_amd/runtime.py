@@ -8,6 +8,7 @@ never materialised except at residual adds.  BatchNorm statistics, scale/shift a
 """
 import collections
 import math
+import os
 import torch
 import torch.distributed as dist
 
@@ -354,6 +355,10 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
         def bwd():
             if out.grad is None and out.pool_grad is None:
                 return
+            if ALG_BN and act == ACT_NONE and not cs.depthwise and not stem and out.pool_grad is None and x.requires_grad \
+                    and rt.training and cs.weight.requires_grad and _alg_supported(cs, d):
+                _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern)
+                return
             if DUAL_DGRAD and act == ACT_NONE and not cs.depthwise and not stem and out.pool_grad is None and x.requires_grad \
                     and rt.training and hip.load().adamml_conv_bwd_data_dual_supported(byref(d)):
                 _conv1x1_backward_dual(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern)
@@ -440,6 +445,67 @@ class _on_wgrad_stream:
             while pend and pend[0][0].query():          # drop the references of the launches that have finished
                 pend.popleft()
         return False
+
+
+ALG_BN = os.environ.get("ADAMML_ALG_BN", "1") != "0"     # algebraic BatchNorm backward through expanding 1x1 convs (A/B aid)
+
+
+def _alg_supported(cs, d):
+    """Expanding 1x1 / stride-1 conv (bottleneck conv3, stride-1 downsample) whose output is large: Cin <= Cout / 2 so that the
+    Gram matrix of the input and the extra K columns are cheap, Cout <= 512 (beyond, the tensors are small and the per-group
+    weight products dominate), no channel padding."""
+    return (cs.kh == 1 and cs.kw == 1 and cs.stride == 1 and cs.pad == 0 and cs.cin_true == d.Cin and d.Cin in (64, 128, 256)
+            and d.Cout % 32 == 0 and 2 * d.Cin <= d.Cout <= 512)
+
+
+def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern):
+    """Backward of z = W a (1x1) followed by a linear train-mode BatchNorm WITHOUT touching z or dz (include/adamml_hip.h,
+    "algebraic BatchNorm backward"): with dz = A g' + B z + C per channel,
+        dx = (W^T diag(A)) g' + (W^T diag(B) W) a + W^T C,      dW = A (.) (g'^T a) + B (.) (W G) + C (x) s,  G = a^T a, s = sum a.
+    The products over pixels (g'^T a, a^T a, sum a) run on the weight-gradient stream; the data gradient is one GEMM over the
+    concatenated input [g' | a] with per-group weights."""
+    G = rt.groups
+    Cout, Cin = d.Cout, d.Cin
+    dev = y.device
+    g, coef = _bn_backward(rt, out, y, vec, bn, ACT_NONE, count, defer_apply=True)
+    aff = torch.empty(G, 3, Cout, dtype=torch.float32, device=dev)
+    call("adamml_bn_bwd_affine", ptr(coef), ptr(vec), ptr(aff), Cout, G)
+    w2 = cs.weight                                              # fp32 master [Cout, Cin, 1, 1], contiguous
+    # ---- data gradient (main stream)
+    w_alg = torch.empty(G, Cin, Cout + Cin, dtype=torch.bfloat16, device=dev)
+    cadd = torch.empty(G, Cin, dtype=torch.float32, device=dev)
+    call("adamml_alg_pack", ptr(w2), ptr(aff), ptr(w_alg), ptr(cadd), Cout, Cin, G)
+    acc = 1
+    if x.grad is None:
+        x.grad = torch.empty_like(x.data)
+        acc = 0
+    tgt = x.src if x.src is not None else x
+    if sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None:
+        sums = rt.bwd_arena.take(G * 2 * Cin * STAT_SLOTS)
+        hip.next_meta = (2 * macs, 3 * in_b + out_b + w_b, kern)
+        call("adamml_conv_bwd_data_alg", byref(d), ptr(g), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(w_alg), ptr(cadd), ptr(x.grad), 0,
+             ptr(tgt.data), ptr(tgt.vec), tgt.act, ptr(sums))
+        tgt.pre_sums = sums
+    else:
+        hip.next_meta = (2 * macs, in_b * (2 + acc) + out_b + w_b, kern)
+        call("adamml_conv_bwd_data_alg", byref(d), ptr(g), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(w_alg), ptr(cadd), ptr(x.grad), acc,
+             None, None, 0, None)
+    # ---- weight gradient (weight-gradient stream): products over the pixels, then the per-group combination
+    with _on_wgrad_stream(rt, (g, x.data, x.scale, aff)):
+        n, h, w_, _ = x.shape
+        P = torch.empty(G, Cout, Cin, dtype=torch.float32, device=dev)
+        Gm = torch.empty(G, Cin, Cin, dtype=torch.float32, device=dev)
+        ws = hip.wgrad_workspace(d, Cin, dev)
+        hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b)
+        call("adamml_conv_bwd_weight_grouped", byref(d), ptr(g), None, None, 0, 0, ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(P), Cin,
+             ptr(ws), ws.numel() * 4)
+        dg = ConvDesc(d.N, d.H, d.W, Cin, d.H, d.W, Cin, 1, 1, 1, 0, 1, d.act, 0, G, d.in_gstride)
+        wsg = hip.wgrad_workspace(dg, Cin, dev)
+        call("adamml_conv_bwd_weight_grouped", byref(dg), ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, x.gs, ptr(x.data), ptr(x.scale),
+             ptr(x.shift), ptr(Gm), Cin, ptr(wsg), wsg.numel() * 4)
+        sv = torch.empty(G, Cin, dtype=torch.float32, device=dev)
+        call("adamml_lazy_colsum", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(sv), n // G * h * w_, Cin, G)
+        call("adamml_alg_wgrad_combine", ptr(w2), ptr(aff), ptr(P), ptr(Gm), ptr(sv), ptr(cs.weight.grad), Cout, Cin, G)
 
 
 DUAL_DGRAD = True     # 1x1 / linear-BatchNorm layers: BatchNorm-backward apply folded into the data-gradient loader

@@ -81,6 +81,27 @@ int adamml_conv_bwd_data_dual(const adamml_conv_desc_t* d, const void* g, const 
                               const void* w_dgrad_packed, void* dx, int accumulate, const void* z_in, const float* bn_vec, int act,
                               double* sums, hipStream_t stream);
 
+/* ---- algebraic BatchNorm backward through a 1x1 conv z = W a followed by a linear BatchNorm (bn3 / downsample of a bottleneck).
+ * With dz = A g' + B z + C per channel (adamml_bn_bwd_affine) and z = W a:
+ *     dx = (W^T diag(A)) g' + (W^T diag(B) W) a + W^T C        dW = A (.) (g'^T a) + B (.) (W G) + C (x) s,   G = a^T a, s = sum_p a
+ * so neither the block-output-sized z nor dz is read or written in backward (7 -> 5 passes over that tensor per bottleneck).
+ *   adamml_conv_bwd_weight_grouped: per-group products out[g] = dz_g^T x_g (OVERWRITTEN; dz may be lazy too: Gram matrix with dz = x)
+ *   adamml_alg_pack:      w_alg [groups][Cin][Cout + Cin] bf16 and epi_add [groups][Cin] from W (fp32 [Cout][Cin]) and aff
+ *   adamml_conv_bwd_data_alg: ONE GEMM per pixel tile over the concatenated input [g' | a] (a with its lazy transform, d->act /
+ *                          d->in_gstride), + epi_add, then the usual accumulate or BatchNorm-fused epilogue
+ *   adamml_alg_wgrad_combine: dW += sum_g A_g (.) P_g + B_g (.) (W G_g) + C_g (x) s_g */
+int adamml_conv_bwd_weight_grouped(const adamml_conv_desc_t* d, const void* dz, const float* dz_scale, const float* dz_shift, int dz_act,
+                                   int dz_gstride, const void* x, const float* in_scale, const float* in_shift, float* out, int cin_true,
+                                   void* workspace, size_t workspace_bytes, hipStream_t stream);
+int adamml_lazy_colsum(const void* x, const float* scale, const float* shift, int gstride, int act, float* s, size_t P, int C, int groups,
+                       hipStream_t stream);     /* s[g][c] = sum_p act(scale x + shift), overwritten */
+int adamml_alg_pack(const float* w, const float* aff, void* w_alg, float* epi_add, int Cout, int Cin, int groups, hipStream_t stream);
+int adamml_alg_wgrad_combine(const float* w, const float* aff, const float* P, const float* G, const float* s, float* dw, int Cout,
+                             int Cin, int groups, hipStream_t stream);
+int adamml_conv_bwd_data_alg(const adamml_conv_desc_t* d, const void* g, const void* a, const float* a_scale, const float* a_shift,
+                             const void* w_alg, const float* epi_add, void* dx, int accumulate, const void* z_in, const float* bn_vec,
+                             int act, double* sums, hipStream_t stream);
+
 /* Data gradient of a 1x1 / stride-1 conv whose INPUT is the output of a residual add  out = act(bn_a(z_a) + idn)
  * (models/resnet.py:110-111; sound_mobilenet_v2.py:67), finishing that add's backward in the epilogue:
  *   g' = (W^T dz [+ dx, when accumulate: the identity-path gradient already stored there]) * act'(res_out)

@@ -866,3 +866,77 @@ def test_batched_weight_pack_equals_single_packs():
     call("adamml_pack_conv_weights_batched", ptr(table), len(specs), blk)
     for o, r in zip(outs, refs):
         assert torch.equal(o, r)
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,G,mode", [(4, 28, 64, 256, 1, "bn"), (3, 14, 64, 256, 3, "acc"), (2, 14, 128, 512, 2, "bn"),
+                                                  (2, 20, 64, 256, 2, "plain")])
+def test_algebraic_bn_backward_equals_explicit_dz(N, H, Cin, Cout, G, mode):
+    """Algebraic BatchNorm backward through a 1x1 conv (adamml_conv_bwd_weight_grouped + adamml_alg_pack +
+    adamml_conv_bwd_data_alg + adamml_alg_wgrad_combine: neither z nor dz is touched) against the explicit path
+    dz = A g' + B z + C -> adamml_conv_bwd_data[_bn] / adamml_conv_bwd_weight on the stored bf16 z.  The two differ by the
+    bf16 rounding of z and dz (explicit) vs of the products W^T diag(B) W (algebraic): 2e-2 of the result's scale."""
+    torch.manual_seed(N * 5 + H + Cout)
+    P = N * H * H
+    w = torch.randn(Cout, Cin, 1, 1, device=DEV) * (2.0 / Cin) ** 0.5
+    xraw = torch.randn(G * N, H, H, Cin, device=DEV).to(torch.bfloat16)
+    vin = torch.rand(G, 4, Cin, device=DEV) + 0.5
+    vin[:, 1] -= 0.6
+    d = ConvDesc(N, H, H, Cin, H, H, Cout, 1, 1, 1, 0, 1, 1, 0, G, 4 * Cin)          # lazy input: relu(scale x + shift)
+    z = torch.empty(G * N, H, H, Cout, dtype=torch.bfloat16, device=DEV)
+    call("adamml_conv_fwd", byref(d), ptr(xraw), ptr(pack(w, Cin, 0)), ptr(vin[0, 0]), ptr(vin[0, 1]), ptr(z), None)
+    g = torch.randn(G * N, H, H, Cout, device=DEV).to(torch.bfloat16)
+    aff = torch.empty(G, 3, Cout, device=DEV)
+    aff[:, 0] = torch.rand(G, Cout, device=DEV) + 0.5
+    aff[:, 1] = (torch.rand(G, Cout, device=DEV) - 0.5) * 0.3
+    aff[:, 2] = (torch.rand(G, Cout, device=DEV) - 0.5) * 0.2
+    # ---- explicit: dz materialised
+    dz = (aff[:, 0].view(G, 1, 1, 1, Cout) * g.float().view(G, N, H, H, Cout) + aff[:, 1].view(G, 1, 1, 1, Cout) * z.float().view(G, N, H, H, Cout)
+          + aff[:, 2].view(G, 1, 1, 1, Cout)).to(torch.bfloat16).view(G * N, H, H, Cout).contiguous()
+    base = torch.randn(G * N, H, H, Cin, device=DEV).to(torch.bfloat16)
+    dx_ref = base.clone()
+    s_ref = torch.zeros(G, STAT_SLOTS, 2 * Cin, dtype=torch.float64, device=DEV)
+    wd = pack(w, Cin, 1)
+    if mode == "bn":
+        call("adamml_conv_bwd_data_bn", byref(d), ptr(dz), ptr(wd), ptr(dx_ref), ptr(xraw), ptr(vin), 1, ptr(s_ref))
+    else:
+        call("adamml_conv_bwd_data", byref(d), ptr(dz), ptr(wd), ptr(dx_ref), 1 if mode == "acc" else 0)
+    dw_ref = torch.zeros_like(w)
+    ws = hip.wgrad_workspace(d, Cin, DEV)
+    call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(xraw), ptr(vin[0, 0]), ptr(vin[0, 1]), ptr(dw_ref), Cin, ptr(ws), ws.numel() * 4)
+    # ---- algebraic
+    Pm = torch.empty(G, Cout, Cin, device=DEV)
+    call("adamml_conv_bwd_weight_grouped", byref(d), ptr(g), None, None, 0, 0, ptr(xraw), ptr(vin[0, 0]), ptr(vin[0, 1]), ptr(Pm), Cin,
+         ptr(ws), ws.numel() * 4)
+    dG = ConvDesc(N, H, H, Cin, H, H, Cin, 1, 1, 1, 0, 1, 1, 0, G, 4 * Cin)
+    wsg = hip.wgrad_workspace(dG, Cin, DEV)
+    Gm = torch.empty(G, Cin, Cin, device=DEV)
+    call("adamml_conv_bwd_weight_grouped", byref(dG), ptr(xraw), ptr(vin[0, 0]), ptr(vin[0, 1]), 1, 4 * Cin, ptr(xraw), ptr(vin[0, 0]), ptr(vin[0, 1]),
+         ptr(Gm), Cin, ptr(wsg), wsg.numel() * 4)
+    a = torch.relu(xraw.float().view(G, P, Cin) * vin[:, 0].view(G, 1, Cin) + vin[:, 1].view(G, 1, Cin)).to(torch.bfloat16).float()
+    assert torch.allclose(Gm, torch.einsum("gpi,gpj->gij", a, a), rtol=2e-3, atol=2e-3 * P)
+    assert torch.allclose(Pm, torch.einsum("gpo,gpi->goi", g.float().view(G, P, Cout), a), rtol=2e-3, atol=2e-3 * P ** 0.5 * 4)
+    sv = a.sum(1).contiguous()
+    w_alg = torch.empty(G, Cin, Cout + Cin, dtype=torch.bfloat16, device=DEV)
+    cadd = torch.empty(G, Cin, device=DEV)
+    w2 = w.view(Cout, Cin).contiguous()
+    call("adamml_alg_pack", ptr(w2), ptr(aff), ptr(w_alg), ptr(cadd), Cout, Cin, G)
+    dx = base.clone()
+    s = torch.zeros_like(s_ref)
+    if mode == "bn":
+        call("adamml_conv_bwd_data_alg", byref(d), ptr(g), ptr(xraw), ptr(vin[0, 0]), ptr(vin[0, 1]), ptr(w_alg), ptr(cadd), ptr(dx), 0,
+             ptr(xraw), ptr(vin), 1, ptr(s))
+    else:
+        call("adamml_conv_bwd_data_alg", byref(d), ptr(g), ptr(xraw), ptr(vin[0, 0]), ptr(vin[0, 1]), ptr(w_alg), ptr(cadd), ptr(dx),
+             1 if mode == "acc" else 0, None, None, 0, None)
+    dw = torch.zeros_like(w)
+    call("adamml_alg_wgrad_combine", ptr(w2), ptr(aff), ptr(Pm), ptr(Gm), ptr(sv), ptr(dw), Cout, Cin, G)
+    sx = dx_ref.float().abs().max().item()
+    ex = (dx.float() - dx_ref.float()).abs().max().item()
+    sw = dw_ref.abs().max().item()
+    ew = (dw - dw_ref).abs().max().item()
+    print("  dx err %.3e of scale %.3e; dW err %.3e of scale %.3e" % (ex, sx, ew, sw))
+    assert ex <= 2e-2 * sx
+    assert ew <= 2e-2 * sw
+    if mode == "bn":
+        a_, b_ = s.sum(1), s_ref.sum(1)
+        assert (a_ - b_).abs().max().item() <= 2e-2 * b_.abs().max().item() + 1e-2
