@@ -425,7 +425,9 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
         // loop (load, mask, store, next row) exposes one HBM round trip per row, and this epilogue is the whole kernel
         // (K = 64..512: a few MFMA steps per tile).
         if (eco < p.Cout) {
-        const f32x8 mu = load_f32x8(p.bn_vec + 2 * p.Cout + eco), is = load_f32x8(p.bn_vec + 3 * p.Cout + eco);
+        // bn_z == nullptr: only sum(g') is accumulated (the algebraic BatchNorm backward derives sum(g' zhat) from g'^T a)
+        f32x8 mu, is;
+        if (p.bn_z) { mu = load_f32x8(p.bn_vec + 2 * p.Cout + eco); is = load_f32x8(p.bn_vec + 3 * p.Cout + eco); }
         f32x8 mu2, is2;
         if (second) { mu2 = load_f32x8(p.bn_vec2 + 2 * p.Cout + eco); is2 = load_f32x8(p.bn_vec2 + 3 * p.Cout + eco); }
         const float rlo = act_lo(p.res_act), rhi = act_hi(p.res_act);
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
                 const int r = erow0 + (b0 + j) * RSTEP;
                 ok[j] = p0 + r < p.P;
                 pr[j] = (size_t)(ok[j] ? p0 + r : p0) * p.Cout + eco;       // clamped: out-of-range rows re-read row p0, never stored
-                zr[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.bn_z + pr[j]));
+                if (p.bn_z) zr[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.bn_z + pr[j]));
                 if (p.accumulate) dr[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.y + pr[j]));
                 if (p.res_mask) mbits[j] = p.res_mask[pr[j] >> 3];
                 else orr[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.res_out + pr[j]));
@@ -451,7 +453,6 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
             for (int j = 0; j < EB; ++j) {
                 const int r = erow0 + (b0 + j) * RSTEP;
                 f32x8 f = bf8_to_f32(*reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16));
-                const f32x8 zv = bf8_to_f32(zr[j]);
                 if (p.accumulate) f += bf8_to_f32(dr[j]);
                 if (p.res_mask) {
 #pragma unroll
@@ -466,8 +467,11 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
                 const float keep = ok[j] ? 1.f : 0.f;
                 f = bf8_to_f32(v) * keep;
                 esum += f;
+                if (p.bn_z) {
+                    const f32x8 zv = bf8_to_f32(zr[j]);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) esq[i] += f[i] * (zv[i] - mu[i]) * is[i];
+                    for (int i = 0; i < 8; ++i) esq[i] += f[i] * (zv[i] - mu[i]) * is[i];
+                }
                 if (second) {
                     const f32x8 z2 = bf8_to_f32(z2r[j]);
 #pragma unroll
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
             *reinterpret_cast<bf16x8*>(dst) = v;
         }
     }
-    if (p.stats && !p.bn_z) {
+    if (p.stats && !p.bn_z && !RES) {
         // Forward statistics on the (otherwise ~90 % idle) matrix cores instead of the VALU: with F = the staged bf16 tile
         // [32 pixels][16 channels] as an MFMA fragment (hardware transpose read), ones * F gives the per-channel sums and
         // F^T F the Gram matrix whose diagonal is the per-channel sum of squares -- exact products of the STORED values,
@@ -552,7 +556,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
             }
         }
     }
-    if (p.stats && p.bn_z) {
+    if (p.stats && (p.bn_z || RES)) {
         // Lanes l, l+CPR, l+2*CPR.. of a wave hold partial sums of the same channel chunk.  They are folded on the VALU
         // with the gfx950 lane-swap instructions (v_permlane32_swap / v_permlane16_swap: "swap the upper half (odd rows)
         // of a with the lower half (even rows) of b", so a' + b' folds TWO values at once and halves the register count
@@ -1298,6 +1302,30 @@ __global__ void alg_wgrad_combine_kernel(const float* w, const float* aff, const
     dw[e] += acc;
 }
 
+// Second BatchNorm-backward moment from the algebraic identity  sum_p g'[p,co] z[p,co] = sum_cj W[co,cj] (g'^T a)[co,cj]  (z = W a):
+// sums [groups][SLOTS][2C] holds sum(g') in its first halves (epilogues run with z == NULL leave the second halves zero);
+// writes sum(g' zhat) = invstd (sum_j W (.) P - mean * sum g') into slot 0 of the second half.
+__global__ void alg_sumfix_kernel(const float* w, const float* P, const float* vec, double* sums, int Cout, int Cin, int groups) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Cout * groups) return;
+    const int g = e / Cout, co = e - g * Cout;
+    double* sg = sums + (size_t)g * ADAMML_STAT_SLOTS * 2 * Cout;
+    double s1 = 0.0;
+    for (int k = 0; k < ADAMML_STAT_SLOTS; ++k) s1 += sg[(size_t)k * 2 * Cout + co];
+    const float* Pg = P + ((size_t)g * Cout + co) * Cin;
+    double dot = 0.0;
+    for (int cj = 0; cj < Cin; ++cj) dot += (double)w[(size_t)co * Cin + cj] * (double)Pg[cj];
+    const float* v = vec + (size_t)g * 4 * Cout;
+    sg[Cout + co] = (double)v[3 * Cout + co] * (dot - (double)v[2 * Cout + co] * s1);
+}
+
+extern "C" int adamml_alg_sumfix(const float* w, const float* P, const float* vec, double* sums, int Cout, int Cin, int groups,
+                                 hipStream_t stream) {
+    if (!w || !P || !vec || !sums) return adamml_set_error(ADAMML_EINVAL, "alg_sumfix: null argument");
+    hipLaunchKernelGGL(alg_sumfix_kernel, dim3(ceil_div(Cout * groups, 128)), dim3(128), 0, stream, w, P, vec, sums, Cout, Cin, groups);
+    return adamml_check_launch("alg_sumfix");
+}
+
 extern "C" int adamml_alg_pack(const float* w, const float* aff, void* w_alg, float* epi_add, int Cout, int Cin, int groups,
                                hipStream_t stream) {
     if (!w || !aff || !w_alg || !epi_add || Cout < 1 || Cin < 1 || groups < 1) return adamml_set_error(ADAMML_EINVAL, "alg_pack: bad arguments");
@@ -1339,7 +1367,7 @@ extern "C" int adamml_conv_bwd_data_res(const adamml_conv_desc_t* d, const void*
                                         int accumulate, const void* res_out, const uint8_t* res_mask, int res_act, const void* z_a, const float* vec_a,
                                         double* sums_a, const void* z_b, const float* vec_b, double* sums_b,
                                         hipStream_t stream) {
-    if (!d || !res_out || !z_a || !vec_a || !sums_a) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_res: null argument");
+    if (!d || !res_out || !sums_a || (z_a && !vec_a)) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_res: null argument");
     if ((z_b != nullptr) != (vec_b != nullptr) || (z_b != nullptr) != (sums_b != nullptr))
         return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_res: incomplete second BatchNorm operand");
     if (!adamml_conv_bwd_data_res_supported(d)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res: only 1x1 / stride-1 convs");
@@ -1514,7 +1542,7 @@ static int wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void*
     rc = adamml_check_launch("conv_bwd_weight");
     if (rc || !ws) return rc;
     if (ex && ex->per_group) {
-        hipMemsetAsync(dw, 0, (size_t)groups * dw_numel * sizeof(float), stream);
+        (void)hipMemsetAsync(dw, 0, (size_t)groups * dw_numel * sizeof(float), stream);
         for (int g = 0; g < groups; ++g) {
             rc = adamml_launch_split_reduce(ws + (size_t)g * pl.nsplit * dw_numel, dw + (size_t)g * dw_numel, dw_numel, pl.nsplit, stream, 1, cin_true);
             if (rc) return rc;

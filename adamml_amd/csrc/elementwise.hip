@@ -657,8 +657,8 @@ __global__ __launch_bounds__(NT) void temporal_pool_residual_bwd_kernel(const bf
     {
         const size_t goff = (size_t)blockIdx.y * NB * T * HW * C;
         gy += (size_t)blockIdx.y * NB * To * HW * C;
-        out += goff; g2 += goff; za += goff;
-        veca += (size_t)blockIdx.y * 4 * C;
+        out += goff; g2 += goff;
+        if (za) { za += goff; veca += (size_t)blockIdx.y * 4 * C; }        // za == nullptr: sum(g') only (algebraic BatchNorm backward)
         sumsa += (size_t)blockIdx.y * ADAMML_STAT_SLOTS * 2 * C;
     }
     ChanMap m(C, threadIdx.x);
@@ -669,7 +669,10 @@ __global__ __launch_bounds__(NT) void temporal_pool_residual_bwd_kernel(const bf
     const size_t ce = cb + cpb < NBHW ? cb + cpb : NBHW;
     if (m.active) {
         const int c = m.chunk * 8;
-        const f32x8 mua = load_f32x8(veca + 2 * C + c), isa = load_f32x8(veca + 3 * C + c);
+        f32x8 mua, isa;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { mua[i] = 0.f; isa[i] = 0.f; }
+        if (za) { mua = load_f32x8(veca + 2 * C + c); isa = load_f32x8(veca + 3 * C + c); }
         const float lo = act_lo(act), hi = act_hi(act);
         const size_t fstride = (size_t)HW * C;                    // elements between consecutive frames of a clip
         for (size_t col = cb + m.rslot; col < ce; col += m.rows_per_pass) {
@@ -681,7 +684,10 @@ __global__ __launch_bounds__(NT) void temporal_pool_residual_bwd_kernel(const bf
 #pragma unroll
             for (int t = 0; t < To; ++t) gv[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(gy + gbase + t * fstride));
 #pragma unroll
-            for (int t = 0; t < T; ++t) zv[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(za + base + t * fstride));
+            for (int t = 0; t < T; ++t) {
+                if (za) zv[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(za + base + t * fstride));
+                else zv[t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};          // isa == 0: the second moment stays 0
+            }
             int bt[To][8];
 #pragma unroll
             for (int to = 0; to < To; ++to) {
@@ -1062,7 +1068,7 @@ extern "C" int adamml_lazy_colsum(const void* x, const float* scale, const float
     CHECK_C(C, "lazy_colsum");
     if (!x || !s) return adamml_set_error(ADAMML_EINVAL, "lazy_colsum: null argument");
     if (groups < 1) groups = 1;
-    hipMemsetAsync(s, 0, (size_t)groups * C * sizeof(float), stream);
+    (void)hipMemsetAsync(s, 0, (size_t)groups * C * sizeof(float), stream);
     if (!P) return ADAMML_OK;
     size_t ppb, nblk;
     reduce_grid(P, C, groups, &ppb, &nblk);
@@ -1175,7 +1181,7 @@ extern "C" int adamml_temporal_pool_bwd_res(const void* g_y, const void* out, in
                                             double* sums_a, int NB, int T, int HW, int C, int groups, hipStream_t stream) {
     CHECK_C(C, "temporal_pool_bwd_res");
     if (!adamml_temporal_pool_bwd_res_supported(T, C, 0)) return adamml_set_error(ADAMML_EUNSUPPORTED, "temporal_pool_bwd_res: T=%d C=%d", T, C);
-    if (!g_y || !out || !g2 || !z_a || !vec_a || !sums_a) return adamml_set_error(ADAMML_EINVAL, "temporal_pool_bwd_res: null argument");
+    if (!g_y || !out || !g2 || !sums_a || (z_a && !vec_a)) return adamml_set_error(ADAMML_EINVAL, "temporal_pool_bwd_res: null argument");
     const size_t cols = (size_t)NB * HW;
     if (!cols) return ADAMML_OK;
     if (groups < 1) groups = 1;

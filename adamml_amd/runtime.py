@@ -27,7 +27,7 @@ def pad8(c):
 class Lazy:
     """Activation tensor [G*N,H,W,C] bf16 (G BatchNorm groups, group-major) whose value is act(scale*data + shift)
     (scale None -> data); group g uses scale + g*gs, shift + g*gs (gs == 0: one pair for all groups)."""
-    __slots__ = ("data", "scale", "shift", "gs", "act", "grad", "requires_grad", "vec", "src", "pre_sums", "res", "res_done", "pool_grad")
+    __slots__ = ("data", "scale", "shift", "gs", "act", "grad", "requires_grad", "vec", "src", "pre_sums", "res", "res_done", "pool_grad", "alg", "sums_partial")
 
     def __init__(self, data, scale=None, shift=None, act=ACT_NONE, requires_grad=True, gs=0):
         self.data, self.scale, self.shift, self.act, self.gs = data, scale, shift, act, gs
@@ -38,6 +38,8 @@ class Lazy:
         self.pre_sums = None        # BatchNorm-backward sums already accumulated by the producer of .grad
         self.pool_grad = None       # (g_y, idx, OH, OW): .grad = routed max-pool gradient, recomputed by the BatchNorm backward
         self.res = None             # (z, idn, act, idn_sole) of the residual add that produced this tensor
+        self.alg = False            # BatchNorm backward of this conv output is algebraic: producers of .grad need not read .data
+        self.sums_partial = False   # .pre_sums holds sum(g') only; sum(g' zhat) is derived from g'^T a (adamml_alg_sumfix)
         self.res_done = False       # .grad is already act-masked and the add's BatchNorm-backward sums are in place
 
     @property
@@ -349,14 +351,15 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
     if rt.training:
         out = Lazy(y, vec[0, 0], vec[0, 1], act, gs=4 * C)
         out.vec = vec
+        out.alg = bool(ALG_BN and rt.tape.need_grad and act == ACT_NONE and not cs.depthwise and not stem and x.requires_grad
+                       and cs.weight.requires_grad and _alg_supported(cs, d))
     else:
         out = Lazy(y, vec[0], vec[1], act)
     if rt.tape.need_grad:
         def bwd():
             if out.grad is None and out.pool_grad is None:
                 return
-            if ALG_BN and act == ACT_NONE and not cs.depthwise and not stem and out.pool_grad is None and x.requires_grad \
-                    and rt.training and cs.weight.requires_grad and _alg_supported(cs, d):
+            if out.alg and out.pool_grad is None:
                 _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern)
                 return
             if DUAL_DGRAD and act == ACT_NONE and not cs.depthwise and not stem and out.pool_grad is None and x.requires_grad \
@@ -393,11 +396,19 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                     fb = idn is not None and idn_sole and idn.requires_grad and idn.vec is not None and idn.grad is None
                     sa = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS)
                     sb = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS) if fb else None
-                    hip.next_meta = (2 * macs, in_b * ((2.0625 if rmask is not None else 3) + acc + (1 if fb else 0)) + out_b + w_b, kern)
+                    fb_alg = fb and idn.alg               # the downsample BatchNorm shares sum(g'); its second moment comes from g'^T a too
+                    hip.next_meta = (2 * macs, in_b * ((1.0625 if rmask is not None else 2) + (0 if z.alg else 1) + acc
+                                                       + (1 if (fb and not (fb and idn.alg)) else 0)) + out_b + w_b, kern)
+                    fbk = fb and not fb_alg
                     call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc, ptr(x.data), ptr(rmask), ract,
-                         ptr(z.data), ptr(z.vec), ptr(sa), ptr(idn.data) if fb else None, ptr(idn.vec) if fb else None, ptr(sb))
+                         None if z.alg else ptr(z.data), ptr(z.vec), ptr(sa), ptr(idn.data) if fbk else None, ptr(idn.vec) if fbk else None,
+                         ptr(sb) if fbk else None)
                     z.pre_sums = sa
+                    z.sums_partial = z.alg
                     if fb:
+                        if fb_alg:
+                            sb.view(G, STAT_SLOTS, 2 * d.Cin)[:, :, :d.Cin].copy_(sa.view(G, STAT_SLOTS, 2 * d.Cin)[:, :, :d.Cin])
+                            idn.sums_partial = True
                         idn.pre_sums = sb
                     x.res_done = True
                 elif sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None:
@@ -467,10 +478,27 @@ def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, m
     G = rt.groups
     Cout, Cin = d.Cout, d.Cin
     dev = y.device
+    w2 = cs.weight                                              # fp32 master [Cout, Cin, 1, 1], contiguous
+    P = torch.empty(G, Cout, Cin, dtype=torch.float32, device=dev)
+    g0 = out.grad
+
+    def products():
+        ws = hip.wgrad_workspace(d, Cin, dev)
+        hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b)
+        call("adamml_conv_bwd_weight_grouped", byref(d), ptr(g0), None, None, 0, 0, ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(P), Cin,
+             ptr(ws), ws.numel() * 4)
+    if out.sums_partial:
+        # the producer of g' did not read z: sum(g' zhat) = invstd (sum_j W (.) P - mean sum g') needs P BEFORE the finalize step,
+        # so P runs on this stream (behind the weight-gradient stream's backlog it would stall the whole data-gradient chain)
+        out.sums_partial = False
+        products()
+        call("adamml_alg_sumfix", ptr(w2), ptr(P), ptr(vec), ptr(out.pre_sums), Cout, Cin, G)
+    else:
+        with _on_wgrad_stream(rt, (g0, x.data, x.scale)):
+            products()
     g, coef = _bn_backward(rt, out, y, vec, bn, ACT_NONE, count, defer_apply=True)
     aff = torch.empty(G, 3, Cout, dtype=torch.float32, device=dev)
     call("adamml_bn_bwd_affine", ptr(coef), ptr(vec), ptr(aff), Cout, G)
-    w2 = cs.weight                                              # fp32 master [Cout, Cin, 1, 1], contiguous
     # ---- data gradient (main stream)
     w_alg = torch.empty(G, Cin, Cout + Cin, dtype=torch.bfloat16, device=dev)
     cadd = torch.empty(G, Cin, dtype=torch.float32, device=dev)
@@ -491,14 +519,9 @@ def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, m
         call("adamml_conv_bwd_data_alg", byref(d), ptr(g), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(w_alg), ptr(cadd), ptr(x.grad), acc,
              None, None, 0, None)
     # ---- weight gradient (weight-gradient stream): products over the pixels, then the per-group combination
-    with _on_wgrad_stream(rt, (g, x.data, x.scale, aff)):
+    with _on_wgrad_stream(rt, (g, x.data, x.scale, aff, P)):
         n, h, w_, _ = x.shape
-        P = torch.empty(G, Cout, Cin, dtype=torch.float32, device=dev)
         Gm = torch.empty(G, Cin, Cin, dtype=torch.float32, device=dev)
-        ws = hip.wgrad_workspace(d, Cin, dev)
-        hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b)
-        call("adamml_conv_bwd_weight_grouped", byref(d), ptr(g), None, None, 0, 0, ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(P), Cin,
-             ptr(ws), ws.numel() * 4)
         dg = ConvDesc(d.N, d.H, d.W, Cin, d.H, d.W, Cin, 1, 1, 1, 0, 1, d.act, 0, G, d.in_gstride)
         wsg = hip.wgrad_workspace(dg, Cin, dev)
         call("adamml_conv_bwd_weight_grouped", byref(dg), ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, x.gs, ptr(x.data), ptr(x.scale),
@@ -673,9 +696,10 @@ def temporal_pool(rt, x, frames, mode, sole_consumer=False):
                 fb = idn is not None and idn_sole and idn.requires_grad and idn.vec is not None and idn.grad is None
                 if z.requires_grad and z.vec is not None and z.grad is None and z.pre_sums is None and not fb:
                     sa = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS)
-                    call("adamml_temporal_pool_bwd_res", ptr(g), ptr(x.data), ract, ptr(gx), ptr(z.data), ptr(z.vec), ptr(sa),
+                    call("adamml_temporal_pool_bwd_res", ptr(g), ptr(x.data), ract, ptr(gx), None if z.alg else ptr(z.data), ptr(z.vec), ptr(sa),
                          nb // G, frames, h * w, C, G)
                     z.pre_sums = sa
+                    z.sums_partial = z.alg
                     x.res_done = True
                     x.grad = gx
                     return

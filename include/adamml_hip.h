@@ -95,6 +95,9 @@ int adamml_conv_bwd_weight_grouped(const adamml_conv_desc_t* d, const void* dz, 
                                    void* workspace, size_t workspace_bytes, hipStream_t stream);
 int adamml_lazy_colsum(const void* x, const float* scale, const float* shift, int gstride, int act, float* s, size_t P, int C, int groups,
                        hipStream_t stream);     /* s[g][c] = sum_p act(scale x + shift), overwritten */
+int adamml_alg_sumfix(const float* w, const float* P, const float* vec, double* sums, int Cout, int Cin, int groups, hipStream_t stream);
+   /* sum(g' zhat) from P = g'^T a when the producer of g' ran with z == NULL (adamml_conv_bwd_data_res / adamml_temporal_pool_bwd_res
+      accept z_a == NULL: sum(g') only) */
 int adamml_alg_pack(const float* w, const float* aff, void* w_alg, float* epi_add, int Cout, int Cin, int groups, hipStream_t stream);
 int adamml_alg_wgrad_combine(const float* w, const float* aff, const float* P, const float* G, const float* s, float* dw, int Cout,
                              int Cin, int groups, hipStream_t stream);
