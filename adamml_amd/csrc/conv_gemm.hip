@@ -1013,7 +1013,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_wgrad_kernel(W3P p) {
 
 // dw[perm(i)] += sum_s ws[s][i]: 16 indices x 16 split lanes per workgroup (the split loop is the long axis).
 // taps > 1: ws is tap-major [co][tap][cin], dw is OIHW [co][cin][tap].
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dw, size_t n, int nsplit, int taps, int cin) {
+// blockIdx.y = output group (per-group products of the algebraic BatchNorm backward: ws [group][split][n] -> dw [group][n], stored)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dw, size_t n, int nsplit, int taps, int cin, int store) {
+    ws += (size_t)blockIdx.y * nsplit * n;
+    dw += (size_t)blockIdx.y * n;
     __shared__ float red[16][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const size_t i = (size_t)blockIdx.x * 16 + tx;
@@ -1033,7 +1036,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
             const int rem = (int)(i - co * per_co), tap = rem / cin, ci = rem - tap * cin;
             o = (co * cin + ci) * taps + tap;
         }
-        dw[o] += t;
+        if (store) dw[o] = t; else dw[o] += t;
     }
 }
 
@@ -1443,7 +1446,7 @@ static int wgrad_plan(const adamml_conv_desc_t* d, int cin_true, WgradPlan* pl) 
 }
 
 int adamml_launch_split_reduce(const float* ws, float* dw, size_t n, int nsplit, hipStream_t stream, int taps, int cin) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, ws, dw, n, nsplit, taps, cin);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, ws, dw, n, nsplit, taps, cin, 0);
     return adamml_check_launch("split_reduce");
 }
 
@@ -1542,12 +1545,9 @@ static int wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void*
     rc = adamml_check_launch("conv_bwd_weight");
     if (rc || !ws) return rc;
     if (ex && ex->per_group) {
-        (void)hipMemsetAsync(dw, 0, (size_t)groups * dw_numel * sizeof(float), stream);
-        for (int g = 0; g < groups; ++g) {
-            rc = adamml_launch_split_reduce(ws + (size_t)g * pl.nsplit * dw_numel, dw + (size_t)g * dw_numel, dw_numel, pl.nsplit, stream, 1, cin_true);
-            if (rc) return rc;
-        }
-        return ADAMML_OK;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((dw_numel + 15) / 16), groups), dim3(256), 0, stream, ws, dw, dw_numel, pl.nsplit,
+                           1, cin_true, 1);
+        return adamml_check_launch("split_reduce");
     }
     return adamml_launch_split_reduce(ws, dw, dw_numel, groups * pl.nsplit, stream, d->KH * d->KW, cin_true);
 }
