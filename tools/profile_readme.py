@@ -3,9 +3,10 @@ import collections, csv, json, re
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open("profiles/r01_bench_single_stream_kernel_stats.csv")):
     n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"conv_gemm_kernel<(\d+), (\d), (\d), (true|false), (true|false)>", n)
+    m = re.match(r"conv_gemm_kernel<(\d+), (\d), (\d), (true|false), (true|false)(?:, (true|false))?>", n)
     if m:
-        n = "conv_gemm_kernel" + (" RES (residual epilogue)" if m.group(4) == "true" else " DUAL (BN-backward loader)" if m.group(5) == "true" else "")
+        n = "conv_gemm_kernel" + (" RES (residual epilogue)" if m.group(4) == "true" else " DUAL (BN-backward loader)" if m.group(5) == "true"
+                                  else " CAT (algebraic BN backward: [g' | a] data gradient)" if m.group(6) == "true" else "")
     else:
         n = re.sub(r"[<(].*", "", n).strip()
     agg[n][0] += int(r["Calls"]); agg[n][1] += float(r["TotalDurationNs"]) / 1e6
