@@ -1260,7 +1260,7 @@ extern "C" int adamml_conv_bwd_data_dual(const adamml_conv_desc_t* d, const void
 //   dx = (W^T diag(A)) g' + (W^T diag(B) W) a + W^T C,   dW = A (.) (g'^T a) + B (.) (W G) + C (x) s,  G = a^T a, s = sum_p a
 // -- neither z nor dz is read or written.  Per BatchNorm group g the data gradient is ONE GEMM over the concatenated input
 // [g' | a] with the weight pack [Cin][Cout + Cin] built here, plus a constant per output channel.
-__global__ void alg_pack_kernel(const float* w, const float* aff, bf16_t* wp, float* cadd, int Cout, int Cin, int groups) {
+__global__ void alg_pack_kernel(const float* w, const float* aff, const float* m_pre, bf16_t* wp, float* cadd, int Cout, int Cin, int groups) {
     // one thread per (group, ci, k): k < Cout -> W[k][ci] * A[k]; else M[ci][k - Cout] = sum_co W[co][ci] B[co] W[co][k - Cout]
     const int K = Cout + Cin;
     const size_t total = (size_t)groups * Cin * K;
@@ -1274,9 +1274,12 @@ __global__ void alg_pack_kernel(const float* w, const float* aff, bf16_t* wp, fl
         if (k < Cout) v = w[(size_t)k * Cin + ci] * A[k];
         else {
             const int cj = k - Cout;
-            float acc = 0.f;
-            for (int co = 0; co < Cout; ++co) acc = fmaf(w[(size_t)co * Cin + ci] * B[co], w[(size_t)co * Cin + cj], acc);
-            v = acc;
+            if (m_pre) v = m_pre[((size_t)g * Cin + ci) * Cin + cj];      // M_g computed by a GEMM (large Cin)
+            else {
+                float acc = 0.f;
+                for (int co = 0; co < Cout; ++co) acc = fmaf(w[(size_t)co * Cin + ci] * B[co], w[(size_t)co * Cin + cj], acc);
+                v = acc;
+            }
         }
         wp[e] = __builtin_bit_cast(bf16_t, (__bf16)v);
         if (k == 0) {
@@ -1289,8 +1292,8 @@ __global__ void alg_pack_kernel(const float* w, const float* aff, bf16_t* wp, fl
 }
 
 // dW[co][ci] += sum_g  A_g[co] P_g[co][ci] + B_g[co] sum_cj W[co][cj] G_g[cj][ci] + C_g[co] s_g[ci]
-__global__ void alg_wgrad_combine_kernel(const float* w, const float* aff, const float* P, const float* G, const float* s, float* dw,
-                                         int Cout, int Cin, int groups) {
+__global__ void alg_wgrad_combine_kernel(const float* w, const float* aff, const float* P, const float* G, const float* wg_pre, const float* s,
+                                         float* dw, int Cout, int Cin, int groups) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= Cout * Cin) return;
     const int co = e / Cin, ci = e - co * Cin;
@@ -1299,7 +1302,9 @@ __global__ void alg_wgrad_combine_kernel(const float* w, const float* aff, const
         const float* A = aff + (size_t)g * 3 * Cout;
         const float* Gg = G + (size_t)g * Cin * Cin;
         float wg = 0.f;
-        for (int cj = 0; cj < Cin; ++cj) wg = fmaf(w[(size_t)co * Cin + cj], Gg[(size_t)cj * Cin + ci], wg);
+        if (wg_pre) wg = wg_pre[(size_t)co * groups * Cin + (size_t)g * Cin + ci];        // (W G_g) computed by a GEMM (large Cin)
+        else
+            for (int cj = 0; cj < Cin; ++cj) wg = fmaf(w[(size_t)co * Cin + cj], Gg[(size_t)cj * Cin + ci], wg);
         acc += A[co] * P[((size_t)g * Cout + co) * Cin + ci] + A[Cout + co] * wg + A[2 * Cout + co] * s[(size_t)g * Cin + ci];
     }
     dw[e] += acc;
@@ -1329,18 +1334,18 @@ extern "C" int adamml_alg_sumfix(const float* w, const float* P, const float* ve
     return adamml_check_launch("alg_sumfix");
 }
 
-extern "C" int adamml_alg_pack(const float* w, const float* aff, void* w_alg, float* epi_add, int Cout, int Cin, int groups,
-                               hipStream_t stream) {
+extern "C" int adamml_alg_pack(const float* w, const float* aff, const float* m_pre, void* w_alg, float* epi_add, int Cout, int Cin,
+                               int groups, hipStream_t stream) {
     if (!w || !aff || !w_alg || !epi_add || Cout < 1 || Cin < 1 || groups < 1) return adamml_set_error(ADAMML_EINVAL, "alg_pack: bad arguments");
     const size_t total = (size_t)groups * Cin * (Cout + Cin);
-    hipLaunchKernelGGL(alg_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, aff, (bf16_t*)w_alg, epi_add, Cout, Cin, groups);
+    hipLaunchKernelGGL(alg_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, aff, m_pre, (bf16_t*)w_alg, epi_add, Cout, Cin, groups);
     return adamml_check_launch("alg_pack");
 }
 
-extern "C" int adamml_alg_wgrad_combine(const float* w, const float* aff, const float* P, const float* G, const float* s, float* dw,
-                                        int Cout, int Cin, int groups, hipStream_t stream) {
-    if (!w || !aff || !P || !G || !s || !dw) return adamml_set_error(ADAMML_EINVAL, "alg_wgrad_combine: null argument");
-    hipLaunchKernelGGL(alg_wgrad_combine_kernel, dim3(ceil_div(Cout * Cin, 256)), dim3(256), 0, stream, w, aff, P, G, s, dw, Cout, Cin, groups);
+extern "C" int adamml_alg_wgrad_combine(const float* w, const float* aff, const float* P, const float* G, const float* wg_pre, const float* s,
+                                        float* dw, int Cout, int Cin, int groups, hipStream_t stream) {
+    if (!w || !aff || !P || (!G && !wg_pre) || !s || !dw) return adamml_set_error(ADAMML_EINVAL, "alg_wgrad_combine: null argument");
+    hipLaunchKernelGGL(alg_wgrad_combine_kernel, dim3(ceil_div(Cout * Cin, 256)), dim3(256), 0, stream, w, aff, P, G, wg_pre, s, dw, Cout, Cin, groups);
     return adamml_check_launch("alg_wgrad_combine");
 }
 

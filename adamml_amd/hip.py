@@ -39,8 +39,8 @@ SIGNATURES = {
     "adamml_conv_bwd_weight_grouped": [_DESC, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _Z, _P],
     "adamml_lazy_colsum": [_P, _P, _P, _I, _I, _P, _Z, _I, _I, _P],
     "adamml_alg_sumfix": [_P, _P, _P, _P, _I, _I, _I, _P],
-    "adamml_alg_pack": [_P, _P, _P, _P, _I, _I, _I, _P],
-    "adamml_alg_wgrad_combine": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "adamml_alg_pack": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "adamml_alg_wgrad_combine": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "adamml_conv_bwd_data_alg": [_DESC, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
     "adamml_conv_bwd_data_res": [_DESC, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "adamml_bn_act_add_mask": [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _Z, _I, _I, _P],

@@ -459,6 +459,8 @@ class _on_wgrad_stream:
 
 
 ALG_BN = os.environ.get("ADAMML_ALG_BN", "1") != "0"     # algebraic BatchNorm backward through expanding 1x1 convs (A/B aid)
+ALG_MAX_COUT = int(os.environ.get("ADAMML_ALG_MAX_COUT", "512"))     # measured: at Cout = 1024 (layer 3) the small per-group products cost more than the saved passes (146.1 vs 144.6 ms)
+ALG_GEMM_CIN = 256     # from this input width on, the small per-group matrix products go through adamml_gemm_f32
 
 
 def _alg_supported(cs, d):
@@ -466,7 +468,7 @@ def _alg_supported(cs, d):
     Gram matrix of the input and the extra K columns are cheap, Cout <= 512 (beyond, the tensors are small and the per-group
     weight products dominate), no channel padding."""
     return (cs.kh == 1 and cs.kw == 1 and cs.stride == 1 and cs.pad == 0 and cs.cin_true == d.Cin and d.Cin in (64, 128, 256)
-            and d.Cout % 32 == 0 and 2 * d.Cin <= d.Cout <= 512)
+            and d.Cout % 32 == 0 and 2 * d.Cin <= d.Cout <= ALG_MAX_COUT)
 
 
 def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern):
@@ -502,7 +504,13 @@ def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, m
     # ---- data gradient (main stream)
     w_alg = torch.empty(G, Cin, Cout + Cin, dtype=torch.bfloat16, device=dev)
     cadd = torch.empty(G, Cin, dtype=torch.float32, device=dev)
-    call("adamml_alg_pack", ptr(w2), ptr(aff), ptr(w_alg), ptr(cadd), Cout, Cin, G)
+    m_pre = None
+    w2d = w2.view(Cout, Cin)
+    if Cin >= ALG_GEMM_CIN:
+        # W^T diag(B_g) W for all groups as ONE fp32 GEMM: [G*Cin, Cout] x [Cout, Cin]
+        wb = (w2d.unsqueeze(1) * aff[:, 1].t().unsqueeze(2)).reshape(Cout, G * Cin)
+        m_pre = gemm_f32(wb, w2d, trans_a=True, trans_b=False)
+    call("adamml_alg_pack", ptr(w2), ptr(aff), ptr(m_pre), ptr(w_alg), ptr(cadd), Cout, Cin, G)
     acc = 1
     if x.grad is None:
         x.grad = torch.empty_like(x.data)
@@ -528,7 +536,11 @@ def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, m
              ptr(x.shift), ptr(Gm), Cin, ptr(wsg), wsg.numel() * 4)
         sv = torch.empty(G, Cin, dtype=torch.float32, device=dev)
         call("adamml_lazy_colsum", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(sv), n // G * h * w_, Cin, G)
-        call("adamml_alg_wgrad_combine", ptr(w2), ptr(aff), ptr(P), ptr(Gm), ptr(sv), ptr(cs.weight.grad), Cout, Cin, G)
+        wg_pre = None
+        if Cin >= ALG_GEMM_CIN:
+            # W G_g for all groups as one GEMM: [Cout, Cin] x [Cin, G*Cin]
+            wg_pre = gemm_f32(w2d, Gm.permute(1, 0, 2).reshape(Cin, G * Cin), trans_b=False)
+        call("adamml_alg_wgrad_combine", ptr(w2), ptr(aff), ptr(P), ptr(Gm), ptr(wg_pre), ptr(sv), ptr(cs.weight.grad), Cout, Cin, G)
 
 
 DUAL_DGRAD = True     # 1x1 / linear-BatchNorm layers: BatchNorm-backward apply folded into the data-gradient loader

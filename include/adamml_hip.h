@@ -98,9 +98,12 @@ int adamml_lazy_colsum(const void* x, const float* scale, const float* shift, in
 int adamml_alg_sumfix(const float* w, const float* P, const float* vec, double* sums, int Cout, int Cin, int groups, hipStream_t stream);
    /* sum(g' zhat) from P = g'^T a when the producer of g' ran with z == NULL (adamml_conv_bwd_data_res / adamml_temporal_pool_bwd_res
       accept z_a == NULL: sum(g') only) */
-int adamml_alg_pack(const float* w, const float* aff, void* w_alg, float* epi_add, int Cout, int Cin, int groups, hipStream_t stream);
-int adamml_alg_wgrad_combine(const float* w, const float* aff, const float* P, const float* G, const float* s, float* dw, int Cout,
-                             int Cin, int groups, hipStream_t stream);
+/* m_pre (optional) = the [groups][Cin][Cin] products W^T diag(B_g) W and wg_pre (optional) = [Cout][groups*Cin] products W G_g when the
+ * caller computed them with adamml_gemm_f32 (large Cin); NULL: formed inside the kernels. */
+int adamml_alg_pack(const float* w, const float* aff, const float* m_pre, void* w_alg, float* epi_add, int Cout, int Cin, int groups,
+                    hipStream_t stream);
+int adamml_alg_wgrad_combine(const float* w, const float* aff, const float* P, const float* G, const float* wg_pre, const float* s, float* dw,
+                             int Cout, int Cin, int groups, hipStream_t stream);
 int adamml_conv_bwd_data_alg(const adamml_conv_desc_t* d, const void* g, const void* a, const float* a_scale, const float* a_shift,
                              const void* w_alg, const float* epi_add, void* dx, int accumulate, const void* z_in, const float* bn_vec,
                              int act, double* sums, hipStream_t stream);

@@ -919,7 +919,7 @@ def test_algebraic_bn_backward_equals_explicit_dz(N, H, Cin, Cout, G, mode):
     w_alg = torch.empty(G, Cin, Cout + Cin, dtype=torch.bfloat16, device=DEV)
     cadd = torch.empty(G, Cin, device=DEV)
     w2 = w.view(Cout, Cin).contiguous()
-    call("adamml_alg_pack", ptr(w2), ptr(aff), ptr(w_alg), ptr(cadd), Cout, Cin, G)
+    call("adamml_alg_pack", ptr(w2), ptr(aff), None, ptr(w_alg), ptr(cadd), Cout, Cin, G)
     dx = base.clone()
     s = torch.zeros_like(s_ref)
     if mode == "bn":
@@ -929,7 +929,7 @@ def test_algebraic_bn_backward_equals_explicit_dz(N, H, Cin, Cout, G, mode):
         call("adamml_conv_bwd_data_alg", byref(d), ptr(g), ptr(xraw), ptr(vin[0, 0]), ptr(vin[0, 1]), ptr(w_alg), ptr(cadd), ptr(dx),
              1 if mode == "acc" else 0, None, None, 0, None)
     dw = torch.zeros_like(w)
-    call("adamml_alg_wgrad_combine", ptr(w2), ptr(aff), ptr(Pm), ptr(Gm), ptr(sv), ptr(dw), Cout, Cin, G)
+    call("adamml_alg_wgrad_combine", ptr(w2), ptr(aff), ptr(Pm), ptr(Gm), None, ptr(sv), ptr(dw), Cout, Cin, G)
     sx = dx_ref.float().abs().max().item()
     ex = (dx.float() - dx_ref.float()).abs().max().item()
     sw = dw_ref.abs().max().item()
