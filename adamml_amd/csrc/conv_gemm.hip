@@ -11,6 +11,7 @@
 #include "common.h"
 #include "../../include/adamml_hip.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -1256,6 +1257,16 @@ extern "C" int adamml_conv_bwd_data_dual(const adamml_conv_desc_t* d, const void
     return conv_launch(&gd, g, w_dgrad_packed, nullptr, nullptr, dx, sums, z_in, bn_vec, act, stream, nullptr, nullptr, &di);
 }
 
+bool adamml_alg_stream_supported(int Cout, int Cin);
+int adamml_alg_stream_launch(const adamml_conv_desc_t* d, const void* g, const void* a, const float* a_scale, const float* a_shift,
+                             const void* w_alg, const float* epi_add, void* dx, int accumulate, const void* z_in, const float* bn_vec,
+                             int act, double* sums, hipStream_t stream);
+static bool alg_stream_enabled() {           // ADAMML_ALG_STREAM=0: A/B aid (falls back to the CAT instance of conv_gemm_kernel)
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ADAMML_ALG_STREAM"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on == 1;
+}
+
 // ---- algebraic BatchNorm backward through a 1x1 conv z = W a followed by a linear BatchNorm (dz = A g' + B z + C per channel):
 //   dx = (W^T diag(A)) g' + (W^T diag(B) W) a + W^T C,   dW = A (.) (g'^T a) + B (.) (W G) + C (x) s,  G = a^T a, s = sum_p a
 // -- neither z nor dz is read or written.  Per BatchNorm group g the data gradient is ONE GEMM over the concatenated input
@@ -1363,6 +1374,8 @@ extern "C" int adamml_conv_bwd_data_alg(const adamml_conv_desc_t* d, const void*
     gd.OH = d->H; gd.OW = d->W; gd.Cout = d->Cin;
     gd.stride = 1; gd.up = 1; gd.pad = 0;
     gd.act = d->act; gd.accumulate = accumulate ? 1 : 0; gd.in_gstride = d->in_gstride;
+    if (adamml_alg_stream_supported(d->Cout, d->Cin) && alg_stream_enabled())
+        return adamml_alg_stream_launch(d, g, a, a_scale, a_shift, w_alg, epi_add, dx, accumulate, z_in, bn_vec, act, sums, stream);
     CatIn c{a, d->Cin, (size_t)d->Cin * (d->Cout + d->Cin), epi_add};
     return conv_launch(&gd, g, w_alg, a_scale, a_shift, dx, sums, z_in, bn_vec, act, stream, nullptr, nullptr, nullptr, &c);
 }
