@@ -198,6 +198,13 @@ def main():
 
     roof = None
     breakdown = None
+    if not args.no_roofline and args.stage != "infer" and rank != 0:
+        # N > 1: the roofline leg below runs two more steps on rank 0; under SyncBN / gradient all-reduce every rank has to
+        # issue the same collectives, so the other ranks run the same two (unprofiled) steps
+        model.use_side_stream = False
+        step()
+        step()
+        model.use_side_stream = not args.single_stream
     if rank == 0 and not args.no_roofline and args.stage != "infer":
         # per-launch HIP-event timing of one more step, single stream (concurrent streams would inflate each launch)
         model.use_side_stream = False
