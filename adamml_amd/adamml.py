@@ -94,6 +94,11 @@ class AdaMML(nn.Module, MeanStdMixin):
             self._flat_policy.ensure_grads()
             self._flat_main.ensure_grads()
         p_x, m_x, num_segments = self.data_layer(x, num_segments)
+        # p_x / m_x are allocated on the caller's stream but read on the side streams, in backward too (the stem weight
+        # gradients read them last).  They stay referenced here until the NEXT forward: by then the end-of-backward join has
+        # ordered the caller's stream behind every side stream, so the caching allocator cannot hand their blocks to
+        # main-stream work while a side-stream kernel still reads them (no Tensor.record_stream: see runtime._on_wgrad_stream).
+        self._live_inputs = (p_x, m_x)
         if self.skip_unselected and not self.training and not torch.is_grad_enabled():
             return self._forward_skipping(x, p_x, m_x, num_segments, gumbel_exponential)
         # Two HIP streams: the ResNet(s) stay on the caller's stream; the MobileNetV2 policy nets and the sound main net

@@ -141,7 +141,10 @@ class HipBackbone(nn.Module):
         return cs
 
     def mark_weights_dirty(self):
+        """Parameters were rewritten through raw pointers (fused optimizer step, checkpoint load into the flat buffer):
+        re-pack the bf16 GEMM operands and drop the cached eval-mode BatchNorm affines."""
         self._packed_version = None
+        self.rt.state_gen += 1
 
     def _repack(self, need_dgrad):
         ver = tuple(cs.weight._version for cs in self._conv_states[:4]) + (self._conv_states[0].weight.data_ptr(), need_dgrad)

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NT) void residual_bwd_kernel(const bf16_t* g_out, c
 }
 
 __global__ void bn_bwd_finalize_kernel(const double* sums, int nslots, int groups, double count, const float* gamma, const float* vec,
-                                       float* dgamma, float* dbeta, float* coef, int C) {
+                                       float* dgamma, float* dbeta, float* coef, int C, float grad_scale) {
     const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), k = threadIdx.x & 31;
     const bool lead = c < C && k == 0;
     float dg = 0.f, db = 0.f;
@@ -280,8 +280,8 @@ __global__ void bn_bwd_finalize_kernel(const double* sums, int nslots, int group
         cf[2 * C + c] = (float)(sgz / count);
     }
     if (lead) {
-        if (dgamma) dgamma[c] += dg;
-        if (dbeta) dbeta[c] += db;
+        if (dgamma) dgamma[c] += dg * grad_scale;
+        if (dbeta) dbeta[c] += db * grad_scale;
     }
 }
 
@@ -1056,10 +1056,10 @@ extern "C" int adamml_residual_bwd(const void* g_out, const void* out, int act, 
 }
 
 extern "C" int adamml_bn_bwd_finalize(const double* sums, int nslots, int groups, double count, const float* gamma, const float* vec,
-                                      float* dgamma, float* dbeta, float* coef, int C, hipStream_t stream) {
+                                      float* dgamma, float* dbeta, float* coef, int C, float grad_scale, hipStream_t stream) {
     if (nslots < 1 || nslots > ADAMML_STAT_SLOTS || groups < 1) return adamml_set_error(ADAMML_EINVAL, "bn_bwd_finalize: nslots=%d groups=%d", nslots, groups);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, stream, sums, nslots, groups, count, gamma, vec, dgamma,
-                       dbeta, coef, C);
+                       dbeta, coef, C, grad_scale);
     return adamml_check_launch("bn_bwd_finalize");
 }
 

@@ -31,10 +31,15 @@ class HipDDP(nn.Module):
         return self.module(*a, **k)
 
     def broadcast_parameters(self, src=0):
+        """Rank `src`'s parameters and buffers to every rank, as torch's DistributedDataParallel does at construction
+        (train_adamml.py:129).  The writes go through .data: the backbones re-pack their bf16 operands afterwards."""
         if self.world == 1:
             return
         for t in list(self.module.parameters()) + list(self.module.buffers()):
             dist.broadcast(t.data, src, group=self.group)
+        for m in self.module.modules():
+            if hasattr(m, "mark_weights_dirty"):
+                m.mark_weights_dirty()
 
     # -- overlapped bucket exchange --------------------------------------------------------------------------------
     def _flat_buffers(self):

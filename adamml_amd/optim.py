@@ -29,12 +29,21 @@ class FlatSGD:
             self.fb.flat_grad.zero_()
 
     def state_dict(self):
-        return {"flat": "sgd", "lr": self.lr, "steps": self.steps, "momentum_buffer": None if self.mom is None else self.mom.detach().cpu()}
+        """torch.optim.SGD layout (`param_groups` + per-parameter `state[idx]['momentum_buffer']`, parameters in
+        `module.parameters()` order): the reference's `optimizer.load_state_dict(checkpoint['optimizer'])`
+        (train_adamml.py:296-297) accepts it as is."""
+        ref = torch.optim.SGD(self.fb.params, lr=self.lr, momentum=self.momentum, weight_decay=self.weight_decay, nesterov=self.nesterov)
+        sd = ref.state_dict()
+        sd["state"] = {} if self.mom is None else {i: {"momentum_buffer": v} for i, v in enumerate(_split_like(self.mom, self.fb.params))}
+        return sd
 
     def load_state_dict(self, sd):
-        self.lr, self.steps = sd.get("lr", self.lr), sd.get("steps", 0)
-        mb = sd.get("momentum_buffer")
-        self.mom = None if mb is None or self.fb.flat is None or mb.numel() != self.fb.flat.numel() else mb.to(self.fb.flat.device)
+        """Accepts torch.optim.SGD's state_dict (a reference checkpoint) or this class's own."""
+        g = sd["param_groups"][0]
+        self.lr, self.momentum, self.weight_decay = g["lr"], g.get("momentum", self.momentum), g.get("weight_decay", self.weight_decay)
+        self.nesterov = g.get("nesterov", self.nesterov)
+        self.mom = _join_state(sd.get("state", {}), "momentum_buffer", self.fb)
+        self.steps = 0 if self.mom is None else 1          # torch creates the buffer on the first step: first_step only without one
 
 
 class FlatAdam:
@@ -60,16 +69,52 @@ class FlatAdam:
             self.fb.flat_grad.zero_()
 
     def state_dict(self):
-        return {"flat": "adam", "lr": self.lr, "steps": self.steps, "exp_avg": None if self.m is None else self.m.detach().cpu(),
-                "exp_avg_sq": None if self.v is None else self.v.detach().cpu()}
+        """torch.optim.Adam layout (`state[idx] = {step, exp_avg, exp_avg_sq}`), loadable by the reference
+        (train_adamml.py:298-299)."""
+        ref = torch.optim.Adam(self.fb.params, lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay)
+        sd = ref.state_dict()
+        if self.m is not None:
+            ms, vs = _split_like(self.m, self.fb.params), _split_like(self.v, self.fb.params)
+            sd["state"] = {i: {"step": torch.tensor(float(self.steps)), "exp_avg": a, "exp_avg_sq": b} for i, (a, b) in enumerate(zip(ms, vs))}
+        return sd
 
     def load_state_dict(self, sd):
-        self.lr, self.steps = sd.get("lr", self.lr), sd.get("steps", 0)
-        m, v = sd.get("exp_avg"), sd.get("exp_avg_sq")
-        ok = m is not None and v is not None and self.fb.flat is not None and m.numel() == self.fb.flat.numel()
-        self.m, self.v = (m.to(self.fb.flat.device), v.to(self.fb.flat.device)) if ok else (None, None)
-        if not ok:
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = g["lr"], tuple(g.get("betas", self.betas)), g.get("eps", self.eps)
+        self.weight_decay = g.get("weight_decay", self.weight_decay)
+        st = sd.get("state", {})
+        self.m, self.v = _join_state(st, "exp_avg", self.fb), _join_state(st, "exp_avg_sq", self.fb)
+        if self.m is None or self.v is None:
+            self.m = self.v = None
             self.steps = 0
+        else:
+            self.steps = int(max(float(e["step"]) for e in st.values()))
+
+
+def _split_like(flat, params):
+    """Per-parameter CPU copies of a flat state buffer (flat-buffer order == module.parameters() order)."""
+    out, off = [], 0
+    for p in params:
+        n = p.numel()
+        out.append(flat[off:off + n].detach().view(p.shape).cpu().clone())
+        off += n
+    return out
+
+
+def _join_state(state, key, fb):
+    """Flat device buffer from torch's per-parameter optimizer state; None when the state is absent or does not match."""
+    params = fb.params
+    if fb.flat is None or len(state) != len(params):
+        return None
+    flat = torch.zeros_like(fb.flat)
+    off = 0
+    for i, p in enumerate(params):
+        e = state.get(i, state.get(str(i)))
+        if e is None or key not in e or e[key].numel() != p.numel():
+            return None
+        flat[off:off + p.numel()].copy_(e[key].reshape(-1))
+        off += p.numel()
+    return flat
 
 
 def _mark_dirty(module):

@@ -156,10 +156,8 @@ class ResNet(HipBackbone, MeanStdMixin):
 
 def resnet(depth, num_classes, without_t_stride, groups, dropout, pooling_method,
            input_channels, imagenet_pretrained=True, **kwargs):
-    """Factory with the signature of models/resnet.py:244-259.  There is no network on the target systems:
-    imagenet_pretrained=True raises instead of downloading; load weights with load_state_dict."""
-    model = ResNet(depth, num_frames=groups, num_classes=num_classes, without_t_stride=without_t_stride,
-                   dropout=dropout, pooling_method=pooling_method, input_channels=input_channels)
-    if imagenet_pretrained and kwargs.get("allow_download", False):
-        raise RuntimeError("adamml_amd.resnet: ImageNet weights cannot be downloaded here; pass a state_dict")
-    return model
+    """Factory with the signature of models/resnet.py:244-259.  The reference downloads ImageNet weights when
+    imagenet_pretrained is set (models/resnet.py:251-257); the target systems have no network, so the flag is accepted
+    and ignored: load weights with load_state_dict / train.load_reference_checkpoint."""
+    return ResNet(depth, num_frames=groups, num_classes=num_classes, without_t_stride=without_t_stride,
+                  dropout=dropout, pooling_method=pooling_method, input_channels=input_channels)

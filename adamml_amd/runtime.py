@@ -124,6 +124,7 @@ class NetRT:
         self.tape = Tape(False)
         self.wgrad_stream = None     # optional side stream for the weight-gradient kernels (_on_wgrad_stream)
         self.wgrad_pending = collections.deque()      # (event, operand tensors) of weight-gradient launches still in flight
+        self.state_gen = 0           # bumped whenever BatchNorm tensors change behind torch's back (raw-pointer writes)
 
     def begin_forward(self, device, training, need_grad, groups=1):
         """groups = number of independent BatchNorm groups batched in this call: the S per-segment module calls of the
@@ -141,6 +142,7 @@ class NetRT:
         (one multi-tensor launch per backbone call instead of one per layer)."""
         if self.training and self.touched_bns:
             torch._foreach_add_([b.num_batches_tracked for b in self.touched_bns], self.groups)
+            self.state_gen += 1      # adamml_bn_finalize rewrote running_mean / running_var through raw pointers
         self.touched_bns = []
 
 
@@ -226,11 +228,13 @@ def _bn_vectors(rt, bn, stats, count, C, device):
     return vec
 
 
-def _bn_eval_vectors(bn, C, device):
+def _bn_eval_vectors(rt, bn, C, device):
     """Eval-mode BatchNorm as a per-channel affine (scale, shift).  Cached on the module while its four tensors are
-    unchanged (inference runs the same weights over and over: 157 tiny launches per forward otherwise)."""
+    unchanged (inference runs the same weights over and over: 157 tiny launches per forward otherwise).  The HIP kernels
+    write gamma / beta (fused optimizers) and the running statistics (adamml_bn_finalize) through raw pointers, which
+    torch's `_version` counters do not see: `rt.state_gen` counts those writes (NetRT.end_forward, mark_weights_dirty)."""
     key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
-           bn.weight.data_ptr(), bn.running_mean.data_ptr(), str(device))
+           bn.weight.data_ptr(), bn.running_mean.data_ptr(), str(device), rt.state_gen)
     cached = getattr(bn, "_hip_eval_vec", None)
     if cached is not None and cached[0] == key and not hip.profiler:
         return cached[1]
@@ -261,7 +265,7 @@ def _bn_backward(rt, out, y, vec, bn, act, count, defer_apply=False):
         coef = torch.empty(G, 3, C, dtype=torch.float32, device=y.device)
         train_bn = bn.weight.requires_grad
         call("adamml_bn_bwd_finalize", ptr(sums), nslots, G, float(count * rt.sync.world), ptr(bn.weight), ptr(vec),
-             ptr(bn.weight.grad) if train_bn else None, ptr(bn.bias.grad) if train_bn else None, ptr(coef), C)
+             ptr(bn.weight.grad) if train_bn else None, ptr(bn.bias.grad) if train_bn else None, ptr(coef), C, 1.0 / rt.sync.world)
         dz = torch.empty_like(y)
         call("adamml_maxpool2d_bwd_bn_apply", ptr(gy), ptr(idx), ptr(y), ptr(vec), act, ptr(coef), ptr(dz), n // G, oh, ow, C, poh, pow_, G)
         return dz
@@ -274,7 +278,7 @@ def _bn_backward(rt, out, y, vec, bn, act, count, defer_apply=False):
     coef = torch.empty(G, 3, C, dtype=torch.float32, device=y.device)
     train_bn = bn.weight.requires_grad
     call("adamml_bn_bwd_finalize", ptr(sums), nslots, G, float(count * rt.sync.world), ptr(bn.weight), ptr(vec),
-         ptr(bn.weight.grad) if train_bn else None, ptr(bn.bias.grad) if train_bn else None, ptr(coef), C)
+         ptr(bn.weight.grad) if train_bn else None, ptr(bn.bias.grad) if train_bn else None, ptr(coef), C, 1.0 / rt.sync.world)
     if defer_apply:
         return g, coef
     dz = torch.empty_like(y)
@@ -347,7 +351,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
             call("adamml_conv_stem_fwd", byref(d), ptr(x.data), ptr(cs.w_stem), ptr(y), None)
         else:
             call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), None)
-        vec = _bn_eval_vectors(bn, C, dev)
+        vec = _bn_eval_vectors(rt, bn, C, dev)
     if rt.training:
         out = Lazy(y, vec[0, 0], vec[0, 1], act, gs=4 * C)
         out.vec = vec

@@ -5,7 +5,8 @@ three-stage schedule (train_adamml.py:340-626: warm-up of the main nets with the
 epochs with Gumbel-temperature decay -> fine-tuning of the main nets from the best checkpoint), two optimizers
 (SGD-momentum for the main nets, Adam for the policy: train_adamml.py:250-257) with the reference's learning-rate
 schedules, and the reference's checkpoint dictionary (`state_dict` with the DDP `module.` prefix, `stage`, `temperature`,
-`epoch`, `best_top1`, ...), so checkpoints interchange with the reference in both directions.
+`epoch`, `best_top1`, ...), so checkpoints (weights, optimizer state in torch.optim's
+per-parameter layout, scheduler epoch, stage, temperature) interchange with the reference in both directions.
 
 The dataset / decoding / augmentation pipeline of the reference is out of scope of this repository (SURVEY.md section 8:
 CPU-side I/O): pass your own iterables of `(list_of_modal_tensors, target)` to `main(train_loader=..., val_loader=...)`,
@@ -144,7 +145,8 @@ class LRSchedule:
         self.opt.lr = lr
 
     def state_dict(self):
-        return {"last_epoch": self.last, "base_lr": self.base}
+        """The keys torch's StepLR / MultiStepLR / CosineAnnealingLR restore from (`__dict__.update`, train_adamml.py:300-301)."""
+        return {"last_epoch": self.last, "base_lrs": [self.base], "_last_lr": [self.opt.lr], "_step_count": self.last + 1}
 
     def load_state_dict(self, sd):
         self.step(sd.get("last_epoch", 0))
@@ -342,16 +344,23 @@ def main(argv=None, train_loader=None, val_loader=None, log=print):
         sched.load_state_dict(ck.get("scheduler", {}))
         p_sched.load_state_dict(ck.get("p_scheduler", {}))
         for o, key in ((opt, "optimizer"), (p_opt, "p_optimizer")):
-            if isinstance(ck.get(key), dict) and "flat" in ck[key]:
-                o.load_state_dict(ck[key])
+            if isinstance(ck.get(key), dict) and "param_groups" in ck[key]:
+                o.load_state_dict(ck[key])                                  # torch.optim layout: the reference's checkpoints too
+            elif rank == 0:
+                log("resume: no usable '%s' state in the checkpoint, optimizer state starts from zero" % key)
+    # torch's DistributedDataParallel broadcasts rank 0's parameters and buffers at construction (train_adamml.py:129)
+    ddp.broadcast_parameters()
 
     def snapshot(epoch, st, is_best, suffix):
-        if rank != 0:
-            return
-        save_checkpoint({"epoch": epoch, "arch": arch_name, "state_dict": reference_state_dict(model), "best_top1": best_top1,
-                         "p_optimizer": p_opt.state_dict(), "optimizer": opt.state_dict(), "p_scheduler": p_sched.state_dict(),
-                         "scheduler": sched.state_dict(), "temperature": model.policy_net.temperature, "stage": st},
-                        is_best, log_folder, epoch, suffix)
+        """Rank 0 writes; every rank leaves only when the files are complete (the reference brackets validation and saving
+        with dist.barrier(), train_adamml.py:355,421,453,468) -- the fine-tune stage reads model_best.pth.tar on all ranks."""
+        if rank == 0:
+            save_checkpoint({"epoch": epoch, "arch": arch_name, "state_dict": reference_state_dict(model), "best_top1": best_top1,
+                             "p_optimizer": p_opt.state_dict(), "optimizer": opt.state_dict(), "p_scheduler": p_sched.state_dict(),
+                             "scheduler": sched.state_dict(), "temperature": model.policy_net.temperature, "stage": st},
+                            is_best, log_folder, epoch, suffix)
+        if dist.is_initialized():
+            dist.barrier()
 
     zero_cost = [0.0] * len(args.modality)
     if args.evaluate:
@@ -398,8 +407,11 @@ def main(argv=None, train_loader=None, val_loader=None, log=print):
         if rank == 0:
             log("Stage [Post finetuning]: Finetune the main network {} epochs".format(args.finetune_epochs))
         best = os.path.join(log_folder, "model_best.pth.tar")
+        if dist.is_initialized():
+            dist.barrier()                                                  # rank 0's last snapshot is on disk
         if args.start_epoch == 0 and os.path.exists(best):
             load_reference_checkpoint(model, best)
+            ddp.broadcast_parameters()                                      # (and identical even if a rank read a stale file)
         model.freeze_policy_net()
         model.unfreeze_main_net()
         for epoch in range(args.start_epoch, args.finetune_epochs):

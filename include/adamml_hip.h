@@ -193,10 +193,13 @@ int adamml_residual_bwd(const void* g_out, const void* out, int act, void* g2, c
 /* BatchNorm backward: per-channel sums of g' = g*act'(scale*z+shift) and g'*zhat (sums [groups][SLOTS][2C], caller zeroes) */
 int adamml_bn_bwd_reduce(const void* g, const void* z, const float* bn_vec, int act, double* sums, size_t P, int C, int groups,
                          hipStream_t stream);
-/* dgamma += sum_groups sum(g' zhat); dbeta += sum_groups sum(g');
- * coef[g][0..C) = gamma*invstd, [C..2C) = sum g'/count, [2C..3C) = sum g' zhat/count */
+/* dgamma += grad_scale * sum_groups sum(g' zhat); dbeta += grad_scale * sum_groups sum(g');
+ * coef[g][0..C) = gamma*invstd, [C..2C) = sum g'/count, [2C..3C) = sum g' zhat/count.
+ * grad_scale = 1 normally; 1/world under SyncBatchNorm, where `sums` are already summed over the ranks and the
+ * data-parallel gradient average sums dgamma / dbeta over the ranks once more (torch's SyncBatchNorm keeps
+ * grad_weight / grad_bias local, train_adamml.py:126-129). */
 int adamml_bn_bwd_finalize(const double* sums, int nslots, int groups, double count, const float* gamma, const float* bn_vec,
-                           float* dgamma, float* dbeta, float* coef, int C, hipStream_t stream);
+                           float* dgamma, float* dbeta, float* coef, int C, float grad_scale, hipStream_t stream);
 /* dz = coef0 * (g' - coef1 - zhat*coef2) */
 int adamml_bn_bwd_apply(const void* g, const void* z, const float* bn_vec, int act, const float* coef, void* dz, size_t P, int C,
                         int groups, hipStream_t stream);

@@ -183,3 +183,47 @@ def test_interleaver_is_deterministic_round_robin_and_propagates_errors():
         raise ValueError("boom")
     with pytest.raises(ValueError):
         interleave.run_interleaved([(job("x", 2), None), (boom, None)], None)
+
+
+def test_optimizer_state_interchanges_with_torch_optim():
+    """Checkpoint interchange (train_adamml.py:296-301, 373-383): the flat optimizers save torch.optim's per-parameter
+    layout and load it back, so `optimizer.load_state_dict(checkpoint['optimizer'])` works in both directions."""
+    import torch.nn as nn
+    from adamml_amd.backbone import FlatBuffers
+    from adamml_amd.optim import FlatSGD, FlatAdam
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(3, 4, 3), nn.BatchNorm2d(4), nn.Linear(4, 2))
+    fb = FlatBuffers(net)
+    fb.ensure(torch.device("cpu"))
+    # ours -> torch
+    sgd = FlatSGD(fb, lr=0.05, momentum=0.9, weight_decay=1e-4)
+    sgd.mom, sgd.steps = torch.randn_like(fb.flat), 3
+    ref = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9)
+    ref.load_state_dict(sgd.state_dict())
+    assert ref.param_groups[0]["lr"] == 0.05 and ref.param_groups[0]["weight_decay"] == 1e-4
+    off = 0
+    for p in net.parameters():
+        assert torch.equal(ref.state[p]["momentum_buffer"].reshape(-1), sgd.mom[off:off + p.numel()])
+        off += p.numel()
+    # torch -> ours (a real torch step creates the state)
+    for p in net.parameters():
+        p.grad = torch.randn_like(p)
+    ref.step()
+    sgd2 = FlatSGD(fb, lr=0.01)
+    sgd2.load_state_dict(ref.state_dict())
+    assert sgd2.lr == 0.05 and sgd2.steps == 1
+    assert torch.equal(sgd2.mom, torch.cat([ref.state[p]["momentum_buffer"].reshape(-1) for p in net.parameters()]))
+    adam = torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=5e-4)
+    adam.step()
+    adam.step()
+    fa = FlatAdam(fb, lr=1.0)
+    fa.load_state_dict(adam.state_dict())
+    assert fa.steps == 2 and fa.lr == 1e-3 and fa.weight_decay == 5e-4
+    assert torch.equal(fa.v, torch.cat([adam.state[p]["exp_avg_sq"].reshape(-1) for p in net.parameters()]))
+    adam2 = torch.optim.Adam(net.parameters(), lr=1.0)
+    adam2.load_state_dict(fa.state_dict())
+    for p in net.parameters():
+        assert torch.equal(adam2.state[p]["exp_avg"], adam.state[p]["exp_avg"]) and float(adam2.state[p]["step"]) == 2.0
+    # a checkpoint without optimizer state (or with another parameter list) leaves the state empty instead of mis-assigning it
+    fa.load_state_dict({"param_groups": adam.state_dict()["param_groups"], "state": {}})
+    assert fa.m is None and fa.steps == 0

@@ -196,7 +196,7 @@ def test_batchnorm_train_fwd_bwd(C, P, act):
     call("adamml_bn_bwd_reduce", ptr(gb), ptr(zb), ptr(vec), act, ptr(sums), P, C, 1)
     dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     coef = torch.empty(3, C, device=DEV)
-    call("adamml_bn_bwd_finalize", ptr(sums), STAT_SLOTS, 1, float(P), ptr(gamma), ptr(vec), ptr(dgam), ptr(dbet), ptr(coef), C)
+    call("adamml_bn_bwd_finalize", ptr(sums), STAT_SLOTS, 1, float(P), ptr(gamma), ptr(vec), ptr(dgam), ptr(dbet), ptr(coef), C, 1.0)
     dz = torch.empty(P, C, dtype=torch.bfloat16, device=DEV)
     call("adamml_bn_bwd_apply", ptr(gb), ptr(zb), ptr(vec), act, ptr(coef), ptr(dz), P, C, 1)
     close(dgam, gamma.grad, what="dgamma")
@@ -481,7 +481,7 @@ def test_batchnorm_groups_equal_successive_calls(C, P, act):
     call("adamml_bn_bwd_reduce", ptr(gb), ptr(z), ptr(vec), act, ptr(sums), P, C, G)
     dgam, dbet = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     coef = torch.empty(G, 3, C, device=DEV)
-    call("adamml_bn_bwd_finalize", ptr(sums), STAT_SLOTS, G, float(P), ptr(gamma), ptr(vec), ptr(dgam), ptr(dbet), ptr(coef), C)
+    call("adamml_bn_bwd_finalize", ptr(sums), STAT_SLOTS, G, float(P), ptr(gamma), ptr(vec), ptr(dgam), ptr(dbet), ptr(coef), C, 1.0)
     dz = torch.empty(G, P, C, dtype=torch.bfloat16, device=DEV)
     call("adamml_bn_bwd_apply", ptr(gb), ptr(z), ptr(vec), act, ptr(coef), ptr(dz), P, C, G)
     close(dgam, gr.grad, what="grouped dgamma")

@@ -14,6 +14,10 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 S, B = 2, 4
+# BatchNorm gamma / beta gradients right under the classifier heads (above the noisy part of the backward pass): torch's
+# SyncBatchNorm keeps them LOCAL and DDP averages them, so the averaged value equals the single-process gradient
+BN_GRAD_KEYS = ("main_net.nets.0.layer4.2.bn3.weight", "main_net.nets.0.layer4.2.bn3.bias",
+                "main_net.nets.1.features.18.1.weight", "main_net.nets.1.features.18.1.bias")
 
 
 def _build():
@@ -50,6 +54,7 @@ def _step(model, ddp, rank, world):
     return {"loss": float(loss.detach()), "sel": sel.detach().cpu(), "grad": model._flat_main.flat_grad.detach().cpu().clone(),
             "fc_grad": model.main_net.nets[0].fc.weight.grad.detach().cpu().clone(),
             "sound_fc_grad": model.main_net.nets[1].classifier[1].weight.grad.detach().cpu().clone(),
+            "bn_grads": {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if k in BN_GRAD_KEYS},
             "stats": {k: sd[k].detach().cpu().clone() for k in keys}}
 
 
@@ -91,6 +96,10 @@ def test_two_rank_syncbn_step_equals_single_process_full_batch():
     # the classifier heads sit above the chaotic part of the backward pass: their averaged gradients must agree closely
     assert rel(two["fc_grad"], one["fc_grad"]) <= 3e-2
     assert rel(two["sound_fc_grad"], one["sound_fc_grad"]) <= 3e-2
+    for k in BN_GRAD_KEYS:
+        e = rel(two["bn_grads"][k], one["bn_grads"][k])
+        print("  %-60s averaged gradient rel L2 %.2e" % (k, e))
+        assert e <= 6e-2, (k, e)               # (a world-times-too-large SyncBN gamma / beta gradient would read 1.0)
     # deep in a randomly initialised train-mode-BatchNorm ResNet two runs of the SAME pipeline already differ by 0.2-0.5 in
     # relative L2 (atomic order, bf16 storage; tests/test_models_gpu.py GRAD_FLOOR): direction only
     assert cos >= 0.6
