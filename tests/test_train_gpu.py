@@ -21,8 +21,11 @@ def test_three_stage_schedule_checkpoints_and_resume(tmp_path):
     stages = [h[0] for h in res["history"]]
     assert stages == ["warmup", "main", "policy", "finetune"], stages
     assert all(torch.isfinite(torch.tensor(h[2])) for h in res["history"])
-    assert abs(res["temperature"] - 5.0 * 0.965) < 1e-9                      # one decay after the alternating epoch
     folder = res["log_folder"]
+    # one decay after the alternating epoch -- unless that epoch produced a best model: the fine-tune stage then restores
+    # the temperature saved WITH it, i.e. before the decay (train_adamml.py:503-516, 541-545: save, then decay; set_temperature on load)
+    had_best = os.path.exists(os.path.join(folder, "model_best.pth.tar"))
+    assert abs(res["temperature"] - (5.0 if had_best else 5.0 * 0.965)) < 1e-9
     for f in ("checkpoint.pth.tar", "checkpoint_warmup_01.pth.tar", "checkpoint_main_01.pth.tar", "checkpoint_finetune_01.pth.tar"):
         assert os.path.exists(os.path.join(folder, f)), f
     ck = torch.load(os.path.join(folder, "checkpoint.pth.tar"), map_location="cpu")
@@ -43,3 +46,47 @@ def test_three_stage_schedule_checkpoints_and_resume(tmp_path):
     # resume: the saved stage is 'finetune' at epoch 1 of 1 -> nothing left to train, state restored
     res2 = train.main(ARGS + ["--logdir", str(tmp_path), "--auto_resume"], log=lines.append)
     assert res2["history"] == [] and abs(res2["temperature"] - res["temperature"]) < 1e-9
+
+
+def test_eval_after_training_steps_sees_the_updated_weights_and_statistics():
+    """train -> eval -> train -> eval in one process: the fused optimizers and adamml_bn_finalize write gamma / beta and the
+    running statistics through raw pointers, which torch's `_version` counters do not see; the eval-mode BatchNorm affine
+    cache must still be refreshed (validation after every epoch, utils/utils.py:436).  Reference = a FRESH model loaded with
+    the trained state_dict (no cache to go stale): logits bit-identical."""
+    import torch.nn.functional as F
+    from adamml_amd import synth
+    from adamml_amd.backbone import FlatBuffers
+    from adamml_amd.optim import FlatSGD
+    from adamml_amd.resnet import resnet
+
+    def build():
+        m = resnet(depth=50, num_classes=31, without_t_stride=False, groups=8, dropout=0.0, pooling_method="max",
+                   input_channels=3, imagenet_pretrained=False)
+        return m
+    model = build()
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), seed=1234))
+    model.to("cuda")
+    x = synth.synth_inputs(["rgb"], 2, 1, 8, 64, seed=3)[0].to("cuda")
+    y = synth.synth_labels(2, 31, seed=3).to("cuda")
+    opt = None
+    evals = []
+    for rnd in range(2):
+        model.eval()
+        with torch.no_grad():
+            evals.append(model(x).clone())                                   # populates the eval-mode cache
+        model.train()
+        F.cross_entropy(model(x), y).backward()
+        if opt is None:
+            opt = FlatSGD(model.flat_owner, lr=0.05, momentum=0.9)
+        opt.step()
+        opt.zero_grad()
+    model.eval()
+    with torch.no_grad():
+        got = model(x)
+    fresh = build()
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    fresh.to("cuda").eval()
+    with torch.no_grad():
+        want = fresh(x)
+    assert not torch.equal(evals[0], evals[1]) and not torch.equal(evals[1], got)      # every round changed the function
+    assert torch.equal(got, want), (got - want).abs().max().item()
