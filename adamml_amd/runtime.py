@@ -124,6 +124,7 @@ class NetRT:
         self.tape = Tape(False)
         self.wgrad_stream = None     # optional side stream for the weight-gradient kernels (_on_wgrad_stream)
         self.wgrad_pending = collections.deque()      # (event, operand tensors) of weight-gradient launches still in flight
+        self.capture = None          # test aid: dict id(conv weight Parameter) -> list of raw conv outputs of this forward
         self.state_gen = 0           # bumped whenever BatchNorm tensors change behind torch's back (raw-pointer writes)
 
     def begin_forward(self, device, training, need_grad, groups=1):
@@ -352,6 +353,8 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
         else:
             call(fwd, byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), None)
         vec = _bn_eval_vectors(rt, bn, C, dev)
+    if rt.capture is not None:
+        rt.capture.setdefault(id(cs.weight), []).append(y)
     if rt.training:
         out = Lazy(y, vec[0, 0], vec[0, 1], act, gs=4 * C)
         out.vec = vec

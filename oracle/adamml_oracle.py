@@ -33,6 +33,10 @@ MBV2_CFG = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 
 # conv output, residual / pooling outputs) while keeping all arithmetic fp32: the HIP path must match that emulation
 # tightly, and the emulation's own distance from the fp32 result is the stated, intrinsic bf16 tolerance.
 QUANT = None
+# CONV_HOOK(w, y) -> y' (or None): lets a test substitute the value of a conv output while keeping its autograd graph.  The
+# forced-forward replay test (tests/test_parity_fullsize_gpu.py) injects the conv outputs the HIP path actually stored, so
+# that both pipelines take identical ReLU / max-pool decisions and their backward passes can be compared tightly.
+CONV_HOOK = None
 
 
 def bf16_straight_through(x):
@@ -47,8 +51,12 @@ def conv(x, w, stride=1, padding=0, groups=1):
     """nn.Conv2d(bias=False).  Emulation: dense convs read bf16 activations and bf16 weights; depthwise convs
     read the fp32-evaluated activation and fp32 weights; every conv output is stored in bf16."""
     if groups == 1:
-        return _q(F.conv2d(_q(x), _q(w), stride=stride, padding=padding))
-    return _q(F.conv2d(x, w, stride=stride, padding=padding, groups=groups))
+        y = F.conv2d(_q(x), _q(w), stride=stride, padding=padding)
+    else:
+        y = F.conv2d(x, w, stride=stride, padding=padding, groups=groups)
+    if CONV_HOOK is not None:
+        y = CONV_HOOK(w, y)
+    return _q(y)
 
 
 # ----------------------------------------------------------------------------- primitives
@@ -73,9 +81,10 @@ def temporal_pool(x, frames, mode):
     for t in range(t_out):
         taps = [v[:, i] for i in (2 * t - 1, 2 * t, 2 * t + 1) if 0 <= i < frames]
         if mode == "max":
-            r = taps[0]
-            for q in taps[1:]:
-                r = torch.maximum(r, q)
+            # nn.MaxPool3d keeps the FIRST maximum of the window (strict > in scan order) and routes the whole gradient
+            # to it; torch.max(dim) returns the first maximal index too (torch.maximum would split the gradient on ties,
+            # which do occur once activations are stored in bf16)
+            r = torch.stack(taps, 0).max(0)[0]
         elif mode == "avg":
             r = taps[0]
             for q in taps[1:]:

@@ -22,6 +22,12 @@ CASES = {
                                     sound_size=64, modes=["eval", "train_main"]),
     "adamml_4mod": dict(kind="adamml", modality=["rgb", "sound", "flow", "rgbdiff"], groups=8, B=1, S=2, size=64,
                         sound_size=64, modes=["eval", "train_policy"]),
+    # FULL-SIZE, well-conditioned cases (196+ samples per BatchNorm channel everywhere): BASELINE.json configs[0] (C1) and the
+    # configs[1] workload (C2) at B = 4 videos.  full=True stores every running statistic and the head gradients in full;
+    # "eval_cal" = eval mode on running statistics calibrated by one momentum-1 train-mode pass over the same input.
+    "resnet50_c1": dict(kind="resnet", modality=["rgb"], groups=8, B=4, size=224, modes=["eval_cal", "train"], full=True),
+    "adamml_c2": dict(kind="adamml", modality=["rgb", "sound"], groups=8, B=4, S=5, size=224, sound_size=256,
+                      modes=["eval_cal", "train_main", "train_policy"], full=True, margin=0.08),
 }
 
 
@@ -34,6 +40,14 @@ def grad_probe(name, g):
     """[sum, l2-norm, 4 sampled elements] of a gradient tensor (float64 accumulate)."""
     a = np.asarray(g.detach().cpu().double().numpy()).reshape(-1)
     return np.concatenate([[a.sum(), np.sqrt((a * a).sum())], a[_idx(name, a.size)]])
+
+
+HEAD_GRADS = ("fc.weight", "fc.bias", "classifier.1.weight", "classifier.1.bias", "lf_weights", "lstm.bias_ih", "fcs.0.weight",
+              "fcs.1.weight", "joint.2.bias")
+
+
+def is_head(name):
+    return name.endswith(HEAD_GRADS)
 
 
 def stat_probe(t):

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from adamml_amd import synth
 from oracle import adamml_oracle as O
-from tests.golden_cases import CASES, CH, grad_probe, stat_probe
+from tests.golden_cases import CASES, CH, grad_probe, stat_probe, is_head
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -78,13 +78,13 @@ def _oracle_case(c, kind, sd0, xs, target, modes, keep_grads, device):
     B, S = c["B"], c.get("S", 1)
     out = {}
     for mode in (modes or c["modes"]):
-        training = mode != "eval"
+        training = mode not in ("eval", "eval_cal")
         if kind == "adamml":
-            pref = {"eval": (), "train": ("main_net.", "policy_net."), "train_main": ("main_net.",),
+            pref = {"eval": (), "eval_cal": (), "train": ("main_net.", "policy_net."), "train_main": ("main_net.",),
                     "train_policy": ("policy_net.",)}[mode]
         else:
             pref = ("",) if training else ()
-        sd = O.make_leaf_state(sd0, pref)
+        sd = O.make_leaf_state(sd0 if mode != "eval_cal" else calibrated_state(c, sd0, xs, device), pref)
         ctx = torch.enable_grad() if training else torch.no_grad()
         with ctx:
             if kind == "resnet":
@@ -119,6 +119,13 @@ def _oracle_case(c, kind, sd0, xs, target, modes, keep_grads, device):
                       if k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
                 out[mode + ".stat_names"] = np.array(sorted(st.keys()))
                 out[mode + ".stat_probe"] = np.stack([st[k] for k in sorted(st.keys())])
+                if c.get("full"):
+                    keys = [k for k in sorted(sd.keys()) if k.endswith(("running_mean", "running_var"))]
+                    out[mode + ".stats_full_names"] = np.array(keys)
+                    out[mode + ".stats_full"] = np.concatenate([sd[k].detach().cpu().numpy().reshape(-1) for k in keys]).astype(np.float32)
+                    for k, v in sd.items():
+                        if v.requires_grad and v.grad is not None and is_head(k):
+                            out[mode + ".grad." + k] = v.grad.detach().cpu().numpy().astype(np.float32)
                 if keep_grads:
                     out[mode + ".grads"] = {k: v.grad.detach() for k, v in sd.items() if v.requires_grad and v.grad is not None}
                     out[mode + ".state"] = {k: v.detach() for k, v in sd.items()}
@@ -130,6 +137,29 @@ def _oracle_case(c, kind, sd0, xs, target, modes, keep_grads, device):
         out["eval.p_x_probe"] = np.stack([stat_probe(t) for t in p_x])
         out["eval.m_x_probe"] = np.stack([stat_probe(t) for t in m_x])
     return out
+
+
+def calibrated_state(c, sd0, xs, device="cpu"):
+    """"eval_cal" state: running statistics := batch statistics of the case's input, by one train-mode pass with BatchNorm
+    momentum 1 (what tools/gen_golden.py does with the reference's modules); num_batches_tracked back to 0."""
+    cal = {k: v.clone() for k, v in sd0.items()}
+    old = O.BN_MOMENTUM
+    O.BN_MOMENTUM = 1.0
+    try:
+        with torch.no_grad():
+            if c["kind"] == "resnet":
+                O.resnet_forward(cal, "", xs, c["groups"], 50, c.get("pooling", "max"), False, 0.0, True)
+            elif c["kind"] == "sound":
+                O.sound_mbv2_forward(cal, "", xs, 0.0, True)
+            else:
+                O.adamml_forward(cal, xs, c["modality"], c["S"], c["groups"], 50, c.get("tau", 5.0), case_gumbel(c).to(device),
+                                 c.get("causality", "lstm"), c.get("pooling", "max"), False, 0.0, True)
+    finally:
+        O.BN_MOMENTUM = old
+    for k in cal:
+        if k.endswith("num_batches_tracked"):
+            cal[k].zero_()
+    return cal
 
 
 def compare_records(got, ref, rtol=1e-4, atol=1e-5, grad_rtol=2e-3, skip=()):
@@ -150,8 +180,58 @@ def compare_records(got, ref, rtol=1e-4, atol=1e-5, grad_rtol=2e-3, skip=()):
             # the 'sum' column cancels over many elements: allow 5x the bound there
             err[:, 0] /= 5.0
             assert err.max() < grad_rtol, "%s max rel err %g (row %d)" % (k, err.max(), int(err.max(1).argmax()))
+        elif ".grad." in k or k.endswith("stats_full"):
+            err = np.linalg.norm((g - v).ravel().astype(np.float64)) / (np.linalg.norm(v.ravel().astype(np.float64)) + 1e-30)
+            assert err < grad_rtol, "%s rel L2 %g" % (k, err)
         elif k.endswith("decisions"):
             assert np.array_equal(np.round(g), np.round(v)), k
             np.testing.assert_allclose(g, v, atol=1e-5, err_msg=k)
         else:
             np.testing.assert_allclose(g, v, rtol=rtol, atol=atol, err_msg=k)
+
+
+def oracle_case_forced(c, mode, captured, device="cpu"):
+    """FORCED-FORWARD REPLAY: the fp32 oracle runs the case's train step with every conv output REPLACED (value only, the
+    autograd graph stays) by the bf16 tensor the HIP forward stored for that conv -- `captured`: parameter name -> NHWC
+    tensor [G*N, OH, OW, C] (G segment groups, group-major).  Both pipelines then take identical ReLU / ReLU6 / max-pool
+    decisions, so their backward passes differ only by arithmetic (fp32 here, bf16-stored gradients there) and can be
+    compared tightly; without forcing, any two bf16 pipelines decorrelate through rounding-boundary flips.
+    Returns {"logits", "policy_logits", "grads", "state"}."""
+    kind = c["kind"]
+    sd0 = synth.synth_state_dict(manifest(c), seed=1234)
+    xs, target = case_inputs(c)
+    if kind == "adamml":
+        pref = {"train": ("main_net.", "policy_net."), "train_main": ("main_net.",), "train_policy": ("policy_net.",)}[mode]
+    else:
+        pref = ("",)
+    sd = O.make_leaf_state(sd0, pref)
+    names = {id(v): k for k, v in sd.items()}
+    used = {}
+
+    def hook(w, y):
+        k = names[id(w)]
+        i = used.get(k, 0)
+        used[k] = i + 1
+        n = y.shape[0]
+        t = captured[k][i * n:(i + 1) * n].permute(0, 3, 1, 2).float()
+        assert t.shape == y.shape, (k, tuple(t.shape), tuple(y.shape))
+        return y + (t - y).detach()
+    O.CONV_HOOK = hook
+    plog = None
+    try:
+        if kind == "resnet":
+            logits = O.resnet_forward(sd, "", xs, c["groups"], 50, c.get("pooling", "max"), False, 0.0, True)
+        elif kind == "sound":
+            logits = O.sound_mbv2_forward(sd, "", xs, 0.0, True)
+        else:
+            logits, sel, plog = O.adamml_forward(sd, xs, c["modality"], c["S"], c["groups"], 50, c.get("tau", 5.0), case_gumbel(c),
+                                                 c.get("causality", "lstm"), c.get("pooling", "max"), False, 0.0, True)
+        loss = F.cross_entropy(logits, target)
+        if kind == "adamml" and mode in ("train", "train_policy"):
+            loss = loss + O.policy_loss("blockdrop", sel, torch.ones(sel.shape[-1]), torch.tensor(10.0), logits, target)
+        loss.backward()
+    finally:
+        O.CONV_HOOK = None
+    return {"logits": logits.detach(), "policy_logits": None if plog is None else plog.detach(),
+            "grads": {k: v.grad.detach() for k, v in sd.items() if v.requires_grad and v.grad is not None},
+            "state": {k: v.detach() for k, v in sd.items()}}

@@ -1,0 +1,231 @@
+"""Whole-network parity at FULL size on the MI355X, asserted with FIXED numbers (no tolerance derived from an emulation).
+
+Cases (tests/golden_cases.py, fixtures generated from the real reference by tools/gen_golden.py):
+  resnet50_c1  BASELINE.json configs[0]: unimodal RGB ResNet-50, 8 frames, 224^2, b = 4 (models/resnet.py:195-223)
+  adamml_c2    the configs[1] workload at B = 4 videos: RGB+Audio AdaMML, 5 segments, 224^2 / 256^2, both freeze stages
+               (models/adamml.py:69-91)
+
+Two comparators:
+  (1) the fp32 reference golden.  Forward quantities are well conditioned at full size (>= 196 samples per BatchNorm channel)
+      and are asserted directly: logits, policy logits, EVERY running statistic, num_batches_tracked, hard decisions, the
+      classifier-head gradients.  Deep gradients are NOT comparable element-wise between an fp32 and ANY bf16-storage pipeline:
+      rounding moves pre-activations across 0 (ReLU) and across each other (max-pool), every such flip changes the gradient of
+      that element by 100 %, and the relative L2 distance grows like sqrt(fraction flipped) -- tools/conditioning_study.py shows
+      the sqrt(eps) law on the oracle alone (a 1e-3 / 1e-4 / 1e-5 relative weight perturbation moves stem gradients by
+      22 % / 7 % / 1.8 %).  Against the golden they are held to norm agreement only.
+  (2) FORCED-FORWARD REPLAY (tests/oracle_harness.oracle_case_forced): the fp32 oracle re-runs the step with its conv outputs
+      replaced by the tensors the HIP forward stored, so both take identical ReLU / max-pool decisions; what remains is the
+      arithmetic of the backward pass (bf16-stored gradients vs fp32).  This is the tight whole-network gradient statement.
+
+Measured on MI355X (this file prints the numbers): C1 logits 1.0e-2, statistics <= 2.7e-3, replay gradients median 6e-2 /
+max 0.13 (1.4e-2 in layer 4, growing towards the stem with ~100 bf16 gradient roundings); C2 logits 4.5e-2 and policy logits
+5.5e-2 (the random-weight MobileNetV2 stacks amplify any perturbation ~1.09x per layer: the oracle's own bf16-storage
+emulation sits at 5.0e-2 / 5.7e-2; inference on calibrated statistics 4.2e-2 / 7.1e-2), statistics <= 1.8e-2 (p90 5e-3),
+head gradients vs the reference 5e-3 (ResNet fc) .. 5.5e-2 (sound classifier) in the main stage, replay logits 3e-4, replay
+gradients median 2e-2 / p90 8e-2 / max 0.21, <= 3e-2 next to the heads."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from adamml_amd import synth  # noqa: E402
+from tests.golden_cases import CASES, CH, is_head  # noqa: E402
+from tests.oracle_harness import (manifest, load_golden, case_inputs, case_gumbel, oracle_case_forced,  # noqa: E402
+                                  calibrated_state)
+
+DEV = "cuda"
+
+
+def rel_max(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def rel_l2(a, b):
+    a = a.detach().double().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().double().cpu().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-30))
+
+
+def build(c):
+    if c["kind"] == "resnet":
+        from adamml_amd.resnet import resnet
+        return resnet(depth=50, num_classes=31, without_t_stride=False, groups=c["groups"], dropout=0.0, pooling_method="max",
+                      input_channels=3, imagenet_pretrained=False)
+    from adamml_amd import adamml
+    mod = c["modality"]
+    return adamml(groups=c["groups"], modality=mod, input_channels=[CH[m] for m in mod], num_segments=c["S"], rng_policy=False,
+                  rng_threshold=0.5, causality_modeling="lstm", num_classes=31, depth=50, without_t_stride=False, dropout=0.0,
+                  pooling_method="max", fusion_point="logits", unimodality_pretrained=[], learnable_lf_weights=True)
+
+
+def nets_of(model):
+    return model.backbones() if hasattr(model, "backbones") else [model]
+
+
+def hip_train_step(model, c, mode, sd):
+    """One train-mode forward + backward through the HIP path with the conv outputs captured (test hook NetRT.capture)."""
+    xs, target = case_inputs(c)
+    model.load_state_dict(sd)
+    model.to(DEV)
+    cap = {}
+    for n in nets_of(model):
+        n.rt.capture = cap
+    try:
+        model.train()
+        if c["kind"] == "adamml":
+            model.unfreeze_policy_net()
+            model.unfreeze_main_net()
+            (model.freeze_policy_net if mode == "train_main" else model.freeze_main_net)()
+            model.zero_grad()
+            logits, sel = model([t.to(DEV) for t in xs], gumbel_exponential=case_gumbel(c).to(DEV))
+            plog = model.last_policy_logits.detach().cpu()
+        else:
+            model.zero_grad()
+            logits, sel, plog = model(xs.to(DEV)), None, None
+        loss = F.cross_entropy(logits, target.to(DEV))
+        if sel is not None and model.update_policy_net:
+            from oracle import adamml_oracle as O
+            loss = loss + O.policy_loss("blockdrop", sel, torch.ones(sel.shape[-1], device=DEV), torch.tensor(10.0, device=DEV), logits,
+                                        target.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        for n in nets_of(model):
+            n.rt.capture = None
+    pid = {id(p): k for k, p in model.named_parameters()}
+    captured = {pid[i]: (torch.cat([t.cpu() for t in ys]) if len(ys) > 1 else ys[0].cpu()) for i, ys in cap.items()}
+    grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    return logits.detach().cpu(), (None if sel is None else sel.detach().cpu()), plog, grads, state, captured
+
+
+def check_forward_vs_golden(gold, mode, logits, state, logit_tol, stat_tol_all, stat_tol_p90, groups):
+    e = rel_max(logits.numpy(), gold[mode + ".logits"])
+    print("  [%s] logits vs fp32 reference: %.4f of scale (bound %.0e)" % (mode, e, logit_tol))
+    assert e <= logit_tol, e
+    names = list(gold[mode + ".stats_full_names"])
+    flat, off, errs = gold[mode + ".stats_full"], 0, {}
+    for k in names:
+        n = state[k].numel()
+        errs[k] = rel_l2(state[k], flat[off:off + n].reshape(state[k].shape))
+        off += n
+    v = sorted(errs.values())
+    worst = max(errs, key=errs.get)
+    print("  [%s] %d running statistics vs fp32 reference: median %.2e p90 %.2e max %.2e (%s)" % (
+        mode, len(v), v[len(v) // 2], v[int(0.9 * len(v))], v[-1], worst))
+    assert v[-1] <= stat_tol_all, (worst, v[-1])
+    assert v[int(0.9 * len(v))] <= stat_tol_p90
+    for k, t in state.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(t) == groups, (k, int(t))                 # one momentum update per segment call (models/adamml.py:84-86)
+
+
+def check_grads_vs_golden(gold, mode, grads, head_tol):
+    """Head gradients in full; every other tensor by its norm (see the module docstring)."""
+    for k, g in grads.items():
+        if is_head(k) and (mode + ".grad." + k) in gold:
+            e = rel_l2(g, gold[mode + ".grad." + k])
+            print("  [%s] head gradient %-48s rel L2 vs fp32 reference %.2e" % (mode, k, e))
+            assert e <= head_tol, (k, e)
+    names = list(gold[mode + ".grad_names"])
+    ref_l2 = dict(zip(names, gold[mode + ".grad_probe"][:, 1]))
+    gmax = max(ref_l2.values())
+    ratios = {k: float(g.double().norm()) / ref_l2[k] for k, g in grads.items() if ref_l2[k] >= 1e-4 * gmax}
+    r = sorted(ratios.values())
+    inside = sum(0.75 <= x <= 1.35 for x in r) / len(r)
+    print("  [%s] gradient norms HIP / fp32 reference over %d tensors: min %.2f median %.2f max %.2f; %.0f %% within [0.75, 1.35]" % (
+        mode, len(r), r[0], r[len(r) // 2], r[-1], 100 * inside))
+    assert all(np.isfinite(x) for x in r)
+    return inside
+
+
+def check_replay(c, mode, logits, plog, grads, state, captured, top_prefixes, top_tol, p90_tol, max_tol):
+    rep = oracle_case_forced(c, mode, captured)
+    e = rel_max(logits.numpy(), rep["logits"].numpy())
+    print("  [%s] forced-forward replay: logits %.2e" % (mode, e))
+    assert e <= 2e-3, e
+    if plog is not None:
+        ep = rel_max(plog.numpy(), rep["policy_logits"].numpy())
+        print("  [%s] forced-forward replay: policy logits %.2e" % (mode, ep))
+        assert ep <= 2e-3, ep
+    se = max(rel_l2(state[k], v) for k, v in rep["state"].items() if k.endswith(("running_mean", "running_var")))
+    print("  [%s] forced-forward replay: running statistics max rel L2 %.2e" % (mode, se))
+    assert se <= 1e-4, se
+    gmax = max(float(g.norm()) for g in rep["grads"].values())
+    errs = {k: rel_l2(grads[k], g) for k, g in rep["grads"].items() if float(g.norm()) >= 1e-4 * gmax and k in grads}
+    v = sorted(errs.values())
+    worst = max(errs, key=errs.get)
+    top = {k: e_ for k, e_ in errs.items() if k.startswith(top_prefixes)}
+    print("  [%s] forced-forward replay: %d gradient tensors, rel L2 median %.3f p90 %.3f max %.3f (%s); %d tensors next to the "
+          "heads: max %.3f" % (mode, len(v), v[len(v) // 2], v[int(0.9 * len(v))], v[-1], worst, len(top), max(top.values())))
+    assert max(top.values()) <= top_tol, max(top, key=top.get)
+    assert v[int(0.9 * len(v))] <= p90_tol
+    assert v[-1] <= max_tol, (worst, v[-1])
+
+
+def test_c1_resnet50_fullsize():
+    c = CASES["resnet50_c1"]
+    gold = load_golden("resnet50_c1")
+    model = build(c)
+    sd = synth.synth_state_dict(manifest(c), seed=1234)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    print("resnet50_c1 (B=4, 8 frames, 224^2)")
+    logits, _, _, grads, state, captured = hip_train_step(model, c, "train", sd)
+    check_forward_vs_golden(gold, "train", logits, state, logit_tol=2e-2, stat_tol_all=1e-2, stat_tol_p90=5e-3, groups=1)
+    inside = check_grads_vs_golden(gold, "train", grads, head_tol=2e-2)
+    assert inside >= 0.9
+    check_replay(c, "train", logits, None, grads, state, captured, top_prefixes=("layer4.", "fc."), top_tol=3e-2, p90_tol=0.12,
+                 max_tol=0.2)
+    # inference on calibrated running statistics (BatchNorm = fixed affine map)
+    xs, _ = case_inputs(c)
+    model.load_state_dict(calibrated_state(c, sd, xs))
+    model.eval()
+    with torch.no_grad():
+        y = model(xs.to(DEV))
+    e = rel_max(y.cpu().numpy(), gold["eval_cal.logits"])
+    print("  [eval_cal] logits vs fp32 reference: %.4f of scale" % e)
+    assert e <= 2e-2, e
+
+
+@pytest.mark.parametrize("mode", ["train_main", "train_policy"])
+def test_c2_adamml_fullsize(mode):
+    c = CASES["adamml_c2"]
+    gold = load_golden("adamml_c2")
+    model = build(c)
+    sd = synth.synth_state_dict(manifest(c), seed=1234)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    print("adamml_c2 (B=4, S=5, 224^2 / 256^2), golden min decision margin %.3f" % float(gold["min_decision_margin"]))
+    logits, sel, plog, grads, state, captured = hip_train_step(model, c, mode, sd)
+    assert np.array_equal(np.round(sel.numpy()), np.round(gold[mode + ".decisions"])), "decisions differ from the reference"
+    ep = rel_max(plog.numpy(), gold[mode + ".policy_logits"])
+    print("  [%s] policy logits vs fp32 reference: %.4f of scale (bound 1e-1)" % (mode, ep))
+    assert ep <= 1e-1, ep
+    check_forward_vs_golden(gold, mode, logits, state, logit_tol=1e-1, stat_tol_all=3e-2, stat_tol_p90=1e-2, groups=c["S"])
+    # main stage: the heads sit on ResNet / MobileNetV2 features (5.5e-2 worst, the sound classifier); policy stage: the head
+    # gradients are driven by d(loss)/d(decisions), a difference of class logits of the gated main nets (0.23 worst, fcs.1)
+    inside = check_grads_vs_golden(gold, mode, grads, head_tol=0.1 if mode == "train_main" else 0.4)
+    assert inside >= 0.9
+    top = ("main_net.nets.0.layer4.", "main_net.nets.0.fc.", "main_net.nets.1.features.17.", "main_net.nets.1.features.18.",
+           "main_net.nets.1.classifier.", "main_net.lf_weights") if mode == "train_main" else \
+          ("policy_net.fcs.", "policy_net.lstm.", "policy_net.joint_net.joint.")
+    check_replay(c, mode, logits, plog, grads, state, captured, top_prefixes=top, top_tol=5e-2, p90_tol=0.12, max_tol=0.3)
+
+
+def test_c2_adamml_fullsize_inference():
+    c = CASES["adamml_c2"]
+    gold = load_golden("adamml_c2")
+    model = build(c)
+    sd = synth.synth_state_dict(manifest(c), seed=1234)
+    xs, _ = case_inputs(c)
+    model.load_state_dict(calibrated_state(c, sd, xs))
+    model.to(DEV).eval()
+    with torch.no_grad():
+        logits, sel = model([t.to(DEV) for t in xs], gumbel_exponential=case_gumbel(c).to(DEV))
+    assert np.array_equal(np.round(sel.cpu().numpy()), np.round(gold["eval_cal.decisions"])), "decisions differ from the reference"
+    ep = rel_max(model.last_policy_logits.cpu().numpy(), gold["eval_cal.policy_logits"])
+    e = rel_max(logits.cpu().numpy(), gold["eval_cal.logits"])
+    print("adamml_c2 [eval_cal, decision-driven skipping on] policy logits %.4f, logits %.4f of scale vs fp32 reference" % (ep, e))
+    assert ep <= 1e-1 and e <= 1e-1, (ep, e)

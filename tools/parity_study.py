@@ -80,7 +80,41 @@ def main():
         print("  oracle(%s) %.1f s" % ("bf16 emulation" if q else "fp32", time.time() - t0))
         return y.detach(), {k: v.grad for k, v in sd.items() if v.grad is not None}, {k: v.detach() for k, v in sd.items()}, pl
 
-    def run_hip():
+    def run_oracle_forced(cap):
+        """fp32 oracle whose conv outputs are REPLACED by the bf16 tensors the HIP forward stored (same ReLU / max-pool decisions)."""
+        sd = O.make_leaf_state(sd0, pref)
+        names = {id(v): k for k, v in sd.items()}
+        used = {}
+
+        def hook(w, y):
+            k = names[id(w)]
+            i = used.get(k, 0)
+            used[k] = i + 1
+            ys = cap[k]                                  # NHWC bf16 [G*N, OH, OW, C] (groups = segments, group-major)
+            n = y.shape[0]
+            t = ys[i * n:(i + 1) * n].permute(0, 3, 1, 2).float()
+            assert t.shape == y.shape, (k, t.shape, y.shape)
+            return y + (t - y).detach()
+        O.CONV_HOOK = hook
+        try:
+            if kind == "resnet":
+                y = O.resnet_forward(sd, "", xs[0], 8, 50, "max", False, 0.0, True)
+                pl = None
+            else:
+                y, sel, pl = O.adamml_forward(sd, xs, mod, S, 8, 50, 5.0, expo, "lstm", "max", False, 0.0, True)
+            loss = F.cross_entropy(y, tgt)
+            if kind == "adamml" and stage != "main":
+                loss = loss + O.policy_loss("blockdrop", sel, torch.ones(2), torch.tensor(10.0), y, tgt)
+            loss.backward()
+        finally:
+            O.CONV_HOOK = None
+        return y.detach(), {k: v.grad for k, v in sd.items() if v.grad is not None}, {k: v.detach() for k, v in sd.items()}, pl
+
+    def run_hip(capture=None):
+        if capture is not None:
+            nets = model.backbones() if hasattr(model, "backbones") else [model]
+            for n_ in nets:
+                n_.rt.capture = capture
         model.load_state_dict(sd0)
         model.to(dev)
         if kind == "adamml":
@@ -104,8 +138,15 @@ def main():
         st = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
         return y.detach().cpu(), g, st, pl
 
-    y_h, g_h, s_h, pl_h = run_hip()
+    cap = {}
+    y_h, g_h, s_h, pl_h = run_hip(cap)
+    pid = {id(p): k for k, p in model.named_parameters()}
+    cap_named = {pid[i]: torch.cat([t.cpu() for t in ys]) if len(ys) > 1 else ys[0].cpu() for i, ys in cap.items()}
+    cap.clear()
+    for n_ in (model.backbones() if hasattr(model, "backbones") else [model]):
+        n_.rt.capture = None
     y_h2, g_h2, s_h2, _ = run_hip()
+    y_r, g_r, s_r, pl_r = run_oracle_forced(cap_named)
     y_f, g_f, s_f, pl_f = run_oracle(False)
     y_e, g_e, s_e, pl_e = run_oracle(True)
     sc = y_f.abs().max().item()
@@ -128,12 +169,16 @@ def main():
     summarize("grads relL2(HIP,emu)", {k: rl2(g_h[k], g_e[k]) for k in keys})
     summarize("grads relL2(emu,fp32)", {k: rl2(g_e[k], g_f[k]) for k in keys})
     summarize("grads relL2(HIP,HIP')", {k: rl2(g_h[k], g_h2[k]) for k in keys})
+    print("  forced-forward replay: logits |HIP-replay| %.2e" % ((y_h - y_r).abs().max().item() / sc))
+    summarize("running stats relL2(HIP,replay)", {k: rl2(s_h[k], s_r[k]) for k in stat_keys})
+    summarize("grads relL2(HIP,replay)", {k: rl2(g_h[k], g_r[k]) for k in keys})
     summarize("grads 1-cos(HIP,fp32)", {k: 1 - cos(g_h[k], g_f[k]) for k in keys})
     order = [k for k in sd0 if k in keys]
     print("  per tensor (reverse network order): relL2 HIP-fp32 | HIP-emu | emu-fp32 | HIP-HIP'")
     step = max(1, len(order) // 60)
     for k in order[::-1][::step]:
-        print("    %-58s %.4f %.4f %.4f %.2e" % (k, rl2(g_h[k], g_f[k]), rl2(g_h[k], g_e[k]), rl2(g_e[k], g_f[k]), rl2(g_h[k], g_h2[k])))
+        print("    %-58s %.4f %.4f %.4f %.2e | replay %.4f" % (k, rl2(g_h[k], g_f[k]), rl2(g_h[k], g_e[k]), rl2(g_e[k], g_f[k]), rl2(g_h[k], g_h2[k]),
+                                                          rl2(g_h[k], g_r[k])))
 
 
 if __name__ == "__main__":
