@@ -73,6 +73,57 @@ __device__ __forceinline__ f32x4 transform4(bf16x4 raw, const float* scale, cons
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// ---- deterministic reductions (adamml_set_deterministic / ADAMML_DETERMINISTIC=1) -------------------------------------------
+// Default mode accumulates per-channel sums with LDS fp32 atomics inside a workgroup and fp64 atomics across workgroups: fast,
+// but the ORDER of the additions varies from run to run, the last bits of the sums with it, and bf16 rounding downstream
+// amplifies a 1-ulp difference of a BatchNorm scale into visibly different activations.  In deterministic mode every lane adds
+// its fp32 partial EXACTLY into integer bins: the 32 slots of one accumulator ([ADAMML_STAT_SLOTS][2C] doubles, 8 bytes each)
+// are reinterpreted as 32 int64 bins; an addend +-m * 2^(E-150) (24-bit m, biased exponent E) goes to bin E >> 3 as
+// +-(m << (E & 7)).  Integer addition is associative, so the bins -- and the fp64 value decoded from them in a fixed order --
+// do not depend on the order of arrival.  (|addend| < 2^31 per bin: 2^32 addends before an int64 bin can overflow.)
+static __constant__ int c_adamml_det;                    // one copy per translation unit, set through adamml_det_set_<tu>()
+__device__ __forceinline__ bool det_mode() { return c_adamml_det != 0; }
+
+__device__ __forceinline__ void det_add(double* acc, size_t slot_stride, float v) {
+    const unsigned u = __float_as_uint(v);
+    unsigned e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+    if (e == 0xffu) return;                              // inf / nan never reach a statistic of a healthy run
+    if (e) m |= 0x800000u; else e = 1;                   // denormals: no implicit bit, exponent of the smallest normal
+    if (!m) return;
+    long long c = (long long)m << (e & 7);
+    if (u >> 31) c = -c;
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc + (size_t)(e >> 3) * slot_stride), (unsigned long long)c);
+}
+
+// value of bin k of a deterministic accumulator (the 32 bin values are summed in a fixed order by the consumers)
+__device__ __forceinline__ double det_bin_value(const double* acc, size_t slot_stride, int k) {
+    const long long b = *reinterpret_cast<const long long*>(acc + (size_t)k * slot_stride);
+    return scalbn((double)b, 8 * k - 150);
+}
+
+__device__ __forceinline__ double det_decode(const double* acc, size_t slot_stride) {
+    double s = 0.0;
+    for (int k = 0; k < 32; ++k) s += det_bin_value(acc, slot_stride, k);
+    return s;
+}
+
+// overwrite a deterministic accumulator with the fp64 value r (single thread): r = f1 + f2 + f3 exactly (3 x 24 bits >= 53)
+__device__ __forceinline__ void det_encode(double* acc, size_t slot_stride, double r) {
+    for (int k = 0; k < 32; ++k) acc[(size_t)k * slot_stride] = 0.0;          // (all-zero bits == integer 0)
+    for (int i = 0; i < 3; ++i) {
+        const float f = (float)r;
+        det_add(acc, slot_stride, f);
+        r -= (double)f;
+    }
+}
+
+// host side: every translation unit with kernels exports a setter for its copy of c_adamml_det (api.hip calls them all)
+#define ADAMML_DET_SETTER(tu)                                                                               \
+    extern "C" int adamml_det_set_##tu(int v) {                                                             \
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(c_adamml_det), &v, sizeof(int), 0, hipMemcpyHostToDevice); \
+    }
+int adamml_deterministic_enabled(void);                  // host mirror of the flag (api.hip)
+
 // Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private L2.  This bijection gives XCD k
 // the k-th CONTIGUOUS eighth of the logical work list, in dispatch order, so neighbouring tiles (shared halo rows,
 // shared weight tiles) meet in one L2 instead of being fetched from HBM by up to 8 of them.

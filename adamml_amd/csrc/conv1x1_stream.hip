@@ -9,6 +9,8 @@
 #include "common.h"
 #include "../../include/adamml_hip.h"
 
+ADAMML_DET_SETTER(conv1x1_stream)
+
 namespace {
 
 constexpr int K1 = 256, C2 = 64, KT = K1 + C2, KP = KT + 8;      // KP: padded LDS row (bank spread for the 16-lane row reads)
@@ -171,13 +173,18 @@ __global__ __launch_bounds__(256, 3) void alg_stream_kernel(S1P p) {
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
                 if (li == 0) {
-                    atomicAdd(&s_sum[ct * 16 + lg * 4 + r], a);
-                    atomicAdd(&s_sum[C2 + ct * 16 + lg * 4 + r], b);
+                    if (det_mode()) {                                   // exact integer bins instead of float atomics (common.h)
+                        det_add(p.stats + ct * 16 + lg * 4 + r, 2 * C2, a);
+                        det_add(p.stats + C2 + ct * 16 + lg * 4 + r, 2 * C2, b);
+                    } else {
+                        atomicAdd(&s_sum[ct * 16 + lg * 4 + r], a);
+                        atomicAdd(&s_sum[C2 + ct * 16 + lg * 4 + r], b);
+                    }
                 }
             }
         __syncthreads();
         double* slot = p.stats + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * C2;
-        if (tid < 2 * C2) atomicAdd(&slot[tid], (double)s_sum[tid]);
+        if (tid < 2 * C2 && !det_mode()) atomicAdd(&slot[tid], (double)s_sum[tid]);
     }
 }
 

@@ -14,6 +14,8 @@
 #include "common.h"
 #include "../../include/adamml_hip.h"
 
+ADAMML_DET_SETTER(conv3x3_c64)
+
 namespace {
 
 constexpr int NT3 = 512;
@@ -42,7 +44,7 @@ struct C3P {
     size_t gxy;              // elements per group of x and y (same shape)
 };
 
-__device__ __forceinline__ void fold16_to_cs(const f32x8& esum, const f32x8& esq, float* cs, int lane, int ech) {
+__device__ __forceinline__ void fold16_to_cs(const f32x8& esum, const f32x8& esq, float* cs, int lane, int ech, double* gdst) {
     // lanes l, l+8, .., l+56 of a wave hold partial sums of channel chunk `ech` (8 channels): DPP + lane-swap fold
     // (see conv_gemm.hip), then 4 LDS adds from the lanes with bit 3 clear
     float v[16];
@@ -70,7 +72,8 @@ __device__ __forceinline__ void fold16_to_cs(const f32x8& esum, const f32x8& esq
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int id = 4 * j + vsel;
-            atomicAdd(&cs[(id >> 3) * C64 + ech * 8 + (id & 7)], wv[j]);
+            if (gdst) det_add(gdst + (id >> 3) * C64 + ech * 8 + (id & 7), 2 * C64, wv[j]);       // deterministic mode (common.h)
+            else atomicAdd(&cs[(id >> 3) * C64 + ech * 8 + (id & 7)], wv[j]);
         }
     }
 }
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
             if (p.stats && cur_group >= 0) {       // publish the finished group's sums, restart the accumulators
                 __syncthreads();
                 double* slot = p.stats + ((size_t)cur_group * ADAMML_STAT_SLOTS + (blockIdx.x & (ADAMML_STAT_SLOTS - 1))) * 128;
-                if (tid < 128) { atomicAdd(&slot[tid], (double)cs[tid]); cs[tid] = 0.f; }
+                if (tid < 128) { if (!det_mode()) atomicAdd(&slot[tid], (double)cs[tid]); cs[tid] = 0.f; }
             }
             cur_group = g;
         }
@@ -254,10 +257,16 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
                     dsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, f.v, dsum, 0, 0, 0);
                     dsq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v, f.v, dsq, 0, 0, 0);
                 }
-                if (lg == 0) atomicAdd(&cs[cb * 16 + li], dsum[0]);
+                double* gdst = det_mode() ? p.stats + (size_t)g * ADAMML_STAT_SLOTS * 128 : nullptr;
+                if (lg == 0) {
+                    if (gdst) det_add(gdst + cb * 16 + li, 128, dsum[0]);
+                    else atomicAdd(&cs[cb * 16 + li], dsum[0]);
+                }
                 if ((li >> 2) == lg) {
                     const int r = li & 3;
-                    atomicAdd(&cs[64 + cb * 16 + li], r == 0 ? dsq[0] : r == 1 ? dsq[1] : r == 2 ? dsq[2] : dsq[3]);
+                    const float q2 = r == 0 ? dsq[0] : r == 1 ? dsq[1] : r == 2 ? dsq[2] : dsq[3];
+                    if (gdst) det_add(gdst + 64 + cb * 16 + li, 128, q2);
+                    else atomicAdd(&cs[64 + cb * 16 + li], q2);
                 }
             }
         } else {
@@ -285,14 +294,14 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) esq[i] += f[i] * (zv[i] - mu[i]) * is[i];
             }
-            if (p.stats) fold16_to_cs(esum, esq, cs, lane, ech);
+            if (p.stats) fold16_to_cs(esum, esq, cs, lane, ech, det_mode() ? p.stats + (size_t)g * ADAMML_STAT_SLOTS * 128 : nullptr);
         }
         __syncthreads();                                     // staging consumed before the next patch lands
     }
     if (p.stats && cur_group >= 0) {
         __syncthreads();
         double* slot = p.stats + ((size_t)cur_group * ADAMML_STAT_SLOTS + (blockIdx.x & (ADAMML_STAT_SLOTS - 1))) * 128;
-        if (tid < 128) atomicAdd(&slot[tid], (double)cs[tid]);
+        if (tid < 128 && !det_mode()) atomicAdd(&slot[tid], (double)cs[tid]);
     }
 }
 

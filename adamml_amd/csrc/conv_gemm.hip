@@ -13,6 +13,8 @@
 #include <type_traits>
 #include <stdlib.h>
 
+ADAMML_DET_SETTER(conv_gemm)
+
 namespace {
 
 constexpr int BP = 128;      // pixels per block tile
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
         // of a with the lower half (even rows) of b", so a' + b' folds TWO values at once and halves the register count
         // per step) -- 24 VALU ops instead of 32-48 ds_bpermute, which had made this epilogue LDS-pipe-bound (-30 % on
         // the HBM-bound 1x1 layers).  16 values -> 4 registers per lane, then 4 LDS adds per lane.
-        auto fold = [&](const f32x8& s1, const f32x8& s2, float* dst) {
+        auto fold = [&](const f32x8& s1, const f32x8& s2, float* dst, double* gdst) {
             float v[16];
 #pragma unroll
             for (int i = 0; i < 8; ++i) { v[i] = s1[i]; v[8 + i] = s2[i]; }
@@ -593,18 +595,31 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int id = 4 * j + vsel;              // 0..7: sum of channel id; 8..15: second moment of channel id-8
-                    atomicAdd(&dst[(id >> 3) * BC + ech * 8 + (id & 7)], wv[j]);
+                    if (gdst) det_add(gdst + (size_t)(id >> 3) * p.Cout + eco + (id & 7), 2 * (size_t)p.Cout, wv[j]);   // deterministic mode
+                    else atomicAdd(&dst[(id >> 3) * BC + ech * 8 + (id & 7)], wv[j]);
                 }
             }
         };
-        fold(esum, esq, cs);
-        if (second) fold(esum, esq2, cs2);
+        const bool det = det_mode();
+        fold(esum, esq, cs, det ? p.stats : nullptr);
+        if (second) fold(esum, esq2, cs2, det ? p.stats2 : nullptr);
     }
     __syncthreads();                                   // staging tile consumed before the next tile's operands land
     }   // tile loop
     if (p.stats) {
         __syncthreads();
         double* slot = p.stats + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * p.Cout;
+        if (det_mode()) {
+            // forward statistics (each LDS entry was accumulated by ONE wave in tile order: deterministic) go to the integer
+            // bins; the fold() path already added its lanes' partials to the bins directly and left cs / cs2 zero
+            for (int i = tid; i < BC; i += NTHREADS) {
+                if (c0 + i < p.Cout) {
+                    det_add(p.stats + c0 + i, 2 * (size_t)p.Cout, cs[i]);
+                    det_add(p.stats + p.Cout + c0 + i, 2 * (size_t)p.Cout, cs[BC + i]);
+                }
+            }
+            return;
+        }
         for (int i = tid; i < BC; i += NTHREADS) {
             if (c0 + i < p.Cout) {
                 atomicAdd(&slot[c0 + i], (double)cs[i]);
@@ -1330,12 +1345,15 @@ __global__ void alg_sumfix_kernel(const float* w, const float* P, const float* v
     const int g = e / Cout, co = e - g * Cout;
     double* sg = sums + (size_t)g * ADAMML_STAT_SLOTS * 2 * Cout;
     double s1 = 0.0;
-    for (int k = 0; k < ADAMML_STAT_SLOTS; ++k) s1 += sg[(size_t)k * 2 * Cout + co];
+    if (det_mode()) s1 = det_decode(sg + co, 2 * (size_t)Cout);
+    else for (int k = 0; k < ADAMML_STAT_SLOTS; ++k) s1 += sg[(size_t)k * 2 * Cout + co];
     const float* Pg = P + ((size_t)g * Cout + co) * Cin;
     double dot = 0.0;
     for (int cj = 0; cj < Cin; ++cj) dot += (double)w[(size_t)co * Cin + cj] * (double)Pg[cj];
     const float* v = vec + (size_t)g * 4 * Cout;
-    sg[Cout + co] = (double)v[3 * Cout + co] * (dot - (double)v[2 * Cout + co] * s1);
+    const double r = (double)v[3 * Cout + co] * (dot - (double)v[2 * Cout + co] * s1);
+    if (det_mode()) det_encode(sg + Cout + co, 2 * (size_t)Cout, r);
+    else sg[Cout + co] = r;
 }
 
 extern "C" int adamml_alg_sumfix(const float* w, const float* P, const float* vec, double* sums, int Cout, int Cin, int groups,

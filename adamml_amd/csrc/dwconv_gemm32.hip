@@ -4,6 +4,8 @@
 #include "common.h"
 #include "../../include/adamml_hip.h"
 
+ADAMML_DET_SETTER(dwconv)
+
 namespace {
 
 constexpr int NT = 256;
@@ -171,6 +173,16 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
     if (p.stats) {
         for (int i = threadIdx.x; i < 2 * p.C; i += NT) smem[i] = 0.f;
         __syncthreads();
+        if (det_mode()) {                                   // exact integer bins instead of float atomics (common.h)
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    det_add(p.stats + chunk * 4 + i, 2 * (size_t)p.C, s[i]);
+                    det_add(p.stats + p.C + chunk * 4 + i, 2 * (size_t)p.C, q[i]);
+                }
+            }
+            return;
+        }
         if (active) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -367,7 +379,19 @@ __global__ __launch_bounds__(NT, 2) void dwconv_bwd_weight_kernel(DwWP p) {
         }
 #undef DW_STEP
     }
-    if (any) {
+    if (det_mode()) {
+        // deterministic mode: the threads that share a channel chunk (thread ids congruent modulo nchunk) add in turn
+        const int nturn = (NT + nchunk - 1) / nchunk;
+        for (int r = 0; r < nturn; ++r) {
+            if (any && (int)threadIdx.x / nchunk == r) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dsm[t * p.C + c + i] += acc[t][i];
+            }
+            __syncthreads();
+        }
+    } else if (any) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll

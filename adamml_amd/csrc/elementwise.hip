@@ -5,6 +5,8 @@
 #include "common.h"
 #include "../../include/adamml_hip.h"
 
+ADAMML_DET_SETTER(elementwise)
+
 namespace {
 
 constexpr int NT = 256;
@@ -35,6 +37,16 @@ struct ChanMap {
 
 __device__ __forceinline__ void block_channel_publish(const float (&s)[8], const float (&q)[8], const ChanMap& m, float* smem,
                                                       int C, double* out) {
+    if (det_mode()) {                                    // exact integer-bin accumulation, no floating-point atomics (common.h)
+        if (m.active) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                det_add(out + m.chunk * 8 + i, 2 * (size_t)C, s[i]);
+                det_add(out + C + m.chunk * 8 + i, 2 * (size_t)C, q[i]);
+            }
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < 2 * C; i += NT) smem[i] = 0.f;
     __syncthreads();
     if (m.active) {
@@ -58,7 +70,8 @@ __global__ void stats_collapse_kernel(const double* stats, double* out, int C, i
     if (i >= 2 * C * groups) return;
     const int g = i / (2 * C), j = i - g * 2 * C;
     double s = 0.0;
-    for (int k = 0; k < ADAMML_STAT_SLOTS; ++k) s += stats[((size_t)g * ADAMML_STAT_SLOTS + k) * 2 * C + j];
+    if (det_mode()) s = det_decode(stats + (size_t)g * ADAMML_STAT_SLOTS * 2 * C + j, 2 * (size_t)C);
+    else for (int k = 0; k < ADAMML_STAT_SLOTS; ++k) s += stats[((size_t)g * ADAMML_STAT_SLOTS + k) * 2 * C + j];
     out[i] = s;
 }
 
@@ -66,8 +79,13 @@ __global__ void stats_collapse_kernel(const double* stats, double* out, int C, i
 __device__ __forceinline__ void slot_sums(const double* stats, int nslots, int C, int c, int k, double& s1, double& s2) {
     s1 = 0.0; s2 = 0.0;
     if (c < C && k < nslots) {
-        s1 = stats[(size_t)k * 2 * C + c];
-        s2 = stats[(size_t)k * 2 * C + C + c];
+        if (det_mode() && nslots == ADAMML_STAT_SLOTS) {       // integer bins (nslots == 1: already collapsed to plain doubles)
+            s1 = det_bin_value(stats + c, 2 * (size_t)C, k);
+            s2 = det_bin_value(stats + C + c, 2 * (size_t)C, k);
+        } else {
+            s1 = stats[(size_t)k * 2 * C + c];
+            s2 = stats[(size_t)k * 2 * C + C + c];
+        }
     }
 #pragma unroll
     for (int off = 16; off >= 1; off >>= 1) {
@@ -311,6 +329,7 @@ __global__ __launch_bounds__(NT) void lazy_colsum_kernel(const bf16_t* x, const 
     ChanMap m(C, threadIdx.x);
     for (int i = threadIdx.x; i < C; i += NT) smem[i] = 0.f;
     __syncthreads();
+    float accd[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (m.active) {
         const int c = m.chunk * 8;
         f32x8 acc;
@@ -320,8 +339,23 @@ __global__ __launch_bounds__(NT) void lazy_colsum_kernel(const bf16_t* x, const 
         const size_t pe = pb + ppb < P ? pb + ppb : P;
         for (size_t p = pb + m.rslot; p < pe; p += m.rows_per_pass)
             acc += transform8(*reinterpret_cast<const bf16x8*>(x + p * C + c), scale, shift, c, act);
+        if (!det_mode()) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) atomicAdd(&smem[c + i], acc[i]);
+            for (int i = 0; i < 8; ++i) atomicAdd(&smem[c + i], acc[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) accd[i] = acc[i];
+        }
+    }
+    if (det_mode()) {
+        // deterministic mode (one workgroup per group, see the launcher): the row slots add in turn, in a fixed order
+        for (int r = 0; r < m.rows_per_pass; ++r) {
+            if (m.active && m.rslot == r) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) smem[m.chunk * 8 + i] += accd[i];
+            }
+            __syncthreads();
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < C; i += NT) atomicAdd(&s[i], smem[i]);
@@ -1072,6 +1106,7 @@ extern "C" int adamml_lazy_colsum(const void* x, const float* scale, const float
     if (!P) return ADAMML_OK;
     size_t ppb, nblk;
     reduce_grid(P, C, groups, &ppb, &nblk);
+    if (adamml_deterministic_enabled()) { ppb = P; nblk = 1; }     // one workgroup per group: its fp32 adds run in a fixed order
     hipLaunchKernelGGL(lazy_colsum_kernel, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)x, scale, shift, gstride, act, s, P, C, ppb);
     return adamml_check_launch("lazy_colsum");
 }

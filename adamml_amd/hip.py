@@ -119,8 +119,28 @@ def load():
     lib.adamml_pack_block_elems.restype = c_int
     lib.adamml_version.restype = c_int
     lib.adamml_last_error_string.restype = c_char_p
+    lib.adamml_set_deterministic.argtypes = [_I]
+    lib.adamml_set_deterministic.restype = c_int
+    lib.adamml_get_deterministic.restype = c_int
     _lib = lib
+    if os.environ.get("ADAMML_DETERMINISTIC", "0") not in ("", "0") and torch.cuda.is_available():
+        set_deterministic(True)
     return lib
+
+
+def set_deterministic(on=True):
+    """Exact, order-independent accumulation of every per-channel statistic (include/adamml_hip.h: adamml_set_deterministic):
+    two runs of the same step become bit-identical.  Also settable with ADAMML_DETERMINISTIC=1.  Call between steps."""
+    lib = _lib if _lib is not None else load()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    rc = lib.adamml_set_deterministic(1 if on else 0)
+    if rc != 0:
+        raise RuntimeError("adamml_set_deterministic failed (%d): %s" % (rc, lib.adamml_last_error_string().decode()))
+
+
+def deterministic():
+    return bool((_lib if _lib is not None else load()).adamml_get_deterministic())
 
 
 def _stream():

@@ -48,6 +48,12 @@ typedef struct {
 
 int adamml_version(void);
 const char* adamml_last_error_string(void);
+/* Deterministic reductions (process-wide, set while no kernel of this library is in flight): every per-channel statistic /
+ * BatchNorm-backward sum is accumulated exactly (integer bins, order-independent) instead of with floating-point atomics, so
+ * two runs of the same step are bit-identical.  Slower; meant for parity tests and debugging.  The statistic buffers keep
+ * their size and meaning for the caller ([groups][ADAMML_STAT_SLOTS][2C] doubles, zeroed by the caller, opaque in between). */
+int adamml_set_deterministic(int on);
+int adamml_get_deterministic(void);
 
 /* nn.Conv2d(bias=False) forward (models/resnet.py:37-43,138; sound_mobilenet_v2.py:37,60; policy_net.py:40,48,76,84)
  * fused with the PRODUCER's BatchNorm+ReLU/ReLU6 on load and with the per-channel sum / sum-of-squares of its own
