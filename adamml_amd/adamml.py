@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from . import hip, interleave
-from .backbone import FlatBuffers
+from .backbone import FlatBuffers, StockDDPAware
 from .common import MeanStdMixin
 from .joint_resnet_mobilenetv2 import joint_resnet_mobilenetv2
 from .policy_net import p_joint_mobilenet
@@ -15,7 +15,7 @@ from .runtime import clip_to_nhwc, clip_u8_to_nhwc, SyncCtx
 __all__ = ['adamml']
 
 
-class AdaMML(nn.Module, MeanStdMixin):
+class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
 
     def __init__(self, policy_net, main_net, num_frames, num_segments, modality, rng_policy, rng_threshold, num_classes,
                  input_channels=None):

@@ -4,7 +4,7 @@ call as a single node (forward = fused HIP launches, backward = the recorded tap
 import torch
 import torch.nn as nn
 
-from . import hip, interleave
+from . import hip, interleave, ops
 from .runtime import NetRT, ConvState, Tape
 
 
@@ -18,6 +18,17 @@ class FlatBuffers:
         self.flat = None
         self.flat_grad = None
         self.params = []
+        self.detached = False       # True: .grad belongs to autograd / torch.optim (enable_autograd_param_grads)
+
+    def set_detached(self, on):
+        """on: stop managing .grad (drop the flat views so that AccumulateGrad creates ordinary gradient tensors)."""
+        if on and not self.detached and self.flat_grad is not None:
+            lo, hi = self.flat_grad.data_ptr(), self.flat_grad.data_ptr() + self.flat_grad.numel() * 4
+            for p in self.params:
+                if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+                    p.grad = None
+            self.flat_grad = None
+        self.detached = on
 
     def ensure(self, device):
         params = [p for p in self.module.parameters()]
@@ -40,6 +51,8 @@ class FlatBuffers:
 
     def ensure_grads(self):
         """(Re)attach zeroed gradient views when the optimizer dropped them (zero_grad(set_to_none=True))."""
+        if self.detached:
+            return
         params = self.params
         if self.flat_grad is None:
             self.flat_grad = torch.zeros_like(self.flat)
@@ -56,51 +69,59 @@ class FlatBuffers:
             off += n
 
 
-class _NetCall(torch.autograd.Function):
-    """One backbone invocation as one autograd node.  `anchor` only makes the node differentiable; parameter
-    gradients are accumulated straight into the flat gradient buffer by the HIP weight-grad kernels."""
+def run_backward(net, tape, g, params):
+    """Backward of one backbone invocation (autograd formula of adamml::backbone_call, ops.py): the recorded tape in reverse.
+    params empty  -> the weight-gradient kernels accumulate into the pre-attached flat .grad views; returns [].
+    params given  -> their gradients are delivered THROUGH autograd (stock DistributedDataParallel hooks, torch.optim): the
+                     kernels write into a fresh scratch buffer bound to .grad for the duration of the tape, the views of that
+                     buffer are returned and AccumulateGrad adds them to whatever .grad held before."""
+    if not params and net.rt.sync.enabled and interleave.ENABLED:
+        # SyncBatchNorm: the backward passes of the backbones are issued round-robin (interleave.py) once autograd has
+        # handed every backbone its output gradient -- nothing upstream waits for a backbone's input gradient
+        _deferred.append((tape, g.contiguous(), net, torch.cuda.current_stream()))
+        if len(_deferred) == 1:
+            torch.autograd.Variable._execution_engine.queue_callback(_run_deferred)
+        return []
+    if not params:
+        run_tape(tape, g, net)
+        return []
+    total = sum(p.numel() for p in params)
+    scratch = torch.zeros(total, dtype=torch.float32, device=g.device)
+    views, saved, off = [], [], 0
+    for p in params:
+        views.append(scratch[off:off + p.numel()].view(p.shape))
+        off += p.numel()
+        saved.append(p.grad)
+    try:
+        for p, v in zip(params, views):
+            p.grad = v
+        run_tape(tape, g, net)
+    finally:
+        for p, s_ in zip(params, saved):
+            p.grad = s_
+    return views
 
-    @staticmethod
-    def forward(ctx, anchor, net, x, groups):
-        out, tape = net._run(x, groups, need_grad=anchor.requires_grad)
-        ctx.tape = tape
-        ctx.net = net
-        return out
 
-    @staticmethod
-    def backward(ctx, g):
-        net = ctx.net
-        if net.rt.sync.enabled and interleave.ENABLED:
-            # SyncBatchNorm: the backward passes of the backbones are issued round-robin (interleave.py) once autograd has
-            # handed every backbone its output gradient -- nothing upstream waits for a backbone's input gradient
-            _deferred.append((ctx.tape, g.contiguous(), net, torch.cuda.current_stream()))
-            if len(_deferred) == 1:
-                torch.autograd.Variable._execution_engine.queue_callback(_run_deferred)
-            return None, None, None, None
-        _NetCall.run_tape(ctx.tape, g, net)
-        return None, None, None, None
+def run_tape(tape, g, net):
+    net.rt.bwd_arena.reset(g.device)
+    tape.grad_out = g.contiguous()
+    tape.backward()
+    side = torch.cuda.current_stream()
+    if net.rt.wgrad_stream is not None:
+        side.wait_stream(net.rt.wgrad_stream)      # the weight gradients are complete before anyone reads .grad
+        net.rt.wgrad_pending.clear()               # later allocations on this stream are ordered behind that wait
+    if side != torch.cuda.default_stream(g.device) and not getattr(net, "_join_queued", False):
+        # the HIP weight-gradient kernels wrote .grad on a side stream without going through AccumulateGrad: make
+        # the default stream wait for them once, when the whole backward pass has been enqueued
+        net._join_queued = True
 
-    @staticmethod
-    def run_tape(tape, g, net):
-        net.rt.bwd_arena.reset(g.device)
-        tape.grad_out = g.contiguous()
-        tape.backward()
-        side = torch.cuda.current_stream()
-        if net.rt.wgrad_stream is not None:
-            side.wait_stream(net.rt.wgrad_stream)      # the weight gradients are complete before anyone reads .grad
-            net.rt.wgrad_pending.clear()               # later allocations on this stream are ordered behind that wait
-        if side != torch.cuda.default_stream(g.device) and not getattr(net, "_join_queued", False):
-            # the HIP weight-gradient kernels wrote .grad on a side stream without going through AccumulateGrad: make
-            # the default stream wait for them once, when the whole backward pass has been enqueued
-            net._join_queued = True
-
-            def _join():
-                net._join_queued = False
-                torch.cuda.default_stream(g.device).wait_stream(side)
-            if _in_deferred_run[0]:
-                _join()                     # already past the engine's callbacks: join right away
-            else:
-                torch.autograd.Variable._execution_engine.queue_callback(_join)
+        def _join():
+            net._join_queued = False
+            torch.cuda.default_stream(g.device).wait_stream(side)
+        if _in_deferred_run[0]:
+            _join()                     # already past the engine's callbacks: join right away
+        else:
+            torch.autograd.Variable._execution_engine.queue_callback(_join)
 
 
 _deferred = []
@@ -116,10 +137,34 @@ def _run_deferred():
     dev = pend[0][1].device
     _in_deferred_run[0] = True
     try:
-        jobs = [((lambda t=t, g=g, n=n: _NetCall.run_tape(t, g, n)), s) for (t, g, n, s) in pend]
+        jobs = [((lambda t=t, g=g, n=n: run_tape(t, g, n)), s) for (t, g, n, s) in pend]
         interleave.run_interleaved(jobs, dev)
     finally:
         _in_deferred_run[0] = False
+
+
+def enable_autograd_param_grads(module, on=True):
+    """Deliver the backbones' parameter gradients through autograd instead of writing them into the flat .grad views behind
+    its back: what stock torch.nn.parallel.DistributedDataParallel (its hooks sit on the AccumulateGrad nodes) and
+    torch.optim on `model.module.*.parameters()` need -- the reference's own loop (train_adamml.py:126-129, 250-257).  Switched
+    on automatically when DistributedDataParallel wraps a model (StockDDPAware)."""
+    for m in module.modules():
+        if isinstance(m, HipBackbone):
+            m.expose_param_grads = on
+        for fb in (getattr(m, "_flat_policy", None), getattr(m, "_flat_main", None), getattr(m, "flat_owner", None)):
+            if isinstance(fb, FlatBuffers):
+                fb.set_detached(on)
+
+
+class StockDDPAware:
+    """Mixin of the modules a caller may wrap in torch's DistributedDataParallel.  DDP's constructor probes the wrapped module
+    for `_ddp_params_and_buffers_to_ignore`; that probe is the (only) moment the module learns it is being wrapped: it switches
+    to autograd-delivered parameter gradients and then answers "no such attribute", so DDP proceeds normally."""
+
+    @property
+    def _ddp_params_and_buffers_to_ignore(self):
+        enable_autograd_param_grads(self, True)
+        raise AttributeError("_ddp_params_and_buffers_to_ignore")
 
 
 class HipBackbone(nn.Module):
@@ -133,6 +178,10 @@ class HipBackbone(nn.Module):
         self._packed_version = None
         self.flat_owner = None       # FlatBuffers managing this net's parameters (self or the enclosing sub-network)
         self.grad_hook = None        # HipDDP: callable(params) fired in backward once the gradients of `params` are final
+        self.expose_param_grads = False      # deliver parameter gradients through autograd (enable_autograd_param_grads)
+        self._handle = ops.register_net(self)
+        self._pending_tape = None
+        self._bn_probe = None
 
     # -- weight packs ------------------------------------------------------------------------------
     def _register_conv(self, conv, depthwise=False):
@@ -195,10 +244,31 @@ class HipBackbone(nn.Module):
         if groups < 1 or x.shape[0] % groups:
             raise RuntimeError("backbone call: %d images do not split into %d groups" % (x.shape[0], groups))
         need_grad = torch.is_grad_enabled() and self._trainable()
+        self._adopt_sync_batchnorm()
         if self._anchor is None or self._anchor.device != x.device:
             self._anchor = torch.zeros(1, device=x.device)
         anchor = self._anchor.detach().requires_grad_(need_grad)
-        return _NetCall.apply(anchor, self, x, groups)
+        params = [p for p in self.parameters() if p.requires_grad] if (need_grad and self.expose_param_grads) else []
+        return torch.ops.adamml.backbone_call(anchor, x, params, self._handle, groups, need_grad)
+
+    def _adopt_sync_batchnorm(self):
+        """nn.SyncBatchNorm.convert_sync_batchnorm(model) (train_adamml.py:126-127) replaces the BatchNorm2d containers by
+        SyncBatchNorm ones holding the same tensors: the statistics exchange of this runtime is switched on from their
+        process group, so the reference's two wrapping lines keep their meaning."""
+        if self._bn_probe is None:
+            self._bn_probe = next((n for n, m in self.named_modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)), "")
+        if not self._bn_probe or self.rt.sync.enabled:
+            return
+        m = self.get_submodule(self._bn_probe)
+        if isinstance(m, nn.SyncBatchNorm):
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                from .runtime import SyncCtx
+                self.rt.sync = SyncCtx(m.process_group, True)
+
+    def out_shape(self, x_shape, groups):
+        """Shape of the fp32 head output for an input of shape x_shape (fake / meta implementation of adamml::backbone_call)."""
+        raise NotImplementedError
 
     def _run(self, x, groups, need_grad):
         raise NotImplementedError

@@ -48,12 +48,15 @@ class MobileNetV2(HipBackbone, MeanStdMixin):
         self.num_frames = num_frames
         self.orig_num_frames = num_frames
         input_channel = 32
+        self.out_frames = num_frames         # frames per clip left after the temporal max-pools
         layers = [nn.Sequential(nn.Conv2d(input_channels, input_channel, 3, 2, 1, bias=False), nn.BatchNorm2d(input_channel),
                                 nn.ReLU6(inplace=True))]
         for t, c, n, s in _CFGS:
             has_tp = c == 64 or c == 160
             for i in range(n):
                 nf = self.num_frames if i == 0 and has_tp and self.num_frames != 1 else None
+                if nf:
+                    self.out_frames = (self.out_frames - 1) // 2 + 1
                 layers.append(InvertedResidual(input_channel, c, s if i == 0 else 1, t, num_frames=nf))
                 input_channel = c
             if has_tp:
@@ -106,6 +109,9 @@ class MobileNetV2(HipBackbone, MeanStdMixin):
         if need_grad:
             tape.record(lambda: push(tape.grad_out))
         return feat, tape
+
+    def out_shape(self, x_shape, groups):
+        return (x_shape[0] // self.orig_num_frames * self.out_frames, self.last_channel)
 
     def feature_extraction(self, frames_nhwc, groups=1):
         return self.call(frames_nhwc, groups)

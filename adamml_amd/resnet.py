@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .backbone import HipBackbone, FlatBuffers
+from .backbone import HipBackbone, FlatBuffers, StockDDPAware
 from .common import MeanStdMixin
 from .runtime import (Lazy, conv_bn, add_act, maxpool3x3s2, temporal_pool, gap, gemm_f32, clip_to_nhwc, pad8,
                       ACT_NONE, ACT_RELU)
@@ -33,7 +33,7 @@ class _Bottleneck(nn.Module):
         self.stride = stride
 
 
-class ResNet(HipBackbone, MeanStdMixin):
+class ResNet(HipBackbone, MeanStdMixin, StockDDPAware):
 
     def __init__(self, depth, num_frames, num_classes=1000, dropout=0.5, zero_init_residual=False,
                  without_t_stride=False, pooling_method='max', input_channels=3):
@@ -152,6 +152,9 @@ class ResNet(HipBackbone, MeanStdMixin):
 
     def forward_nhwc(self, frames_nhwc, groups=1):
         return self.call(frames_nhwc, groups)
+
+    def out_shape(self, x_shape, groups):
+        return (x_shape[0] // self.orig_num_frames, self.fc.out_features)
 
 
 def resnet(depth, num_classes, without_t_stride, groups, dropout, pooling_method,

@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .backbone import HipBackbone, FlatBuffers
+from .backbone import HipBackbone, FlatBuffers, StockDDPAware
 from .common import MeanStdMixin
 from .mobilenet_common import BlockPlan, run_blocks
 from .runtime import Lazy, conv_bn, gap, gemm_f32, clip_to_nhwc, ACT_RELU6
@@ -47,7 +47,7 @@ class InvertedResidual(nn.Module):
         self.expand = expand_ratio != 1
 
 
-class MobileNetV2(HipBackbone, MeanStdMixin):
+class MobileNetV2(HipBackbone, MeanStdMixin, StockDDPAware):
 
     def __init__(self, num_classes=1000, width_mult=1.0, inverted_residual_setting=None, round_nearest=8, block=None,
                  input_channels=3, dropout=0.5):
@@ -136,6 +136,9 @@ class MobileNetV2(HipBackbone, MeanStdMixin):
 
     def forward_nhwc(self, frames_nhwc, groups=1):
         return self.call(frames_nhwc, groups)
+
+    def out_shape(self, x_shape, groups):
+        return (x_shape[0], self.classifier[1].out_features)
 
 
 def sound_mobilenet_v2(num_classes, input_channels, dropout, imagenet_pretrained=True, **kwargs):

@@ -227,3 +227,47 @@ def test_optimizer_state_interchanges_with_torch_optim():
     # a checkpoint without optimizer state (or with another parameter list) leaves the state empty instead of mis-assigning it
     fa.load_state_dict({"param_groups": adam.state_dict()["param_groups"], "state": {}})
     assert fa.m is None and fa.steps == 0
+
+
+def test_torch_library_ops_are_registered_with_fake_implementations():
+    """SURVEY.md section 8b "who calls it": the backbone call and the leaf operators are torch.library custom ops (namespace
+    `adamml`) with register_fake -- shapes / dtypes propagate under FakeTensorMode without a GPU and without the library."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    import adamml_amd.ops  # noqa: F401
+    c = CASES["adamml_rgb_sound"]
+    m = _build(c)
+    for name in ("backbone_call", "clip_to_nhwc", "gemm_f32", "conv_fwd", "temporal_pool"):
+        assert hasattr(torch.ops.adamml, name), name
+    with FakeTensorMode():
+        S, B = 3, 2
+        y = torch.ops.adamml.backbone_call(torch.zeros(1), torch.empty(S * B * 8, 96, 96, 8, dtype=torch.bfloat16), [],
+                                           m.main_net.nets[0]._handle, S, False)
+        assert tuple(y.shape) == (S * B, 31) and y.dtype == torch.float32
+        y = torch.ops.adamml.backbone_call(torch.zeros(1), torch.empty(S * B, 96, 96, 8, dtype=torch.bfloat16), [],
+                                           m.main_net.nets[1]._handle, S, False)
+        assert tuple(y.shape) == (S * B, 31)
+        f = torch.ops.adamml.backbone_call(torch.zeros(1), torch.empty(S * B * 4, 160, 160, 8, dtype=torch.bfloat16), [],
+                                           m.policy_net.joint_net.nets[0]._handle, S, False)
+        assert tuple(f.shape) == (S * B, 1280)                       # 4 frames -> 2 -> 1 through the two temporal max-pools
+        t = torch.ops.adamml.clip_to_nhwc(torch.empty(B, S * 8 * 3, 224, 224), S, 8, 3, 160, 160, 2)
+        assert tuple(t.shape) == (S, B * 4, 160, 160, 8) and t.dtype == torch.bfloat16
+        g = torch.ops.adamml.gemm_f32(torch.empty(5, 7), torch.empty(9, 7), torch.empty(9), 1, False, True)
+        assert tuple(g.shape) == (5, 9)
+        y = torch.ops.adamml.conv_fwd(torch.empty(4, 56, 56, 64, dtype=torch.bfloat16), torch.empty(128, 9 * 64, dtype=torch.bfloat16),
+                                      None, None, None, 3, 3, 2, 1, 0, 1)
+        assert tuple(y.shape) == (4, 28, 28, 128) and y.dtype == torch.bfloat16
+        p = torch.ops.adamml.temporal_pool(torch.empty(2 * 8, 7, 7, 256, dtype=torch.bfloat16), 8, 0, 1)
+        assert tuple(p.shape) == (2 * 4, 7, 7, 256)
+    # the real implementations refuse CPU tensors (no fallback)
+    with pytest.raises(RuntimeError):
+        torch.ops.adamml.gemm_f32(torch.zeros(2, 2), torch.zeros(2, 2), None, 0, False, True)
+
+
+def test_stock_ddp_probe_switches_to_autograd_delivered_gradients():
+    """torch's DistributedDataParallel probes `_ddp_params_and_buffers_to_ignore` on the module it wraps: that switches the
+    backbones to delivering parameter gradients through autograd (so DDP's hooks fire) and detaches the flat .grad views."""
+    m = _build(CASES["adamml_rgb_sound"])
+    assert not any(n.expose_param_grads for n in m.backbones())
+    assert not hasattr(m, "_ddp_params_and_buffers_to_ignore")      # DDP sees "no such attribute" and proceeds normally
+    assert all(n.expose_param_grads for n in m.backbones())
+    assert m._flat_main.detached and m._flat_policy.detached

@@ -99,7 +99,7 @@ def test_two_rank_syncbn_step_equals_single_process_full_batch():
     for k in BN_GRAD_KEYS:
         e = rel(two["bn_grads"][k], one["bn_grads"][k])
         print("  %-60s averaged gradient rel L2 %.2e" % (k, e))
-        assert e <= 6e-2, (k, e)               # (a world-times-too-large SyncBN gamma / beta gradient would read 1.0)
+        assert e <= 0.15, (k, e)               # (a world-times-too-large SyncBN gamma / beta gradient would read 1.0; measured 2e-2 .. 7e-2)
     # deep in a randomly initialised train-mode-BatchNorm ResNet two runs of the SAME pipeline already differ by 0.2-0.5 in
     # relative L2 (atomic order, bf16 storage; tests/test_models_gpu.py GRAD_FLOOR): direction only
     assert cos >= 0.6
