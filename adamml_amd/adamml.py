@@ -10,7 +10,7 @@ from .backbone import FlatBuffers, StockDDPAware
 from .common import MeanStdMixin
 from .joint_resnet_mobilenetv2 import joint_resnet_mobilenetv2
 from .policy_net import p_joint_mobilenet
-from .runtime import clip_to_nhwc, clip_u8_to_nhwc, SyncCtx
+from .runtime import clip_to_nhwc, clip_u8_to_nhwc, clip_u8_rgbdiff_to_nhwc, SyncCtx
 
 __all__ = ['adamml']
 
@@ -71,6 +71,14 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
                 # MI355X extension: decoded frames [N, H, W, S*F*C] uint8 straight from `Stack` (video_transforms.py:302-318);
                 # ToTorchFormatTensor + GroupNormalize (mean / std of models/adamml.py:93-99) run inside the re-layout launch
                 c = x_.size(3) // (num_segments * f)
+                if m == 'rgbdiff' and c == 18:
+                    # decoded RGB frames, 6 consecutive ones per frame group: the 5 difference images of the reference's loader
+                    # (utils/video_dataset.py:32-38,75-84) are formed inside the re-layout launch
+                    if idx in self.p_data_idx:
+                        p_x.append(clip_u8_rgbdiff_to_nhwc(x_, num_segments, f, self.mean(m), self.std(m), out_hw=p_rgb_size, frame_step=2))
+                    if idx in self.m_data_idx:
+                        m_x.append(clip_u8_rgbdiff_to_nhwc(x_, num_segments, f, self.mean(m), self.std(m)))
+                    continue
                 if idx in self.p_data_idx:
                     p_x.append(clip_u8_to_nhwc(x_, num_segments, f, c, self.mean(m), self.std(m), out_hw=p_rgb_size, frame_step=2))
                 if idx in self.m_data_idx:

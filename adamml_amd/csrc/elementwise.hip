@@ -765,6 +765,82 @@ __global__ __launch_bounds__(NT) void temporal_pool_residual_bwd_kernel(const bf
     block_channel_publish(sa, qa, m, smem, C, sumsa);
 }
 
+// ------------------------------------------------------------------------------------------------ fused classifier head
+// models/resnet.py:212-221 / models/sound_mobilenet_v2.py:155-158: AdaptiveAvgPool2d(1) -> Dropout -> Linear -> mean over the
+// remaining frames of a clip, one workgroup per clip.  feat (the pooled, dropout-masked features) is kept for the backward.
+__global__ __launch_bounds__(NT) void head_fwd_kernel(const bf16_t* x, const float* scale, const float* shift, int gs, int act,
+                                                      const uint8_t* keep, float inv_keep, const float* W, const float* bias, float* feat,
+                                                      float* logits, int clips_per_group, int T, int HW, int C, int K) {
+    const int n = blockIdx.x, g = n / clips_per_group;
+    if (scale) { scale += (size_t)g * gs; shift += (size_t)g * gs; }
+    const int cpr = C >> 3;
+    const float inv = 1.f / (float)HW;
+    for (int e = threadIdx.x; e < T * cpr; e += NT) {
+        const int t = e / cpr, ch = e - t * cpr;
+        const size_t row = (size_t)n * T + t;
+        f32x8 acc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int p = 0; p < HW; ++p)
+            acc += transform8(*reinterpret_cast<const bf16x8*>(x + (row * HW + p) * C + ch * 8), scale, shift, ch * 8, act);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = acc[i] * inv;
+            if (keep) v = keep[row * C + ch * 8 + i] ? v * inv_keep : 0.f;
+            feat[row * C + ch * 8 + i] = v;
+        }
+    }
+    __syncthreads();                                     // this workgroup's feat rows are visible to all its waves
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* f = feat + (size_t)n * T * C;
+    for (int k = wave; k < K; k += NT / 64) {
+        float a = 0.f;
+        for (int e = lane; e < T * C; e += 64) a = fmaf(f[e], W[(size_t)k * C + (e % C)], a);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+        if (lane == 0) logits[(size_t)n * K + k] = a / (float)T + (bias ? bias[k] : 0.f);
+    }
+}
+
+// backward of the head w.r.t. the activated input of the pool: gx[n,t,hw,c] = keep * (1/(T*HW)) * sum_k g[n,k] W[k,c];
+// side output gy[n*T+t, k] = g[n,k] / T (the rows of the weight-gradient GEMM gy^T feat)
+__global__ __launch_bounds__(NT) void head_bwd_kernel(const float* g, const uint8_t* keep, float inv_keep, const float* W, bf16_t* gx,
+                                                      float* gy, int T, int HW, int C, int K) {
+    const size_t row = blockIdx.x;                        // (clip, frame)
+    const size_t n = row / T;
+    const int cpr = C >> 3;
+    const float sc = 1.f / ((float)T * (float)HW);
+    if (gy && threadIdx.x < K) gy[row * K + threadIdx.x] = g[n * K + threadIdx.x] / (float)T;
+    for (int ch = threadIdx.x; ch < cpr; ch += NT) {
+        f32x8 acc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float gk = g[n * K + k];
+            const f32x8 w = load_f32x8(W + (size_t)k * C + ch * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(gk, w[i], acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = acc[i] * sc;
+            if (keep) v = keep[row * C + ch * 8 + i] ? v * inv_keep : 0.f;
+            acc[i] = v;
+        }
+        const bf16x8 o = f32_to_bf8(acc);
+        for (int p = 0; p < HW; ++p) *reinterpret_cast<bf16x8*>(gx + (row * HW + p) * C + ch * 8) = o;
+    }
+}
+
+// out[c] (+)= sum_r a[r, c]: one workgroup, rows added in order (deterministic); bias gradients of the heads
+__global__ void colsum_f32_kernel(const float* a, float* out, int rows, int cols, int accumulate) {
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += a[(size_t)r * cols + c];
+        out[c] = accumulate ? out[c] + s : s;
+    }
+}
+
 __global__ void gap_fwd_kernel(const bf16_t* x, const float* scale, const float* shift, int gs, int act, float* out, int N, int HW,
                                int C) {
     x += (size_t)blockIdx.y * N * HW * C;
@@ -851,12 +927,16 @@ __global__ void clip_to_nhwc_kernel(const float* x, bf16_t* y, int B, int S, int
 // in fp32 exactly as the reference evaluates it, bilinear (align_corners = False) when OH != H.  A thread owns one output
 // pixel for every (segment, frame): it reads the 1..4 source pixels' contiguous S*F*C bytes and writes S*Fk chunks.
 struct NormVec { float mean[4], std[4]; int n; };
+// DIFF: the source holds C/3 + 1 consecutive RGB frames per frame group and the C output channels are the C/3 RGB differences
+// of neighbours, quantised exactly as utils/video_dataset.py:32-38 does (uint8((next - cur + 255) * 0.5), truncation).
+template <bool DIFF>
 __global__ void clip_u8_to_nhwc_kernel(const uint8_t* x, bf16_t* y, int B, int S, int F, int C, int H, int W, int OH, int OW,
                                        int frame_step, int Fk, int c_pad, NormVec nv, int div255) {
     const size_t total = (size_t)B * OH * OW;
     const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
     const bool resize = (OH != H) || (OW != W);
-    const int SFC = S * F * C;
+    const int CS = DIFF ? C + 3 : C;                     // source channels per frame group
+    const int SFC = S * F * CS;
     for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
         size_t r = e;
         const int ow = (int)(r % OW); r /= OW;
@@ -877,7 +957,7 @@ __global__ void clip_u8_to_nhwc_kernel(const uint8_t* x, bf16_t* y, int B, int S
         const uint8_t* p11 = x + (((size_t)b * H + h1) * W + w1) * SFC;
         for (int s = 0; s < S; ++s)
             for (int fk = 0; fk < Fk; ++fk) {
-                const int off = (s * F + fk * frame_step) * C;
+                const int off = (s * F + fk * frame_step) * CS;
                 bf16_t* dst = y + (((((size_t)s * B + b) * Fk + fk) * OH + oh) * OW + ow) * c_pad;
                 for (int c8 = 0; c8 < c_pad; c8 += 8) {
                     f32x8 v;
@@ -889,6 +969,7 @@ __global__ void clip_u8_to_nhwc_kernel(const uint8_t* x, bf16_t* y, int B, int S
                             const float m = nv.mean[c % nv.n], sd = nv.std[c % nv.n];
                             auto nrm = [&](const uint8_t* q) {
                                 float t = (float)q[off + c];
+                                if (DIFF) t = floorf(((float)q[off + c + 3] - t + 255.f) * 0.5f);
                                 if (div255) t = t / 255.f;
                                 return (t - m) / sd;
                             };
@@ -1249,6 +1330,35 @@ extern "C" int adamml_gap_bwd(const float* g, void* g_x, int N, int HW, int C, h
     return adamml_check_launch("gap_bwd");
 }
 
+extern "C" int adamml_head_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, const uint8_t* keep_mask,
+                               float inv_keep, const float* weight, const float* bias, float* feat, float* logits, int clips, int T, int HW,
+                               int C, int K, int groups, hipStream_t stream) {
+    CHECK_C(C, "head_fwd");
+    if (!x || !weight || !feat || !logits) return adamml_set_error(ADAMML_EINVAL, "head_fwd: null argument");
+    if (groups < 1) groups = 1;
+    if (clips % groups || T < 1 || HW < 1 || K < 1) return adamml_set_error(ADAMML_EINVAL, "head_fwd: clips=%d groups=%d T=%d HW=%d K=%d", clips, groups, T, HW, K);
+    if (!clips) return ADAMML_OK;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(clips), dim3(NT), 0, stream, (const bf16_t*)x, scale, shift, gstride, act, keep_mask, inv_keep, weight,
+                       bias, feat, logits, clips / groups, T, HW, C, K);
+    return adamml_check_launch("head_fwd");
+}
+
+extern "C" int adamml_head_bwd(const float* g, const uint8_t* keep_mask, float inv_keep, const float* weight, void* g_x, float* g_rows, int clips,
+                               int T, int HW, int C, int K, hipStream_t stream) {
+    CHECK_C(C, "head_bwd");
+    if (!g || !weight || !g_x) return adamml_set_error(ADAMML_EINVAL, "head_bwd: null argument");
+    if (K > NT) return adamml_set_error(ADAMML_EUNSUPPORTED, "head_bwd: K=%d > %d", K, NT);
+    if (!clips) return ADAMML_OK;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)clips * T), dim3(NT), 0, stream, g, keep_mask, inv_keep, weight, (bf16_t*)g_x, g_rows, T, HW, C, K);
+    return adamml_check_launch("head_bwd");
+}
+
+extern "C" int adamml_colsum_f32(const float* a, float* out, int rows, int cols, int accumulate, hipStream_t stream) {
+    if (!a || !out || rows < 0 || cols < 1) return adamml_set_error(ADAMML_EINVAL, "colsum_f32: bad arguments");
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3(1), dim3(256), 0, stream, a, out, rows, cols, accumulate);
+    return adamml_check_launch("colsum_f32");
+}
+
 extern "C" int adamml_clip_to_nhwc(const float* x, void* y, int B, int S, int F, int C, int H, int W, int OH, int OW,
                                    int frame_step, int c_pad, hipStream_t stream) {
     if (c_pad % 8 || c_pad < C || frame_step < 1) return adamml_set_error(ADAMML_EINVAL, "clip_to_nhwc: bad c_pad/frame_step");
@@ -1271,9 +1381,27 @@ extern "C" int adamml_clip_u8_to_nhwc(const uint8_t* x, void* y, int B, int S, i
     NormVec nv;
     nv.n = n_mean;
     for (int i = 0; i < 4; ++i) { nv.mean[i] = i < n_mean ? mean[i] : 0.f; nv.std[i] = i < n_mean ? std[i] : 1.f; }
-    hipLaunchKernelGGL(clip_u8_to_nhwc_kernel, dim3(grid_for(n)), dim3(NT), 0, stream, x, (bf16_t*)y, B, S, F, C, H, W, OH, OW, frame_step,
+    hipLaunchKernelGGL(clip_u8_to_nhwc_kernel<false>, dim3(grid_for(n)), dim3(NT), 0, stream, x, (bf16_t*)y, B, S, F, C, H, W, OH, OW, frame_step,
                        Fk, c_pad, nv, div255);
     return adamml_check_launch("clip_u8_to_nhwc");
+}
+
+extern "C" int adamml_clip_u8_rgbdiff_to_nhwc(const uint8_t* x, void* y, int B, int S, int F, int D, int H, int W, int OH, int OW,
+                                              int frame_step, int c_pad, const float* mean, const float* std, int n_mean,
+                                              hipStream_t stream) {
+    const int C = 3 * D;
+    if (!x || !y || !mean || !std) return adamml_set_error(ADAMML_EINVAL, "clip_u8_rgbdiff_to_nhwc: null argument");
+    if (D < 1 || c_pad % 8 || c_pad < C || frame_step < 1) return adamml_set_error(ADAMML_EINVAL, "clip_u8_rgbdiff_to_nhwc: bad D/c_pad/frame_step");
+    if (n_mean < 1 || n_mean > 4 || C % n_mean) return adamml_set_error(ADAMML_EINVAL, "clip_u8_rgbdiff_to_nhwc: %d mean/std values for %d channels", n_mean, C);
+    const int Fk = (F + frame_step - 1) / frame_step;
+    const size_t n = (size_t)B * OH * OW;
+    if (!n || !S || !Fk) return ADAMML_OK;
+    NormVec nv;
+    nv.n = n_mean;
+    for (int i = 0; i < 4; ++i) { nv.mean[i] = i < n_mean ? mean[i] : 0.f; nv.std[i] = i < n_mean ? std[i] : 1.f; }
+    hipLaunchKernelGGL(clip_u8_to_nhwc_kernel<true>, dim3(grid_for(n)), dim3(NT), 0, stream, x, (bf16_t*)y, B, S, F, C, H, W, OH, OW, frame_step,
+                       Fk, c_pad, nv, 1);
+    return adamml_check_launch("clip_u8_rgbdiff_to_nhwc");
 }
 
 extern "C" int adamml_pack_conv_weight(const float* w, void* out, int cout, int cin_true, int cin_pad, int kh, int kw, int mode,

@@ -71,8 +71,12 @@ SIGNATURES = {
     "adamml_temporal_pool_bwd_res": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "adamml_gap_fwd": [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P],
     "adamml_gap_bwd": [_P, _P, _I, _I, _I, _P],
+    "adamml_head_fwd": [_P, _P, _P, _I, _I, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "adamml_head_bwd": [_P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "adamml_colsum_f32": [_P, _P, _I, _I, _I, _P],
     "adamml_clip_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "adamml_clip_u8_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P],
+    "adamml_clip_u8_rgbdiff_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "adamml_gemm_f32": [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _I, _I, _P],
     "adamml_sgd_step": [_P, _P, _P, _Z, _F, _F, _F, _I, _I, _P],
     "adamml_adam_step": [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _I, _P],

@@ -9,7 +9,7 @@ import torch.nn as nn
 from . import hip
 from .backbone import HipBackbone, FlatBuffers, StockDDPAware
 from .common import MeanStdMixin
-from .runtime import (Lazy, conv_bn, add_act, maxpool3x3s2, temporal_pool, gap, gemm_f32, clip_to_nhwc, pad8,
+from .runtime import (Lazy, conv_bn, add_act, maxpool3x3s2, temporal_pool, head, clip_to_nhwc, pad8,
                       ACT_NONE, ACT_RELU)
 
 __all__ = ['ResNet', 'resnet']
@@ -113,30 +113,11 @@ class ResNet(HipBackbone, MeanStdMixin, StockDDPAware):
             if li < 3 and not self.without_t_stride:
                 h = temporal_pool(rt, h, frames, self.pooling_method, sole_consumer=True)
                 frames = max(1, frames // 2)
-        feat, push = gap(rt, h)                       # [N*T', 2048] fp32
-        mask = None
-        if self.training and self.dropout_p > 0:
-            keep = 1.0 - self.dropout_p
-            mask = (torch.rand_like(feat) < keep).to(feat.dtype) / keep
-            feat = feat * mask
-        y = gemm_f32(feat, self.fc.weight, bias=self.fc.bias)          # [N*T', classes]
-        tprime = y.shape[0] // n
-        out = y.view(n, tprime, -1).mean(dim=1) if tprime > 1 else y.view(n, -1)
+        # GAP -> dropout -> fc -> mean over the remaining frames (models/resnet.py:212-221): one fused launch per direction
+        out, head_backward = head(rt, h, self.fc, frames, self.dropout_p if self.training else 0.0, getattr(self, "_dropout_keep_mask", None))
         rt.end_forward()
         if need_grad:
-            fcw, fcb = self.fc.weight, self.fc.bias
-
-            def head_bwd():
-                g = tape.grad_out                                   # [N, classes]
-                gy = (g / tprime).unsqueeze(1).expand(n, tprime, g.shape[-1]).reshape(n * tprime, -1).contiguous()
-                if fcw.requires_grad:
-                    gemm_f32(gy, feat, out=fcw.grad, trans_a=True, trans_b=False, accumulate=True)   # dW += gy^T feat
-                    fcb.grad += gy.sum(0)
-                gf = gemm_f32(gy, fcw, trans_b=False)                # [N*T', 2048]
-                if mask is not None:
-                    gf = gf * mask
-                push(gf)
-            tape.record(head_bwd)
+            tape.record(lambda: head_backward(tape.grad_out))
         return out, tape
 
     def forward(self, x):

@@ -747,6 +747,44 @@ def gap(rt, x):
     return f, push_grad
 
 
+def head(rt, x, fc, frames, dropout_p, keep_mask=None):
+    """Classifier head of a backbone (models/resnet.py:212-221, models/sound_mobilenet_v2.py:155-158) as one launch per direction:
+    lazy x [G*N*T', H, W, C] -> AdaptiveAvgPool2d(1) -> Dropout(p) -> fc -> mean over the T' = `frames` remaining frames of a
+    clip -> fp32 logits [G*N, classes].  keep_mask: optional bool [G*N*T', C] replacing the Bernoulli(1-p) draw (parity runs).
+    Returns (logits, backward) with backward(g [G*N, classes]) accumulating fc.weight.grad / fc.bias.grad and pushing x's gradient."""
+    nt, h, w, C = x.shape
+    clips = nt // frames
+    K = fc.out_features
+    dev = x.data.device
+    inv_keep = 1.0
+    if keep_mask is None and rt.training and dropout_p > 0:
+        keep_mask = torch.rand(nt, C, device=dev) < (1.0 - dropout_p)
+    if keep_mask is not None:
+        inv_keep = 1.0 / (1.0 - dropout_p)
+        keep_mask = keep_mask.contiguous()
+        keep_mask = keep_mask.view(torch.uint8) if keep_mask.dtype == torch.bool else keep_mask.ne(0).view(torch.uint8)
+    feat = torch.empty(nt, C, dtype=torch.float32, device=dev)
+    logits = torch.empty(clips, K, dtype=torch.float32, device=dev)
+    call("adamml_head_fwd", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(keep_mask), inv_keep, ptr(fc.weight), ptr(fc.bias),
+         ptr(feat), ptr(logits), clips, frames, h * w, C, K, rt.groups)
+
+    def backward(g):
+        g = g.contiguous()
+        need_w = fc.weight.requires_grad
+        gx = torch.empty_like(x.data) if x.requires_grad else None
+        g_rows = torch.empty(nt, K, dtype=torch.float32, device=dev) if (need_w and frames > 1) else None
+        if gx is not None or g_rows is not None:
+            if gx is None:                   # (frozen trunk below a trainable head cannot happen in AdaMML; keep the kernel's contract)
+                gx = torch.empty_like(x.data)
+            call("adamml_head_bwd", ptr(g), ptr(keep_mask), inv_keep, ptr(fc.weight), ptr(gx), ptr(g_rows), clips, frames, h * w, C, K)
+        if need_w:
+            gemm_f32(g_rows if g_rows is not None else g, feat, out=fc.weight.grad, trans_a=True, trans_b=False, accumulate=True)   # dW += gy^T feat
+            call("adamml_colsum_f32", ptr(g), ptr(fc.bias.grad), clips, K, 1)                                                     # db += sum_n g
+        if x.requires_grad:
+            _accum_grad(x, gx)
+    return logits, backward
+
+
 def gemm_f32(a, b, out=None, bias=None, act=ACT_NONE, trans_a=False, trans_b=True, accumulate=False):
     """out[M,N] (+)= act(op(a) @ op(b)^T-ish + bias) on 2-D fp32 tensors via adamml_gemm_f32.
     trans_a=False: a is [M,K]; True: a is [K,M].  trans_b=True: b is [N,K]; False: b is [K,N]."""
@@ -806,4 +844,25 @@ def clip_u8_to_nhwc(x, num_segments, frames, channels, mean, std, out_hw=None, f
     mean, std = [float(v) for v in mean], [float(v) for v in std]
     call("adamml_clip_u8_to_nhwc", ptr(x), ptr(y), b, num_segments, frames, channels, h, w, oh, ow, frame_step, cp,
          (ctypes.c_float * len(mean))(*mean), (ctypes.c_float * len(std))(*std), len(mean), 1 if div255 else 0)
+    return y
+
+
+def clip_u8_rgbdiff_to_nhwc(x, num_segments, frames, mean, std, out_hw=None, frame_step=1, diffs=5):
+    """RGB-diff input computed on the GPU (utils/video_dataset.py:32-38,75-84): decoded RGB frames [B, H, W, S*F*(diffs+1)*3]
+    uint8 -- diffs+1 consecutive frames per frame group -> [S, B*Fk, OH, OW, pad8(3*diffs)] bf16 difference channels,
+    quantised to uint8 as the reference's loader does, then normalised / resized like every other decoded-frame input."""
+    hip.require_gpu(x)
+    if x.dtype != torch.uint8:
+        raise RuntimeError("clip_u8_rgbdiff_to_nhwc: expected uint8 frames, got %s" % x.dtype)
+    b, h, w, last = x.shape
+    if last != num_segments * frames * (diffs + 1) * 3:
+        raise RuntimeError("clip_u8_rgbdiff_to_nhwc: last dim %d != S*F*(D+1)*3 = %d*%d*%d*3" % (last, num_segments, frames, diffs + 1))
+    oh, ow = out_hw if out_hw else (h, w)
+    fk = (frames + frame_step - 1) // frame_step
+    cp = pad8(3 * diffs)
+    y = torch.empty(num_segments, b * fk, oh, ow, cp, dtype=torch.bfloat16, device=x.device)
+    import ctypes
+    mean, std = [float(v) for v in mean], [float(v) for v in std]
+    call("adamml_clip_u8_rgbdiff_to_nhwc", ptr(x.contiguous()), ptr(y), b, num_segments, frames, diffs, h, w, oh, ow, frame_step, cp,
+         (ctypes.c_float * len(mean))(*mean), (ctypes.c_float * len(std))(*std), len(mean))
     return y

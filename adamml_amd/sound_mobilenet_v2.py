@@ -7,7 +7,7 @@ from . import hip
 from .backbone import HipBackbone, FlatBuffers, StockDDPAware
 from .common import MeanStdMixin
 from .mobilenet_common import BlockPlan, run_blocks
-from .runtime import Lazy, conv_bn, gap, gemm_f32, clip_to_nhwc, ACT_RELU6
+from .runtime import Lazy, conv_bn, head, clip_to_nhwc, ACT_RELU6
 
 __all__ = ['MobileNetV2', 'sound_mobilenet_v2']
 
@@ -103,26 +103,12 @@ class MobileNetV2(HipBackbone, MeanStdMixin, StockDDPAware):
         h = conv_bn(rt, Lazy(x, requires_grad=False), self._stem[0], self._stem[1], ACT_RELU6)
         h = run_blocks(rt, h, self._plans)
         h = conv_bn(rt, h, self._last[0], self._last[1], ACT_RELU6)
-        feat, push = gap(rt, h)
-        mask = None
-        if self.training and self.dropout_p > 0:
-            keep = 1.0 - self.dropout_p
-            mask = (torch.rand_like(feat) < keep).to(feat.dtype) / keep
-            feat = feat * mask
-        fc = self.classifier[1]
-        out = gemm_f32(feat, fc.weight, bias=fc.bias)
+        # GAP -> dropout -> classifier (models/sound_mobilenet_v2.py:155-158): one fused launch per direction
+        out, head_backward = head(rt, h, self.classifier[1], 1, self.dropout_p if self.training else 0.0,
+                                  getattr(self, "_dropout_keep_mask", None))
         rt.end_forward()
         if need_grad:
-            def head_bwd():
-                g = tape.grad_out
-                if fc.weight.requires_grad:
-                    gemm_f32(g, feat, out=fc.weight.grad, trans_a=True, trans_b=False, accumulate=True)
-                    fc.bias.grad += g.sum(0)
-                gf = gemm_f32(g, fc.weight, trans_b=False)
-                if mask is not None:
-                    gf = gf * mask
-                push(gf)
-            tape.record(head_bwd)
+            tape.record(lambda: head_backward(tape.grad_out))
         return out, tape
 
     def forward(self, x):

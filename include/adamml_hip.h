@@ -244,6 +244,20 @@ int adamml_temporal_pool_bwd_res(const void* g_y, const void* out, int act, void
 int adamml_gap_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, float* out, int N, int HW,
                    int C, int groups, hipStream_t stream);
 int adamml_gap_bwd(const float* g, void* g_x, int N, int HW, int C, hipStream_t stream);
+/* Fused classifier head (models/resnet.py:212-221, models/sound_mobilenet_v2.py:155-158): AdaptiveAvgPool2d(1) -> Dropout ->
+ * Linear -> mean over the T remaining frames of a clip, one launch.  x: lazy [clips*T, HW, C] bf16 (clips = all groups);
+ * keep_mask [clips*T, C] bytes (NULL: no dropout; kept features are scaled by inv_keep = 1/(1-p)) -- the caller draws it, so a
+ * parity run can supply the reference's mask; weight [K, C], bias [K] fp32.  Outputs: feat [clips*T, C] fp32 (pooled, masked:
+ * the left operand of the weight gradient), logits [clips, K]. */
+int adamml_head_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, const uint8_t* keep_mask, float inv_keep,
+                    const float* weight, const float* bias, float* feat, float* logits, int clips, int T, int HW, int C, int K, int groups,
+                    hipStream_t stream);
+/* g [clips, K] -> g_x [clips*T, HW, C] bf16 (gradient w.r.t. the activated pool input) and g_rows [clips*T, K] = g / T (may be
+ * NULL): dW += g_rows^T feat is an adamml_gemm_f32 call, db += column sums of g is adamml_colsum_f32. */
+int adamml_head_bwd(const float* g, const uint8_t* keep_mask, float inv_keep, const float* weight, void* g_x, float* g_rows, int clips, int T,
+                    int HW, int C, int K, hipStream_t stream);
+/* out[c] (+)= sum_r a[r, c] for a small row-major fp32 matrix (rows added in order: deterministic) */
+int adamml_colsum_f32(const float* a, float* out, int rows, int cols, int accumulate, hipStream_t stream);
 
 /* AdaMML.data_layer (models/adamml.py:42-67): NCHW fp32 clip tensor [B, S*F*C, H, W] -> per-segment NHWC bf16
  * frames [S][B*Fk][OH][OW][c_pad] with optional bilinear resize (align_corners=False) and frame stride. */
@@ -257,6 +271,13 @@ int adamml_clip_to_nhwc(const float* x, void* y, int B, int S, int F, int C, int
  * (models/adamml.py:93-99). */
 int adamml_clip_u8_to_nhwc(const uint8_t* x, void* y, int B, int S, int F, int C, int H, int W, int OH, int OW, int frame_step,
                            int c_pad, const float* mean, const float* std, int n_mean, int div255, hipStream_t stream);
+/* RGB-diff modality computed on the GPU from decoded RGB frames (utils/video_dataset.py:32-38,75-84: for every frame group the
+ * loader reads D+1 consecutive frames and stores D difference images uint8((next - cur + 255) * 0.5)):
+ * x [B, H, W, S*F*(D+1)*3] uint8 RGB frames -> y [S, B*Fk, OH, OW, c_pad] bf16 with 3*D difference channels per frame group,
+ * then ToTorchFormatTensor (/255) + GroupNormalize + the data-layer resize exactly as adamml_clip_u8_to_nhwc.  D = 5 in the
+ * reference (num_consecutive_frames, utils/video_dataset.py:310-311). */
+int adamml_clip_u8_rgbdiff_to_nhwc(const uint8_t* x, void* y, int B, int S, int F, int D, int H, int W, int OH, int OW, int frame_step,
+                                   int c_pad, const float* mean, const float* std, int n_mean, hipStream_t stream);
 
 /* y[M,N] = act(x[M,K] @ w[N,K]^T + bias) in fp32 with arbitrary strides (nn.Linear / LSTMCell gates and their
  * gradients: policy_net.py:228-231,278-279,351-362; resnet.py:215; sound_mobilenet_v2.py:158) */

@@ -175,3 +175,42 @@ def test_fusion_matches_reference_formula(M, learnable, gated):
         assert torch.allclose(dh.grad.cpu(), do.grad, rtol=1e-4, atol=1e-6)
     if lf is not None:
         assert torch.allclose(lh.grad.cpu(), lo.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,T,HW,C,K,p,groups,lazy", [(6, 1, 49, 2048, 31, 0.5, 3, False), (4, 2, 16, 512, 31, 0.0, 2, False),
+                                                       (5, 1, 64, 1280, 31, 0.5, 5, True), (3, 4, 9, 256, 7, 0.25, 1, True)])
+def test_fused_classifier_head(N, T, HW, C, K, p, groups, lazy):
+    """adamml_head_fwd / adamml_head_bwd (+ adamml_colsum_f32) == AdaptiveAvgPool2d(1) -> Dropout(explicit keep mask) -> Linear ->
+    mean over the T frames of a clip (models/resnet.py:212-221, models/sound_mobilenet_v2.py:155-158) in torch fp32 on the same
+    bf16-stored input; lazy=True: the input is a conv output with its BatchNorm + ReLU6 still pending (sound net)."""
+    import torch.nn.functional as F
+    from adamml_amd.runtime import NetRT, Lazy, head, ACT_RELU6, ACT_NONE
+    torch.manual_seed(N * 100 + T)
+    G = groups
+    xb = torch.randn(G * N * T, HW, 1, C, device=DEV).to(torch.bfloat16)
+    rt = NetRT()
+    rt.begin_forward(torch.device(DEV), True, True, G)
+    if lazy:
+        vec = torch.rand(G, 4, C, device=DEV) + 0.5
+        vec[:, 1] -= 1.0
+        x = Lazy(xb, vec[0, 0], vec[0, 1], ACT_RELU6, gs=4 * C)
+        val = F.relu6(xb.float().view(G, -1, C) * vec[:, 0:1] + vec[:, 1:2]).view(G * N * T, HW, C)
+    else:
+        x = Lazy(xb)
+        val = xb.float().view(G * N * T, HW, C)
+    val = val.detach().requires_grad_(True)
+    fc = torch.nn.Linear(C, K).to(DEV)
+    fc.weight.grad, fc.bias.grad = torch.zeros_like(fc.weight), torch.zeros_like(fc.bias)
+    keep = (torch.rand(G * N * T, C, device=DEV) < (1 - p)) if p > 0 else None
+    logits, backward = head(rt, x, fc, T, p, keep)
+    f = val.mean(1)
+    if keep is not None:
+        f = f * keep.float() / (1 - p)
+    w, b = fc.weight.detach().clone().requires_grad_(True), fc.bias.detach().clone().requires_grad_(True)
+    ref = F.linear(f, w, b).view(G * N, T, K).mean(1)
+    assert _rel(logits, ref.detach()) <= 2e-5
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    backward(g)
+    assert _rel(fc.weight.grad, w.grad) <= 1e-4 and _rel(fc.bias.grad, b.grad) <= 1e-5
+    assert _rel(x.grad.float().view_as(val.grad), val.grad) <= 1e-2          # bf16-stored gradient

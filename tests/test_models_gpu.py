@@ -264,6 +264,10 @@ def test_adamml(name):
         logits, sel = model(xs, gumbel_exponential=expo)
         pl_err = rel_err(model.last_policy_logits.detach().cpu().numpy(), gold[mode + ".policy_logits"])
         print("  [%s] policy logits rel err vs golden %.4f" % (mode, pl_err))
+        # reduced fixtures (B = 1-2, 64-96 px: 4-18 samples per BatchNorm channel in the deep layers) are ill-conditioned by
+        # construction -- measured 2e-2 .. 0.35 here; the asserted bound for policy logits is in tests/test_parity_fullsize_gpu.py
+        # (full size: 5e-2 measured, 1e-1 asserted; forced-forward replay 1e-6).  Here: plumbing-level sanity only.
+        assert pl_err <= 0.6, pl_err
         assert np.array_equal(np.round(sel.detach().cpu().numpy()), np.round(gold[mode + ".decisions"])), "decisions differ"
         loss = F.cross_entropy(logits, target)
         if model.update_policy_net:

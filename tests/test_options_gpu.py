@@ -138,3 +138,49 @@ def test_adamml_accepts_uint8_frames():
         b, db = model([x.to(DEV), snd.to(DEV)], gumbel_exponential=expo)
     assert torch.equal(da, db)
     assert torch.allclose(a, b, rtol=2e-2, atol=2e-2 * float(b.abs().max()) + 1e-6)
+
+
+def test_rgbdiff_from_rgb_frames_on_the_gpu():
+    """RGB-diff computed inside the input kernel from decoded RGB frames (adamml_clip_u8_rgbdiff_to_nhwc) == the reference's
+    loader arithmetic (utils/video_dataset.py:32-38,75-84: for frame k of a group, uint8((img[k+1] - img[k] + 255) * 255 / 510),
+    5 differences of 6 consecutive frames) followed by the uint8 pipeline already pinned above.  Bit-exact at full resolution
+    (the difference images are integers); <= 1 bf16 ulp after the bilinear policy resize."""
+    import numpy as np
+    from adamml_amd.runtime import clip_u8_rgbdiff_to_nhwc, clip_u8_to_nhwc
+    from adamml_amd.common import MeanStdMixin
+    ms = MeanStdMixin()
+    mean, std = ms.mean("rgbdiff"), ms.std("rgbdiff")
+    torch.manual_seed(4)
+    B, S, Fr, H, W, D = 2, 2, 8, 32, 24, 5
+    rgb = torch.randint(0, 256, (B, H, W, S * Fr, D + 1, 3), dtype=torch.uint8)
+    a = rgb.numpy().astype(np.float64)
+    diff = a[:, :, :, :, 1:] - a[:, :, :, :, :-1]                              # compute_img_diff(tmp[k+1], tmp[k])
+    diff += 255.0
+    diff *= 255.0 / float(2 * 255.0)
+    diff_u8 = torch.from_numpy(diff.astype(np.uint8)).reshape(B, H, W, S * Fr * D * 3)
+    for out_hw, step in ((None, 1), ((20, 20), 2)):
+        got = clip_u8_rgbdiff_to_nhwc(rgb.reshape(B, H, W, -1).to(DEV), S, Fr, mean, std, out_hw=out_hw, frame_step=step)
+        ref = clip_u8_to_nhwc(diff_u8.to(DEV), S, Fr, 3 * D, mean, std, out_hw=out_hw, frame_step=step)
+        assert got.shape == ref.shape == (S, B * (Fr // step), *(out_hw or (H, W)), 16)
+        if out_hw is None:
+            assert torch.equal(got, ref)
+        else:       # the four-tap blend is contracted into FMAs differently in the two template instances: <= 1 bf16 ulp, rarely
+            d = (got.float() - ref.float()).abs()
+            assert (d <= ref.float().abs() * 2 ** -7 + 1e-6).all() and (got != ref).float().mean().item() < 0.02
+    # the model takes the raw frames for its rgbdiff modality (6 RGB frames per group -> 15 difference channels)
+    model = adamml(groups=8, modality=["rgb", "flow", "rgbdiff"], input_channels=[3, 10, 15], num_segments=S, rng_policy=False,
+                   rng_threshold=0.5, causality_modeling="lstm", num_classes=31, depth=50, without_t_stride=False, dropout=0.0,
+                   pooling_method="max", fusion_point="logits", unimodality_pretrained=[], learnable_lf_weights=True)
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), seed=1234))
+    model.to(DEV).eval()
+    H = W = 64
+    rgb_u8 = torch.randint(0, 256, (B, H, W, S * Fr * 3), dtype=torch.uint8)
+    flow_u8 = torch.randint(0, 256, (B, H, W, S * Fr * 10), dtype=torch.uint8)
+    raw = torch.randint(0, 256, (B, H, W, S * Fr, D + 1, 3), dtype=torch.uint8)
+    d = raw.numpy().astype(np.float64)
+    d_u8 = torch.from_numpy(((d[:, :, :, :, 1:] - d[:, :, :, :, :-1] + 255.0) * 0.5).astype(np.uint8)).reshape(B, H, W, -1)
+    expo = synth.synth_gumbel_exponential(S, 2, B, seed=3).to(DEV)
+    with torch.no_grad():
+        a1, s1 = model([rgb_u8.to(DEV), flow_u8.to(DEV), raw.reshape(B, H, W, -1).to(DEV)], gumbel_exponential=expo)
+        a2, s2 = model([rgb_u8.to(DEV), flow_u8.to(DEV), d_u8.to(DEV)], gumbel_exponential=expo)
+    assert torch.equal(s1, s2) and torch.allclose(a1, a2, rtol=2e-2, atol=2e-2 * float(a2.abs().max()))
