@@ -60,6 +60,14 @@ struct ConvP {
     int K1, C2;
     size_t gw;
     const float* epi_add;
+    // FADD kernels (forward 1x1 conv whose BatchNorm vectors are known BEFORE the launch -- eval mode, or train mode with the
+    // statistics derived from the Gram matrix of the input, adamml_gram_stats): the epilogue applies bn_vec (scale, shift of
+    // THIS conv's BatchNorm), adds the identity operand res_out (optionally lazily normalised with id_scale / id_shift),
+    // applies res_act and writes the block output + its 1-bit activation mask; the raw conv output never reaches HBM
+    const float* id_scale;
+    const float* id_shift;
+    int id_gstride;
+    uint8_t* mask_out;
     // MODE 3 (one parity class of the data gradient of a stride-2 conv, see conv_dgrad_stride2)
     int wK;                      // weight row stride in elements (== K except in MODE 3, where K covers the class taps only)
     int cls_nt;                  // taps of this class (0..4)
@@ -95,7 +103,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // a second register ring for z, 2 workgroups per CU, deep prefetch).
 // CAT: K-concatenated second input + per-group weights + epilogue constant (algebraic BatchNorm backward); own instantiation
 // for the same reason.
-template <int BC, int MODE, int PD, bool RES = false, bool DUAL = false, bool CAT = false>
+// FADD: forward conv + BatchNorm + residual add + activation in the epilogue (see ConvP::id_scale); own instantiation.
+template <int BC, int MODE, int PD, bool RES = false, bool DUAL = false, bool CAT = false, bool FADD = false>
 __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
     constexpr int WROWS = BC / 64;          // weight rows staged per thread
@@ -127,6 +136,12 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
             p.x2 += (size_t)g * p.gx;
             p.aff += (size_t)g * 3 * p.K;
             if (p.side) p.side += (size_t)g * p.gx;
+        }
+        if (FADD) {
+            p.bn_vec += (size_t)g * 4 * p.Cout;
+            if (p.res_out) p.res_out += (size_t)g * p.gy;
+            if (p.mask_out) p.mask_out += ((size_t)g * p.gy) >> 3;
+            if (p.id_scale) { p.id_scale += (size_t)g * p.id_gstride; p.id_shift += (size_t)g * p.id_gstride; }
         }
         if (RES) {
             p.res_out += (size_t)g * p.gy;
@@ -420,7 +435,57 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
             *reinterpret_cast<bf16x4*>(smem + prow * CROW + ccol * 2) = f32_to_bf4(acc[ct][pt]);
         }
     __syncthreads();
-    if (RES) {
+    if (FADD) {
+        // out = act(scale * z + shift + identity): z is the bf16-rounded tile staged above (the value the unfused path would
+        // have stored and re-read), the identity operand streams in once, the block output and its activation mask stream
+        // out once.  All identity loads of a batch of rows are issued before the first store (in-order vmcnt, see RES).
+        if (eco < p.Cout) {
+            const f32x8 sc = load_f32x8(p.bn_vec + eco), sh = load_f32x8(p.bn_vec + p.Cout + eco);
+            f32x8 isc, ish;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { isc[i] = 1.f; ish[i] = 0.f; }
+            if (p.id_scale) { isc = load_f32x8(p.id_scale + eco); ish = load_f32x8(p.id_shift + eco); }
+            const float rlo = act_lo(p.res_act), rhi = act_hi(p.res_act);
+            constexpr int NR = BP / RSTEP, EB = NR < 4 ? NR : 4;
+#pragma unroll
+            for (int b0 = 0; b0 < NR; b0 += EB) {
+                bf16x8 ir[EB];
+                size_t pr[EB];
+                bool ok[EB];
+#pragma unroll
+                for (int j = 0; j < EB; ++j) {
+                    const int r = erow0 + (b0 + j) * RSTEP;
+                    ok[j] = p0 + r < p.P;
+                    pr[j] = (size_t)(ok[j] ? p0 + r : p0) * p.Cout + eco;
+                    if (p.res_out) ir[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.res_out + pr[j]));
+                }
+#pragma unroll
+                for (int j = 0; j < EB; ++j) {
+                    const int r = erow0 + (b0 + j) * RSTEP;
+                    f32x8 f = bf8_to_f32(*reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16));
+                    if (p.res_out) {
+                        const f32x8 w = bf8_to_f32(ir[j]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) f[i] = clamp_act(fmaf(f[i], sc[i], sh[i]) + fmaf(w[i], isc[i], ish[i]), rlo, rhi);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) f[i] = clamp_act(fmaf(f[i], sc[i], sh[i]), rlo, rhi);
+                    }
+                    const bf16x8 v = f32_to_bf8(f);
+                    if (ok[j]) {
+                        *reinterpret_cast<bf16x8*>(p.y + pr[j]) = v;
+                        if (p.mask_out) {
+                            const f32x8 q = bf8_to_f32(v);
+                            unsigned bits = 0;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) bits |= (q[i] > rlo && q[i] < rhi) ? (1u << i) : 0u;
+                            p.mask_out[pr[j] >> 3] = (uint8_t)bits;
+                        }
+                    }
+                }
+            }
+        }
+    } else if (RES) {
         // Residual form: y already holds the identity-path gradient (accumulate), the mask is act'(block output), and a
         // second BatchNorm operand of the add (downsample branch) gets its sum(g' * zhat2) in the same pass.  Rows are
         // processed in batches of EB: ALL global loads of a batch (z, identity-path gradient, block output, second z) are
@@ -1082,14 +1147,16 @@ struct ResEpi { const void* res_out; const uint8_t* res_mask; int res_act; const
 struct DualIn { const void* z; const float* aff; void* side; };
 // K-concatenated second input, per-group weights, epilogue constant (ConvP::xb ..)
 struct CatIn { const void* xb; int C2; size_t gw; const float* epi_add; };
+// forward BatchNorm + residual-add epilogue (ConvP::id_scale ..)
+struct FaddEpi { const float* vec; const void* idn; const float* id_scale; const float* id_shift; int id_gstride; int act; uint8_t* mask_out; };
 
 static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
                        const float* in_shift, void* y, double* stats, const void* bn_z, const float* bn_vec, int bn_act,
                        hipStream_t stream, const DgradClass* cls = nullptr, const ResEpi* res = nullptr, const DualIn* dual = nullptr,
-                       const CatIn* cat = nullptr) {
+                       const CatIn* cat = nullptr, const FaddEpi* fadd = nullptr) {
     if (!d || !x || !w_packed || !y) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: null argument");
     if (d->Cin % 8 || d->Cout % 8) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: channels must be multiples of 8 (Cin=%d Cout=%d)", d->Cin, d->Cout);
-    if (!cls && adamml_conv3x3_c64_supported(d))
+    if (!cls && !fadd && adamml_conv3x3_c64_supported(d))
         return adamml_conv3x3_c64_launch(d, x, w_packed, in_scale, in_shift, y, stats, bn_z, bn_vec, bn_act, stream);
     ConvP p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.in_scale = in_scale; p.in_shift = in_shift;
@@ -1101,6 +1168,9 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     p.x2 = dual ? (const bf16_t*)dual->z : nullptr; p.aff = dual ? dual->aff : nullptr; p.side = dual ? (bf16_t*)dual->side : nullptr;
     p.xb = cat ? (const bf16_t*)cat->xb : nullptr; p.K1 = d->Cin; p.C2 = cat ? cat->C2 : 0; p.gw = cat ? cat->gw : 0;
     p.epi_add = cat ? cat->epi_add : nullptr;
+    p.id_scale = fadd ? fadd->id_scale : nullptr; p.id_shift = fadd ? fadd->id_shift : nullptr; p.id_gstride = fadd ? fadd->id_gstride : 0;
+    p.mask_out = fadd ? fadd->mask_out : nullptr;
+    if (fadd) { p.bn_vec = fadd->vec; p.res_out = (const bf16_t*)fadd->idn; p.res_act = fadd->act; }
     const int groups = d->groups < 1 ? 1 : d->groups;
     p.gx = (size_t)d->N * d->H * d->W * d->Cin;
     p.gy = (size_t)d->N * d->OH * d->OW * d->Cout;
@@ -1149,6 +1219,12 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     if (mode == 2 && !multitap) { p.cin_shift = 30; }      // 1x1 strided dgrad: tap = k >> 30 = 0, ci = k
     const int nk = ceil_div(p.K, BK);
     const bool deep = (long)grid.x * grid.y <= 768 && nk >= 8;        // < 1 wave of workgroups per CU slot and a long K loop
+    if (fadd) {
+        if (mode != 0 || res || dual || cat || stats) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd_bn_add: only 1x1 / stride-1 convs");
+        if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, false, false, false, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, false, false, false, true>), grid, block, 0, stream, p);
+        return adamml_check_launch("conv_fwd_bn_add");
+    }
     if (res) {
         if (mode != 0) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res: only 1x1 / stride-1 convs");
         if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, true>), grid, block, 0, stream, p);
@@ -1190,6 +1266,52 @@ extern "C" int adamml_conv_fused_input_supported(const adamml_conv_desc_t* d) {
 extern "C" int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
                                const float* in_shift, void* y, double* stats, hipStream_t stream) {
     return conv_launch(d, x, w_packed, in_scale, in_shift, y, stats, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int adamml_conv_fwd_bn_add_supported(const adamml_conv_desc_t* d) {
+    return d && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && (d->up <= 1) && d->Cin % 8 == 0 && d->Cout % 8 == 0 ? 1 : 0;
+}
+
+extern "C" int adamml_conv_fwd_bn_add(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
+                                      const float* in_shift, const float* bn_vec, const void* idn, const float* id_scale,
+                                      const float* id_shift, int id_gstride, int act, void* out, uint8_t* mask_out, hipStream_t stream) {
+    if (!adamml_conv_fwd_bn_add_supported(d)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd_bn_add: 1x1 / stride-1 convs only");
+    if (!bn_vec) return adamml_set_error(ADAMML_EINVAL, "conv_fwd_bn_add: null BatchNorm vectors");
+    FaddEpi f{bn_vec, idn, id_scale, id_shift, id_gstride, act, mask_out};
+    return conv_launch(d, x, w_packed, in_scale, in_shift, out, nullptr, nullptr, nullptr, 0, stream, nullptr, nullptr, nullptr, nullptr, &f);
+}
+
+// Per-channel sum / sum of squares of z = W a over the pixels of each group WITHOUT z: sum z[co] = W[co,:] . s and
+// sum z[co]^2 = W[co,:] G W[co,:]^T with the Gram matrix G = a^T a [Cin, Cin] and the column sums s [Cin] of the conv input
+// (both over the pixels, fp32 from adamml_conv_bwd_weight_grouped / adamml_lazy_colsum).  W = the bf16 forward pack the conv
+// multiplies with.  sums: [groups][2*Cout] plain doubles (nslots = 1 for adamml_bn_finalize).  One wave per (group, cout).
+__global__ void gram_stats_kernel(const bf16_t* w, const float* G, const float* s, double* sums, int Cout, int Cin) {
+    const int co = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    const bf16_t* wr = w + (size_t)co * Cin;
+    const float* Gg = G + (size_t)g * Cin * Cin;
+    const float* sg = s + (size_t)g * Cin;
+    double a1 = 0.0, a2 = 0.0;
+    for (int ci = lane; ci < Cin; ci += 64) {
+        const double wi = (double)__builtin_bit_cast(float, (unsigned)wr[ci] << 16);
+        const float* row = Gg + (size_t)ci * Cin;
+        double t = 0.0;
+        for (int cj = 0; cj < Cin; ++cj) t += (double)row[cj] * (double)__builtin_bit_cast(float, (unsigned)wr[cj] << 16);
+        a1 += wi * (double)sg[ci];
+        a2 += wi * t;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { a1 += __shfl_xor(a1, off, 64); a2 += __shfl_xor(a2, off, 64); }
+    if (lane == 0) {
+        sums[(size_t)g * 2 * Cout + co] = a1;
+        sums[(size_t)g * 2 * Cout + Cout + co] = a2;
+    }
+}
+
+extern "C" int adamml_gram_stats(const void* w_packed, const float* G, const float* s, double* sums, int Cout, int Cin, int groups,
+                                 hipStream_t stream) {
+    if (!w_packed || !G || !s || !sums || Cout < 1 || Cin < 1 || groups < 1) return adamml_set_error(ADAMML_EINVAL, "gram_stats: bad arguments");
+    hipLaunchKernelGGL(gram_stats_kernel, dim3(Cout, groups), dim3(64), 0, stream, (const bf16_t*)w_packed, G, s, sums, Cout, Cin);
+    return adamml_check_launch("gram_stats");
 }
 
 // Data gradient of a stride-2 conv (3x3 pad 1 / 1x1 pad 0: every strided conv of the hot path) WITHOUT the 4x wasted work

@@ -337,8 +337,9 @@ __global__ __launch_bounds__(NT) void lazy_colsum_kernel(const bf16_t* x, const 
         for (int i = 0; i < 8; ++i) acc[i] = 0.f;
         const size_t pb = (size_t)blockIdx.x * ppb;
         const size_t pe = pb + ppb < P ? pb + ppb : P;
+        // (rounded to bf16 like the operand the conv kernels stage: s is then the exact column sum of what the MFMAs multiply)
         for (size_t p = pb + m.rslot; p < pe; p += m.rows_per_pass)
-            acc += transform8(*reinterpret_cast<const bf16x8*>(x + p * C + c), scale, shift, c, act);
+            acc += bf8_to_f32(f32_to_bf8(transform8(*reinterpret_cast<const bf16x8*>(x + p * C + c), scale, shift, c, act)));
         if (!det_mode()) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) atomicAdd(&smem[c + i], acc[i]);

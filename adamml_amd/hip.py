@@ -33,6 +33,8 @@ _DESC = POINTER(ConvDesc)
 SIGNATURES = {
     "adamml_conv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "adamml_conv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
+    "adamml_conv_fwd_bn_add": [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "adamml_gram_stats": [_P, _P, _P, _P, _I, _I, _I, _P],
     "adamml_conv_bwd_data_bn": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
     "adamml_bn_bwd_affine": [_P, _P, _P, _I, _I, _P],
     "adamml_conv_bwd_data_dual": [_DESC, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
@@ -112,6 +114,8 @@ def load():
     lib.adamml_dwconv_bwd_weight_workspace.restype = c_size_t
     lib.adamml_conv_fused_input_supported.argtypes = [_DESC]
     lib.adamml_conv_fused_input_supported.restype = c_int
+    lib.adamml_conv_fwd_bn_add_supported.argtypes = [_DESC]
+    lib.adamml_conv_fwd_bn_add_supported.restype = c_int
     lib.adamml_conv_bwd_data_dual_supported.argtypes = [_DESC]
     lib.adamml_conv_bwd_data_dual_supported.restype = c_int
     lib.adamml_conv_bwd_data_res_supported.argtypes = [_DESC]

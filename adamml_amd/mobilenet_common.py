@@ -1,6 +1,6 @@
 """Shared executor of the two MobileNetV2 variants (sound main net, policy net): inverted-residual blocks as
 pointwise MFMA convs + depthwise VALU convs with lazily applied BatchNorm/ReLU6."""
-from .runtime import conv_bn, add_act, temporal_pool, ACT_NONE, ACT_RELU6
+from .runtime import conv_bn, conv_bn_add, conv_bn_add_supported, add_act, temporal_pool, ACT_NONE, ACT_RELU6
 
 
 class BlockPlan:
@@ -21,6 +21,9 @@ def run_blocks(rt, h, plans):
             # the expansion conv is recorded before the block's own residual add, so it is reversed after it: last consumer
             y = conv_bn(rt, y, bp.pw[0], bp.pw[1], ACT_RELU6, last_consumer=True)
         y = conv_bn(rt, y, bp.dw[0], bp.dw[1], ACT_RELU6)
+        if bp.residual and conv_bn_add_supported(rt, y, bp.pwl[0], rt.tape.need_grad):
+            h = conv_bn_add(rt, y, bp.pwl[0], bp.pwl[1], x, ACT_NONE)               # inference: projection + BatchNorm + add in one kernel
+            continue
         y = conv_bn(rt, y, bp.pwl[0], bp.pwl[1], ACT_NONE, sole_consumer=True)      # the dw output feeds only this conv
         h = add_act(rt, y, x, ACT_NONE) if bp.residual else y
     return h

@@ -9,7 +9,7 @@ import torch.nn as nn
 from . import hip
 from .backbone import HipBackbone, FlatBuffers, StockDDPAware
 from .common import MeanStdMixin
-from .runtime import (Lazy, conv_bn, add_act, maxpool3x3s2, temporal_pool, head, clip_to_nhwc, pad8,
+from .runtime import (Lazy, conv_bn, conv_bn_add, conv_bn_add_supported, add_act, maxpool3x3s2, temporal_pool, head, clip_to_nhwc, pad8,
                       ACT_NONE, ACT_RELU)
 
 __all__ = ['ResNet', 'resnet']
@@ -108,8 +108,12 @@ class ResNet(HipBackbone, MeanStdMixin, StockDDPAware):
                 # the add is reversed first): its data-gradient epilogue finishes the previous block's residual backward
                 o = conv_bn(rt, h, b._cs1, b.bn1, ACT_RELU, last_consumer=b._csd is None)
                 o = conv_bn(rt, o, b._cs2, b.bn2, ACT_RELU, sole_consumer=True)
-                o = conv_bn(rt, o, b._cs3, b.bn3, ACT_NONE, sole_consumer=True)
-                h = add_act(rt, o, idn, ACT_RELU, idn_sole=b._csd is not None)
+                if conv_bn_add_supported(rt, o, b._cs3, need_grad):
+                    # conv3 + bn3 + residual add + ReLU in one kernel (statistics from the Gram matrix of conv3's input in train mode)
+                    h = conv_bn_add(rt, o, b._cs3, b.bn3, idn, ACT_RELU, idn_sole=b._csd is not None)
+                else:
+                    o = conv_bn(rt, o, b._cs3, b.bn3, ACT_NONE, sole_consumer=True)
+                    h = add_act(rt, o, idn, ACT_RELU, idn_sole=b._csd is not None)
             if li < 3 and not self.without_t_stride:
                 h = temporal_pool(rt, h, frames, self.pooling_method, sole_consumer=True)
                 frames = max(1, frames // 2)

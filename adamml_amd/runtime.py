@@ -27,7 +27,8 @@ def pad8(c):
 class Lazy:
     """Activation tensor [G*N,H,W,C] bf16 (G BatchNorm groups, group-major) whose value is act(scale*data + shift)
     (scale None -> data); group g uses scale + g*gs, shift + g*gs (gs == 0: one pair for all groups)."""
-    __slots__ = ("data", "scale", "shift", "gs", "act", "grad", "requires_grad", "vec", "src", "pre_sums", "res", "res_done", "pool_grad", "alg", "sums_partial")
+    __slots__ = ("data", "scale", "shift", "gs", "act", "grad", "requires_grad", "vec", "src", "pre_sums", "res", "res_done", "pool_grad", "alg", "sums_partial",
+                 "recompute", "_shape")
 
     def __init__(self, data, scale=None, shift=None, act=ACT_NONE, requires_grad=True, gs=0):
         self.data, self.scale, self.shift, self.act, self.gs = data, scale, shift, act, gs
@@ -41,10 +42,18 @@ class Lazy:
         self.alg = False            # BatchNorm backward of this conv output is algebraic: producers of .grad need not read .data
         self.sums_partial = False   # .pre_sums holds sum(g') only; sum(g' zhat) is derived from g'^T a (adamml_alg_sumfix)
         self.res_done = False       # .grad is already act-masked and the add's BatchNorm-backward sums are in place
+        self.recompute = None       # data is None: the raw tensor was never written (conv_bn_add); recompute() materialises it
+        self._shape = None
 
     @property
     def shape(self):
-        return self.data.shape
+        return self.data.shape if self.data is not None else self._shape
+
+    def ensure_data(self):
+        """The raw tensor, materialising it first if the forward never stored it (rare fallback paths of conv_bn_add)."""
+        if self.data is None:
+            self.data = self.recompute()
+        return self.data
 
 
 class Tape:
@@ -465,6 +474,23 @@ class _on_wgrad_stream:
         return False
 
 
+def _gram_colsum(rt, x, d):
+    """G = a^T a [groups, Cin, Cin] and s = sum a [groups, Cin] over the pixels of each group, a = the lazily normalised conv
+    input exactly as the conv's loader stages it (bf16).  Feeds the algebraic BatchNorm backward and, computed in the forward
+    pass, the train-mode statistics of conv_bn_add (adamml_gram_stats)."""
+    G, Cin, dev = rt.groups, d.Cin, x.data.device
+    n, h, w_, _ = x.shape
+    Gm = torch.empty(G, Cin, Cin, dtype=torch.float32, device=dev)
+    dg = ConvDesc(d.N, d.H, d.W, Cin, d.H, d.W, Cin, 1, 1, 1, 0, 1, d.act, 0, G, d.in_gstride)
+    wsg = hip.wgrad_workspace(dg, Cin, dev)
+    hip.next_meta = (2.0 * G * d.N * d.H * d.W * Cin * Cin, 2.0 * G * d.N * d.H * d.W * Cin)
+    call("adamml_conv_bwd_weight_grouped", byref(dg), ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, x.gs, ptr(x.data), ptr(x.scale),
+         ptr(x.shift), ptr(Gm), Cin, ptr(wsg), wsg.numel() * 4)
+    sv = torch.empty(G, Cin, dtype=torch.float32, device=dev)
+    call("adamml_lazy_colsum", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(sv), n // G * h * w_, Cin, G)
+    return Gm, sv
+
+
 ALG_BN = os.environ.get("ADAMML_ALG_BN", "1") != "0"     # algebraic BatchNorm backward through expanding 1x1 convs (A/B aid)
 ALG_MAX_COUT = int(os.environ.get("ADAMML_ALG_MAX_COUT", "512"))     # measured: at Cout = 1024 (layer 3) the small per-group products cost more than the saved passes (146.1 vs 144.6 ms)
 ALG_GEMM_CIN = 256     # from this input width on, the small per-group matrix products go through adamml_gemm_f32
@@ -478,7 +504,7 @@ def _alg_supported(cs, d):
             and d.Cout % 32 == 0 and 2 * d.Cin <= d.Cout <= ALG_MAX_COUT)
 
 
-def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern):
+def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern, Gm=None, sv=None):
     """Backward of z = W a (1x1) followed by a linear train-mode BatchNorm WITHOUT touching z or dz (include/adamml_hip.h,
     "algebraic BatchNorm backward"): with dz = A g' + B z + C per channel,
         dx = (W^T diag(A)) g' + (W^T diag(B) W) a + W^T C,      dW = A (.) (g'^T a) + B (.) (W G) + C (x) s,  G = a^T a, s = sum a.
@@ -537,14 +563,8 @@ def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, m
              None, None, 0, None)
     # ---- weight gradient (weight-gradient stream): products over the pixels, then the per-group combination
     with _on_wgrad_stream(rt, (g, x.data, x.scale, aff, P)):
-        n, h, w_, _ = x.shape
-        Gm = torch.empty(G, Cin, Cin, dtype=torch.float32, device=dev)
-        dg = ConvDesc(d.N, d.H, d.W, Cin, d.H, d.W, Cin, 1, 1, 1, 0, 1, d.act, 0, G, d.in_gstride)
-        wsg = hip.wgrad_workspace(dg, Cin, dev)
-        call("adamml_conv_bwd_weight_grouped", byref(dg), ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, x.gs, ptr(x.data), ptr(x.scale),
-             ptr(x.shift), ptr(Gm), Cin, ptr(wsg), wsg.numel() * 4)
-        sv = torch.empty(G, Cin, dtype=torch.float32, device=dev)
-        call("adamml_lazy_colsum", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(sv), n // G * h * w_, Cin, G)
+        if Gm is None:            # (conv_bn_add computed the Gram matrix and the column sums in the forward pass: its statistics)
+            Gm, sv = _gram_colsum(rt, x, d)
         wg_pre = None
         if Cin >= ALG_GEMM_CIN:
             # W G_g for all groups as one GEMM: [Cout, Cin] x [Cin, G*Cin]
@@ -628,38 +648,135 @@ def add_act(rt, z, idn, act, idn_sole=False):
     out = Lazy(out_t)
     out.res = (z, idn, act, idn_sole, mask_t)
     if rt.tape.need_grad:
-        def bwd():
-            g = out.grad
-            out.grad = None
-            if g is None:
-                return
-            fa = z.requires_grad and z.vec is not None and z.grad is None
-            fb = idn is not None and idn_sole and idn.requires_grad and idn.vec is not None and idn.grad is None
-            if out.res_done:
-                # the last consumer's data-gradient epilogue already masked g and accumulated the sums (conv_bn)
-                out.res_done = False
-                _accum_grad(z, g)
-                if idn is not None:
-                    _accum_grad(idn, g)
-                return
-            g2 = torch.empty_like(g) if act != ACT_NONE else g
-            if fa or fb:
-                sa = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS) if fa else None
-                sb = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS) if fb else None
-                call("adamml_residual_bwd", ptr(g), ptr(out_t), act, ptr(g2), ptr(z.data) if fa else None,
-                     ptr(z.vec) if fa else None, ptr(sa), ptr(idn.data) if fb else None, ptr(idn.vec) if fb else None, ptr(sb),
-                     P, C, G)
-                if fa:
-                    z.pre_sums = sa
-                if fb:
-                    idn.pre_sums = sb
-            elif act != ACT_NONE:
-                call("adamml_act_bwd_from_output", ptr(g), ptr(out_t), act, ptr(g2), g.numel())
-            _accum_grad(z, g2)
-            if idn is not None:
-                _accum_grad(idn, g2)
-        rt.tape.record(bwd)
+        rt.tape.record(lambda: _add_backward(rt, out, out_t, z, idn, act, idn_sole, P, C))
     return out
+
+
+def _add_backward(rt, out, out_t, z, idn, act, idn_sole, P, C):
+    """Backward of out = act(value(z) + value(idn)) (add_act / conv_bn_add)."""
+    G = rt.groups
+    g = out.grad
+    out.grad = None
+    if g is None:
+        return
+    fa = z.requires_grad and z.vec is not None and z.grad is None
+    fb = idn is not None and idn_sole and idn.requires_grad and idn.vec is not None and idn.grad is None
+    if out.res_done:
+        # the last consumer's data-gradient epilogue already masked g and accumulated the sums (conv_bn)
+        out.res_done = False
+        _accum_grad(z, g)
+        if idn is not None:
+            _accum_grad(idn, g)
+        return
+    g2 = torch.empty_like(g) if act != ACT_NONE else g
+    if fa or fb:
+        sa = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS) if fa else None
+        sb = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS) if fb else None
+        call("adamml_residual_bwd", ptr(g), ptr(out_t), act, ptr(g2), ptr(z.ensure_data()) if fa else None,
+             ptr(z.vec) if fa else None, ptr(sa), ptr(idn.data) if fb else None, ptr(idn.vec) if fb else None, ptr(sb),
+             P, C, G)
+        if fa:
+            z.pre_sums = sa
+        if fb:
+            idn.pre_sums = sb
+    elif act != ACT_NONE:
+        call("adamml_act_bwd_from_output", ptr(g), ptr(out_t), act, ptr(g2), g.numel())
+    _accum_grad(z, g2)
+    if idn is not None:
+        _accum_grad(idn, g2)
+
+
+FUSE_ADD = os.environ.get("ADAMML_FUSE_ADD", "1") != "0"     # conv3 + BatchNorm + residual add in one kernel (A/B aid)
+
+
+def conv_bn_add_supported(rt, x, cs, need_grad):
+    """Can `conv (1x1) -> BatchNorm -> (+ identity) -> activation` run as conv_bn_add?  Eval mode: every 1x1 / stride-1 conv (the
+    BatchNorm is a known affine map).  Train mode: the statistics must come from the Gram matrix of the conv INPUT, which only
+    pays for expanding convs (bottleneck conv3 of layers 1-2: same shapes as the algebraic BatchNorm backward, whose products it
+    shares), and the backward must be the algebraic one (it never reads the raw conv output)."""
+    if not FUSE_ADD or cs.depthwise or cs.stem or x.shape[3] != cs.cin:
+        return False
+    d = cs.desc(x.shape, x.act, rt.groups, x.gs)
+    if not hip.load().adamml_conv_fwd_bn_add_supported(byref(d)):
+        return False
+    if not rt.training:
+        return not need_grad
+    if not (ALG_BN and _alg_supported(cs, d)):
+        return False
+    return (not need_grad) or (x.requires_grad and cs.weight.requires_grad)
+
+
+def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False):
+    """out = act(BatchNorm(conv1x1(x)) + value(idn)) in ONE kernel whose epilogue normalises, adds and activates
+    (adamml_conv_fwd_bn_add): the raw conv output is never written to HBM nor re-read by a separate add pass.
+    Train mode: BatchNorm needs the batch statistics BEFORE that epilogue runs; for z = W a they follow from the Gram matrix
+    G = a^T a and the column sums s of the (4x narrower) conv input: sum z = W s, sum z^2 = diag(W G W^T) (adamml_gram_stats).
+    G and s are exactly the products the algebraic BatchNorm backward needs (_conv1x1_backward_alg), so computing them here
+    only moves work from backward to forward.  Caller checks conv_bn_add_supported()."""
+    G = rt.groups
+    d = cs.desc(x.shape, x.act, G, x.gs)
+    dev = x.data.device
+    C, Cin = d.Cout, d.Cin
+    count = d.N * d.OH * d.OW
+    need_grad = rt.tape.need_grad
+    macs = float(count) * G * C * cs.cin_true
+    in_b, out_b, w_b = 2.0 * G * count * cs.cin_true, 2.0 * G * count * C, 2.0 * C * cs.cin_true
+    kern = "conv_gemm_kernel"
+    Gm = sv = None
+    if rt.training:
+        Gm, sv = _gram_colsum(rt, x, d)
+        sums = torch.empty(G * 2 * C, dtype=torch.float64, device=dev)
+        call("adamml_gram_stats", ptr(cs.w_fwd), ptr(Gm), ptr(sv), ptr(sums), C, Cin, G)
+        if rt.sync.enabled:                  # SyncBatchNorm: the (already collapsed) sums are all-reduced, as SyncCtx.reduce does
+            dist.all_reduce(sums, group=rt.sync.group)
+            interleave.yield_point()
+        vec = torch.empty(G, 4, C, dtype=torch.float32, device=dev)
+        call("adamml_bn_finalize", ptr(sums), 1, G, float(count * rt.sync.world), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+             ptr(bn.running_var), BN_MOMENTUM, BN_EPS, ptr(vec), C)
+        rt.touched_bns.append(bn)
+    else:
+        ev = _bn_eval_vectors(rt, bn, C, dev)
+        vec = torch.zeros(G, 4, C, dtype=torch.float32, device=dev)
+        vec[:, 0], vec[:, 1] = ev[0], ev[1]
+    out_t = torch.empty(G * d.N, d.OH, d.OW, C, dtype=torch.bfloat16, device=dev)
+    mask_t = torch.empty(G * d.N, d.OH, d.OW, C // 8, dtype=torch.uint8, device=dev) if (need_grad and act != ACT_NONE) else None
+    hip.next_meta = (2 * macs, in_b + (2 if idn is not None else 1) * out_b + w_b + (out_b / 16 if mask_t is not None else 0), kern)
+    call("adamml_conv_fwd_bn_add", byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(vec),
+         ptr(idn.data) if idn is not None else None, ptr(idn.scale) if idn is not None else None,
+         ptr(idn.shift) if idn is not None else None, idn.gs if idn is not None else 0, act, ptr(out_t), ptr(mask_t))
+    out = Lazy(out_t)
+    if not need_grad:
+        return out
+    # the raw conv output as a (never materialised) lazy tensor: the generic residual machinery only needs its BatchNorm vectors
+    z = Lazy(None, vec[0, 0], vec[0, 1], ACT_NONE, gs=4 * C)
+    z._shape = out_t.shape
+    z.vec = vec
+    z.alg = True
+
+    def recompute():
+        y = torch.empty_like(out_t)
+        call("adamml_conv_fwd", byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), None)
+        return y
+    z.recompute = recompute
+    out.res = (z, idn, act, idn_sole, mask_t)
+
+    def conv_bwd():
+        if z.grad is None:
+            return
+        if z.pre_sums is None:
+            z.ensure_data()              # the producer of g' could not fuse the BatchNorm-backward sums: the reduction pass reads z
+        y = z.data if z.data is not None else _Meta(out_t.shape, dev)
+        _conv1x1_backward_alg(rt, z, x, y, vec, bn, cs, d, count, True, macs, in_b, out_b, w_b, kern, Gm=Gm, sv=sv)
+    rt.tape.record(conv_bwd)
+    rt.tape.record(lambda: _add_backward(rt, out, out_t, z, idn, act, idn_sole, count, C))
+    return out
+
+
+class _Meta:
+    """Shape / device stand-in for a tensor that was never materialised (only its metadata is consulted)."""
+
+    def __init__(self, shape, device):
+        self.shape, self.device = shape, device
 
 
 def maxpool3x3s2(rt, x, sole_consumer=False):

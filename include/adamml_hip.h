@@ -65,7 +65,21 @@ int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const void* w_pa
  * 3x3 / stride 1 / pad 1 / 64 -> 64 channels), so the caller need not materialise the normalised input first; 0 when the
  * implicit-GEMM loader would re-apply it once per tap. */
 int adamml_conv_fused_input_supported(const adamml_conv_desc_t* d);
-/* autograd of the above w.r.t. its input (d = forward descriptor; w packed with mode 1) */
+/* Forward 1x1 / stride-1 conv with BatchNorm + residual add + activation in its epilogue (a bottleneck's conv3 + bn3 + add +
+ * ReLU, models/resnet.py:104-112; a MobileNetV2 projection + add) -- for the cases where the BatchNorm vectors are known before
+ * the launch: eval mode, or train mode with statistics from adamml_gram_stats.  bn_vec [groups][4][Cout] (scale, shift, ..) of
+ * THIS conv's BatchNorm; idn [same shape as out] or NULL, lazily normalised with id_scale / id_shift [Cout] (group stride
+ * id_gstride floats) when given; out = act(scale*z + shift + idn'), mask_out (optional) = 1 bit per element, act'(out) != 0.
+ * The raw conv output z is never written. */
+int adamml_conv_fwd_bn_add_supported(const adamml_conv_desc_t* d);
+int adamml_conv_fwd_bn_add(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
+                           const float* bn_vec, const void* idn, const float* id_scale, const float* id_shift, int id_gstride, int act,
+                           void* out, uint8_t* mask_out, hipStream_t stream);
+/* Train-mode BatchNorm statistics of z = W a without z: sums[g][co] = W[co,:] . s_g, sums[g][Cout+co] = W[co,:] G_g W[co,:]^T from
+ * the Gram matrix G [groups][Cin][Cin] = a^T a and the column sums s [groups][Cin] of the conv INPUT (fp32), W = the bf16
+ * forward pack [Cout][Cin].  sums [groups][2*Cout] doubles: pass to adamml_bn_finalize with nslots = 1. */
+int adamml_gram_stats(const void* w_packed, const float* G, const float* s, double* sums, int Cout, int Cin, int groups, hipStream_t stream);
+/* autograd of adamml_conv_fwd w.r.t. its input (d = forward descriptor; w packed with mode 1) */
 int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
                          int accumulate, hipStream_t stream);
 /* same, when dx is the gradient w.r.t. a lazily normalised tensor act(BN(z_in)) with a single consumer: the epilogue

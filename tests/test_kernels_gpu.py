@@ -940,3 +940,63 @@ def test_algebraic_bn_backward_equals_explicit_dz(N, H, Cin, Cout, G, mode):
     if mode == "bn":
         a_, b_ = s.sum(1), s_ref.sum(1)
         assert (a_ - b_).abs().max().item() <= 2e-2 * b_.abs().max().item() + 1e-2
+
+
+@pytest.mark.parametrize("G,N,H,Cin,Cout,lazy_idn,act", [(3, 2, 28, 64, 256, False, 1), (2, 3, 14, 128, 512, True, 1), (1, 2, 10, 96, 24, False, 0),
+                                                         (5, 1, 7, 256, 512, False, 1)])
+def test_conv_fwd_bn_add_and_gram_statistics(G, N, H, Cin, Cout, lazy_idn, act):
+    """conv3 + BatchNorm + residual add + activation in ONE kernel (adamml_conv_fwd_bn_add) == conv (adamml_conv_fwd) followed
+    by adamml_bn_act_add_mask, i.e. models/resnet.py:104-112 on a lazily normalised input; the train-mode statistics it needs
+    beforehand come from the Gram matrix of the conv INPUT (adamml_gram_stats): compared with the sums adamml_conv_fwd accumulates
+    from the conv OUTPUT it no longer writes."""
+    from adamml_amd.runtime import NetRT, Lazy, _gram_colsum, ACT_RELU
+    torch.manual_seed(G * 10 + N)
+    x = (torch.randn(G * N, H, H, Cin, device=DEV) * 1.5).to(torch.bfloat16)
+    xvec = torch.rand(G, 4, Cin, device=DEV) + 0.5
+    xvec[:, 1] -= 0.7
+    w = torch.randn(Cout, Cin, 1, 1, device=DEV) * (2.0 / Cin) ** 0.5
+    wp = pack(w, Cin, 0)
+    d = ConvDesc(N, H, H, Cin, H, H, Cout, 1, 1, 1, 0, 1, ACT_RELU, 0, G, 4 * Cin)
+    # reference: the unfused pair
+    z = torch.empty(G * N, H, H, Cout, dtype=torch.bfloat16, device=DEV)
+    st = torch.zeros(G, STAT_SLOTS, 2 * Cout, dtype=torch.float64, device=DEV)
+    call("adamml_conv_fwd", byref(d), ptr(x), ptr(wp), ptr(xvec[0, 0]), ptr(xvec[0, 1]), ptr(z), ptr(st))
+    ref_sums = torch.empty(G, 2 * Cout, dtype=torch.float64, device=DEV)
+    call("adamml_stats_collapse", ptr(st), ptr(ref_sums), Cout, G)
+    # statistics from the Gram matrix of the input
+    rt = NetRT()
+    rt.begin_forward(torch.device(DEV), True, False, G)
+    xin = Lazy(x, xvec[0, 0], xvec[0, 1], ACT_RELU, gs=4 * Cin)
+    Gm, sv = _gram_colsum(rt, xin, d)
+    sums = torch.empty(G, 2 * Cout, dtype=torch.float64, device=DEV)
+    call("adamml_gram_stats", ptr(wp), ptr(Gm), ptr(sv), ptr(sums), Cout, Cin, G)
+    P = N * H * H
+    # exact reference: z = a W^T in fp64 from the operands the MFMA sees (bf16 a = act(scale*x+shift), bf16 W), before any rounding of z
+    a = torch.relu(x.float().view(G, P, Cin) * xvec[:, 0:1] + xvec[:, 1:2]).to(torch.bfloat16).double()
+    zx = a @ wp.double().t()                                                                     # [G, P, Cout]
+    assert torch.allclose(sums[:, :Cout], zx.sum(1), rtol=1e-5, atol=1e-5 * zx.abs().sum(1).max().item())
+    assert torch.allclose(sums[:, Cout:], (zx * zx).sum(1), rtol=2e-5)
+    # and they agree with what adamml_conv_fwd accumulates from its bf16-ROUNDED output up to that rounding (2^-9 per element)
+    mean_g, mean_r = sums[:, :Cout] / P, ref_sums[:, :Cout] / P
+    ex2_g, ex2_r = sums[:, Cout:] / P, ref_sums[:, Cout:] / P
+    assert ((mean_g - mean_r).abs() <= 2.0 ** -8 * ex2_r.sqrt() + 1e-6).all()
+    assert ((ex2_g - ex2_r).abs() <= 2.0 ** -7 * ex2_r + 1e-9).all()
+    # fused epilogue vs conv + bn_act_add_mask with the same BatchNorm vectors
+    vec = torch.rand(G, 4, Cout, device=DEV) + 0.25
+    vec[:, 1] -= 0.5
+    idn = torch.randn(G * N, H, H, Cout, device=DEV).to(torch.bfloat16)
+    ivec = (torch.rand(G, 4, Cout, device=DEV) + 0.5) if lazy_idn else None
+    want = torch.empty_like(z)
+    want_mask = torch.empty(G * N, H, H, Cout // 8, dtype=torch.uint8, device=DEV)
+    call("adamml_bn_act_add_mask", ptr(z), ptr(vec[0, 0]), ptr(vec[0, 1]), 4 * Cout, act, ptr(idn), ptr(ivec[0, 0]) if lazy_idn else None,
+         ptr(ivec[0, 1]) if lazy_idn else None, 4 * Cout if lazy_idn else 0, ptr(want), ptr(want_mask), P, Cout, G)
+    got = torch.empty_like(z)
+    got_mask = torch.zeros_like(want_mask)
+    call("adamml_conv_fwd_bn_add", byref(d), ptr(x), ptr(wp), ptr(xvec[0, 0]), ptr(xvec[0, 1]), ptr(vec), ptr(idn),
+         ptr(ivec[0, 0]) if lazy_idn else None, ptr(ivec[0, 1]) if lazy_idn else None, 4 * Cout if lazy_idn else 0, act, ptr(got), ptr(got_mask))
+    assert torch.equal(got, want)                        # same staged bf16 conv tile, same fp32 epilogue arithmetic
+    assert torch.equal(got_mask, want_mask)
+    # without an identity operand and without a mask
+    call("adamml_bn_act_add_mask", ptr(z), ptr(vec[0, 0]), ptr(vec[0, 1]), 4 * Cout, act, None, None, None, 0, ptr(want), None, P, Cout, G)
+    call("adamml_conv_fwd_bn_add", byref(d), ptr(x), ptr(wp), ptr(xvec[0, 0]), ptr(xvec[0, 1]), ptr(vec), None, None, None, 0, act, ptr(got), None)
+    assert torch.equal(got, want)
