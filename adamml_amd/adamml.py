@@ -140,11 +140,23 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
                 net, xin = self.main_net.nets[m_i], m_x[m_i].flatten(0, 1)
                 jobs.append(((lambda net=net, xin=xin: net.forward_nhwc(xin, S)), side if self.main_net.modality[m_i] == 'sound' else main))
             if not self.rng_policy:
-                jobs.append(((lambda: self.policy_net.decide(self.policy_net.all_segment_features(p_x), gumbel_exponential)), pside))
+                # one job per policy backbone (each on its own stream): the lock-step rounds then carry the statistics of ALL
+                # backbones of a BatchNorm depth in one collective, 53 rounds per direction instead of 53 + 2 x 52
+                pstreams = [pside] + [self._side_stream(dev, 1 + k) for k in range(1, len(self.policy_net.joint_net.nets))]
+                for ps in pstreams[1:]:
+                    ps.wait_stream(main)
+                for k, net in enumerate(self.policy_net.joint_net.nets):
+                    jobs.append(((lambda net=net, xin=p_x[k].flatten(0, 1): net.feature_extraction(xin, S)), pstreams[k]))
             res = interleave.run_interleaved(jobs, dev)
             stacked = res[:self.num_modality]
             if not self.rng_policy:
-                decisions, decision_logits = res[-1]
+                with torch.cuda.stream(pside):
+                    feats = res[self.num_modality:]
+                    for ps, f in zip(pstreams[1:], feats[1:]):
+                        pside.wait_stream(ps)
+                        f.record_stream(pside)
+                    joint = self.policy_net.joint_net.joint_features(feats)
+                    decisions, decision_logits = self.policy_net.decide(list(joint.view(S, -1, joint.shape[-1]).unbind(0)), gumbel_exponential)
                 self.last_policy_logits = decision_logits
             else:
                 decisions = (torch.rand((num_segments, self.num_modality, x[0].size(0)), dtype=torch.float32, device=dev)
@@ -207,6 +219,8 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
     def _side_stream(self, dev, idx=0):
         if self._side is None or self._side[0].device != dev:
             self._side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        while len(self._side) <= idx:
+            self._side.append(torch.cuda.Stream(device=dev))
         return self._side[idx]
 
     @property

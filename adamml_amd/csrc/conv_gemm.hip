@@ -12,6 +12,7 @@
 #include "../../include/adamml_hip.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <stdio.h>
 
 ADAMML_DET_SETTER(conv_gemm)
 
@@ -1218,7 +1219,10 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     const int mode = cls ? 3 : (p.up > 1 ? 2 : (multitap ? (taps <= 64 ? 1 : 2) : 0));
     if (mode == 2 && !multitap) { p.cin_shift = 30; }      // 1x1 strided dgrad: tap = k >> 30 = 0, ci = k
     const int nk = ceil_div(p.K, BK);
-    const bool deep = (long)grid.x * grid.y <= 768 && nk >= 8;        // < 1 wave of workgroups per CU slot and a long K loop
+    // < 1 wave of workgroups per CU slot and a long K loop: explicit look-ahead instead of occupancy.  Measured (tools/bench_conv.py,
+    // B = 72): it pays for the 1x1 layers of layer 4 (0.115 vs 0.137 ms) and costs on its 3x3 layers (0.189 vs 0.139 ms forward,
+    // 0.197 vs 0.146 ms data gradient: the tap gathers of MODE 1 hit L2 and the deeper ring only lowers the occupancy)
+    const bool deep = (long)grid.x * grid.y <= 768 && nk >= 8 && mode != 1;
     if (fadd) {
         if (mode != 0 || res || dual || cat || stats) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd_bn_add: only 1x1 / stride-1 convs");
         if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, false, false, false, true>), grid, block, 0, stream, p);

@@ -140,7 +140,11 @@ class JointMobileNetV2(nn.Module):
 
     def features(self, multi_modalities, groups=1):
         """multi_modalities: list of NHWC bf16 frame tensors (`groups` segments stacked along dim 0).  -> [G*B, 2048]."""
-        out = torch.cat([net.feature_extraction(x, groups) for net, x in zip(self.nets, multi_modalities)], dim=1)
+        return self.joint_features([net.feature_extraction(x, groups) for net, x in zip(self.nets, multi_modalities)])
+
+    def joint_features(self, feats):
+        """cat over modalities -> Linear -> ReLU -> Linear -> ReLU (models/policy_net.py:243-245) on the backbones' pooled features."""
+        out = torch.cat(list(feats), dim=1)
         out = hip_linear(out, self.joint[0].weight, self.joint[0].bias, ACT_RELU)
         return hip_linear(out, self.joint[2].weight, self.joint[2].bias, ACT_RELU)
 

@@ -116,9 +116,9 @@ class SyncCtx:
             return t, STAT_SLOTS
         out = torch.empty(groups * 2 * C, dtype=torch.float64, device=t.device)
         call("adamml_stats_collapse", ptr(t), ptr(out), C, groups)
-        dist.all_reduce(out, group=self.group)
-        interleave.yield_point()            # round-robin host issue of the backbones (interleave.py); no-op otherwise
-        return out, 1
+        # one all-reduce -- coalesced with the exchanges the other backbones have pending in this round when the backbones are
+        # issued in lock-step (interleave.py): one collective per BatchNorm DEPTH instead of one per BatchNorm
+        return interleave.exchange(out, self.group), 1
 
 
 class NetRT:
@@ -728,8 +728,7 @@ def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False):
         sums = torch.empty(G * 2 * C, dtype=torch.float64, device=dev)
         call("adamml_gram_stats", ptr(cs.w_fwd), ptr(Gm), ptr(sv), ptr(sums), C, Cin, G)
         if rt.sync.enabled:                  # SyncBatchNorm: the (already collapsed) sums are all-reduced, as SyncCtx.reduce does
-            dist.all_reduce(sums, group=rt.sync.group)
-            interleave.yield_point()
+            sums = interleave.exchange(sums, rt.sync.group)
         vec = torch.empty(G, 4, C, dtype=torch.float32, device=dev)
         call("adamml_bn_finalize", ptr(sums), 1, G, float(count * rt.sync.world), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
              ptr(bn.running_var), BN_MOMENTUM, BN_EPS, ptr(vec), C)

@@ -208,6 +208,13 @@ class SyntheticLoader:
             yield [x.to(self.device) for x in xs], y.to(self.device)
 
 
+def concat_all_gather(tensor, group=None):
+    """utils/utils.py:539-550: all-gather a per-rank tensor and concatenate along dim 0 in rank order (no gradient)."""
+    lst = [torch.empty_like(tensor) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(lst, tensor.contiguous(), group=group)
+    return torch.cat(lst, dim=0)
+
+
 # ------------------------------------------------------------------------------------------------ one epoch
 def train_epoch(loader, ddp, opt, p_opt, epoch, args, cost_weights, rank=0, log=print):
     """utils/utils.py:320-426."""
@@ -280,11 +287,7 @@ def validate(loader, ddp, args, num_segments):
         sels.append(selection)
     output, target, selection = torch.cat(outs), torch.cat(labels), torch.cat(sels)
     if dist.is_initialized():
-        def gather(t):
-            lst = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-            dist.all_gather(lst, t.contiguous())
-            return torch.cat(lst)
-        output, target, selection = gather(output), gather(target), gather(selection)
+        output, target, selection = concat_all_gather(output), concat_all_gather(target), concat_all_gather(selection)
     top1, top5 = accuracy(output, target)
     return top1.item(), top5.item(), loss_m.avg, selection
 

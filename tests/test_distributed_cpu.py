@@ -160,3 +160,58 @@ def test_syncbn_sum_exchange_equals_global_batch_statistics():
     full = torch.randn(8, 6, 5, 5).double()
     assert torch.allclose(m0, full.mean((0, 2, 3))) and torch.allclose(m1, m0)
     assert torch.allclose(v0, full.var((0, 2, 3), unbiased=False)) and torch.allclose(v1, v0)
+
+
+def _gather(rank, world):
+    from adamml_amd.train import concat_all_gather
+    out = torch.arange(6, dtype=torch.float32).reshape(3, 2) + 100 * rank          # per-rank `output [B, classes]`
+    tgt = torch.tensor([rank, rank + 10, rank + 20])                                 # `target [B]` (int64)
+    sel = torch.full((3, 2, 2), float(rank))                                         # `selection [B, S, M]`
+    return concat_all_gather(out), concat_all_gather(tgt), concat_all_gather(sel)
+
+
+def test_validation_all_gather_concatenates_in_rank_order():
+    """utils/utils.py:484-490,539-550 (`-e` / per-epoch validation): outputs, targets and selections of all ranks are gathered
+    and concatenated along the batch axis in rank order before the global top-k is taken."""
+    r0, r1 = _run(_gather)
+    for a, b in zip(r0, r1):
+        assert torch.equal(a, b)                                                     # every rank holds the same global tensors
+    out, tgt, sel = r0
+    assert out.shape == (6, 2) and torch.equal(out[3:], out[:3] + 100)
+    assert tgt.tolist() == [0, 10, 20, 1, 11, 21] and tgt.dtype == torch.int64
+    assert sel.shape == (6, 2, 2) and float(sel[:3].sum()) == 0.0 and float(sel[3:].mean()) == 1.0
+
+
+def _coalesced(rank, world):
+    """Three "backbones" with 3 / 1 / 2 statistic exchanges each, issued in lock-step rounds (adamml_amd.interleave)."""
+    from adamml_amd import interleave
+    interleave.stats["collectives"] = interleave.stats["coalesced_vectors"] = 0
+    log = []
+
+    def job(name, n, width):
+        def f():
+            got = []
+            for i in range(n):
+                t = torch.full((width,), float((rank + 1) * (i + 1)), dtype=torch.float64) + ord(name)
+                log.append((name, i))
+                got.append(interleave.exchange(t).clone())
+            return got
+        return f
+    res = interleave.run_interleaved([(job("a", 3, 4), None), (job("b", 1, 2), None), (job("c", 2, 6), None)], None)
+    lone = interleave.exchange(torch.tensor([float(rank)], dtype=torch.float64))         # outside run_interleaved: a plain all-reduce
+    return res, log, dict(interleave.stats), lone
+
+
+def test_statistic_exchanges_of_a_round_are_one_collective():
+    """SyncBatchNorm exchange (train_adamml.py:126-127): the vectors the backbones have pending at the same depth travel in ONE
+    all-reduce; every job still receives exactly the sum over the ranks of ITS vector; the issue order is fixed."""
+    (r0, log0, st0, lone0), (r1, log1, st1, lone1) = _run(_coalesced)
+    assert log0 == log1 == [("a", 0), ("b", 0), ("c", 0), ("a", 1), ("c", 1), ("a", 2)]
+    for name, n, width, got in (("a", 3, 4, r0[0]), ("b", 1, 2, r0[1]), ("c", 2, 6, r0[2])):
+        for i in range(n):
+            want = sum(float((rk + 1) * (i + 1)) + ord(name) for rk in range(2))
+            assert got[i].shape == (width,) and torch.all(got[i] == want), (name, i, got[i], want)
+    for a, b in zip(r0, r1):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert st0["collectives"] == 3 + 1 and st0["coalesced_vectors"] == 6 + 1        # 3 rounds for 6 vectors (+ the lone exchange)
+    assert float(lone0) == float(lone1) == 1.0

@@ -271,3 +271,34 @@ def test_stock_ddp_probe_switches_to_autograd_delivered_gradients():
     assert not hasattr(m, "_ddp_params_and_buffers_to_ignore")      # DDP sees "no such attribute" and proceeds normally
     assert all(n.expose_param_grads for n in m.backbones())
     assert m._flat_main.detached and m._flat_policy.detached
+
+
+def test_lr_schedules_match_torch_schedulers():
+    """train.LRSchedule (closed form, stepped with the epoch like train_adamml.py:499-500 `scheduler.step(epoch + 1)`... the
+    reference builds StepLR / MultiStepLR / CosineAnnealingLR at train_adamml.py:259-270) gives torch's learning rates."""
+    import warnings
+    from adamml_amd.train import LRSchedule
+
+    class Opt:
+        lr = 0.0
+    base, epochs, steps = 0.01, 20, [6, 12, 17]
+    for kind in ("step", "multisteps", "cosine"):
+        p = torch.nn.Parameter(torch.zeros(1))
+        ref_opt = torch.optim.SGD([p], lr=base)
+        ref = {"step": lambda: torch.optim.lr_scheduler.StepLR(ref_opt, steps[0]),
+               "multisteps": lambda: torch.optim.lr_scheduler.MultiStepLR(ref_opt, steps),
+               "cosine": lambda: torch.optim.lr_scheduler.CosineAnnealingLR(ref_opt, epochs, eta_min=0)}[kind]()
+        o = Opt()
+        mine = LRSchedule(o, kind, base, epochs, steps)
+        for epoch in range(1, epochs + 1):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref_opt.step()
+                ref.step()
+            mine.step(epoch)
+            assert abs(o.lr - ref_opt.param_groups[0]["lr"]) <= 1e-12 + 1e-9 * base, (kind, epoch, o.lr, ref_opt.param_groups[0]["lr"])
+        # checkpointed state restores the same point (train_adamml.py:300-301)
+        o2 = Opt()
+        m2 = LRSchedule(o2, kind, base, epochs, steps)
+        m2.load_state_dict(mine.state_dict())
+        assert o2.lr == o.lr

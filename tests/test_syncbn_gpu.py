@@ -65,11 +65,14 @@ def _worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from adamml_amd.distributed import HipDDP
+        from adamml_amd import interleave
         model = _build()
         ddp = HipDDP(model, sync_bn=True)
+        interleave.stats["collectives"] = interleave.stats["coalesced_vectors"] = 0
         r = _step(model, ddp, rank, world)
         if rank == 0:
             ret["r"] = r
+            ret["exchange"] = dict(interleave.stats)
     finally:
         dist.destroy_process_group()
 
@@ -80,6 +83,12 @@ def test_two_rank_syncbn_step_equals_single_process_full_batch():
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     two = ret["r"]
+    # SyncBatchNorm exchanges of one step (S = 2 segments batched as groups): the 4 backbones have 53 / 52 / 52 / 52 BatchNorm
+    # layers in forward and the two trainable ones 53 / 52 in backward = 314 statistic vectors; issued in lock-step rounds they
+    # travel in one collective per BatchNorm depth: <= 53 forward + 53 backward
+    ex = ret["exchange"]
+    print("  SyncBatchNorm exchange: %d statistic vectors in %d collectives" % (ex["coalesced_vectors"], ex["collectives"]))
+    assert ex["coalesced_vectors"] == 53 + 3 * 52 + 53 + 52 and ex["collectives"] <= 53 + 53
     one = _step(_build(), None, 0, 1)
     assert torch.equal(two["sel"], one["sel"][0::2])                     # rank 0 holds videos 0, 2 and takes the same decisions
     rel = lambda a, b: ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile refresh on the GPU box: parity tests, default bench line, single-stream rocprofv3 kernel stats.
 # Usage (from the repo root, through gpurun): bash tools/gpu_refresh.sh <tag>
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
