@@ -446,7 +446,7 @@ class _on_wgrad_stream:
     most of the machine idle.  The tensors they read are kept alive by rt.wgrad_pending until an event recorded behind
     the kernel has completed (or the stream has been joined) -- NOT by Tensor.record_stream: with ~70 multi-GB blocks per
     step parked in the caching allocator's cross-stream list the step time degraded from 152 ms to over a second within
-    eight steps (measured).  The backbone joins the stream before its gradients are consumed (backbone._NetCall.backward,
+    eight steps (measured).  The backbone joins the stream before its gradients are consumed (backbone.run_tape,
     HipDDP bucket hooks)."""
 
     def __init__(self, rt, tensors):
