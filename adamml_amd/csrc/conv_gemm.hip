@@ -914,6 +914,164 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Weight gradient with LDS-DMA staging (global_load_lds_dwordx4) for operands that are PLAIN in memory (no lazy transform):
+// the same tiles, LDS image and MFMA schedule as conv_wgrad_kernel, but the operand tiles go global -> LDS directly --
+// no VGPR ring, no ds_write pass -- through a ring of ST LDS stages with counted vmcnt across raw barriers, so that ST-2
+// K steps of loads stay in flight while one is being multiplied.  (Ablation of the register-staged kernel, layer-2 3x3: 418
+// TFLOP/s as is, 481 without its LDS stores, 717 without its global loads, 956 without both, 447 without its MFMAs: it is
+// bound by its staging, not by the matrix cores.)  The LDS destination of an LDS-DMA is wave-uniform base + lane * 16, so the
+// image is lane-linear and the bank swizzle of the transposed reads is applied to the SOURCE chunk index instead (an
+// involution within a pixel row: the same cache lines are fetched).  Out-of-range chunks (padding taps, tails) read a zero page.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+
+template <int BM, int BN, int ST>
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_glds_kernel(WgradP p, const bf16_t* zeros) {
+    constexpr int AROW = BM * 2, BROW = BN * 2;
+    constexpr int TILE_BYTES = 32 * (AROW + BROW);
+    constexpr int MT = BM / 32, NT = BN / 32;
+    __shared__ __attribute__((aligned(1024))) char smem[ST * TILE_BYTES];
+    const int lb = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+    const int tile = lb % p.n_tiles;
+    const int unit = lb / p.n_tiles;
+    const int split = unit % p.nsplit, grp = unit / p.nsplit;
+    p.dz += (size_t)grp * p.gdz;
+    p.x += (size_t)grp * p.gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int co0 = (tile % p.n_cotiles) * BM;
+    const int n0 = (tile / p.n_cotiles) * BN;
+    const int ps = split * p.pix_per_block;
+    const int pe = min(p.P, ps + p.pix_per_block);
+    constexpr int ACH = BM / 8, BCH = BN / 8;
+    constexpr int AL = (32 * ACH) / NTHREADS, BL = (32 * BCH) / NTHREADS;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    // staging slots of this thread: LDS chunk e = l * 256 + tid of a tile region, i.e. row e / CH at position e % CH, which holds
+    // SOURCE chunk position ^ swizzle(row)
+    int a_row[AL], a_co[AL];
+    bool a_cok[AL];
+#pragma unroll
+    for (int l = 0; l < AL; ++l) {
+        const int e = tid + l * NTHREADS;
+        a_row[l] = e / ACH;
+        const int ch = (e - a_row[l] * ACH) ^ (tr_swz<BM>(a_row[l]) >> 1);
+        a_co[l] = co0 + ch * 8;
+        a_cok[l] = a_co[l] < p.Cout;
+    }
+    int b_row[BL], b_kh[BL], b_kw[BL], b_ci[BL], b_n[BL], b_oh[BL], b_ow[BL];
+    bool b_ok[BL];
+#pragma unroll
+    for (int l = 0; l < BL; ++l) {
+        const int e = tid + l * NTHREADS;
+        b_row[l] = e / BCH;
+        const int ch = (e - b_row[l] * BCH) ^ (tr_swz<BN>(b_row[l]) >> 1);
+        const int n = n0 + ch * 8;
+        b_ok[l] = n < p.NK;
+        const int tap = n >> p.cin_shift;
+        b_ci[l] = n - (tap << p.cin_shift);
+        b_kh[l] = tap / p.KW - p.pad;
+        b_kw[l] = tap - (tap / p.KW) * p.KW - p.pad;
+        const int pp = ps + b_row[l];
+        b_n[l] = pp / (p.OH * p.OW);
+        const int rem = pp - b_n[l] * (p.OH * p.OW);
+        b_oh[l] = rem / p.OW;
+        b_ow[l] = rem - b_oh[l] * p.OW;
+    }
+    auto stage = [&](int pbase, int st) {                       // 4 LDS-DMAs per thread (128 x 128 tile)
+        const unsigned sbase = lds0 + st * TILE_BYTES + wave * 1024;
+#pragma unroll
+        for (int l = 0; l < AL; ++l) {
+            const int pp = pbase + a_row[l];
+            const bf16_t* src = (pp < pe && a_cok[l]) ? p.dz + (size_t)pp * p.Cout + a_co[l] : zeros;
+            glds16(src, __builtin_amdgcn_readfirstlane(sbase + l * NTHREADS * 16));
+        }
+#pragma unroll
+        for (int l = 0; l < BL; ++l) {
+            const int ih = b_oh[l] * p.stride + b_kh[l], iw = b_ow[l] * p.stride + b_kw[l];
+            const bool ok = (pbase + b_row[l] < pe) && b_ok[l] && ih >= 0 && iw >= 0 && ih < p.H && iw < p.W;
+            const bf16_t* src = ok ? p.x + ((size_t)(b_n[l] * p.H + ih) * p.W + iw) * p.Cin + b_ci[l] : zeros;
+            glds16(src, __builtin_amdgcn_readfirstlane(sbase + 32 * AROW + l * NTHREADS * 16));
+            b_ow[l] += 32;
+            while (b_ow[l] >= p.OW) { b_ow[l] -= p.OW; ++b_oh[l]; }
+            while (b_oh[l] >= p.OH) { b_oh[l] -= p.OH; ++b_n[l]; }
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NT; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = pe > ps ? (pe - ps + 31) / 32 : 0;
+    const int li = lane & 15, lg = lane >> 4;
+    const int trow = 8 * lg + (li >> 2), tq = li & 3;
+    const int a_lo = trow * AROW, a_hi = (trow + 4) * AROW, b_lo = trow * BROW, b_hi = (trow + 4) * BROW;
+    const int ax_lo = tr_swz<BM>(trow), ax_hi = tr_swz<BM>(trow + 4), bx_lo = tr_swz<BN>(trow), bx_hi = tr_swz<BN>(trow + 4);
+    auto compute = [&](int st) {
+        const char* base = smem + st * TILE_BYTES;
+        bf16x8 fa[MT], fb[NT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int u = (wm * (BM / 2) + t * 16) / 4 + tq;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a_lo + ((u ^ ax_lo) << 3)));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a_hi + ((u ^ ax_hi) << 3)));
+            union { struct { s16x4 a, b; } s; bf16x8 v; } cvt;
+            cvt.s.a = lo; cvt.s.b = hi;
+            fa[t] = cvt.v;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int u = (wn * (BN / 2) + t * 16) / 4 + tq;
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 32 * AROW + b_lo + ((u ^ bx_lo) << 3)));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 32 * AROW + b_hi + ((u ^ bx_hi) << 3)));
+            union { struct { s16x4 a, b; } s; bf16x8 v; } cvt;
+            cvt.s.a = lo; cvt.s.b = hi;
+            fb[t] = cvt.v;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+    };
+    // ring of ST stages: steps kt+1 .. kt+ST-2 stay in flight (vmcnt counts this thread's LDS-DMAs, AL + BL per step) while step kt
+    // is multiplied; ONE raw barrier per step orders "step kt landed for every wave" and "everyone is done reading stage (kt-1) % ST"
+    constexpr int PER = AL + BL;
+#pragma unroll
+    for (int s0 = 0; s0 < ST - 1; ++s0)
+        if (s0 < nk) stage(ps + s0 * 32, s0);
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + ST - 2 <= nk - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + ST - 1 < nk) stage(ps + (kt + ST - 1) * 32, st == 0 ? ST - 1 : st - 1);
+        compute(st);
+        st = st + 1 == ST ? 0 : st + 1;
+    }
+    const int taps = p.KH * p.KW;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int nn = n0 + wn * (BN / 2) + nt * 16 + li;
+            const int tap = nn >> p.cin_shift;
+            const int ci = nn - (tap << p.cin_shift);
+            if (nn >= p.NK || ci >= p.cin_true) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wm * (BM / 2) + mt * 16 + lg * 4 + r;
+                if (co >= p.Cout) continue;
+                p.ws[((size_t)grp * p.nsplit + split) * p.dw_numel + ((size_t)co * taps + tap) * p.cin_true + ci] = acc[mt][nt][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 3x3 weight gradient, all nine taps per workgroup.  One K step = up to 32 output pixels of one image (a row
 // segment, or floor(32/OW) whole rows); the matching input patch (with its 1-pixel halo) is staged ONCE in LDS and
 // the nine shifted B operands are fetched from it with per-lane transpose reads, so dz and the activations are
@@ -1621,7 +1779,7 @@ extern "C" size_t adamml_conv_bwd_weight_workspace(const adamml_conv_desc_t* d, 
         const size_t n3 = (size_t)adamml_conv3x3_c64_wgrad_blocks(d, nullptr) * 64 * 576 * sizeof(float);
         if (n3 > need) need = n3;
     }
-    return need;
+    return need + 256;                  // + a zero page (the LDS-DMA weight-gradient kernel reads it for padding taps and tails)
 }
 
 struct WgradExtra { const float* dz_scale; const float* dz_shift; int dz_act, dz_gstride; bool per_group; };
@@ -1693,6 +1851,27 @@ static int wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void*
         p.pix_per_block = pl.per_block;
         p.dz_scale = ex ? ex->dz_scale : nullptr; p.dz_shift = ex ? ex->dz_shift : nullptr;
         p.dz_act = ex ? ex->dz_act : 0; p.dz_gstride = ex ? ex->dz_gstride : 0;
+        static const bool glds_on = !(getenv("ADAMML_WGRAD_GLDS") && getenv("ADAMML_WGRAD_GLDS")[0] == '0');
+        const size_t ws_floats = (size_t)groups * pl.nsplit * dw_numel;
+        if (glds_on && ws && !in_scale && !(ex && ex->dz_scale) && pl.BM == 128 && pl.BN == 128 &&
+            workspace_bytes >= ws_floats * sizeof(float) + 256) {
+            // both operands plain in memory: LDS-DMA staging
+            bf16_t* zeros = reinterpret_cast<bf16_t*>(ws + ws_floats);
+            (void)hipMemsetAsync(zeros, 0, 256, stream);
+            // 256-wide tiles halve the operand bytes fetched per MAC (this kernel is bound by the L1 load path: 16 KB per 128 x 128 x 32
+            // step = 256 cycles of 64 B/clk against 256 cycles of MFMA).  Measured (tools/bench_conv.py, B = 72, TFLOP/s 128^2 -> wide):
+            // 256 x 128 for Cout % 256 == 0: layer 3 conv1 366 -> 476, conv2 458 -> 616, downsample 329 -> 451, layer-2 downsample
+            // 407 -> 512; it loses where the pixel axis is short and the tile list long (layer 4 conv2 / downsample: 376 -> 367, 366 -> 339);
+            // 128 x 256 for a single cout tile: layer-2 conv1 374 -> 453.
+            if (d->Cout % 256 == 0 && pl.n_tiles <= 64) {
+                p.n_cotiles = d->Cout / 256; p.n_tiles = p.n_cotiles * ceil_div(pl.NK, 128);
+                hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 128, 2>), dim3(pl.nsplit * p.n_tiles * groups), block, 0, stream, p, (const bf16_t*)zeros);
+            } else if (d->Cout == 128 && pl.NK % 256 == 0) {
+                p.n_tiles = p.n_cotiles * (pl.NK / 256);
+                hipLaunchKernelGGL((conv_wgrad_glds_kernel<128, 256, 2>), dim3(pl.nsplit * p.n_tiles * groups), block, 0, stream, p, (const bf16_t*)zeros);
+            } else
+            hipLaunchKernelGGL((conv_wgrad_glds_kernel<128, 128, 3>), grid, block, 0, stream, p, (const bf16_t*)zeros);
+        } else
         if (ex && ex->dz_scale) {
             if (pl.BM == 64 && pl.BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, true>), grid, block, 0, stream, p);
             else if (pl.BM == 128 && pl.BN == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 1, true>), grid, block, 0, stream, p);
