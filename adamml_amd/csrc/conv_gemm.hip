@@ -94,6 +94,14 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+__device__ const uint4 g_zero_page[4] = {};          // 64 zero bytes: source of the out-of-range chunks of an LDS-DMA tile
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+
 // PD = register prefetch depth (K steps of global loads in flight).  PD 1 keeps 3-4 workgroups per CU (latency hidden by
 // occupancy: best for the big, short-K layers); PD 3 is for small grids with long K loops (layer3/4), where a CU holds a
 // single workgroup and only explicit look-ahead hides the HBM round trip.
@@ -105,21 +113,24 @@ __device__ __forceinline__ void static_for(F&& f) {
 // CAT: K-concatenated second input + per-group weights + epilogue constant (algebraic BatchNorm backward); own instantiation
 // for the same reason.
 // FADD: forward conv + BatchNorm + residual add + activation in the epilogue (see ConvP::id_scale); own instantiation.
-template <int BC, int MODE, int PD, bool RES = false, bool DUAL = false, bool CAT = false, bool FADD = false>
+// GLDS: operands that are plain in memory (no lazy transform) are staged global -> LDS by LDS-DMA through a ring of three tile
+// buffers with counted vmcnt across raw barriers (as conv_wgrad_glds_kernel): no register ring, no ds_write pass.
+template <int BC, int MODE, int PD, bool RES = false, bool DUAL = false, bool CAT = false, bool FADD = false, bool GLDS = false>
 __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
     constexpr int WROWS = BC / 64;          // weight rows staged per thread
     constexpr int TILE_BYTES = (BP + BC) * 64;
     constexpr int EPI_BYTES = BP * (BC * 2 + 16);
-    constexpr int STAGE_BYTES = (2 * TILE_BYTES) > EPI_BYTES ? (2 * TILE_BYTES) : EPI_BYTES;
+    constexpr int NBUF = GLDS ? 3 : 2;
+    constexpr int STAGE_BYTES = (NBUF * TILE_BYTES) > EPI_BYTES ? (NBUF * TILE_BYTES) : EPI_BYTES;
     constexpr int CS2_OFF = STAGE_BYTES + 2 * BC * 4 + 256 + (MODE == 3 ? BP * 4 + 16 : 0);     // second sum set (RES)
     // MODE 0: the per-input-channel vectors of the loader transform (lazy BatchNorm scale / shift, or the three DUAL affine
     // vectors) are staged in LDS once per workgroup when K <= VEC_MAXK: read from global inside store_tile they were an
     // exposed L1/L2 round trip in every K step (the loads can only be issued when the tile registers are consumed)
     constexpr int VEC_MAXK = 1024;
     constexpr int VEC_OFF = CS2_OFF + (RES ? 2 * BC * 4 : 0);
-    constexpr int SMEM_BYTES = VEC_OFF + (MODE == 0 ? (DUAL ? 3 : 2) * VEC_MAXK * 4 : 0);   // + per-channel sums + tap-offset table (+ MODE 3: output row table, weight tap table)
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    constexpr int SMEM_BYTES = VEC_OFF + ((MODE == 0 && !GLDS) ? (DUAL ? 3 : 2) * VEC_MAXK * 4 : 0);   // + per-channel sums + tap-offset table (+ MODE 3: output row table, weight tap table)
+    __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
 
     {   // BatchNorm group of this workgroup: one launch covers the S per-segment calls of the reference
         const int g = blockIdx.y;
@@ -404,6 +415,53 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
             for (int pt = 0; pt < 4; ++pt)
                 acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ct], fa[pt], acc[ct][pt], 0, 0, 0);
     };
+    if constexpr (GLDS) {
+        // LDS-DMA staging: position `chunk` of an LDS row holds source chunk chunk ^ swizzle(row) (lds_off is an involution)
+        const bf16_t* zeros = reinterpret_cast<const bf16_t*>(g_zero_page);
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + wave * 1024;
+        const int kc8 = (chunk ^ (((row_a >> 3) & 1) << 1)) * 8;
+        auto glds_stage = [&](int kt, int buf) {
+            const int k = kt * BK + kc8;
+            const bool kok = k < p.K;
+            const unsigned base = lds0 + buf * TILE_BYTES;
+            int kw_off = k;
+            if (MODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const bf16_t* src = (a_ok[r] && kok) ? p.x + (size_t)(unsigned)(a_base[r] + k) : zeros;
+                    glds16(src, __builtin_amdgcn_readfirstlane(base + r * 4096));
+                }
+            } else {
+                const int tap = kok ? (k >> p.cin_shift) : 0;
+                const int ci = k & (p.Cin - 1);
+                const int toff = s_tapoff[tap] + ci;
+                if (MODE == 3) kw_off = s_wtap[tap] + ci;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const bool ok = kok && ((a_mask[r] >> tap) & 1ull);
+                    const bf16_t* src = ok ? p.x + (size_t)(unsigned)(a_base[r] + toff) : zeros;
+                    glds16(src, __builtin_amdgcn_readfirstlane(base + r * 4096));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < WROWS; ++r) {
+                const bf16_t* src = (w_ok[r] && kok) ? wrow[r] + kw_off : zeros;
+                glds16(src, __builtin_amdgcn_readfirstlane(base + BP * 64 + r * 4096));
+            }
+        };
+        constexpr int PER = 2 + WROWS;                       // LDS-DMAs of this thread per K step
+        glds_stage(0, 0);
+        if (nk > 1) glds_stage(1, 1);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");       // step kt landed, step kt + 1 may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // ... for every wave; and everyone is past compute(kt - 1)
+            if (kt + 2 < nk) glds_stage(kt + 2, buf == 0 ? 2 : buf - 1);
+            compute(buf);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    } else {
     // prologue: fill the ring
     static_for<PD>([&](auto sc) {
         if ((int)decltype(sc)::value < nk) issue_loads(sc, (int)decltype(sc)::value);
@@ -418,6 +476,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
                 compute(kt & 1);
             }
         });
+    }
     }
     __syncthreads();                                     // operand tiles consumed: the epilogue reuses the LDS
 
@@ -922,14 +981,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
 // bound by its staging, not by the matrix cores.)  The LDS destination of an LDS-DMA is wave-uniform base + lane * 16, so the
 // image is lane-linear and the bank swizzle of the transposed reads is applied to the SOURCE chunk index instead (an
 // involution within a pixel row: the same cache lines are fetched).  Out-of-range chunks (padding taps, tails) read a zero page.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
-}
-
 template <int BM, int BN, int ST>
-__global__ __launch_bounds__(NTHREADS) void conv_wgrad_glds_kernel(WgradP p, const bf16_t* zeros) {
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_glds_kernel(WgradP p) {
+    const bf16_t* zeros = reinterpret_cast<const bf16_t*>(g_zero_page);
     constexpr int AROW = BM * 2, BROW = BN * 2;
     constexpr int TILE_BYTES = 32 * (AROW + BROW);
     constexpr int MT = BM / 32, NT = BN / 32;
@@ -1405,16 +1459,21 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
         else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 3, false, true>), grid, block, 0, stream, p);
         return adamml_check_launch("conv_bwd_data_dual");
     }
+    static const bool glds_on = !(getenv("ADAMML_CONV_GLDS") && getenv("ADAMML_CONV_GLDS")[0] == '0');
+    const bool glds = glds_on && !in_scale && mode != 2;
 #define LAUNCH_CONV(BCV, MODEV)                                                                             \
     do {                                                                                                    \
-        if (deep) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 3>), grid, block, 0, stream, p);          \
+        if (glds) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1, false, false, false, false, true>), grid, block, 0, stream, p); \
+        else if (deep) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 3>), grid, block, 0, stream, p);     \
         else hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1>), grid, block, 0, stream, p);               \
     } while (0)
     if (BC == 64) {
         if (mode == 0) LAUNCH_CONV(64, 0); else if (mode == 1) LAUNCH_CONV(64, 1); else if (mode == 2) LAUNCH_CONV(64, 2);
+        else if (glds) hipLaunchKernelGGL((conv_gemm_kernel<64, 3, 1, false, false, false, false, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((conv_gemm_kernel<64, 3, 1>), grid, block, 0, stream, p);
     } else {
         if (mode == 0) LAUNCH_CONV(128, 0); else if (mode == 1) LAUNCH_CONV(128, 1); else if (mode == 2) LAUNCH_CONV(128, 2);
+        else if (glds) hipLaunchKernelGGL((conv_gemm_kernel<128, 3, 1, false, false, false, false, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((conv_gemm_kernel<128, 3, 1>), grid, block, 0, stream, p);
     }
 #undef LAUNCH_CONV
@@ -1779,7 +1838,7 @@ extern "C" size_t adamml_conv_bwd_weight_workspace(const adamml_conv_desc_t* d, 
         const size_t n3 = (size_t)adamml_conv3x3_c64_wgrad_blocks(d, nullptr) * 64 * 576 * sizeof(float);
         if (n3 > need) need = n3;
     }
-    return need + 256;                  // + a zero page (the LDS-DMA weight-gradient kernel reads it for padding taps and tails)
+    return need;
 }
 
 struct WgradExtra { const float* dz_scale; const float* dz_shift; int dz_act, dz_gstride; bool per_group; };
@@ -1852,12 +1911,8 @@ static int wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void*
         p.dz_scale = ex ? ex->dz_scale : nullptr; p.dz_shift = ex ? ex->dz_shift : nullptr;
         p.dz_act = ex ? ex->dz_act : 0; p.dz_gstride = ex ? ex->dz_gstride : 0;
         static const bool glds_on = !(getenv("ADAMML_WGRAD_GLDS") && getenv("ADAMML_WGRAD_GLDS")[0] == '0');
-        const size_t ws_floats = (size_t)groups * pl.nsplit * dw_numel;
-        if (glds_on && ws && !in_scale && !(ex && ex->dz_scale) && pl.BM == 128 && pl.BN == 128 &&
-            workspace_bytes >= ws_floats * sizeof(float) + 256) {
+        if (glds_on && ws && !in_scale && !(ex && ex->dz_scale) && pl.BM == 128 && pl.BN == 128) {
             // both operands plain in memory: LDS-DMA staging
-            bf16_t* zeros = reinterpret_cast<bf16_t*>(ws + ws_floats);
-            (void)hipMemsetAsync(zeros, 0, 256, stream);
             // 256-wide tiles halve the operand bytes fetched per MAC (this kernel is bound by the L1 load path: 16 KB per 128 x 128 x 32
             // step = 256 cycles of 64 B/clk against 256 cycles of MFMA).  Measured (tools/bench_conv.py, B = 72, TFLOP/s 128^2 -> wide):
             // 256 x 128 for Cout % 256 == 0: layer 3 conv1 366 -> 476, conv2 458 -> 616, downsample 329 -> 451, layer-2 downsample
@@ -1865,12 +1920,12 @@ static int wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void*
             // 128 x 256 for a single cout tile: layer-2 conv1 374 -> 453.
             if (d->Cout % 256 == 0 && pl.n_tiles <= 64) {
                 p.n_cotiles = d->Cout / 256; p.n_tiles = p.n_cotiles * ceil_div(pl.NK, 128);
-                hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 128, 2>), dim3(pl.nsplit * p.n_tiles * groups), block, 0, stream, p, (const bf16_t*)zeros);
+                hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 128, 2>), dim3(pl.nsplit * p.n_tiles * groups), block, 0, stream, p);
             } else if (d->Cout == 128 && pl.NK % 256 == 0) {
                 p.n_tiles = p.n_cotiles * (pl.NK / 256);
-                hipLaunchKernelGGL((conv_wgrad_glds_kernel<128, 256, 2>), dim3(pl.nsplit * p.n_tiles * groups), block, 0, stream, p, (const bf16_t*)zeros);
+                hipLaunchKernelGGL((conv_wgrad_glds_kernel<128, 256, 2>), dim3(pl.nsplit * p.n_tiles * groups), block, 0, stream, p);
             } else
-            hipLaunchKernelGGL((conv_wgrad_glds_kernel<128, 128, 3>), grid, block, 0, stream, p, (const bf16_t*)zeros);
+            hipLaunchKernelGGL((conv_wgrad_glds_kernel<128, 128, 3>), grid, block, 0, stream, p);
         } else
         if (ex && ex->dz_scale) {
             if (pl.BM == 64 && pl.BN == 64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 1, true>), grid, block, 0, stream, p);
