@@ -1443,6 +1443,11 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     }
     if (res) {
         if (mode != 0) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res: only 1x1 / stride-1 convs");
+        static const bool res_glds = !(getenv("ADAMML_RES_GLDS") && getenv("ADAMML_RES_GLDS")[0] == '0');
+        if (res_glds && !in_scale) {
+            if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, true, false, false, false, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, true, false, false, false, true>), grid, block, 0, stream, p);
+        } else
         if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, true>), grid, block, 0, stream, p);
         return adamml_check_launch("conv_bwd_data_res");
