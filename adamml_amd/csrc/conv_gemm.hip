@@ -115,21 +115,33 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
 // FADD: forward conv + BatchNorm + residual add + activation in the epilogue (see ConvP::id_scale); own instantiation.
 // GLDS: operands that are plain in memory (no lazy transform) are staged global -> LDS by LDS-DMA through a ring of three tile
 // buffers with counted vmcnt across raw barriers (as conv_wgrad_glds_kernel): no register ring, no ds_write pass.
-template <int BC, int MODE, int PD, bool RES = false, bool DUAL = false, bool CAT = false, bool FADD = false, bool GLDS = false>
-__global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
+// EID (FADD / RES): the epilogue's identity-side operands (identity tensor; identity-path gradient + activation mask bits) are
+// requested at the START of a tile, behind the first operand loads, instead of in the epilogue: the whole tile then costs ONE HBM
+// round trip instead of three (operands, 2 x 4 identity rows), and a workgroup keeps ~3x the bytes in flight.  PMC on the layer-1
+// shapes: these kernels held ~350 reads outstanding at the fabric against ~700-900 of the elementwise kernels (TCC_EA0_RDREQ_LEVEL),
+// at a LOWER latency per read -- they were bound by their own request rate, not by HBM.  Costs 32 VGPRs: 2 workgroups per CU.
+// LZF (GLDS, MODE 0): the lazy BatchNorm + activation transform of the INPUT is applied to the MFMA fragment after its ds_read
+// instead of on the way into LDS, so that lazily normalised inputs can be staged by LDS-DMA as well (raw tile global -> LDS, deep
+// counted-vmcnt pipeline, no register ring / ds_write pass / exec-masked loads).  Same fma / clamp / round sequence on the same
+// values: bit-identical to the staging-side transform.  The two waves that share a pixel half repeat the transform (VALU has the
+// slack on these HBM-bound layers); K <= 512 (per-channel vectors in LDS).
+template <int BC, int MODE, int PD, bool RES = false, bool DUAL = false, bool CAT = false, bool FADD = false, bool GLDS = false, int EID = 0,
+          bool LZF = false>
+__global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
     constexpr int WROWS = BC / 64;          // weight rows staged per thread
     constexpr int TILE_BYTES = (BP + BC) * 64;
     constexpr int EPI_BYTES = BP * (BC * 2 + 16);
     constexpr int NBUF = GLDS ? 3 : 2;
     constexpr int STAGE_BYTES = (NBUF * TILE_BYTES) > EPI_BYTES ? (NBUF * TILE_BYTES) : EPI_BYTES;
-    constexpr int CS2_OFF = STAGE_BYTES + 2 * BC * 4 + 256 + (MODE == 3 ? BP * 4 + 16 : 0);     // second sum set (RES)
+    constexpr int CS2_OFF = STAGE_BYTES + 2 * BC * 4 + (MODE == 0 ? 0 : 256) + (MODE == 3 ? BP * 4 + 16 : 0);     // second sum set (RES); 256: tap tables
     // MODE 0: the per-input-channel vectors of the loader transform (lazy BatchNorm scale / shift, or the three DUAL affine
     // vectors) are staged in LDS once per workgroup when K <= VEC_MAXK: read from global inside store_tile they were an
     // exposed L1/L2 round trip in every K step (the loads can only be issued when the tile registers are consumed)
     constexpr int VEC_MAXK = 1024;
     constexpr int VEC_OFF = CS2_OFF + (RES ? 2 * BC * 4 : 0);
-    constexpr int SMEM_BYTES = VEC_OFF + ((MODE == 0 && !GLDS) ? (DUAL ? 3 : 2) * VEC_MAXK * 4 : 0);   // + per-channel sums + tap-offset table (+ MODE 3: output row table, weight tap table)
+    constexpr int LZF_MAXK = 512;              // LZF keeps 3 workgroups per CU at BC = 128: 3 x (3 tiles + sums + 4 KB of vectors) <= 160 KB
+    constexpr int SMEM_BYTES = VEC_OFF + (LZF ? 2 * LZF_MAXK * 4 : (MODE == 0 && !GLDS) ? (DUAL ? 3 : 2) * VEC_MAXK * 4 : 0);   // + per-channel sums + tap-offset table (+ MODE 3: output row table, weight tap table)
     __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
 
     {   // BatchNorm group of this workgroup: one launch covers the S per-segment calls of the reference
@@ -165,6 +177,16 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
     float* s_vec = reinterpret_cast<float*>(smem + (MODE == 0 ? VEC_OFF : 0));
     const int nvec = CAT ? p.C2 : p.K;                            // entries of the loader's per-channel vectors
     const bool vec_lds = MODE == 0 && nvec <= VEC_MAXK && (DUAL || p.in_scale != nullptr);
+    if (LZF) {
+        // scale at [0, LZF_MAXK), shift at [LZF_MAXK, 2 LZF_MAXK); zero beyond K up to the K-step boundary (zero weights there, but
+        // 0 * garbage must not make a NaN)
+        const int kpad = (p.K + BK - 1) / BK * BK;
+        for (int i = tid; i < kpad; i += NTHREADS) {
+            s_vec[i] = i < p.K ? p.in_scale[i] : 0.f;
+            s_vec[LZF_MAXK + i] = i < p.K ? p.in_shift[i] : 0.f;
+        }
+        __syncthreads();
+    } else
     if (vec_lds) {
         if (DUAL) {
             for (int i = tid; i < 3 * p.K; i += NTHREADS) s_vec[i] = p.aff[i];
@@ -248,6 +270,14 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
         int pp = p0 + row_a + r * 64;
         a_ok[r] = pp < p.P;
         int ppc = a_ok[r] ? pp : 0;
+        if (MODE == 0 && p.stride == 1 && p.pad == 0) {
+            // 1x1 / stride 1 (pad 0): the input pixel IS the output pixel -- none of the two integer divisions below (~80 VALU
+            // instructions per row, executed per tile AHEAD of the tile's first load)
+            a_n[r] = a_h0[r] = a_w0[r] = 0;
+            a_base[r] = ppc * p.Cin;
+            a_mask[r] = 0;
+            continue;
+        }
         int n = ppc / (p.OH * p.OW);
         int rem = ppc - n * (p.OH * p.OW);
         int oh = rem / p.OW;
@@ -285,6 +315,28 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
         s_orow[tid] = orow;
     }
     if ((MODE == 1 || MODE == 3) && it == 0) __syncthreads();          // tap-offset tables visible
+
+    // EID: identity-side operands of this tile's epilogue (every lane loads -- clamped addresses -- so that the number of
+    // outstanding VMEM operations is the same for every wave: the LDS-DMA loop below waits with counted vmcnt)
+    constexpr int NRE = BP / RSTEP;
+    bf16x8 eid[EID ? NRE : 1];
+    unsigned embits[EID ? NRE : 1];
+    auto issue_eid = [&]() {
+        if constexpr (EID != 0) {
+            const int ecoc = eco < p.Cout ? eco : 0;
+#pragma unroll
+            for (int j = 0; j < NRE; ++j) {
+                const int r = erow0 + j * RSTEP;
+                const size_t pre = (size_t)(p0 + r < p.P ? p0 + r : p0) * p.Cout + ecoc;
+                if (FADD) eid[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.res_out + pre));
+                else {
+                    eid[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.y + pre));
+                    embits[j] = p.res_mask[pre >> 3];
+                }
+            }
+        }
+    };
+    constexpr int NEID = EID ? (FADD ? NRE : 2 * NRE) : 0;       // VMEM loads issue_eid() puts in flight per thread
 
     // register prefetch ring of depth PD: global loads run PD K-steps ahead of the MFMAs.  One K step of compute is
     // ~0.15 us but an HBM round trip is 1-2 us, so a one-step look-ahead left the kernel latency-bound.
@@ -400,12 +452,30 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
-    auto compute = [&](int buf) {
+    const bool tail_rows = p0 + BP > p.P;                     // (uniform) this tile has rows past the last pixel
+    auto compute = [&](int buf, int kt = 0) {
         const char* base = smem + buf * TILE_BYTES;
         bf16x8 fa[4], fw[WCT];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             fa[t] = *reinterpret_cast<const bf16x8*>(base + lds_off(wp * 64 + t * 16 + li, lg));
+        if constexpr (LZF) {
+            // fragment lane (pixel li of tile t, K chunk lg) = 8 consecutive input channels kt*32 + lg*8 ..+7 of one pixel
+            const f32x8 sc = load_f32x8(s_vec + kt * BK + lg * 8), sh = load_f32x8(s_vec + LZF_MAXK + kt * BK + lg * 8);
+            const float lo = act_lo(p.act), hi = act_hi(p.act);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x8 f = bf8_to_f32(fa[t]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] = clamp_act(fmaf(f[i], sc[i], sh[i]), lo, hi);
+                fa[t] = f32_to_bf8(f);
+            }
+            if (tail_rows) {                              // zero-filled rows must stay zero (statistics, never-stored outputs)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (p0 + wp * 64 + t * 16 + li >= p.P) fa[t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
 #pragma unroll
         for (int t = 0; t < WCT; ++t)
             fw[t] = *reinterpret_cast<const bf16x8*>(base + BP * 64 + lds_off(wc * (BC / 2) + t * 16 + li, lg));
@@ -452,13 +522,19 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
         constexpr int PER = 2 + WROWS;                       // LDS-DMAs of this thread per K step
         glds_stage(0, 0);
         if (nk > 1) glds_stage(1, 1);
+        issue_eid();                                         // in flight behind steps 0 and 1, ahead of steps 2..
         int buf = 0;
         for (int kt = 0; kt < nk; ++kt) {
+            // step kt landed; step kt + 1 may fly -- and, while the steps waited for are OLDER than the EID loads (kt <= 1), so may they
+            if (NEID && kt <= 1) {
+                if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER + NEID) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEID) : "memory");
+            } else
             if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");       // step kt landed, step kt + 1 may fly
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                    // ... for every wave; and everyone is past compute(kt - 1)
             if (kt + 2 < nk) glds_stage(kt + 2, buf == 0 ? 2 : buf - 1);
-            compute(buf);
+            compute(buf, kt);
             buf = buf == 2 ? 0 : buf + 1;
         }
     } else {
@@ -466,6 +542,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
     static_for<PD>([&](auto sc) {
         if ((int)decltype(sc)::value < nk) issue_loads(sc, (int)decltype(sc)::value);
     });
+    issue_eid();
     for (int kt0 = 0; kt0 < nk; kt0 += PD) {
         static_for<PD>([&](auto sc) {
             const int kt = kt0 + (int)decltype(sc)::value;
@@ -506,7 +583,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
             for (int i = 0; i < 8; ++i) { isc[i] = 1.f; ish[i] = 0.f; }
             if (p.id_scale) { isc = load_f32x8(p.id_scale + eco); ish = load_f32x8(p.id_shift + eco); }
             const float rlo = act_lo(p.res_act), rhi = act_hi(p.res_act);
-            constexpr int NR = BP / RSTEP, EB = NR < 4 ? NR : 4;
+            constexpr int NR = BP / RSTEP, EB = EID ? NR : (NR < 4 ? NR : 4);
 #pragma unroll
             for (int b0 = 0; b0 < NR; b0 += EB) {
                 bf16x8 ir[EB];
@@ -517,7 +594,8 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
                     const int r = erow0 + (b0 + j) * RSTEP;
                     ok[j] = p0 + r < p.P;
                     pr[j] = (size_t)(ok[j] ? p0 + r : p0) * p.Cout + eco;
-                    if (p.res_out) ir[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.res_out + pr[j]));
+                    if constexpr (EID != 0) ir[j] = eid[b0 + j];                 // requested at the start of the tile
+                    else if (p.res_out) ir[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.res_out + pr[j]));
                 }
 #pragma unroll
                 for (int j = 0; j < EB; ++j) {
@@ -559,10 +637,10 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
         f32x8 mu2, is2;
         if (second) { mu2 = load_f32x8(p.bn_vec2 + 2 * p.Cout + eco); is2 = load_f32x8(p.bn_vec2 + 3 * p.Cout + eco); }
         const float rlo = act_lo(p.res_act), rhi = act_hi(p.res_act);
-        constexpr int NR = BP / RSTEP, EB = NR < 4 ? NR : 4;
+        constexpr int NR = BP / RSTEP, EB = EID ? NR : (NR < 4 ? NR : 4);
 #pragma unroll
         for (int b0 = 0; b0 < NR; b0 += EB) {
-            bf16x8 zr[EB], dr[EB], orr[EB], z2r[EB];
+            bf16x8 zr[EID ? 1 : EB], dr[EB], orr[EID ? 1 : EB], z2r[EID ? 1 : EB];
             unsigned mbits[EB];
             size_t pr[EB];
             bool ok[EB];
@@ -571,22 +649,28 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
                 const int r = erow0 + (b0 + j) * RSTEP;
                 ok[j] = p0 + r < p.P;
                 pr[j] = (size_t)(ok[j] ? p0 + r : p0) * p.Cout + eco;       // clamped: out-of-range rows re-read row p0, never stored
+                if constexpr (EID != 0) {
+                    // (the launcher selects EID only for: accumulate, 1-bit mask, no z operands -- the algebraic backward's form)
+                    dr[j] = eid[b0 + j];
+                    mbits[j] = embits[b0 + j];
+                } else {
                 if (p.bn_z) zr[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.bn_z + pr[j]));
                 if (p.accumulate) dr[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.y + pr[j]));
                 if (p.res_mask) mbits[j] = p.res_mask[pr[j] >> 3];
                 else orr[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.res_out + pr[j]));
                 if (second) z2r[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.bn_z2 + pr[j]));
+                }
             }
 #pragma unroll
             for (int j = 0; j < EB; ++j) {
                 const int r = erow0 + (b0 + j) * RSTEP;
                 f32x8 f = bf8_to_f32(*reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16));
-                if (p.accumulate) f += bf8_to_f32(dr[j]);
-                if (p.res_mask) {
+                if (EID || p.accumulate) f += bf8_to_f32(dr[j]);
+                if (EID || p.res_mask) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) f[i] = (mbits[j] >> i) & 1u ? f[i] : 0.f;
                 } else {
-                    const f32x8 ov = bf8_to_f32(orr[j]);
+                    const f32x8 ov = bf8_to_f32(orr[EID ? 0 : j]);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) f[i] *= mask_act(ov[i], rlo, rhi);
                 }
@@ -595,6 +679,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
                 const float keep = ok[j] ? 1.f : 0.f;
                 f = bf8_to_f32(v) * keep;
                 esum += f;
+                if constexpr (EID == 0) {
                 if (p.bn_z) {
                     const f32x8 zv = bf8_to_f32(zr[j]);
 #pragma unroll
@@ -604,6 +689,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT) ? 2 : (PD == 1 ? (BC
                     const f32x8 z2 = bf8_to_f32(z2r[j]);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) esq2[i] += f[i] * (z2[i] - mu2[i]) * is2[i];
+                }
                 }
             }
         }
@@ -1437,6 +1523,24 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     const bool deep = (long)grid.x * grid.y <= 768 && nk >= 8 && mode != 1;
     if (fadd) {
         if (mode != 0 || res || dual || cat || stats) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd_bn_add: only 1x1 / stride-1 convs");
+        static const int fadd_glds = getenv("ADAMML_FADD_GLDS") ? atoi(getenv("ADAMML_FADD_GLDS")) : 2;     // 0: register ring, 1: LDS-DMA, 2: + EID
+        if (fadd_glds && (!in_scale || p.K <= 512)) {
+            // operands by LDS-DMA (a lazily normalised input is transformed at the fragment: LZF); with an identity operand, that one is
+            // requested at the start of each tile (EID)
+            const bool eid = fadd_glds > 1 && p.res_out;
+#define LAUNCH_FADD(BCV)                                                                                                                   \
+            do {                                                                                                                           \
+                if (in_scale) {                                                                                                            \
+                    if (eid) hipLaunchKernelGGL((conv_gemm_kernel<BCV, 0, 1, false, false, false, true, true, 1, true>), grid, block, 0, stream, p);  \
+                    else hipLaunchKernelGGL((conv_gemm_kernel<BCV, 0, 1, false, false, false, true, true, 0, true>), grid, block, 0, stream, p);      \
+                } else {                                                                                                                   \
+                    if (eid) hipLaunchKernelGGL((conv_gemm_kernel<BCV, 0, 1, false, false, false, true, true, 1, false>), grid, block, 0, stream, p); \
+                    else hipLaunchKernelGGL((conv_gemm_kernel<BCV, 0, 1, false, false, false, true, true, 0, false>), grid, block, 0, stream, p);     \
+                }                                                                                                                          \
+            } while (0)
+            if (BC == 64) LAUNCH_FADD(64); else LAUNCH_FADD(128);
+#undef LAUNCH_FADD
+        } else
         if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, false, false, false, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, false, false, false, true>), grid, block, 0, stream, p);
         return adamml_check_launch("conv_fwd_bn_add");
@@ -1444,6 +1548,12 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     if (res) {
         if (mode != 0) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res: only 1x1 / stride-1 convs");
         static const bool res_glds = !(getenv("ADAMML_RES_GLDS") && getenv("ADAMML_RES_GLDS")[0] == '0');
+        static const bool res_eid = !(getenv("ADAMML_RES_EID") && getenv("ADAMML_RES_EID")[0] == '0');
+        if (res_glds && res_eid && !in_scale && p.res_mask && p.accumulate && !p.bn_z && !p.bn_z2) {
+            // the algebraic backward's form (identity gradient + 1-bit mask, sum(g') only): identity-side loads at the start of each tile
+            if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, true, false, false, false, true, 1>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, true, false, false, false, true, 1>), grid, block, 0, stream, p);
+        } else
         if (res_glds && !in_scale) {
             if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, true, false, false, false, true>), grid, block, 0, stream, p);
             else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, true, false, false, false, true>), grid, block, 0, stream, p);
@@ -1465,7 +1575,17 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
         return adamml_check_launch("conv_bwd_data_dual");
     }
     static const bool glds_on = !(getenv("ADAMML_CONV_GLDS") && getenv("ADAMML_CONV_GLDS")[0] == '0');
+    // (measured, tools/explore_stream.py: the fragment-side transform LOSES on the plain forward convs -- layer-1 conv3 1.77 vs 1.61 ms,
+    // layer 2 0.59 vs 0.54, layer 3 0.23 vs 0.21: each pixel half is transformed by two waves, between the ds_read and the MFMA --
+    // and only pays together with the early identity loads of the FADD kernel; opt-in for A/B)
+    static const bool lzf_on = getenv("ADAMML_CONV_LZF") && getenv("ADAMML_CONV_LZF")[0] == '1';
     const bool glds = glds_on && !in_scale && mode != 2;
+    if (glds_on && lzf_on && in_scale && mode == 0 && p.K <= 512 && !deep) {
+        // 1x1 conv of a lazily normalised input: LDS-DMA staging, transform at the fragment (LZF)
+        if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, false, false, false, false, true, 0, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, false, false, false, false, true, 0, true>), grid, block, 0, stream, p);
+        return adamml_check_launch("conv_fwd");
+    }
 #define LAUNCH_CONV(BCV, MODEV)                                                                             \
     do {                                                                                                    \
         if (glds) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1, false, false, false, false, true>), grid, block, 0, stream, p); \

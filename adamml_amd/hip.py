@@ -35,6 +35,7 @@ SIGNATURES = {
     "adamml_conv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
     "adamml_conv_fwd_bn_add": [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "adamml_gram_stats": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "adamml_gram_colsum": [_P, _P, _P, _I, _I, _P, _P, _Z, _I, _I, _P, _Z, _P],
     "adamml_conv_bwd_data_bn": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
     "adamml_bn_bwd_affine": [_P, _P, _P, _I, _I, _P],
     "adamml_conv_bwd_data_dual": [_DESC, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
@@ -112,6 +113,10 @@ def load():
     lib.adamml_conv_stem_bwd_weight_workspace.restype = c_size_t
     lib.adamml_dwconv_bwd_weight_workspace.argtypes = [_DESC]
     lib.adamml_dwconv_bwd_weight_workspace.restype = c_size_t
+    lib.adamml_gram_colsum_workspace.argtypes = [_Z, _I, _I]
+    lib.adamml_gram_colsum_workspace.restype = c_size_t
+    lib.adamml_gram_colsum_supported.argtypes = [_I]
+    lib.adamml_gram_colsum_supported.restype = c_int
     lib.adamml_conv_fused_input_supported.argtypes = [_DESC]
     lib.adamml_conv_fused_input_supported.restype = c_int
     lib.adamml_conv_fwd_bn_add_supported.argtypes = [_DESC]
@@ -205,9 +210,12 @@ def call(name, *args):
 _wgrad_ws = {}
 
 
-def wgrad_workspace(desc, cin_true, device, depthwise=False, stem=False):
-    """Persistent per-device scratch for the split weight-gradient partial tiles (grown on demand)."""
-    if stem:
+def wgrad_workspace(desc, cin_true, device, depthwise=False, stem=False, gram=None):
+    """Persistent per-device scratch for the split weight-gradient partial tiles (grown on demand); gram = (P, C, groups):
+    the partials of adamml_gram_colsum instead."""
+    if gram is not None:
+        need = load().adamml_gram_colsum_workspace(*gram)
+    elif stem:
         need = load().adamml_conv_stem_bwd_weight_workspace(ctypes.byref(desc))
     elif depthwise:
         need = load().adamml_dwconv_bwd_weight_workspace(ctypes.byref(desc))

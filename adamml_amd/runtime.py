@@ -481,16 +481,24 @@ def _gram_colsum(rt, x, d):
     G, Cin, dev = rt.groups, d.Cin, x.data.device
     n, h, w_, _ = x.shape
     Gm = torch.empty(G, Cin, Cin, dtype=torch.float32, device=dev)
+    sv = torch.empty(G, Cin, dtype=torch.float32, device=dev)
+    if GRAM_KERNEL and hip.load().adamml_gram_colsum_supported(Cin):
+        # one streaming pass (csrc/gram.hip) instead of the generic weight-gradient kernel with dz = x plus a column-sum pass
+        P = n // G * h * w_
+        wsg = hip.wgrad_workspace(None, 0, dev, gram=(P, Cin, G))
+        hip.next_meta = (2.0 * G * P * Cin * Cin, 2.0 * G * P * Cin)
+        call("adamml_gram_colsum", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(Gm), ptr(sv), P, Cin, G, ptr(wsg), wsg.numel() * 4)
+        return Gm, sv
     dg = ConvDesc(d.N, d.H, d.W, Cin, d.H, d.W, Cin, 1, 1, 1, 0, 1, d.act, 0, G, d.in_gstride)
     wsg = hip.wgrad_workspace(dg, Cin, dev)
     hip.next_meta = (2.0 * G * d.N * d.H * d.W * Cin * Cin, 2.0 * G * d.N * d.H * d.W * Cin)
     call("adamml_conv_bwd_weight_grouped", byref(dg), ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, x.gs, ptr(x.data), ptr(x.scale),
          ptr(x.shift), ptr(Gm), Cin, ptr(wsg), wsg.numel() * 4)
-    sv = torch.empty(G, Cin, dtype=torch.float32, device=dev)
     call("adamml_lazy_colsum", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(sv), n // G * h * w_, Cin, G)
     return Gm, sv
 
 
+GRAM_KERNEL = os.environ.get("ADAMML_GRAM_KERNEL", "1") != "0"     # dedicated Gram + column-sum kernel (A/B aid)
 ALG_BN = os.environ.get("ADAMML_ALG_BN", "1") != "0"     # algebraic BatchNorm backward through expanding 1x1 convs (A/B aid)
 ALG_MAX_COUT = int(os.environ.get("ADAMML_ALG_MAX_COUT", "512"))     # measured: at Cout = 1024 (layer 3) the small per-group products cost more than the saved passes (146.1 vs 144.6 ms)
 ALG_GEMM_CIN = 256     # from this input width on, the small per-group matrix products go through adamml_gemm_f32

@@ -79,6 +79,14 @@ int adamml_conv_fwd_bn_add(const adamml_conv_desc_t* d, const void* x, const voi
  * the Gram matrix G [groups][Cin][Cin] = a^T a and the column sums s [groups][Cin] of the conv INPUT (fp32), W = the bf16
  * forward pack [Cout][Cin].  sums [groups][2*Cout] doubles: pass to adamml_bn_finalize with nslots = 1. */
 int adamml_gram_stats(const void* w_packed, const float* G, const float* s, double* sums, int Cout, int Cin, int groups, hipStream_t stream);
+/* G [groups][C][C] = a^T a and s [groups][C] = sum_p a over the P pixels of each group, a = act(scale x + shift) rounded to bf16
+ * as the conv loaders stage it (scale == NULL: a = x), in one streaming pass over x (csrc/gram.hip) -- the inputs of
+ * adamml_gram_stats and of the algebraic BatchNorm backward (models/resnet.py:103-111: bn3 statistics without storing conv3's
+ * output).  C in {64, 128}; workspace of adamml_gram_colsum_workspace() bytes (per-workgroup partials, summed in a fixed order). */
+int adamml_gram_colsum_supported(int C);
+size_t adamml_gram_colsum_workspace(size_t P, int C, int groups);
+int adamml_gram_colsum(const void* x, const float* scale, const float* shift, int gstride, int act, float* G, float* s, size_t P, int C,
+                       int groups, void* workspace, size_t workspace_bytes, hipStream_t stream);
 /* autograd of adamml_conv_fwd w.r.t. its input (d = forward descriptor; w packed with mode 1) */
 int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
                          int accumulate, hipStream_t stream);

@@ -1000,3 +1000,44 @@ def test_conv_fwd_bn_add_and_gram_statistics(G, N, H, Cin, Cout, lazy_idn, act):
     call("adamml_bn_act_add_mask", ptr(z), ptr(vec[0, 0]), ptr(vec[0, 1]), 4 * Cout, act, None, None, None, 0, ptr(want), None, P, Cout, G)
     call("adamml_conv_fwd_bn_add", byref(d), ptr(x), ptr(wp), ptr(xvec[0, 0]), ptr(xvec[0, 1]), ptr(vec), None, None, None, 0, act, ptr(got), None)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("C,P,G,lazy,act", [(64, 3136, 3, True, 1), (64, 777, 1, False, 0), (128, 1570, 2, True, 1), (128, 31, 5, True, 2),
+                                            (64, 70001, 2, True, 1)])
+def test_gram_colsum_kernel(C, P, G, lazy, act):
+    """adamml_gram_colsum (csrc/gram.hip): G = a^T a and s = sum a over the pixels of each group for a = act(scale x + shift) rounded
+    to bf16 as the conv loaders stage it -- against the fp64 products of the same bf16 operand, and against the pair of launches it
+    replaces (adamml_conv_bwd_weight_grouped with dz = x, adamml_lazy_colsum); ragged pixel counts, plain (non-lazy) input."""
+    torch.manual_seed(C + P)
+    x = (torch.randn(G, P, C, device=DEV) * 1.5).to(torch.bfloat16)
+    vec = torch.rand(G, 4, C, device=DEV) + 0.5
+    vec[:, 1] -= 0.6
+    sc, sh = (ptr(vec[0, 0]), ptr(vec[0, 1])) if lazy else (None, None)
+    Gm = torch.empty(G, C, C, device=DEV)
+    sv = torch.empty(G, C, device=DEV)
+    need = hip.load().adamml_gram_colsum_workspace(P, C, G)
+    ws = torch.empty(need // 4 + 1, device=DEV)
+    for _ in range(2):                                   # twice: the workspace partials are overwritten, not accumulated
+        call("adamml_gram_colsum", ptr(x), sc, sh, 4 * C, act, ptr(Gm), ptr(sv), P, C, G, ptr(ws), ws.numel() * 4)
+    a = x.float()
+    if lazy:
+        a = a * vec[:, 0:1] + vec[:, 1:2]
+        a = a.clamp_min(0) if act else a
+        a = a.clamp_max(6) if act == 2 else a
+    a = a.to(torch.bfloat16).double()
+    Gref = a.transpose(1, 2) @ a
+    sref = a.sum(1)
+    assert torch.allclose(Gm.double(), Gref, rtol=2e-5, atol=2e-5 * Gref.abs().max().item())
+    assert torch.allclose(sv.double(), sref, rtol=2e-5, atol=2e-5 * sref.abs().max().item())
+    # bit-identical from run to run (fixed-order partial sums)
+    G2, s2 = torch.empty_like(Gm), torch.empty_like(sv)
+    call("adamml_gram_colsum", ptr(x), sc, sh, 4 * C, act, ptr(G2), ptr(s2), P, C, G, ptr(ws), ws.numel() * 4)
+    assert torch.equal(G2, Gm) and torch.equal(s2, sv)
+    if P % 7 == 0:                                       # the launches it replaces (one case is enough: P = 3136 / 777 / 70001)
+        d = ConvDesc(1, P, 1, C, P, 1, C, 1, 1, 1, 0, 1, act, 0, G, 4 * C)
+        wsg = hip.wgrad_workspace(d, C, DEV)
+        Gold, sold = torch.empty_like(Gm), torch.empty_like(sv)
+        call("adamml_conv_bwd_weight_grouped", byref(d), ptr(x), sc, sh, act, 4 * C, ptr(x), sc, sh, ptr(Gold), C, ptr(wsg), wsg.numel() * 4)
+        call("adamml_lazy_colsum", ptr(x), sc, sh, 4 * C, act, ptr(sold), P, C, G)
+        assert torch.allclose(Gm, Gold, rtol=1e-4, atol=1e-4 * Gref.abs().max().item())
+        assert torch.allclose(sv, sold, rtol=1e-4, atol=1e-4 * sref.abs().max().item())
