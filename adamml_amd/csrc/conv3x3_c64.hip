@@ -78,6 +78,9 @@ __device__ __forceinline__ void fold16_to_cs(const f32x8& esum, const f32x8& esq
     }
 }
 
+// BNZ: the data-gradient form (activation mask + BatchNorm-backward sums in the epilogue, p.bn_z != null) is its own instantiation, so
+// that its epilogue -- which keeps a batch of z rows in flight -- does not weigh on the register allocation of the forward kernel.
+template <bool BNZ>
 __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_w = smem;                                              // [64][WROW3]
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
         }
         __syncthreads();
         const size_t obase = (size_t)g * p.gxy + ((size_t)n * p.H + oh0) * p.W * C64;
-        if (!p.bn_z) {
+        if constexpr (!BNZ) {
             for (int e = tid; e < npx * 8; e += NT3) {
                 const int q = e >> 3;
                 const s16x4 lo = *reinterpret_cast<const s16x4*>(s_patch + q * SROW3 + ech * 16);
@@ -277,22 +280,40 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
             f32x8 esum, esq;
 #pragma unroll
             for (int i = 0; i < 8; ++i) esum[i] = esq[i] = 0.f;
-            for (int e = tid; e < npx * 8; e += NT3) {
-                const int q = e >> 3;
-                const s16x4 lo = *reinterpret_cast<const s16x4*>(s_patch + q * SROW3 + ech * 16);
-                const s16x4 hi = *reinterpret_cast<const s16x4*>(s_patch + q * SROW3 + ech * 16 + 8);
-                union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-                u.s.a = lo; u.s.b = hi;
-                f32x8 f = bf8_to_f32(u.v);
-                const f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(p.bn_z + obase + (size_t)q * C64 + ech * 8));
+            // the z rows of a batch of 4 are requested before the batch's first store (unconditional loads from clamped addresses):
+            // loads and stores retire in order through vmcnt and the compiler cannot move a z load above a store to y, so the
+            // row-at-a-time loop exposed one HBM round trip per row (7 per tile: the data gradient ran 1.33 ms against 0.89 ms forward)
+            constexpr int MAXE = MAXPX3 * 8 / NT3, EBZ = 4;
+#pragma unroll 1
+            for (int b0 = 0; b0 < MAXE; b0 += EBZ) {                // (not unrolled: eight rows of address arithmetic hoisted at once spill)
+                if ((b0 * NT3) >= npx * 8) break;                  // (uniform)
+                bf16x8 zr[EBZ];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) f[i] *= act_mask(fmaf(zv[i], bsc[i], bsh[i]), p.bn_act);
-                const bf16x8 v = f32_to_bf8(f);
-                *reinterpret_cast<bf16x8*>(p.y + obase + (size_t)q * C64 + ech * 8) = v;
-                f = bf8_to_f32(v);
-                esum += f;
+                for (int k = 0; k < EBZ; ++k) {
+                    const int q = min((tid + (b0 + k) * NT3) >> 3, npx - 1);
+                    zr[k] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.bn_z + obase + (size_t)q * C64 + ech * 8));
+                }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) esq[i] += f[i] * (zv[i] - mu[i]) * is[i];
+                for (int k = 0; k < EBZ; ++k) {
+                    const int e = tid + (b0 + k) * NT3;
+                    if (e < npx * 8) {
+                        const int q = e >> 3;
+                        const s16x4 lo = *reinterpret_cast<const s16x4*>(s_patch + q * SROW3 + ech * 16);
+                        const s16x4 hi = *reinterpret_cast<const s16x4*>(s_patch + q * SROW3 + ech * 16 + 8);
+                        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+                        u.s.a = lo; u.s.b = hi;
+                        f32x8 f = bf8_to_f32(u.v);
+                        const f32x8 zv = bf8_to_f32(zr[k]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) f[i] *= act_mask(fmaf(zv[i], bsc[i], bsh[i]), p.bn_act);
+                        const bf16x8 v = f32_to_bf8(f);
+                        *reinterpret_cast<bf16x8*>(p.y + obase + (size_t)q * C64 + ech * 8) = v;
+                        f = bf8_to_f32(v);
+                        esum += f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) esq[i] += f[i] * (zv[i] - mu[i]) * is[i];
+                    }
+                }
             }
             if (p.stats) fold16_to_cs(esum, esq, cs, lane, ech, det_mode() ? p.stats + (size_t)g * ADAMML_STAT_SLOTS * 128 : nullptr);
         }
@@ -515,11 +536,13 @@ int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const 
     const size_t lds = C64 * WROW3 + 512 + (patch > stage ? patch : stage);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv3x3_c64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(ceil_div(p.total_tiles, p.tpb)), dim3(NT3), lds, stream, p);
+    if (p.bn_z) hipLaunchKernelGGL(conv3x3_c64_kernel<true>, dim3(ceil_div(p.total_tiles, p.tpb)), dim3(NT3), lds, stream, p);
+    else hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3(ceil_div(p.total_tiles, p.tpb)), dim3(NT3), lds, stream, p);
     return adamml_check_launch("conv3x3_c64");
 }
 

@@ -125,8 +125,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
 // counted-vmcnt pipeline, no register ring / ds_write pass / exec-masked loads).  Same fma / clamp / round sequence on the same
 // values: bit-identical to the staging-side transform.  The two waves that share a pixel half repeat the transform (VALU has the
 // slack on these HBM-bound layers); K <= 512 (per-channel vectors in LDS).
+// EPI: which epilogue of the plain (non-RES / non-FADD) kernels is compiled.  -1: all of them, selected at run time (the CAT / DUAL /
+// deep-prefetch / MODE 2 instances); 0: forward (plain store + statistics on the matrix cores); 1: data gradient with the activation
+// mask and the BatchNorm-backward sums (bn_z); 2: data gradient, optionally accumulating into y.  One kernel body for all three made
+// every edit of a data-gradient epilogue move the register allocation of the forward instances (spills inside their K loops); apart,
+// the forward instances carry no dead epilogue state and the data-gradient ones can request a batch of rows ahead of their stores.
 template <int BC, int MODE, int PD, bool RES = false, bool DUAL = false, bool CAT = false, bool FADD = false, bool GLDS = false, int EID = 0,
-          bool LZF = false>
+          bool LZF = false, int EPI = -1>
 __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
     constexpr int WROWS = BC / 64;          // weight rows staged per thread
@@ -245,6 +250,8 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
     float* cs = reinterpret_cast<float*>(smem + STAGE_BYTES);          // [2*BC] channel sums, live across the tile loop
     float* cs2 = reinterpret_cast<float*>(smem + CS2_OFF);             // [2*BC] sums of the second BatchNorm (RES only)
     const bool second = RES && p.bn_z2 != nullptr;
+    const bool epi_bnz = EPI < 0 ? p.bn_z != nullptr : EPI == 1;
+    const bool epi_acc = EPI < 0 ? p.accumulate != 0 : (EPI == 2 && p.accumulate != 0);
     if (p.stats) {
         for (int i = tid; i < 2 * BC; i += NTHREADS) cs[i] = 0.f;
         if (second)
@@ -694,7 +701,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
             }
         }
         }
-    } else if (eco < p.Cout && p.bn_z) {
+    } else if (eco < p.Cout && epi_bnz) {
         // data gradient w.r.t. a lazily normalised tensor: apply the activation mask here, store g' and accumulate
         // sum(g') and sum(g' * zhat) -- the BatchNorm-backward reduction pass never has to re-read g and z
         const f32x8 sc = load_f32x8(p.bn_vec + eco), sh = load_f32x8(p.bn_vec + p.Cout + eco);
@@ -703,42 +710,74 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
 #pragma unroll
         for (int i = 0; i < 8; ++i) cadd[i] = 0.f;
         if (CAT) cadd = load_f32x8(p.epi_add + eco);
+        // EPI 1: the z rows of a batch of rows are requested before the batch's first store (clamped addresses).  The compiler cannot
+        // move a z load above a store to y, and loads / stores retire in order through vmcnt: row at a time, every row exposes one
+        // HBM round trip.
+        constexpr int NRZ = BP / RSTEP, EBZ = EPI == 1 ? (NRZ < 4 ? NRZ : 4) : 1;
+#pragma unroll 1
+        for (int b0 = 0; b0 < NRZ; b0 += EBZ) {                    // (batches not unrolled: less address arithmetic hoisted into registers)
+            bf16x8 zrow[EBZ];
 #pragma unroll
-        for (int r = erow0; r < BP; r += RSTEP) {
-            if (p0 + r >= p.P) break;
-            const size_t pp = MODE == 3 ? (size_t)s_orow[r] : (size_t)(p0 + r);
-            f32x8 f = bf8_to_f32(*reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16)) + cadd;
-            const f32x8 zv = bf8_to_f32(*reinterpret_cast<const bf16x8*>(p.bn_z + pp * p.Cout + eco));
+            for (int j = 0; j < EBZ; ++j) {
+                const int r = erow0 + (b0 + j) * RSTEP;
+                const int rc = p0 + r < p.P ? r : 0;
+                const size_t pp = MODE == 3 ? (size_t)s_orow[rc] : (size_t)(p0 + rc);
+                zrow[j] = *reinterpret_cast<const bf16x8*>(p.bn_z + pp * p.Cout + eco);
+            }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) f[i] *= act_mask(fmaf(zv[i], sc[i], sh[i]), p.bn_act);
-            const bf16x8 v = f32_to_bf8(f);
-            *reinterpret_cast<bf16x8*>(p.y + pp * p.Cout + eco) = v;
-            f = bf8_to_f32(v);
-            esum += f;
+            for (int j = 0; j < EBZ; ++j) {
+                const int r = erow0 + (b0 + j) * RSTEP;
+                if (p0 + r < p.P) {
+                    const size_t pp = MODE == 3 ? (size_t)s_orow[r] : (size_t)(p0 + r);
+                    f32x8 f = bf8_to_f32(*reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16)) + cadd;
+                    const f32x8 zv = bf8_to_f32(zrow[j]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) esq[i] += f[i] * (zv[i] - mu[i]) * is[i];
+                    for (int i = 0; i < 8; ++i) f[i] *= act_mask(fmaf(zv[i], sc[i], sh[i]), p.bn_act);
+                    const bf16x8 v = f32_to_bf8(f);
+                    *reinterpret_cast<bf16x8*>(p.y + pp * p.Cout + eco) = v;
+                    f = bf8_to_f32(v);
+                    esum += f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) esq[i] += f[i] * (zv[i] - mu[i]) * is[i];
+                }
+            }
         }
     } else if (eco < p.Cout) {
+        // (EPI 2: the rows of the tensor accumulated into are requested per batch of rows, as above)
+        constexpr int NRA = BP / RSTEP, EBA = EPI == 2 ? (NRA < 4 ? NRA : 4) : 1;
+#pragma unroll 1
+        for (int b0 = 0; b0 < NRA; b0 += EBA) {
+            bf16x8 arow[EBA];
+            if (epi_acc) {
 #pragma unroll
-        for (int r = erow0; r < BP; r += RSTEP) {
-            if (p0 + r >= p.P) break;
-            const size_t pp = MODE == 3 ? (size_t)s_orow[r] : (size_t)(p0 + r);
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16);
-            bf16_t* dst = p.y + pp * p.Cout + eco;
-            f32x8 f = bf8_to_f32(v);
-            if (CAT) {
-                f += load_f32x8(p.epi_add + eco);
-                v = f32_to_bf8(f);
+                for (int j = 0; j < EBA; ++j) {
+                    const int r = erow0 + (b0 + j) * RSTEP;
+                    const int rc = p0 + r < p.P ? r : 0;
+                    const size_t pp = MODE == 3 ? (size_t)s_orow[rc] : (size_t)(p0 + rc);
+                    arow[j] = *reinterpret_cast<const bf16x8*>(p.y + pp * p.Cout + eco);
+                }
             }
-            if (p.accumulate) {
-                f += bf8_to_f32(*reinterpret_cast<const bf16x8*>(dst));
-                v = f32_to_bf8(f);
-                f = bf8_to_f32(v);
+#pragma unroll
+            for (int j = 0; j < EBA; ++j) {
+                const int r = erow0 + (b0 + j) * RSTEP;
+                if (p0 + r < p.P) {
+                    const size_t pp = MODE == 3 ? (size_t)s_orow[r] : (size_t)(p0 + r);
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16);
+                    f32x8 f = bf8_to_f32(v);
+                    if (CAT) {
+                        f += load_f32x8(p.epi_add + eco);
+                        v = f32_to_bf8(f);
+                    }
+                    if (epi_acc) {
+                        f += bf8_to_f32(arow[j]);
+                        v = f32_to_bf8(f);
+                    }
+                    *reinterpret_cast<bf16x8*>(p.y + pp * p.Cout + eco) = v;
+                }
             }
-            *reinterpret_cast<bf16x8*>(dst) = v;
         }
     }
-    if (p.stats && !p.bn_z && !RES) {
+    if (p.stats && !epi_bnz && !RES) {
         // Forward statistics on the (otherwise ~90 % idle) matrix cores instead of the VALU: with F = the staged bf16 tile
         // [32 pixels][16 channels] as an MFMA fragment (hardware transpose read), ones * F gives the per-channel sums and
         // F^T F the Gram matrix whose diagonal is the per-channel sum of squares -- exact products of the STORED values,
@@ -770,7 +809,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
             }
         }
     }
-    if (p.stats && (p.bn_z || RES)) {
+    if (p.stats && (epi_bnz || RES)) {
         // Lanes l, l+CPR, l+2*CPR.. of a wave hold partial sums of the same channel chunk.  They are folded on the VALU
         // with the gfx950 lane-swap instructions (v_permlane32_swap / v_permlane16_swap: "swap the upper half (odd rows)
         // of a with the lower half (even rows) of b", so a' + b' folds TWO values at once and halves the register count
@@ -1586,22 +1625,35 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
         else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, false, false, false, false, true, 0, true>), grid, block, 0, stream, p);
         return adamml_check_launch("conv_fwd");
     }
+    // the epilogue is a template parameter (EPI) of the LDS-DMA and one-step instances; deep-prefetch and MODE 2 keep the run-time form
+    static const bool epi_on = !(getenv("ADAMML_CONV_EPI") && getenv("ADAMML_CONV_EPI")[0] == '0');
+    const int epi = !epi_on ? -1 : (bn_z ? 1 : (p.accumulate ? 2 : 0));
+#define LAUNCH_EPI(BCV, MODEV, GL)                                                                                                          \
+    do {                                                                                                                                    \
+        if (epi == 0) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1, false, false, false, false, GL, 0, false, 0>), grid, block, 0, stream, p);       \
+        else if (epi == 1) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1, false, false, false, false, GL, 0, false, 1>), grid, block, 0, stream, p);  \
+        else if (epi == 2) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1, false, false, false, false, GL, 0, false, 2>), grid, block, 0, stream, p);  \
+        else hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1, false, false, false, false, GL>), grid, block, 0, stream, p);               \
+    } while (0)
 #define LAUNCH_CONV(BCV, MODEV)                                                                             \
     do {                                                                                                    \
-        if (glds) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1, false, false, false, false, true>), grid, block, 0, stream, p); \
+        if (glds) LAUNCH_EPI(BCV, MODEV, true);                                                             \
         else if (deep) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 3>), grid, block, 0, stream, p);     \
-        else hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1>), grid, block, 0, stream, p);               \
+        else LAUNCH_EPI(BCV, MODEV, false);                                                                 \
     } while (0)
     if (BC == 64) {
-        if (mode == 0) LAUNCH_CONV(64, 0); else if (mode == 1) LAUNCH_CONV(64, 1); else if (mode == 2) LAUNCH_CONV(64, 2);
-        else if (glds) hipLaunchKernelGGL((conv_gemm_kernel<64, 3, 1, false, false, false, false, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_kernel<64, 3, 1>), grid, block, 0, stream, p);
+        if (mode == 0) LAUNCH_CONV(64, 0); else if (mode == 1) LAUNCH_CONV(64, 1);
+        else if (mode == 2) { if (deep) hipLaunchKernelGGL((conv_gemm_kernel<64, 2, 3>), grid, block, 0, stream, p); else hipLaunchKernelGGL((conv_gemm_kernel<64, 2, 1>), grid, block, 0, stream, p); }
+        else if (glds) LAUNCH_EPI(64, 3, true);
+        else LAUNCH_EPI(64, 3, false);
     } else {
-        if (mode == 0) LAUNCH_CONV(128, 0); else if (mode == 1) LAUNCH_CONV(128, 1); else if (mode == 2) LAUNCH_CONV(128, 2);
-        else if (glds) hipLaunchKernelGGL((conv_gemm_kernel<128, 3, 1, false, false, false, false, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_kernel<128, 3, 1>), grid, block, 0, stream, p);
+        if (mode == 0) LAUNCH_CONV(128, 0); else if (mode == 1) LAUNCH_CONV(128, 1);
+        else if (mode == 2) { if (deep) hipLaunchKernelGGL((conv_gemm_kernel<128, 2, 3>), grid, block, 0, stream, p); else hipLaunchKernelGGL((conv_gemm_kernel<128, 2, 1>), grid, block, 0, stream, p); }
+        else if (glds) LAUNCH_EPI(128, 3, true);
+        else LAUNCH_EPI(128, 3, false);
     }
 #undef LAUNCH_CONV
+#undef LAUNCH_EPI
     return adamml_check_launch("conv_fwd");
 }
 
