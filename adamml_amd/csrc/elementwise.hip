@@ -435,17 +435,34 @@ __global__ void maxpool_fwd_kernel(const bf16_t* x, const float* scale, const fl
         int bi[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bi[i] = 0; }
+        // all nine taps are loaded UNCONDITIONALLY from clamped coordinates and the padding taps are turned into -inf afterwards: a
+        // branch around each load makes the compiler wait for one tap before the next is requested (nine dependent L2 / HBM round
+        // trips per output chunk: 2.6 ms at the stem shape against 1.2 ms of traffic)
+        bf16x8 raw[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ih = min(max(oh * 2 - 1 + kh, 0), H - 1), iw = min(max(ow * 2 - 1 + kw, 0), W - 1);
+                raw[kh * 3 + kw] = *reinterpret_cast<const bf16x8*>(x + (((size_t)n * H + ih) * W + iw) * C + ch * 8);
+            }
+        f32x8 tsc, tsh;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { tsc[i] = 1.f; tsh[i] = 0.f; }
+        if (scale) { tsc = load_f32x8(scale + ch * 8); tsh = load_f32x8(shift + ch * 8); }
+        const float tlo = scale ? act_lo(act) : -INFINITY, thi = scale ? act_hi(act) : INFINITY;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
-                if (ih < 0 || iw < 0 || ih >= H || iw >= W) continue;
-                f32x8 v = transform8(*reinterpret_cast<const bf16x8*>(x + (((size_t)n * H + ih) * W + iw) * C + ch * 8), scale,
-                                     shift, ch * 8, act);
+                const bool ok = ih >= 0 && iw >= 0 && ih < H && iw < W;
+                f32x8 v = bf8_to_f32(raw[kh * 3 + kw]);
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (v[i] > best[i]) { best[i] = v[i]; bi[i] = kh * 3 + kw; }
+                for (int i = 0; i < 8; ++i) {
+                    const float t = ok ? clamp_act(fmaf(v[i], tsc[i], tsh[i]), tlo, thi) : -INFINITY;
+                    if (t > best[i]) { best[i] = t; bi[i] = kh * 3 + kw; }
+                }
             }
         *reinterpret_cast<bf16x8*>(y + e * 8) = f32_to_bf8(best);
         uint64_t packed = 0;
@@ -539,7 +556,8 @@ __global__ __launch_bounds__(NT) void maxpool_bwd_bn_kernel(const bf16_t* gy, co
                 for (int b = 0; b < 2; ++b) {
                     const bool ok = k + a < OH && j + b < OW;
                     const size_t o = (((size_t)n * OH + (ok ? k + a : 0)) * OW + (ok ? j + b : 0)) * C + c;
-                    wi[a][b] = ok ? *reinterpret_cast<const uint64_t*>(idx + o) : ~0ull;        // 0xff never equals a tap
+                    const uint64_t iv = *reinterpret_cast<const uint64_t*>(idx + o);              // (unconditional: clamped address)
+                    wi[a][b] = ok ? iv : ~0ull;                                                   // 0xff never equals a tap
                     wg[a][b] = *reinterpret_cast<const bf16x8*>(gy + o);
                 }
             bf16x8 zr[2][2];
@@ -615,16 +633,81 @@ __global__ void temporal_pool_fwd_kernel(const bf16_t* x, const float* scale, co
         f32x8 accv;
 #pragma unroll
         for (int i = 0; i < 8; ++i) accv[i] = mode == 0 ? -INFINITY : 0.f;
+        // the three frames are loaded unconditionally (clamped frame index) and the padding frames neutralised afterwards: a branch
+        // around each load serialises the three round trips
+        bf16x8 raw[3];
 #pragma unroll
-        for (int k = -1; k <= 1; ++k) {
-            const int t = 2 * to + k;
-            if (t < 0 || t >= T) continue;
-            f32x8 v = transform8(*reinterpret_cast<const bf16x8*>(x + (((size_t)nb * T + t) * hwc8 + in) * 8), scale, shift, c, act);
+        for (int k = 0; k < 3; ++k) {
+            const int t = min(max(2 * to + k - 1, 0), T - 1);
+            raw[k] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(x + (((size_t)nb * T + t) * hwc8 + in) * 8));
+        }
+        f32x8 tsc, tsh;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) accv[i] = mode == 0 ? fmaxf(accv[i], v[i]) : accv[i] + v[i];
+        for (int i = 0; i < 8; ++i) { tsc[i] = 1.f; tsh[i] = 0.f; }
+        if (scale) { tsc = load_f32x8(scale + c); tsh = load_f32x8(shift + c); }
+        const float tlo = scale ? act_lo(act) : -INFINITY, thi = scale ? act_hi(act) : INFINITY;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int t = 2 * to + k - 1;
+            const bool ok = t >= 0 && t < T;
+            const f32x8 v = bf8_to_f32(raw[k]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float tv = clamp_act(fmaf(v[i], tsc[i], tsh[i]), tlo, thi);
+                accv[i] = mode == 0 ? fmaxf(accv[i], ok ? tv : -INFINITY) : accv[i] + (ok ? tv : 0.f);
+            }
         }
         if (mode == 1) accv *= (1.f / 3.f);
         *reinterpret_cast<bf16x8*>(y + e * 8) = f32_to_bf8(accv);
+    }
+}
+
+// The same pool as a column walk for the frame counts of the hot path (T = 8, 4, 2: models/resnet.py:207-210 halves the frames after
+// layers 1-3): a thread owns one 8-channel chunk of one pixel for ALL T frames, requests the T rows up front, transforms each once
+// and emits the To = T/2 outputs -- every input row is read once (the per-output form reads the shared odd frames twice, 1.5x the
+// loads) and the frame loop is compile-time (no branches around the loads).
+template <int T>
+__global__ __launch_bounds__(NT) void temporal_pool_fwd_walk_kernel(const bf16_t* x, const float* scale, const float* shift, int gs, int act,
+                                                                   bf16_t* y, int NB, size_t hwc8, int C, int mode) {
+    constexpr int To = (T - 1) / 2 + 1;
+    x += (size_t)blockIdx.y * NB * T * hwc8 * 8;
+    y += (size_t)blockIdx.y * NB * To * hwc8 * 8;
+    if (scale) { scale += (size_t)blockIdx.y * gs; shift += (size_t)blockIdx.y * gs; }
+    const size_t total = (size_t)NB * hwc8;
+    const int cpr = C >> 3;
+    const float lo = scale ? act_lo(act) : -INFINITY, hi = scale ? act_hi(act) : INFINITY;
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+        const size_t in = e % hwc8, nb = e / hwc8;
+        const int c = (int)(in % cpr) * 8;
+        bf16x8 raw[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) raw[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(x + ((nb * T + t) * hwc8 + in) * 8));
+        f32x8 sc, sh;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
+        if (scale) { sc = load_f32x8(scale + c); sh = load_f32x8(shift + c); }
+        f32x8 v[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            v[t] = bf8_to_f32(raw[t]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[t][i] = clamp_act(fmaf(v[t][i], sc[i], sh[i]), lo, hi);
+        }
+#pragma unroll
+        for (int to = 0; to < To; ++to) {
+            f32x8 acc;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = mode == 0 ? -INFINITY : 0.f;
+#pragma unroll
+            for (int k = -1; k <= 1; ++k) {
+                const int t = 2 * to + k;
+                if (t < 0 || t >= T) continue;                   // (compile-time)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = mode == 0 ? fmaxf(acc[i], v[t][i]) : acc[i] + v[t][i];
+            }
+            if (mode == 1) acc *= (1.f / 3.f);
+            __builtin_nontemporal_store(f32_to_bf8(acc), reinterpret_cast<bf16x8*>(y + ((nb * To + to) * hwc8 + in) * 8));
+        }
     }
 }
 
@@ -1273,6 +1356,14 @@ extern "C" int adamml_temporal_pool_fwd(const void* x, const float* scale, const
     const size_t n = (size_t)NB * To * (HWC / 8);
     if (!n) return ADAMML_OK;
     if (groups < 1) groups = 1;
+    if (T == 8 || T == 4 || T == 2) {
+        const dim3 grid(grid_for((size_t)NB * (HWC / 8), NT, 8192 / groups + 1), groups);
+#define LAUNCH_TP(TV) hipLaunchKernelGGL(temporal_pool_fwd_walk_kernel<TV>, grid, dim3(NT), 0, stream, (const bf16_t*)x, scale, shift, gstride, act, \
+                                         (bf16_t*)y, NB, HWC / 8, C, mode)
+        if (T == 8) LAUNCH_TP(8); else if (T == 4) LAUNCH_TP(4); else LAUNCH_TP(2);
+#undef LAUNCH_TP
+        return adamml_check_launch("temporal_pool_fwd");
+    }
     hipLaunchKernelGGL(temporal_pool_fwd_kernel, dim3(grid_for(n, NT, 4096 / groups + 1), groups), dim3(NT), 0, stream, (const bf16_t*)x,
                        scale, shift, gstride, act, (bf16_t*)y, NB, T, To, HWC / 8, C, mode);
     return adamml_check_launch("temporal_pool_fwd");
