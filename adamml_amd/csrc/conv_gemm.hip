@@ -1106,7 +1106,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
 // bound by its staging, not by the matrix cores.)  The LDS destination of an LDS-DMA is wave-uniform base + lane * 16, so the
 // image is lane-linear and the bank swizzle of the transposed reads is applied to the SOURCE chunk index instead (an
 // involution within a pixel row: the same cache lines are fetched).  Out-of-range chunks (padding taps, tails) read a zero page.
-template <int BM, int BN, int ST>
+// LZB (1x1 convs): a lazily normalised x operand is staged RAW and its BatchNorm + activation transform is applied to the B fragment
+// after the transpose read.  That fragment holds 8 pixels of ONE channel per lane, so the transform needs one scale / shift pair per
+// lane and fragment (registers, loaded once) and ~28 VALU instructions beside 4-8 MFMAs -- unlike the forward kernels' fragments
+// (8 channels of one pixel per lane).  Rows past the pixel range hold zeros in the dz operand, so whatever act(shift) the transform
+// makes of the x operand's zero rows is multiplied by 0; K x K convs keep the staging-side transform (their padding taps must BE zero).
+template <int BM, int BN, int ST, bool LZB = false>
 __global__ __launch_bounds__(NTHREADS) void conv_wgrad_glds_kernel(WgradP p) {
     const bf16_t* zeros = reinterpret_cast<const bf16_t*>(g_zero_page);
     constexpr int AROW = BM * 2, BROW = BN * 2;
@@ -1190,6 +1195,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_glds_kernel(WgradP p) {
     const int trow = 8 * lg + (li >> 2), tq = li & 3;
     const int a_lo = trow * AROW, a_hi = (trow + 4) * AROW, b_lo = trow * BROW, b_hi = (trow + 4) * BROW;
     const int ax_lo = tr_swz<BM>(trow), ax_hi = tr_swz<BM>(trow + 4), bx_lo = tr_swz<BN>(trow), bx_hi = tr_swz<BN>(trow + 4);
+    float bsc[LZB ? NT : 1], bsh[LZB ? NT : 1];
+    if constexpr (LZB) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int nn = min(n0 + wn * (BN / 2) + t * 16 + li, p.NK - 1);        // (1x1: the flattened index IS the input channel)
+            bsc[t] = p.in_scale[(size_t)grp * p.in_gstride + nn];
+            bsh[t] = p.in_shift[(size_t)grp * p.in_gstride + nn];
+        }
+    }
+    const float blo = act_lo(p.act), bhi = act_hi(p.act);
     auto compute = [&](int st) {
         const char* base = smem + st * TILE_BYTES;
         bf16x8 fa[MT], fb[NT];
@@ -1210,6 +1225,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_glds_kernel(WgradP p) {
             union { struct { s16x4 a, b; } s; bf16x8 v; } cvt;
             cvt.s.a = lo; cvt.s.b = hi;
             fb[t] = cvt.v;
+            if constexpr (LZB) {
+                f32x8 f = bf8_to_f32(fb[t]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[i] = clamp_act(fmaf(f[i], bsc[t], bsh[t]), blo, bhi);
+                fb[t] = f32_to_bf8(f);
+            }
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -2088,6 +2109,18 @@ static int wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void*
         p.dz_scale = ex ? ex->dz_scale : nullptr; p.dz_shift = ex ? ex->dz_shift : nullptr;
         p.dz_act = ex ? ex->dz_act : 0; p.dz_gstride = ex ? ex->dz_gstride : 0;
         static const bool glds_on = !(getenv("ADAMML_WGRAD_GLDS") && getenv("ADAMML_WGRAD_GLDS")[0] == '0');
+        static const bool lzb_on = !(getenv("ADAMML_WGRAD_LZB") && getenv("ADAMML_WGRAD_LZB")[0] == '0');
+        if (glds_on && lzb_on && ws && in_scale && !(ex && ex->dz_scale) && pl.BM == 128 && pl.BN == 128 && d->KH * d->KW == 1 && d->pad == 0) {
+            // 1x1 conv with a lazily normalised input: LDS-DMA staging of the raw tensor, transform at the B fragment (LZB); same tile choice
+            if (d->Cout % 256 == 0 && pl.n_tiles <= 64) {
+                p.n_cotiles = d->Cout / 256; p.n_tiles = p.n_cotiles * ceil_div(pl.NK, 128);
+                hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 128, 2, true>), dim3(pl.nsplit * p.n_tiles * groups), block, 0, stream, p);
+            } else if (d->Cout == 128 && pl.NK % 256 == 0) {
+                p.n_tiles = p.n_cotiles * (pl.NK / 256);
+                hipLaunchKernelGGL((conv_wgrad_glds_kernel<128, 256, 2, true>), dim3(pl.nsplit * p.n_tiles * groups), block, 0, stream, p);
+            } else
+            hipLaunchKernelGGL((conv_wgrad_glds_kernel<128, 128, 3, true>), grid, block, 0, stream, p);
+        } else
         if (glds_on && ws && !in_scale && !(ex && ex->dz_scale) && pl.BM == 128 && pl.BN == 128) {
             // both operands plain in memory: LDS-DMA staging
             // 256-wide tiles halve the operand bytes fetched per MAC (this kernel is bound by the L1 load path: 16 KB per 128 x 128 x 32
