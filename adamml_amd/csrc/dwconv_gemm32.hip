@@ -560,7 +560,12 @@ static int dw_wgrad_blocks(const adamml_conv_desc_t* d, int* rows_per_thread, in
     long nb = (threads + NT - 1) / NT;
     // NT * nblk must be a multiple of nchunk (a thread keeps its channel group across tasks): 45 | nblk covers every
     // C/4 in {8,12,24,36,48,96,144,240}; otherwise fall back to a multiple of nchunk
-    const long cap = 2160 / groups / 45 * 45 > 0 ? 2160 / groups / 45 * 45 : 45;
+    long cap = 2160 / groups / 45 * 45 > 0 ? 2160 / groups / 45 * 45 : 45;
+    // every workgroup publishes one [9][C] fp32 partial (36 C bytes) that a second launch sums: keep that traffic well below the
+    // ~4 C bytes per pixel a workgroup reads -- at most one workgroup per 144 output pixels of a group.  (The small late layers were
+    // split over the full cap: 2025 partials of 35 KB for a 90 MB problem, a 0.18 ms floor per layer.)
+    const long by_work = ((long)d->N * d->OH * d->OW / 144 + 44) / 45 * 45;
+    if (by_work < cap) cap = by_work > 45 ? by_work : 45;
     int nblk = nb >= cap ? (int)cap : (int)((nb + 44) / 45 * 45);
     if ((NT * (long)nblk) % nchunk != 0) nblk = (int)((nblk + nchunk - 1) / nchunk * nchunk);
     return nblk;
