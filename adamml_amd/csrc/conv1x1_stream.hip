@@ -96,6 +96,17 @@ __global__ __launch_bounds__(256, 3) void alg_stream_kernel(S1P p) {
         };
 #pragma unroll
         for (int k = 0; k < PD; ++k) issue(k, k);
+        // the epilogue's z rows (BatchNorm-fused form) / the rows accumulated into are requested HERE, behind the first K steps:
+        // issued inside the epilogue each of the eight loads sat between two stores to dx, which the compiler may not reorder
+        // (aliasing) and in-order vmcnt then exposes as eight dependent HBM round trips per tile
+        bf16x4 zpre[NPG][4];
+        if (p.bn_z || p.accumulate) {
+            const bf16_t* src = p.bn_z ? p.bn_z : p.dx;
+#pragma unroll
+            for (int pg = 0; pg < NPG; ++pg)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) zpre[pg][ct] = *reinterpret_cast<const bf16x4*>(src + prow[pg] * C2 + ct * 16 + lg * 4);
+        }
 #pragma unroll
         for (int k = 0; k < NKS; ++k) {
             bf16x8 fb[NPG];
@@ -138,7 +149,7 @@ __global__ __launch_bounds__(256, 3) void alg_stream_kernel(S1P p) {
                 for (int r = 0; r < 4; ++r) f[r] += s_add[ch + r];
                 bf16_t* dst = p.dx + prow[pg] * C2 + ch;
                 if (p.bn_z) {
-                    const f32x4 zv = bf4_to_f32(*reinterpret_cast<const bf16x4*>(p.bn_z + prow[pg] * C2 + ch));
+                    const f32x4 zv = bf4_to_f32(zpre[pg][ct]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) f[r] *= mask_act(fmaf(zv[r], s_bn[ch + r], s_bn[C2 + ch + r]), blo, bhi);
                     const bf16x4 v = f32_to_bf4(f);
@@ -153,7 +164,7 @@ __global__ __launch_bounds__(256, 3) void alg_stream_kernel(S1P p) {
                     }
                 } else {
                     if (p.accumulate) {
-                        const f32x4 d0 = bf4_to_f32(*reinterpret_cast<const bf16x4*>(dst));
+                        const f32x4 d0 = bf4_to_f32(zpre[pg][ct]);
                         f = bf4_to_f32(f32_to_bf4(f));                  // the GEMM kernels round the tile before accumulating
 #pragma unroll
                         for (int r = 0; r < 4; ++r) f[r] += d0[r];

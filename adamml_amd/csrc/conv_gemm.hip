@@ -713,7 +713,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
         // EPI 1: the z rows of a batch of rows are requested before the batch's first store (clamped addresses).  The compiler cannot
         // move a z load above a store to y, and loads / stores retire in order through vmcnt: row at a time, every row exposes one
         // HBM round trip.
-        constexpr int NRZ = BP / RSTEP, EBZ = EPI == 1 ? (NRZ < 4 ? NRZ : 4) : 1;
+        constexpr int NRZ = BP / RSTEP, EBZ = (EPI == 1 || CAT || DUAL) ? (NRZ < 4 ? NRZ : 4) : 1;     // (CAT / DUAL: 2 workgroups per CU, registers to spare)
 #pragma unroll 1
         for (int b0 = 0; b0 < NRZ; b0 += EBZ) {                    // (batches not unrolled: less address arithmetic hoisted into registers)
             bf16x8 zrow[EBZ];
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
         }
     } else if (eco < p.Cout) {
         // (EPI 2: the rows of the tensor accumulated into are requested per batch of rows, as above)
-        constexpr int NRA = BP / RSTEP, EBA = EPI == 2 ? (NRA < 4 ? NRA : 4) : 1;
+        constexpr int NRA = BP / RSTEP, EBA = (EPI == 2 || CAT || DUAL) ? (NRA < 4 ? NRA : 4) : 1;
 #pragma unroll 1
         for (int b0 = 0; b0 < NRA; b0 += EBA) {
             bf16x8 arow[EBA];
