@@ -2141,6 +2141,7 @@ static int wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void*
         p.dz_act = ex ? ex->dz_act : 0; p.dz_gstride = ex ? ex->dz_gstride : 0;
         static const bool glds_on = !(getenv("ADAMML_WGRAD_GLDS") && getenv("ADAMML_WGRAD_GLDS")[0] == '0');
         static const bool lzb_on = !(getenv("ADAMML_WGRAD_LZB") && getenv("ADAMML_WGRAD_LZB")[0] == '0');
+        static const bool ragged256 = !(getenv("ADAMML_WGRAD_RAGGED") && getenv("ADAMML_WGRAD_RAGGED")[0] == '0');   // measured +4 % (layer-2 3x3)
         if (glds_on && lzb_on && ws && in_scale && !(ex && ex->dz_scale) && pl.BM == 128 && pl.BN == 128 && d->KH * d->KW == 1 && d->pad == 0) {
             // 1x1 conv with a lazily normalised input: LDS-DMA staging of the raw tensor, transform at the B fragment (LZB); same tile choice
             if (d->Cout % 256 == 0 && pl.n_tiles <= 64) {
@@ -2162,8 +2163,9 @@ static int wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void*
             if (d->Cout % 256 == 0 && pl.n_tiles <= 64) {
                 p.n_cotiles = d->Cout / 256; p.n_tiles = p.n_cotiles * ceil_div(pl.NK, 128);
                 hipLaunchKernelGGL((conv_wgrad_glds_kernel<256, 128, 2>), dim3(pl.nsplit * p.n_tiles * groups), block, 0, stream, p);
-            } else if (d->Cout == 128 && pl.NK % 256 == 0) {
-                p.n_tiles = p.n_cotiles * (pl.NK / 256);
+            } else if (d->Cout == 128 && (pl.NK % 256 == 0 || (ragged256 && pl.NK > 512))) {
+                // (NK % 256 != 0: the last tile is half empty -- 3x3 / 128 -> 128: 5 tiles of 256 instead of 9 of 128)
+                p.n_tiles = p.n_cotiles * ceil_div(pl.NK, 256);
                 hipLaunchKernelGGL((conv_wgrad_glds_kernel<128, 256, 2>), dim3(pl.nsplit * p.n_tiles * groups), block, 0, stream, p);
             } else
             hipLaunchKernelGGL((conv_wgrad_glds_kernel<128, 128, 3>), grid, block, 0, stream, p);
