@@ -13,7 +13,7 @@ P = "profiles/%s_" % R
 
 def kname(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"conv_gemm_kernel<(\d+), (\d), (\d), (true|false), (true|false)(?:, (true|false))?(?:, (true|false))?>", n)
+    m = re.match(r"conv_gemm_kernel<(\d+), (\d), (\d), (true|false), (true|false)(?:, (true|false))?(?:, (true|false))?[^>]*>", n)
     if m:
         tag = (" FADD (forward conv3 + BatchNorm + residual add + ReLU epilogue)" if m.group(7) == "true" else
                " RES (residual-backward epilogue)" if m.group(4) == "true" else
@@ -70,6 +70,13 @@ out.append("Other bench lines of this round (one MI355X): " + "; ".join(
     "`%s_%s.json` %.0f clips/s" % (R, n, json.load(open(P + n + ".json"))["value"])
     for n in ("bench_policy_stage", "bench_inference_skipping", "bench_c4_rgb_flow_rgbdiff_b72", "bench_c5_four_modalities_b48")) + ".")
 out.append("Full-size parity study (HIP vs fp32 oracle vs bf16-storage emulation vs forced-forward replay, per tensor): `%s_parity_study_*.log` (`tools/parity_study.py`)." % R)
-out.append("\nPer-layer micro-benchmarks behind DESIGN.md section 4: `tools/bench_conv.py`, `tools/bench_fused.py`, `tools/bench_dw.py`, `tools/bench_elementwise.py`.")
+out.append("\nPer-layer tables of the same build (B = 72 shapes): `%s_per_layer_bench_conv.txt` (every ResNet-50 conv: forward / data gradient / weight gradient, GB/s and TFLOP/s;"
+           " `tools/bench_conv.py`), `%s_per_layer_bench_fused.txt` (RES / DUAL forms), `%s_per_layer_bench_dw.txt` (depthwise), `%s_bench_elementwise.txt` (BatchNorm / residual passes"
+           " against a plain copy), `%s_streaming_kernels_layer1_2.txt` (FADD, RES, algebraic data gradient, Gram kernel, products in the form the net runs them; `tools/explore_stream.py`),"
+           " `%s_launch_table_resnet.txt` / `%s_launch_table_sound.txt` (every launch of one backbone step with its excess over a 5.3 TB/s / 800 TFLOP/s floor; `tools/launch_table.py`),"
+           " `%s_bench_nets.txt` (each backbone alone)." % ((R,) * 8))
+out.append("Counter studies behind the round's kernel changes: `%s_pmc_streaming_kernels_memory_counters.txt` (reads outstanding at the fabric, TCC / TCP latencies of the layer-1 streaming kernels"
+           " against the elementwise kernels, BEFORE the early identity loads; `tools/gpu_pmc_stream.sh`), `%s_pmc_streaming_kernels_sq_counters_layer2.txt` (instruction mix and stall split of the"
+           " layer-2 kernels: 30-35 %% of the wave time is VALU issue; `tools/gpu_pmc_sq.sh`)." % (R, R))
 open("profiles/README.md", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
