@@ -69,6 +69,15 @@ struct ConvP {
     const float* id_shift;
     int id_gstride;
     uint8_t* mask_out;
+    // PF (RES + EID kernels): the per-group product P[g][cout][c] = sum_p g'[p][cout] * a[p][c] of the gradient tile this kernel
+    // has just formed with a second, lazily normalised tensor a [pixels][pf_C] (the input of the conv whose output gradient g'
+    // is -- the g'^T a of the algebraic BatchNorm backward) is accumulated on the matrix cores from the staged tile: the separate
+    // pass over g' and a (adamml_conv_bwd_weight_grouped) disappears.  One partial [BC][pf_C] per workgroup -> pf_ws.
+    const bf16_t* pf_a;
+    const float* pf_scale;
+    const float* pf_shift;
+    float* pf_ws;                // [group][cout tile][split = workgroup of that pair][BC][pf_C]
+    int pf_act, pf_gs, pf_nsplit;
     // MODE 3 (one parity class of the data gradient of a stride-2 conv, see conv_dgrad_stride2)
     int wK;                      // weight row stride in elements (== K except in MODE 3, where K covers the class taps only)
     int cls_nt;                  // taps of this class (0..4)
@@ -92,6 +101,14 @@ __device__ __forceinline__ void static_for(F&& f) {
         static_for<N - 1>(f);
         f(std::integral_constant<int, N - 1>{});
     }
+}
+
+// LDS image of one K step: [32 pixels][CH channels] bf16, row-major, 8-byte units XOR-swizzled so that the
+// ds_read_b64_tr_b16 of a 32-lane service group (rows {r..r+3} U {r+8..r+11}) touches 64 distinct banks.
+template <int CH>
+__device__ __forceinline__ int tr_swz(int row) {
+    if (CH >= 128) return ((row & 3) | (((row >> 3) & 1) << 2)) << 2;       // 256-byte rows: all rows start at bank 0
+    return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 2;               // 128-byte rows: parity picks the bank half
 }
 
 __device__ const uint4 g_zero_page[4] = {};          // 64 zero bytes: source of the out-of-range chunks of an LDS-DMA tile
@@ -130,8 +147,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
 // mask and the BatchNorm-backward sums (bn_z); 2: data gradient, optionally accumulating into y.  One kernel body for all three made
 // every edit of a data-gradient epilogue move the register allocation of the forward instances (spills inside their K loops); apart,
 // the forward instances carry no dead epilogue state and the data-gradient ones can request a batch of rows ahead of their stores.
+// PF: see ConvP::pf_a (BC = 128, 64 channels of a; RES + GLDS + EID only).
 template <int BC, int MODE, int PD, bool RES = false, bool DUAL = false, bool CAT = false, bool FADD = false, bool GLDS = false, int EID = 0,
-          bool LZF = false, int EPI = -1>
+          bool LZF = false, int EPI = -1, bool PF = false>
 __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
     constexpr int WROWS = BC / 64;          // weight rows staged per thread
@@ -146,7 +164,9 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
     constexpr int VEC_MAXK = 1024;
     constexpr int VEC_OFF = CS2_OFF + (RES ? 2 * BC * 4 : 0);
     constexpr int LZF_MAXK = 512;              // LZF keeps 3 workgroups per CU at BC = 128: 3 x (3 tiles + sums + 4 KB of vectors) <= 160 KB
-    constexpr int SMEM_BYTES = VEC_OFF + (LZF ? 2 * LZF_MAXK * 4 : (MODE == 0 && !GLDS) ? (DUAL ? 3 : 2) * VEC_MAXK * 4 : 0);   // + per-channel sums + tap-offset table (+ MODE 3: output row table, weight tap table)
+    constexpr int PF_C = 64;                   // channels of the PF operand
+    constexpr int PF_OFF = (VEC_OFF + (LZF ? 2 * LZF_MAXK * 4 : (MODE == 0 && !GLDS) ? (DUAL ? 3 : 2) * VEC_MAXK * 4 : 0) + 1023) / 1024 * 1024;
+    constexpr int SMEM_BYTES = PF ? PF_OFF + BP * PF_C * 2 : VEC_OFF + (LZF ? 2 * LZF_MAXK * 4 : (MODE == 0 && !GLDS) ? (DUAL ? 3 : 2) * VEC_MAXK * 4 : 0);   // + per-channel sums + tap-offset table (+ MODE 3: output row table, weight tap table)
     __shared__ __attribute__((aligned(1024))) char smem[SMEM_BYTES];
 
     {   // BatchNorm group of this workgroup: one launch covers the S per-segment calls of the reference
@@ -171,6 +191,10 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
             if (p.res_out) p.res_out += (size_t)g * p.gy;
             if (p.mask_out) p.mask_out += ((size_t)g * p.gy) >> 3;
             if (p.id_scale) { p.id_scale += (size_t)g * p.id_gstride; p.id_shift += (size_t)g * p.id_gstride; }
+        }
+        if (PF) {
+            p.pf_a += (size_t)g * p.P * PF_C;
+            if (p.pf_scale) { p.pf_scale += (size_t)g * p.pf_gs; p.pf_shift += (size_t)g * p.pf_gs; }
         }
         if (RES) {
             p.res_out += (size_t)g * p.gy;
@@ -262,6 +286,22 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
     const int ech = tid % CPR, erow0 = tid / CPR;
     const int eco = c0 + ech * 8;
 
+    // PF: product accumulators of this wave (64 cout x 32 a-channels of the workgroup's [128][64] block), live across the tile loop,
+    // and the per-lane scale / shift of the transposed a fragment (8 pixels of ONE channel per lane: conv_wgrad_glds_kernel LZB)
+    f32x4 pacc[PF ? 4 : 1][PF ? 2 : 1];
+    float pfs[PF ? 2 : 1], pfh[PF ? 2 : 1];
+    if constexpr (PF) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ch = wc * 32 + t * 16 + li;
+            pfs[t] = p.pf_scale ? p.pf_scale[ch] : 1.f;
+            pfh[t] = p.pf_scale ? p.pf_shift[ch] : 0.f;
+        }
+    }
     // a workgroup walks `tpb` consecutive pixel tiles of its cout tile: statistics are published once per workgroup
     for (int it = 0; it < p.tpb; ++it) {
     const int ptile = pgrp * p.tpb + it;
@@ -329,6 +369,20 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
     bf16x8 eid[EID ? NRE : 1];
     unsigned embits[EID ? NRE : 1];
     auto issue_eid = [&]() {
+        if constexpr (PF) {
+            // a tile [128 pixels][64 channels] raw, as four [32][64] transpose-read images (source-side swizzle, conv_wgrad_glds_kernel):
+            // LDS chunk e = l * 256 + tid -> row e / 8, position e % 8 holds source chunk position ^ swizzle(row % 32)
+            const bf16_t* zeros = reinterpret_cast<const bf16_t*>(g_zero_page);
+            const unsigned pbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + PF_OFF + wave * 1024;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const int e = tid + l * NTHREADS;
+                const int row = e >> 3;
+                const int ch = (e & 7) ^ (tr_swz<64>(row & 31) >> 1);
+                const bf16_t* src = (p0 + row < p.P) ? p.pf_a + (size_t)(p0 + row) * PF_C + ch * 8 : zeros;
+                glds16(src, __builtin_amdgcn_readfirstlane(pbase + l * NTHREADS * 16));
+            }
+        }
         if constexpr (EID != 0) {
             const int ecoc = eco < p.Cout ? eco : 0;
 #pragma unroll
@@ -343,7 +397,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
             }
         }
     };
-    constexpr int NEID = EID ? (FADD ? NRE : 2 * NRE) : 0;       // VMEM loads issue_eid() puts in flight per thread
+    constexpr int NEID = (EID ? (FADD ? NRE : 2 * NRE) : 0) + (PF ? 4 : 0);       // VMEM loads issue_eid() puts in flight per thread
 
     // register prefetch ring of depth PD: global loads run PD K-steps ahead of the MFMAs.  One K step of compute is
     // ~0.15 us but an HBM round trip is 1-2 us, so a one-step look-ahead left the kernel latency-bound.
@@ -683,6 +737,8 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
                 }
                 const bf16x8 v = f32_to_bf8(f);
                 if (ok[j]) *reinterpret_cast<bf16x8*>(p.y + pr[j]) = v;
+                if constexpr (PF)          // g' replaces the raw GEMM tile in LDS (zero rows past the last pixel): A operand of the product
+                    *reinterpret_cast<bf16x8*>(smem + r * CROW + ech * 16) = ok[j] ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 const float keep = ok[j] ? 1.f : 0.f;
                 f = bf8_to_f32(v) * keep;
                 esum += f;
@@ -854,8 +910,56 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
         fold(esum, esq, cs, det ? p.stats : nullptr);
         if (second) fold(esum, esq2, cs2, det ? p.stats2 : nullptr);
     }
+    if constexpr (PF) {
+        // P[cout][c] += sum over the tile's 128 pixels of g'[p][cout] * a[p][c]: both operands pixel-major in LDS -> transpose reads.
+        // g' tile: rows of CROW bytes (the padded epilogue image, as the MFMA statistics read it); a tile: four swizzled [32][64] images
+        // staged raw by LDS-DMA at the start of the tile, BatchNorm + activation applied to the fragment (one channel per lane).
+        __syncthreads();                               // every row of g' is back in LDS (and the a tile landed: vmcnt(0) of the last K step)
+        const int trow = 8 * lg + (li >> 2), tq = li & 3;
+        const int x_lo = tr_swz<64>(trow), x_hi = tr_swz<64>(trow + 4);
+        const float plo = p.pf_scale ? act_lo(p.pf_act) : -INFINITY, phi = p.pf_scale ? act_hi(p.pf_act) : INFINITY;
+#pragma unroll
+        for (int ks = 0; ks < BP / 32; ++ks) {
+            bf16x8 fa[4], fb[2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const char* fp = smem + (ks * 32 + trow) * CROW + (wp * 64 + t * 16 + 4 * tq) * 2;
+                union { s16x4 h[2]; bf16x8 v; } f;
+                f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(fp));
+                f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(fp + 4 * CROW));
+                fa[t] = f.v;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const char* base = smem + PF_OFF + ks * 32 * 128;
+                const int u = (wc * 32 + t * 16) / 4 + tq;
+                union { s16x4 h[2]; bf16x8 v; } f;
+                f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + trow * 128 + ((u ^ x_lo) << 3)));
+                f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + (trow + 4) * 128 + ((u ^ x_hi) << 3)));
+                f32x8 q = bf8_to_f32(f.v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = clamp_act(fmaf(q[i], pfs[t], pfh[t]), plo, phi);
+                fb[t] = f32_to_bf8(q);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) pacc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], pacc[mt][nt], 0, 0, 0);
+        }
+    }
     __syncthreads();                                   // staging tile consumed before the next tile's operands land
     }   // tile loop
+    if constexpr (PF) {
+        // one partial [BC][64] per workgroup (plain stores; summed in a fixed order by wgrad_reduce_kernel): wave (wp, wc) holds rows
+        // wp*64 + mt*16 + lg*4 + r (cout within the tile), column wc*32 + nt*16 + li
+        float* out = p.pf_ws + (((size_t)blockIdx.y * p.n_ctiles + ctile) * p.pf_nsplit + pgrp) * (BC * PF_C);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(size_t)(wp * 64 + mt * 16 + lg * 4 + r) * PF_C + wc * 32 + nt * 16 + li] = pacc[mt][nt][r];
+    }
     if (p.stats) {
         __syncthreads();
         double* slot = p.stats + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * p.Cout;
@@ -911,13 +1015,6 @@ struct WgradP {
     int dz_act, dz_gstride;
 };
 
-// LDS image of one K step: [32 pixels][CH channels] bf16, row-major, 8-byte units XOR-swizzled so that the
-// ds_read_b64_tr_b16 of a 32-lane service group (rows {r..r+3} U {r+8..r+11}) touches 64 distinct banks.
-template <int CH>
-__device__ __forceinline__ int tr_swz(int row) {
-    if (CH >= 128) return ((row & 3) | (((row >> 3) & 1) << 2)) << 2;       // 256-byte rows: all rows start at bank 0
-    return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 2;               // 128-byte rows: parity picks the bank half
-}
 
 template <int BM, int BN, int WPD = 1, bool LZ = false>
 __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(WgradP p) {
@@ -1519,12 +1616,14 @@ struct DualIn { const void* z; const float* aff; void* side; };
 // K-concatenated second input, per-group weights, epilogue constant (ConvP::xb ..)
 struct CatIn { const void* xb; int C2; size_t gw; const float* epi_add; };
 // forward BatchNorm + residual-add epilogue (ConvP::id_scale ..)
+// product with a second tensor accumulated from the gradient tile (ConvP::pf_a ..); ws: partial workspace, nsplit: out
+struct PfIn { const void* a; const float* scale; const float* shift; int act, gs, C; float* out; void* ws; size_t ws_bytes; };
 struct FaddEpi { const float* vec; const void* idn; const float* id_scale; const float* id_shift; int id_gstride; int act; uint8_t* mask_out; };
 
 static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
                        const float* in_shift, void* y, double* stats, const void* bn_z, const float* bn_vec, int bn_act,
                        hipStream_t stream, const DgradClass* cls = nullptr, const ResEpi* res = nullptr, const DualIn* dual = nullptr,
-                       const CatIn* cat = nullptr, const FaddEpi* fadd = nullptr) {
+                       const CatIn* cat = nullptr, const FaddEpi* fadd = nullptr, const PfIn* pf = nullptr) {
     if (!d || !x || !w_packed || !y) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: null argument");
     if (d->Cin % 8 || d->Cout % 8) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: channels must be multiples of 8 (Cin=%d Cout=%d)", d->Cin, d->Cout);
     if (!cls && !fadd && adamml_conv3x3_c64_supported(d))
@@ -1541,6 +1640,7 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     p.epi_add = cat ? cat->epi_add : nullptr;
     p.id_scale = fadd ? fadd->id_scale : nullptr; p.id_shift = fadd ? fadd->id_shift : nullptr; p.id_gstride = fadd ? fadd->id_gstride : 0;
     p.mask_out = fadd ? fadd->mask_out : nullptr;
+    p.pf_a = nullptr; p.pf_scale = p.pf_shift = nullptr; p.pf_ws = nullptr; p.pf_act = p.pf_gs = p.pf_nsplit = 0;
     if (fadd) { p.bn_vec = fadd->vec; p.res_out = (const bf16_t*)fadd->idn; p.res_act = fadd->act; }
     const int groups = d->groups < 1 ? 1 : d->groups;
     p.gx = (size_t)d->N * d->H * d->W * d->Cin;
@@ -1582,6 +1682,14 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     p.tpb = (int)((long)p.n_ptiles * p.n_ctiles * groups / 2048);
     if (p.tpb < 1) p.tpb = 1;
     if (p.tpb > 8) p.tpb = 8;
+    if (pf) {
+        // one [BC][64] partial per workgroup: few, long-lived workgroups (~6 per CU slot pair over all groups and cout tiles)
+        const long target = 1536;
+        long nsp = target / ((long)p.n_ctiles * groups);
+        if (nsp < 1) nsp = 1;
+        p.tpb = (int)ceil_div(p.n_ptiles, (int)nsp);
+        if (p.tpb < 1) p.tpb = 1;
+    }
     dim3 grid(ceil_div(p.n_ptiles, p.tpb) * p.n_ctiles, groups), block(NTHREADS);
     const int taps = d->KH * d->KW;
     // MODE 0 needs the whole row base in 32-bit element offsets (true for every layer of the hot path)
@@ -1621,6 +1729,23 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
         if (mode != 0) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res: only 1x1 / stride-1 convs");
         static const bool res_glds = !(getenv("ADAMML_RES_GLDS") && getenv("ADAMML_RES_GLDS")[0] == '0');
         static const bool res_eid = !(getenv("ADAMML_RES_EID") && getenv("ADAMML_RES_EID")[0] == '0');
+        if (pf) {
+            if (BC != 128 || d->Cout % 128 || pf->C != 64 || in_scale || !p.res_mask || !p.accumulate || p.bn_z || p.bn_z2 || !stats)
+                return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res_prod: needs Cout %% 128 == 0, a 64-channel product operand, "
+                                                             "the accumulate + 1-bit-mask + sum(g')-only form");
+            p.pf_nsplit = ceil_div(p.n_ptiles, p.tpb);
+            const size_t need = (size_t)groups * p.n_ctiles * p.pf_nsplit * 128 * 64 * sizeof(float);
+            if (!pf->ws || pf->ws_bytes < need) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_res_prod: workspace too small (need %zu bytes)", need);
+            p.pf_a = (const bf16_t*)pf->a; p.pf_scale = pf->scale; p.pf_shift = pf->scale ? pf->shift : nullptr; p.pf_act = pf->act; p.pf_gs = pf->gs;
+            p.pf_ws = (float*)pf->ws;
+            hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, true, false, false, false, true, 1, false, -1, true>), grid, block, 0, stream, p);
+            int rc = adamml_check_launch("conv_bwd_data_res_prod");
+            if (rc) return rc;
+            // P[g][ctile * 128 + r][c] = sum over the workgroups of (g, ctile), in workgroup order
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(128 * 64 / 16), groups * p.n_ctiles), dim3(256), 0, stream, (const float*)pf->ws, pf->out,
+                               (size_t)128 * 64, p.pf_nsplit, 1, 64, 1);
+            return adamml_check_launch("conv_bwd_data_res_prod (reduce)");
+        }
         if (res_glds && res_eid && !in_scale && p.res_mask && p.accumulate && !p.bn_z && !p.bn_z2) {
             // the algebraic backward's form (identity gradient + 1-bit mask, sum(g') only): identity-side loads at the start of each tile
             if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, true, false, false, false, true, 1>), grid, block, 0, stream, p);
@@ -1989,6 +2114,35 @@ extern "C" int adamml_conv_bwd_data_res(const adamml_conv_desc_t* d, const void*
     g.act = ACT_NONE; g.accumulate = accumulate ? 1 : 0; g.in_gstride = 0;
     ResEpi r{res_out, res_mask, res_act, z_b, vec_b, sums_b};
     return conv_launch(&g, dz, w_dgrad_packed, nullptr, nullptr, dx, sums_a, z_a, vec_a, ACT_NONE, stream, nullptr, &r);
+}
+
+extern "C" size_t adamml_conv_bwd_data_res_prod_workspace(const adamml_conv_desc_t* d) {
+    if (!d) return 0;
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    const int n_ptiles = ceil_div(d->N * d->OH * d->OW, BP), n_ctiles = ceil_div(d->Cin, 128);      // (dgrad: the output channels are d->Cin)
+    long nsp = 1536 / ((long)n_ctiles * groups);
+    if (nsp < 1) nsp = 1;
+    const int tpb = ceil_div(n_ptiles, (int)nsp);
+    return (size_t)groups * n_ctiles * ceil_div(n_ptiles, tpb < 1 ? 1 : tpb) * 128 * 64 * sizeof(float);
+}
+
+extern "C" int adamml_conv_bwd_data_res_prod_supported(const adamml_conv_desc_t* d, int a_channels) {
+    return d && adamml_conv_bwd_data_res_supported(d) && d->Cin % 128 == 0 && a_channels == 64 &&
+           (long)ceil_div(d->N * d->OH * d->OW, BP) * (d->Cin / 128) * (d->groups < 1 ? 1 : d->groups) >= 4096 ? 1 : 0;
+}
+
+extern "C" int adamml_conv_bwd_data_res_prod(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
+                                             const uint8_t* res_mask, int res_act, double* sums_a, const void* a, const float* a_scale,
+                                             const float* a_shift, int a_act, int a_gstride, int a_channels, float* prod,
+                                             void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!adamml_conv_bwd_data_res_prod_supported(d, a_channels)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res_prod: unsupported shape");
+    if (!res_mask || !sums_a || !a || !prod) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_res_prod: null argument");
+    adamml_conv_desc_t dd = *d;                          // data gradient of d: swap the channel roles, as adamml_conv_bwd_data_res does
+    dd.H = d->OH; dd.W = d->OW; dd.Cin = d->Cout; dd.OH = d->H; dd.OW = d->W; dd.Cout = d->Cin;
+    dd.stride = 1; dd.up = 1; dd.pad = 0; dd.act = ACT_NONE; dd.accumulate = 1; dd.in_gstride = 0;
+    ResEpi r{dx, res_mask, res_act, nullptr, nullptr, nullptr};       // (res_out is never read in the mask form)
+    PfIn pf{a, a_scale, a_shift, a_act, a_gstride, a_channels, prod, workspace, workspace_bytes};
+    return conv_launch(&dd, dz, w_dgrad_packed, nullptr, nullptr, dx, sums_a, nullptr, nullptr, 0, stream, nullptr, &r, nullptr, nullptr, nullptr, &pf);
 }
 
 extern "C" int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "adamml_alg_wgrad_combine": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "adamml_conv_bwd_data_alg": [_DESC, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
     "adamml_conv_bwd_data_res": [_DESC, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "adamml_conv_bwd_data_res_prod": [_DESC, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _Z, _P],
     "adamml_bn_act_add_mask": [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _Z, _I, _I, _P],
     "adamml_residual_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _I, _I, _P],
     "adamml_conv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _I, _P, _Z, _P],
@@ -117,6 +118,10 @@ def load():
     lib.adamml_gram_colsum_workspace.restype = c_size_t
     lib.adamml_gram_colsum_supported.argtypes = [_I]
     lib.adamml_gram_colsum_supported.restype = c_int
+    lib.adamml_conv_bwd_data_res_prod_workspace.argtypes = [_DESC]
+    lib.adamml_conv_bwd_data_res_prod_workspace.restype = c_size_t
+    lib.adamml_conv_bwd_data_res_prod_supported.argtypes = [_DESC, _I]
+    lib.adamml_conv_bwd_data_res_prod_supported.restype = c_int
     lib.adamml_conv_fused_input_supported.argtypes = [_DESC]
     lib.adamml_conv_fused_input_supported.restype = c_int
     lib.adamml_conv_fwd_bn_add_supported.argtypes = [_DESC]
@@ -225,6 +230,16 @@ def wgrad_workspace(desc, cin_true, device, depthwise=False, stem=False, gram=No
     buf = _wgrad_ws.get(key)
     if buf is None or buf.numel() * 4 < need:
         buf = torch.empty(max(need // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
+        _wgrad_ws[key] = buf
+    return buf
+
+
+def scratch(nbytes, device):
+    """The per-stream scratch buffer of wgrad_workspace(), grown to at least nbytes."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    buf = _wgrad_ws.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty(max(nbytes // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
         _wgrad_ws[key] = buf
     return buf
 

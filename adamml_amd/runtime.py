@@ -28,7 +28,7 @@ class Lazy:
     """Activation tensor [G*N,H,W,C] bf16 (G BatchNorm groups, group-major) whose value is act(scale*data + shift)
     (scale None -> data); group g uses scale + g*gs, shift + g*gs (gs == 0: one pair for all groups)."""
     __slots__ = ("data", "scale", "shift", "gs", "act", "grad", "requires_grad", "vec", "src", "pre_sums", "res", "res_done", "pool_grad", "alg", "sums_partial",
-                 "recompute", "_shape")
+                 "recompute", "_shape", "alg_in", "prod")
 
     def __init__(self, data, scale=None, shift=None, act=ACT_NONE, requires_grad=True, gs=0):
         self.data, self.scale, self.shift, self.act, self.gs = data, scale, shift, act, gs
@@ -43,6 +43,8 @@ class Lazy:
         self.sums_partial = False   # .pre_sums holds sum(g') only; sum(g' zhat) is derived from g'^T a (adamml_alg_sumfix)
         self.res_done = False       # .grad is already act-masked and the add's BatchNorm-backward sums are in place
         self.recompute = None       # data is None: the raw tensor was never written (conv_bn_add); recompute() materialises it
+        self.alg_in = None          # (lazy input of the conv that produced this tensor, its descriptor): algebraic backward only
+        self.prod = None            # P = g'^T a [G, C, Cin] already accumulated by the producer of .grad (adamml_conv_bwd_data_res_prod)
         self._shape = None
 
     @property
@@ -416,9 +418,22 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                     hip.next_meta = (2 * macs, in_b * ((1.0625 if rmask is not None else 2) + (0 if z.alg else 1) + acc
                                                        + (1 if (fb and not (fb and idn.alg)) else 0)) + out_b + w_b, kern)
                     fbk = fb and not fb_alg
-                    call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc, ptr(x.data), ptr(rmask), ract,
-                         None if z.alg else ptr(z.data), ptr(z.vec), ptr(sa), ptr(idn.data) if fbk else None, ptr(idn.vec) if fbk else None,
-                         ptr(sb) if fbk else None)
+                    ain = z.alg_in
+                    if (RES_PROD and z.alg and ain is not None and (not fb or fb_alg) and acc == 1 and rmask is not None and ain[0].data is not None
+                            and hip.load().adamml_conv_bwd_data_res_prod_supported(byref(d), ain[1].Cin)):
+                        # the product g'^T a of the algebraic backward of the conv that produced z (its input a = ain[0]) is accumulated
+                        # from the gradient tile inside this kernel: no separate pass over g' and a
+                        xa = ain[0]
+                        z.prod = torch.empty(G, d.Cin, ain[1].Cin, dtype=torch.float32, device=dz.device)
+                        need = hip.load().adamml_conv_bwd_data_res_prod_workspace(byref(d))
+                        wsp = hip.scratch(need, dz.device)
+                        hip.next_meta = (2 * macs + 2.0 * G * d.N * d.H * d.W * d.Cin * ain[1].Cin, in_b * 2.0625 + out_b + w_b + 2.0 * G * d.N * d.H * d.W * ain[1].Cin, kern)
+                        call("adamml_conv_bwd_data_res_prod", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), ptr(rmask), ract, ptr(sa), ptr(xa.data),
+                             ptr(xa.scale), ptr(xa.shift), xa.act, xa.gs, ain[1].Cin, ptr(z.prod), ptr(wsp), wsp.numel() * 4)
+                    else:
+                        call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc, ptr(x.data), ptr(rmask), ract,
+                             None if z.alg else ptr(z.data), ptr(z.vec), ptr(sa), ptr(idn.data) if fbk else None, ptr(idn.vec) if fbk else None,
+                             ptr(sb) if fbk else None)
                     z.pre_sums = sa
                     z.sums_partial = z.alg
                     if fb:
@@ -498,6 +513,7 @@ def _gram_colsum(rt, x, d):
     return Gm, sv
 
 
+RES_PROD = os.environ.get("ADAMML_RES_PROD", "1") != "0"     # g'^T a accumulated inside the residual-backward data gradient (A/B aid)
 GRAM_KERNEL = os.environ.get("ADAMML_GRAM_KERNEL", "1") != "0"     # dedicated Gram + column-sum kernel (A/B aid)
 ALG_BN = os.environ.get("ADAMML_ALG_BN", "1") != "0"     # algebraic BatchNorm backward through expanding 1x1 convs (A/B aid)
 ALG_MAX_COUT = int(os.environ.get("ADAMML_ALG_MAX_COUT", "512"))     # measured: at Cout = 1024 (layer 3) the small per-group products cost more than the saved passes (146.1 vs 144.6 ms)
@@ -522,7 +538,7 @@ def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, m
     Cout, Cin = d.Cout, d.Cin
     dev = y.device
     w2 = cs.weight                                              # fp32 master [Cout, Cin, 1, 1], contiguous
-    P = torch.empty(G, Cout, Cin, dtype=torch.float32, device=dev)
+    P = out.prod if out.prod is not None else torch.empty(G, Cout, Cin, dtype=torch.float32, device=dev)
     g0 = out.grad
 
     def products():
@@ -534,8 +550,11 @@ def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, m
         # the producer of g' did not read z: sum(g' zhat) = invstd (sum_j W (.) P - mean sum g') needs P BEFORE the finalize step,
         # so P runs on this stream (behind the weight-gradient stream's backlog it would stall the whole data-gradient chain)
         out.sums_partial = False
-        products()
+        if out.prod is None:
+            products()
         call("adamml_alg_sumfix", ptr(w2), ptr(P), ptr(vec), ptr(out.pre_sums), Cout, Cin, G)
+    elif out.prod is not None:
+        pass
     else:
         with _on_wgrad_stream(rt, (g0, x.data, x.scale)):
             products()
@@ -765,6 +784,7 @@ def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False):
         call("adamml_conv_fwd", byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), None)
         return y
     z.recompute = recompute
+    z.alg_in = (x, d)
     out.res = (z, idn, act, idn_sole, mask_t)
 
     def conv_bwd():

@@ -149,6 +149,18 @@ int adamml_conv_bwd_data_res(const adamml_conv_desc_t* d, const void* dz, const 
                              int accumulate, const void* res_out, const uint8_t* res_mask, int res_act, const void* z_a, const float* vec_a,
                              double* sums_a, const void* z_b, const float* vec_b, double* sums_b, hipStream_t stream);
 
+/* adamml_conv_bwd_data_res in the form the algebraic BatchNorm backward uses it (accumulate onto the identity-path gradient in dx, 1-bit
+ * mask, sum(g') only) which ALSO accumulates the per-group product  prod[g][c_out][c] = sum_p g'[p][c_out] * a[p][c]  of the gradient
+ * tile it has just formed with a second, lazily normalised tensor a [pixels][a_channels] (value act(a_scale*a + a_shift), group stride
+ * a_gstride): a = the input of the conv whose OUTPUT gradient g' is (models/resnet.py:103-111: conv3 of the previous bottleneck), i.e.
+ * the g'^T a that adamml_conv_bwd_weight_grouped would compute in a separate pass over g' and a.  a_channels == 64, d->Cin % 128 == 0;
+ * workspace of adamml_conv_bwd_data_res_prod_workspace() bytes; prod is overwritten. */
+int adamml_conv_bwd_data_res_prod_supported(const adamml_conv_desc_t* d, int a_channels);
+size_t adamml_conv_bwd_data_res_prod_workspace(const adamml_conv_desc_t* d);
+int adamml_conv_bwd_data_res_prod(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx, const uint8_t* res_mask,
+                                  int res_act, double* sums_a, const void* a, const float* a_scale, const float* a_shift, int a_act,
+                                  int a_gstride, int a_channels, float* prod, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 /* autograd w.r.t. the weight: dw (fp32 OIHW, cin_true input channels) += dz^T * im2col(act(x)).  The pixel axis is
  * split over workgroups; with a workspace of adamml_conv_bwd_weight_workspace() bytes the partial tiles are written
  * with plain stores and summed by a second launch (device-scope fp32 atomics run at ~20 G/s on MI355X and would

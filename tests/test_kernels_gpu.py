@@ -1041,3 +1041,54 @@ def test_gram_colsum_kernel(C, P, G, lazy, act):
         call("adamml_lazy_colsum", ptr(x), sc, sh, 4 * C, act, ptr(sold), P, C, G)
         assert torch.allclose(Gm, Gold, rtol=1e-4, atol=1e-4 * Gref.abs().max().item())
         assert torch.allclose(sv, sold, rtol=1e-4, atol=1e-4 * sref.abs().max().item())
+
+
+def test_conv_bwd_data_res_prod_equals_res_then_grouped_product():
+    """adamml_conv_bwd_data_res_prod: the residual-backward data gradient in the algebraic backward's form (accumulate + 1-bit mask +
+    sum(g') only) which also accumulates P = g'^T a from the gradient tile it forms -- dx and the sums must equal
+    adamml_conv_bwd_data_res bit for bit, and P the product adamml_conv_bwd_weight_grouped computes in its own pass over the g' that
+    kernel wrote (same bf16 operands, fp32 accumulation in another order) and the fp64 product."""
+    torch.manual_seed(11)
+    G, N, H, Cb, Cm, Ca = 2, 45, 56, 256, 64, 64
+    P = N * H * H
+    d = ConvDesc(N, H, H, Cb, H, H, Cm, 1, 1, 1, 0, 1, 0, 0, G, 0)                  # conv1 of the NEXT block: Cb -> Cm; its data gradient has Cb channels
+    assert hip.load().adamml_conv_bwd_data_res_prod_supported(byref(d), Ca)
+    dz = (torch.randn(G * N, H, H, Cm, device=DEV) * 0.5).to(torch.bfloat16)
+    w = torch.randn(Cm, Cb, 1, 1, device=DEV) * (2.0 / Cb) ** 0.5
+    wd = pack(w, Cb, 1)
+    gid = torch.randn(G * N, H, H, Cb, device=DEV).to(torch.bfloat16)
+    mask = torch.randint(0, 256, (G * P * Cb // 8,), dtype=torch.uint8, device=DEV)
+    a = (torch.randn(G * N, H, H, Ca, device=DEV) * 1.5).to(torch.bfloat16)
+    avec = torch.rand(G, 4, Ca, device=DEV) + 0.5
+    avec[:, 1] -= 0.6
+    vec = torch.rand(G, 4, Cb, device=DEV) + 0.5
+    # reference: RES, then the grouped product over what it wrote
+    dx_ref = gid.clone()
+    s_ref = torch.zeros(G, STAT_SLOTS, 2 * Cb, dtype=torch.float64, device=DEV)
+    call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(wd), ptr(dx_ref), 1, ptr(dx_ref), ptr(mask), 1, None, ptr(vec), ptr(s_ref), None, None, None)
+    d3 = ConvDesc(N, H, H, Ca, H, H, Cb, 1, 1, 1, 0, 1, 1, 0, G, 4 * Ca)             # the conv whose output gradient g' is: Ca -> Cb, lazy input a
+    ws = hip.wgrad_workspace(d3, Ca, DEV)
+    P_ref = torch.empty(G, Cb, Ca, device=DEV)
+    call("adamml_conv_bwd_weight_grouped", byref(d3), ptr(dx_ref), None, None, 0, 0, ptr(a), ptr(avec[0, 0]), ptr(avec[0, 1]), ptr(P_ref), Ca, ptr(ws),
+         ws.numel() * 4)
+    # fused
+    dx = gid.clone()
+    s = torch.zeros_like(s_ref)
+    Pf = torch.empty_like(P_ref)
+    need = hip.load().adamml_conv_bwd_data_res_prod_workspace(byref(d))
+    wsp = torch.empty(need // 4 + 1, device=DEV)
+    call("adamml_conv_bwd_data_res_prod", byref(d), ptr(dz), ptr(wd), ptr(dx), ptr(mask), 1, ptr(s), ptr(a), ptr(avec[0, 0]), ptr(avec[0, 1]), 1, 4 * Ca, Ca,
+         ptr(Pf), ptr(wsp), wsp.numel() * 4)
+    assert torch.equal(dx, dx_ref)
+    cs, cr = torch.empty(G, 2 * Cb, dtype=torch.float64, device=DEV), torch.empty(G, 2 * Cb, dtype=torch.float64, device=DEV)
+    call("adamml_stats_collapse", ptr(s), ptr(cs), Cb, G)
+    call("adamml_stats_collapse", ptr(s_ref), ptr(cr), Cb, G)
+    assert torch.allclose(cs, cr, rtol=1e-6, atol=1e-6 * cr.abs().max().item())
+    av = torch.relu(a.float().view(G, P, Ca) * avec[:, 0:1] + avec[:, 1:2]).to(torch.bfloat16).double()
+    P64 = dx_ref.double().view(G, P, Cb).transpose(1, 2) @ av
+    scale = P64.abs().max().item()
+    # fp32 accumulation over 141 000 pixels (MFMA partial sums per workgroup, then a fixed-order sum of the partials): equal to the
+    # separate product kernel to 2e-5 of the largest entry, and both within 2e-4 of the fp64 product (measured 1.1e-4: the fp64
+    # reference forms a = act(scale x + shift) with a separate multiply and add, the kernels with one fma -- a few bf16 roundings flip)
+    e64, ekern = (Pf.double() - P64).abs().max().item() / scale, (Pf - P_ref).abs().max().item() / scale
+    assert e64 <= 2e-4 and ekern <= 2e-5, (e64, ekern)

@@ -18,14 +18,23 @@ snd = torch.randn(B, S, 256, 256, device=dev)
 p_x, m_x, _ = m.data_layer([rgb, snd], S)
 del rgb
 res, sound = m.main_net.nets
-net, x = (res, m_x[0].flatten(0, 1)) if which == "resnet" else (sound, m_x[1].flatten(0, 1))
 import os
 os.environ["ADAMML_WGRAD_STREAM"] = "0"
+if which in ("policy_rgb", "policy_sound"):                # frozen policy backbones of the main-net stage: forward only, train-mode BatchNorm
+    m.freeze_policy_net()
+    pr, ps = m.policy_net.joint_net.nets
+    net, x = (pr, p_x[0].flatten(0, 1)) if which == "policy_rgb" else (ps, p_x[1].flatten(0, 1))
+    net.train()
 
+    def step():
+        with torch.no_grad():
+            net.call(x, S)
+else:
+    net, x = (res, m_x[0].flatten(0, 1)) if which == "resnet" else (sound, m_x[1].flatten(0, 1))
 
-def step():
-    out = net.forward_nhwc(x, S)
-    out.sum().backward()
+    def step():
+        out = net.forward_nhwc(x, S)
+        out.sum().backward()
 
 
 step(); step(); torch.cuda.synchronize()
