@@ -215,12 +215,9 @@ def call(name, *args):
 _wgrad_ws = {}
 
 
-def wgrad_workspace(desc, cin_true, device, depthwise=False, stem=False, gram=None):
-    """Persistent per-device scratch for the split weight-gradient partial tiles (grown on demand); gram = (P, C, groups):
-    the partials of adamml_gram_colsum instead."""
-    if gram is not None:
-        need = load().adamml_gram_colsum_workspace(*gram)
-    elif stem:
+def wgrad_workspace(desc, cin_true, device, depthwise=False, stem=False):
+    """Persistent per-device scratch for the split weight-gradient partial tiles (grown on demand)."""
+    if stem:
         need = load().adamml_conv_stem_bwd_weight_workspace(ctypes.byref(desc))
     elif depthwise:
         need = load().adamml_dwconv_bwd_weight_workspace(ctypes.byref(desc))

@@ -500,7 +500,7 @@ def _gram_colsum(rt, x, d):
     if GRAM_KERNEL and hip.load().adamml_gram_colsum_supported(Cin):
         # one streaming pass (csrc/gram.hip) instead of the generic weight-gradient kernel with dz = x plus a column-sum pass
         P = n // G * h * w_
-        wsg = hip.wgrad_workspace(None, 0, dev, gram=(P, Cin, G))
+        wsg = hip.scratch(hip.load().adamml_gram_colsum_workspace(P, Cin, G), dev)
         hip.next_meta = (2.0 * G * P * Cin * Cin, 2.0 * G * P * Cin)
         call("adamml_gram_colsum", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(Gm), ptr(sv), P, Cin, G, ptr(wsg), wsg.numel() * 4)
         return Gm, sv

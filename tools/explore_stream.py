@@ -96,7 +96,7 @@ run("grouped P = g'^T a", X + m, lambda: call("adamml_conv_bwd_weight_grouped", 
 run("grouped Gram a^T a", m, lambda: call("adamml_conv_bwd_weight_grouped", byref(dg), ptr(xm), ptr(vecm[0, 0]), ptr(vecm[0, 1]), 1, 4 * Cm, ptr(xm),
                                            ptr(vecm[0, 0]), ptr(vecm[0, 1]), ptr(gout), Cm, ptr(wsg), wsg.numel() * 4))
 if hip.load().adamml_gram_colsum_supported(Cm):
-    wgc = hip.wgrad_workspace(None, 0, DEV, gram=(P, Cm, G))
+    wgc = hip.scratch(hip.load().adamml_gram_colsum_workspace(P, Cm, G), DEV)
     scol2 = torch.empty(G, Cm, device=DEV)
     run("gram_colsum kernel (G and s)", m, lambda: call("adamml_gram_colsum", ptr(xm), ptr(vecm[0, 0]), ptr(vecm[0, 1]), 4 * Cm, 1, ptr(gout), ptr(scol2), P, Cm, G,
                                                          ptr(wgc), wgc.numel() * 4))
