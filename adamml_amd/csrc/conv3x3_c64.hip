@@ -173,6 +173,14 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
         }
         __syncthreads();
         if (it + 1 < p.tpb && tile + 1 < p.total_tiles) load_patch(tile + 1);
+        // BNZ: the epilogue reads the z rows of this strip (one 128-byte line per pixel, contiguous) with nothing to overlap them with --
+        // one 8-wave workgroup per CU, every register and all of the LDS taken.  One dword per line requested HERE, ahead of the ~14 us
+        // of MFMA work, pulls the strip into L2: the epilogue's two batches of row loads then cost an L2 round trip instead of an HBM one.
+        unsigned ztouch = 0;
+        if constexpr (BNZ) {
+            const size_t zb = (size_t)g * p.gxy + ((size_t)n * p.H + oh0) * p.W * C64;
+            ztouch = *reinterpret_cast<const unsigned*>(p.bn_z + zb + (size_t)min(tid, npx - 1) * C64);
+        }
 
         // ---- MFMA: wave w owns pixel tiles w, w+8, w+16, w+24 (16 consecutive output pixels, row-major over the strip) ---
         f32x4 acc[4][MAXPT];
@@ -216,6 +224,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
                 }
             }
         }
+        if constexpr (BNZ) asm volatile("" ::"v"(ztouch));   // (keeps the touch load's destination allocated until it has landed)
         __syncthreads();                                     // patch consumed: its LDS becomes the staging tile
 
         // ---- stage [npt*16][64] bf16 (rows >= npx zero) ---------------------------------------------------------------
