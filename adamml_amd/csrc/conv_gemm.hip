@@ -1772,26 +1772,17 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
         return adamml_check_launch("conv_bwd_data_dual");
     }
     static const bool glds_on = !(getenv("ADAMML_CONV_GLDS") && getenv("ADAMML_CONV_GLDS")[0] == '0');
-    // (measured, tools/explore_stream.py: the fragment-side transform LOSES on the plain forward convs -- layer-1 conv3 1.77 vs 1.61 ms,
-    // layer 2 0.59 vs 0.54, layer 3 0.23 vs 0.21: each pixel half is transformed by two waves, between the ds_read and the MFMA --
-    // and only pays together with the early identity loads of the FADD kernel; opt-in for A/B)
-    static const bool lzf_on = getenv("ADAMML_CONV_LZF") && getenv("ADAMML_CONV_LZF")[0] == '1';
+    // (the fragment-side lazy transform, LZF, is NOT used for the plain forward convs: measured 5-10 % slower than the register-staged
+    // loader -- layer-1 conv3 1.77 vs 1.61 ms, layer 2 0.59 vs 0.54, layer 3 0.23 vs 0.21: each pixel half is transformed by two waves,
+    // between the ds_read and the MFMA; it only pays together with the early identity loads of the FADD kernel)
     const bool glds = glds_on && !in_scale && mode != 2;
-    if (glds_on && lzf_on && in_scale && mode == 0 && p.K <= 512 && !deep) {
-        // 1x1 conv of a lazily normalised input: LDS-DMA staging, transform at the fragment (LZF)
-        if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, false, false, false, false, true, 0, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, false, false, false, false, true, 0, true>), grid, block, 0, stream, p);
-        return adamml_check_launch("conv_fwd");
-    }
     // the epilogue is a template parameter (EPI) of the LDS-DMA and one-step instances; deep-prefetch and MODE 2 keep the run-time form
-    static const bool epi_on = !(getenv("ADAMML_CONV_EPI") && getenv("ADAMML_CONV_EPI")[0] == '0');
-    const int epi = !epi_on ? -1 : (bn_z ? 1 : (p.accumulate ? 2 : 0));
+    const int epi = bn_z ? 1 : (p.accumulate ? 2 : 0);
 #define LAUNCH_EPI(BCV, MODEV, GL)                                                                                                          \
     do {                                                                                                                                    \
         if (epi == 0) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1, false, false, false, false, GL, 0, false, 0>), grid, block, 0, stream, p);       \
         else if (epi == 1) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1, false, false, false, false, GL, 0, false, 1>), grid, block, 0, stream, p);  \
-        else if (epi == 2) hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1, false, false, false, false, GL, 0, false, 2>), grid, block, 0, stream, p);  \
-        else hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1, false, false, false, false, GL>), grid, block, 0, stream, p);               \
+        else hipLaunchKernelGGL((conv_gemm_kernel<BCV, MODEV, 1, false, false, false, false, GL, 0, false, 2>), grid, block, 0, stream, p);               \
     } while (0)
 #define LAUNCH_CONV(BCV, MODEV)                                                                             \
     do {                                                                                                    \
