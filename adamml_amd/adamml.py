@@ -82,13 +82,13 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
                 if idx in self.p_data_idx:
                     p_x.append(clip_u8_to_nhwc(x_, num_segments, f, c, self.mean(m), self.std(m), out_hw=p_rgb_size, frame_step=2))
                 if idx in self.m_data_idx:
-                    m_x.append(clip_u8_to_nhwc(x_, num_segments, f, c, self.mean(m), self.std(m)))
+                    m_x.append(clip_u8_to_nhwc(x_, num_segments, f, c, self.mean(m), self.std(m), cpad=self._main_cpad(m, x_.size(1), x_.size(2))))
                 continue
             c = x_.size(1) // (num_segments * f)
             if idx in self.p_data_idx:
                 p_x.append(clip_to_nhwc(x_, num_segments, f, c, out_hw=p_rgb_size, frame_step=2))
             if idx in self.m_data_idx:
-                m_x.append(clip_to_nhwc(x_, num_segments, f, c))
+                m_x.append(clip_to_nhwc(x_, num_segments, f, c, cpad=self._main_cpad(m, x_.size(-2), x_.size(-1))))
         return p_x, m_x, num_segments
 
     def forward(self, x, num_segments=None, gumbel_exponential=None):
@@ -215,6 +215,12 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
             ran.append(int(idx.numel()))
         self.last_skip_stats = {"clips": S * B, "executed_per_modality": ran}
         return self.main_net.fuse_segments(stacked, decisions, S), decisions.permute((2, 0, 1))
+
+    def _main_cpad(self, modality, h, w):
+        """Channel padding the main net of `modality` wants for its NHWC input (ResNet.input_cpad: 4-channel pixels for the 7x7 stem
+        kernel), None = the generic multiple of 8."""
+        net = self.main_net.nets[self.main_net.modality.index(modality)]
+        return net.input_cpad(h, w) if hasattr(net, "input_cpad") else None
 
     def _side_stream(self, dev, idx=0):
         if self._side is None or self._side[0].device != dev:

@@ -984,6 +984,26 @@ __global__ void clip_to_nhwc_kernel(const float* x, bf16_t* y, int B, int S, int
         }
         const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
         bf16_t* dst = y + e * c_pad;
+        if (c_pad == 4) {
+            // 4-channel pixels (8 bytes): the layout the 7x7 stem kernels read for <= 4 input channels -- half the bytes of the 8-channel
+            // padding in this kernel's store and in the stem's forward / weight-gradient loads
+            f32x4 v4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float val = 0.f;
+                if (i < C) {
+                    const float* pl = src + (size_t)i * H * W;
+                    if (resize)
+                        val = lh0 * (lw0 * pl[(size_t)h0 * W + w0] + lw1 * pl[(size_t)h0 * W + w1]) +
+                              lh1 * (lw0 * pl[(size_t)h1 * W + w0] + lw1 * pl[(size_t)h1 * W + w1]);
+                    else
+                        val = pl[(size_t)oh * W + ow];
+                }
+                v4[i] = val;
+            }
+            *reinterpret_cast<bf16x4*>(dst) = f32_to_bf4(v4);
+            continue;
+        }
         for (int c8 = 0; c8 < c_pad; c8 += 8) {
             f32x8 v;
 #pragma unroll
@@ -1043,13 +1063,14 @@ __global__ void clip_u8_to_nhwc_kernel(const uint8_t* x, bf16_t* y, int B, int S
             for (int fk = 0; fk < Fk; ++fk) {
                 const int off = (s * F + fk * frame_step) * CS;
                 bf16_t* dst = y + (((((size_t)s * B + b) * Fk + fk) * OH + oh) * OW + ow) * c_pad;
+                const int cw = c_pad == 4 ? 4 : 8;               // 4-channel pixels: see clip_to_nhwc_kernel
                 for (int c8 = 0; c8 < c_pad; c8 += 8) {
                     f32x8 v;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int c = c8 + i;
                         float val = 0.f;
-                        if (c < C) {
+                        if (c < C && i < cw) {
                             const float m = nv.mean[c % nv.n], sd = nv.std[c % nv.n];
                             auto nrm = [&](const uint8_t* q) {
                                 float t = (float)q[off + c];
@@ -1061,7 +1082,8 @@ __global__ void clip_u8_to_nhwc_kernel(const uint8_t* x, bf16_t* y, int B, int S
                         }
                         v[i] = val;
                     }
-                    *reinterpret_cast<bf16x8*>(dst + c8) = f32_to_bf8(v);
+                    if (cw == 4) *reinterpret_cast<bf16x4*>(dst) = f32_to_bf4(f32x4{v[0], v[1], v[2], v[3]});
+                    else *reinterpret_cast<bf16x8*>(dst + c8) = f32_to_bf8(v);
                 }
             }
     }
@@ -1453,7 +1475,7 @@ extern "C" int adamml_colsum_f32(const float* a, float* out, int rows, int cols,
 
 extern "C" int adamml_clip_to_nhwc(const float* x, void* y, int B, int S, int F, int C, int H, int W, int OH, int OW,
                                    int frame_step, int c_pad, hipStream_t stream) {
-    if (c_pad % 8 || c_pad < C || frame_step < 1) return adamml_set_error(ADAMML_EINVAL, "clip_to_nhwc: bad c_pad/frame_step");
+    if ((c_pad % 8 && c_pad != 4) || c_pad < C || frame_step < 1) return adamml_set_error(ADAMML_EINVAL, "clip_to_nhwc: bad c_pad/frame_step");
     const int Fk = (F + frame_step - 1) / frame_step;
     const size_t n = (size_t)S * B * Fk * OH * OW;
     if (!n) return ADAMML_OK;
@@ -1465,7 +1487,7 @@ extern "C" int adamml_clip_to_nhwc(const float* x, void* y, int B, int S, int F,
 extern "C" int adamml_clip_u8_to_nhwc(const uint8_t* x, void* y, int B, int S, int F, int C, int H, int W, int OH, int OW, int frame_step,
                                       int c_pad, const float* mean, const float* std, int n_mean, int div255, hipStream_t stream) {
     if (!x || !y || !mean || !std) return adamml_set_error(ADAMML_EINVAL, "clip_u8_to_nhwc: null argument");
-    if (c_pad % 8 || c_pad < C || frame_step < 1) return adamml_set_error(ADAMML_EINVAL, "clip_u8_to_nhwc: bad c_pad/frame_step");
+    if ((c_pad % 8 && c_pad != 4) || c_pad < C || frame_step < 1) return adamml_set_error(ADAMML_EINVAL, "clip_u8_to_nhwc: bad c_pad/frame_step");
     if (n_mean < 1 || n_mean > 4 || C % n_mean) return adamml_set_error(ADAMML_EINVAL, "clip_u8_to_nhwc: %d mean/std values for %d channels", n_mean, C);
     const int Fk = (F + frame_step - 1) / frame_step;
     const size_t n = (size_t)B * OH * OW;

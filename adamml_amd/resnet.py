@@ -3,6 +3,8 @@ libadamml_hip (bf16 MFMA implicit-GEMM convs with fused BatchNorm statistics).
 
 Mirrors the interface and state_dict of models/resnet.py:116-259 (class ResNet, factory resnet()).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -31,6 +33,9 @@ class _Bottleneck(nn.Module):
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.downsample = downsample
         self.stride = stride
+
+
+STEM_PAD4 = os.environ.get("ADAMML_STEM_PAD4", "1") != "0"      # 4-channel input pixels for the 7x7 stem kernels (A/B aid)
 
 
 class ResNet(HipBackbone, MeanStdMixin, StockDDPAware):
@@ -132,8 +137,20 @@ class ResNet(HipBackbone, MeanStdMixin, StockDDPAware):
             self.flat_owner.ensure_grads()
         n, c_t, hh, ww = x.shape
         frames = self.orig_num_frames if c_t != 1 else 1
-        xs = clip_to_nhwc(x, 1, frames, c_t // frames)[0]
+        xs = clip_to_nhwc(x, 1, frames, c_t // frames, cpad=self.input_cpad(hh, ww))[0]
         return self.call(xs)
+
+    def input_cpad(self, h, w):
+        """Channel padding of the NHWC input this net wants for h x w frames: 4 when the 7x7 stem kernel (csrc/conv_stem.hip, <= 4
+        input channels) serves the shape -- it reads 8 bytes per pixel, and 4-channel pixels halve the bytes of the re-layout store
+        and of the stem's forward / weight-gradient loads -- else the generic 8-channel multiple."""
+        cs = self._stem
+        if cs.stem and STEM_PAD4:
+            from ctypes import byref
+            d = cs.desc((1, h, w, 4), 0, 1, 0)
+            if hip.load().adamml_conv_stem_supported(byref(d)):
+                return 4
+        return pad8(cs.cin_true)
 
     def forward_nhwc(self, frames_nhwc, groups=1):
         return self.call(frames_nhwc, groups)

@@ -331,7 +331,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
             not hip.load().adamml_conv_fused_input_supported(byref(cs.desc(x.shape, x.act, G, x.gs))):
         x = materialize(rt, x)
     d = cs.desc(x.shape, x.act, G, x.gs)
-    if x.shape[3] != cs.cin:
+    if x.shape[3] != cs.cin and not (cs.stem and x.shape[3] == 4):        # (4-channel pixels: the 7x7 stem kernels only, checked below)
         raise RuntimeError("conv_bn: input has %d channels, weight pack expects %d" % (x.shape[3], cs.cin))
     if x.shape[0] % G:
         raise RuntimeError("conv_bn: %d images do not split into %d BatchNorm groups" % (x.shape[0], G))
@@ -341,6 +341,8 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
     count = d.N * d.OH * d.OW               # elements per channel per group
     fwd = "adamml_dwconv_fwd" if cs.depthwise else "adamml_conv_fwd"
     stem = cs.stem and x.scale is None and hip.load().adamml_conv_stem_supported(byref(d))
+    if x.shape[3] != cs.cin and not stem:
+        raise RuntimeError("conv_bn: 4-channel pixels need the 7x7 stem kernel, which does not support this shape")
     # algorithmic work of this layer (true input channels, each tensor touched once), for the roofline report
     macs = float(count) * G * C * cs.kh * cs.kw * (1 if cs.depthwise else cs.cin_true)
     in_b, out_b = 2.0 * G * d.N * d.H * d.W * cs.cin_true, 2.0 * G * count * C
@@ -953,15 +955,16 @@ def gemm_f32(a, b, out=None, bias=None, act=ACT_NONE, trans_a=False, trans_b=Tru
     return out
 
 
-def clip_to_nhwc(x, num_segments, frames, channels, out_hw=None, frame_step=1):
-    """AdaMML.data_layer re-layout (models/adamml.py:53-65): [B, S*F*C, H, W] fp32 -> [S, B*Fk, OH, OW, pad8(C)] bf16."""
+def clip_to_nhwc(x, num_segments, frames, channels, out_hw=None, frame_step=1, cpad=None):
+    """AdaMML.data_layer re-layout (models/adamml.py:53-65): [B, S*F*C, H, W] fp32 -> [S, B*Fk, OH, OW, pad8(C)] bf16.
+    cpad = 4: 4-channel pixels for a consumer that is the 7x7 stem kernel (ResNet.input_cpad)."""
     hip.require_gpu(x)
     b, sfc, h, w = x.shape
     if sfc != num_segments * frames * channels:
         raise RuntimeError("clip_to_nhwc: channel dim %d != S*F*C = %d*%d*%d" % (sfc, num_segments, frames, channels))
     oh, ow = out_hw if out_hw else (h, w)
     fk = (frames + frame_step - 1) // frame_step
-    cp = pad8(channels)
+    cp = cpad or pad8(channels)
     x = x.contiguous()
     if x.dtype != torch.float32:
         x = x.float()
@@ -970,7 +973,7 @@ def clip_to_nhwc(x, num_segments, frames, channels, out_hw=None, frame_step=1):
     return y
 
 
-def clip_u8_to_nhwc(x, num_segments, frames, channels, mean, std, out_hw=None, frame_step=1, div255=True):
+def clip_u8_to_nhwc(x, num_segments, frames, channels, mean, std, out_hw=None, frame_step=1, div255=True, cpad=None):
     """Decoded uint8 frames [B, H, W, S*F*C] (the HW(FC) array of utils/video_transforms.py:302-318 `Stack`, batched) ->
     [S, B*Fk, OH, OW, pad8(C)] bf16, normalised as ToTorchFormatTensor + GroupNormalize do (video_transforms.py:62-84,321-343)."""
     hip.require_gpu(x)
@@ -981,7 +984,7 @@ def clip_u8_to_nhwc(x, num_segments, frames, channels, mean, std, out_hw=None, f
         raise RuntimeError("clip_u8_to_nhwc: last dim %d != S*F*C = %d*%d*%d" % (sfc, num_segments, frames, channels))
     oh, ow = out_hw if out_hw else (h, w)
     fk = (frames + frame_step - 1) // frame_step
-    cp = pad8(channels)
+    cp = cpad or pad8(channels)
     x = x.contiguous()
     y = torch.empty(num_segments, b * fk, oh, ow, cp, dtype=torch.bfloat16, device=x.device)
     import ctypes

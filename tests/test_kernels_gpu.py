@@ -302,6 +302,11 @@ def test_clip_to_nhwc_and_resize():
     t = F.interpolate(x, size=(40, 40), mode="bilinear").view(B, S, Fr, C, 40, 40)[:, :, 0::2]
     ref2 = t.transpose(0, 1).reshape(S, B * 4, C, 40, 40).permute(0, 1, 3, 4, 2)
     assert torch.allclose(y2[..., :C].float(), ref2, rtol=1e-2, atol=2e-2)
+    # 4-channel pixels for the 7x7 stem kernels (ResNet.input_cpad): same values, 8 bytes per pixel
+    y4 = clip_to_nhwc(x, S, Fr, C, cpad=4)
+    assert y4.shape[-1] == 4 and torch.equal(y4[..., :C], y[..., :C]) and y4[..., C:].float().abs().max().item() == 0
+    y24 = clip_to_nhwc(x, S, Fr, C, out_hw=(40, 40), frame_step=2, cpad=4)
+    assert torch.equal(y24[..., :C], y2[..., :C]) and y24[..., C:].float().abs().max().item() == 0
     # sound: [B, S, 64, 64] -> [S, B, 64, 64, 8]
     xs = torch.randn(B, S, 64, 64, device=DEV)
     ys = clip_to_nhwc(xs, S, 1, 1)

@@ -116,6 +116,9 @@ def test_uint8_frame_input_path_matches_reference_pipeline():
                 d = (got.float() - ref.float()).abs()
                 assert (d <= ref.float().abs() * 2 ** -7 + 1e-6).all(), (m, d.max().item())
                 assert (got != ref).float().mean().item() < 0.02
+            if C <= 4:                                                       # 4-channel pixels for the stem kernels
+                got4 = clip_u8_to_nhwc(u8.to(DEV), S, Fr, C, mean, std, out_hw=out_hw, frame_step=step, cpad=4)
+                assert got4.shape[-1] == 4 and torch.equal(got4[..., :C], got[..., :C]) and got4[..., C:].float().abs().max().item() == 0
 
 
 def test_adamml_accepts_uint8_frames():
