@@ -416,11 +416,16 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const bf16_t* g, const
 }
 
 // ------------------------------------------------------------------------------------------------ pooling
+// ZSEL: also store the RAW input value at the arg-max tap (z_sel, same shape as y).  The BatchNorm backward of the pool's input
+// then takes its two sums from (g_y, z_sel) -- a quarter of the pixels -- with the plain bn_bwd_reduce kernel: every pooled
+// gradient lands on exactly one input pixel, so sum(g') and sum(g' zhat) over the input equal the same sums over the windows.
+template <bool ZSEL>
 __global__ void maxpool_fwd_kernel(const bf16_t* x, const float* scale, const float* shift, int gs, int act, bf16_t* y,
-                                   uint8_t* idx, int N, int H, int W, int C, int OH, int OW) {
+                                   uint8_t* idx, bf16_t* zsel, int N, int H, int W, int C, int OH, int OW) {
     x += (size_t)blockIdx.y * N * H * W * C;
     y += (size_t)blockIdx.y * N * OH * OW * C;
     idx += (size_t)blockIdx.y * N * OH * OW * C;
+    if (ZSEL) zsel += (size_t)blockIdx.y * N * OH * OW * C;
     if (scale) { scale += (size_t)blockIdx.y * gs; shift += (size_t)blockIdx.y * gs; }
     const int cpr = C >> 3;
     const size_t total = (size_t)N * OH * OW * cpr;
@@ -433,8 +438,9 @@ __global__ void maxpool_fwd_kernel(const bf16_t* x, const float* scale, const fl
         const int n = (int)(pix / OH);
         f32x8 best;
         int bi[8];
+        bf16x8 zs;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bi[i] = 0; }
+        for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bi[i] = 0; zs[i] = 0; }
         // all nine taps are loaded UNCONDITIONALLY from clamped coordinates and the padding taps are turned into -inf afterwards: a
         // branch around each load makes the compiler wait for one tap before the next is requested (nine dependent L2 / HBM round
         // trips per output chunk: 2.6 ms at the stem shape against 1.2 ms of traffic)
@@ -461,10 +467,14 @@ __global__ void maxpool_fwd_kernel(const bf16_t* x, const float* scale, const fl
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float t = ok ? clamp_act(fmaf(v[i], tsc[i], tsh[i]), tlo, thi) : -INFINITY;
-                    if (t > best[i]) { best[i] = t; bi[i] = kh * 3 + kw; }
+                    if (t > best[i]) {
+                        best[i] = t; bi[i] = kh * 3 + kw;
+                        if (ZSEL) zs[i] = raw[kh * 3 + kw][i];
+                    }
                 }
             }
         *reinterpret_cast<bf16x8*>(y + e * 8) = f32_to_bf8(best);
+        if (ZSEL) *reinterpret_cast<bf16x8*>(zsel + e * 8) = zs;
         uint64_t packed = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) packed |= (uint64_t)bi[i] << (8 * i);
@@ -1321,13 +1331,17 @@ extern "C" int adamml_bn_bwd_apply(const void* g, const void* z, const float* ve
 }
 
 extern "C" int adamml_maxpool2d_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, void* y, uint8_t* idx,
-                                    int N, int H, int W, int C, int OH, int OW, int groups, hipStream_t stream) {
+                                    void* z_sel, int N, int H, int W, int C, int OH, int OW, int groups, hipStream_t stream) {
     CHECK_C(C, "maxpool2d_fwd");
     const size_t n = (size_t)N * OH * OW * (C / 8);
     if (!n) return ADAMML_OK;
     if (groups < 1) groups = 1;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n, NT, 4096 / groups + 1), groups), dim3(NT), 0, stream, (const bf16_t*)x, scale,
-                       shift, gstride, act, (bf16_t*)y, idx, N, H, W, C, OH, OW);
+    if (z_sel)
+        hipLaunchKernelGGL(maxpool_fwd_kernel<true>, dim3(grid_for(n, NT, 4096 / groups + 1), groups), dim3(NT), 0, stream, (const bf16_t*)x,
+                           scale, shift, gstride, act, (bf16_t*)y, idx, (bf16_t*)z_sel, N, H, W, C, OH, OW);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel<false>, dim3(grid_for(n, NT, 4096 / groups + 1), groups), dim3(NT), 0, stream, (const bf16_t*)x,
+                           scale, shift, gstride, act, (bf16_t*)y, idx, nullptr, N, H, W, C, OH, OW);
     return adamml_check_launch("maxpool2d_fwd");
 }
 

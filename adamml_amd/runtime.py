@@ -269,10 +269,13 @@ def _bn_backward(rt, out, y, vec, bn, act, count, defer_apply=False):
     if out.pool_grad is not None:
         # the only consumer was a 3x3/2 max-pool: its routed gradient is recomputed from the pooled gradient and the
         # arg-max indices inside both BatchNorm-backward passes instead of being written and re-read twice
-        gy, idx, poh, pow_ = out.pool_grad
+        gy, idx, zsel, poh, pow_ = out.pool_grad
         out.pool_grad = None
         sums = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS)
-        call("adamml_maxpool2d_bwd_bn_reduce", ptr(gy), ptr(idx), ptr(y), ptr(vec), act, ptr(sums), n // G, oh, ow, C, poh, pow_, G)
+        if zsel is not None:                # sums over the windows: each pooled gradient lands on exactly one input pixel
+            call("adamml_bn_bwd_reduce", ptr(gy), ptr(zsel), ptr(vec), act, ptr(sums), n // G * poh * pow_, C, G)
+        else:
+            call("adamml_maxpool2d_bwd_bn_reduce", ptr(gy), ptr(idx), ptr(y), ptr(vec), act, ptr(sums), n // G, oh, ow, C, poh, pow_, G)
         sums, nslots = rt.sync.reduce(sums, C, G)
         coef = torch.empty(G, 3, C, dtype=torch.float32, device=y.device)
         train_bn = bn.weight.requires_grad
@@ -516,6 +519,7 @@ def _gram_colsum(rt, x, d):
 
 
 RES_PROD = os.environ.get("ADAMML_RES_PROD", "1") != "0"     # g'^T a accumulated inside the residual-backward data gradient (A/B aid)
+POOL_ZSEL = os.environ.get("ADAMML_POOL_ZSEL", "1") != "0"   # stem BatchNorm-backward sums over the pool windows (g_y, z_sel) (A/B aid)
 GRAM_KERNEL = os.environ.get("ADAMML_GRAM_KERNEL", "1") != "0"     # dedicated Gram + column-sum kernel (A/B aid)
 ALG_BN = os.environ.get("ADAMML_ALG_BN", "1") != "0"     # algebraic BatchNorm backward through expanding 1x1 convs (A/B aid)
 ALG_MAX_COUT = int(os.environ.get("ADAMML_ALG_MAX_COUT", "512"))     # measured: at Cout = 1024 (layer 3) the small per-group products cost more than the saved passes (146.1 vs 144.6 ms)
@@ -816,7 +820,9 @@ def maxpool3x3s2(rt, x, sole_consumer=False):
     y = torch.empty(n, oh, ow, C, dtype=torch.bfloat16, device=x.data.device)
     idx = torch.empty(n, oh, ow, C, dtype=torch.uint8, device=x.data.device)
     G = rt.groups
-    call("adamml_maxpool2d_fwd", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(y), ptr(idx), n // G, h, w, C, oh, ow, G)
+    fuse_bn = sole_consumer and rt.tape.need_grad and x.requires_grad and x.vec is not None
+    zsel = torch.empty_like(y) if fuse_bn and POOL_ZSEL else None
+    call("adamml_maxpool2d_fwd", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(y), ptr(idx), ptr(zsel), n // G, h, w, C, oh, ow, G)
     out = Lazy(y)
     if rt.tape.need_grad:
         def bwd():
@@ -825,7 +831,7 @@ def maxpool3x3s2(rt, x, sole_consumer=False):
             if g is None or not x.requires_grad:
                 return
             if sole_consumer and x.grad is None and x.vec is not None and x.pre_sums is None:
-                x.pool_grad = (g, idx, oh, ow)
+                x.pool_grad = (g, idx, zsel, oh, ow)
                 return
             acc = 1
             if x.grad is None:

@@ -245,9 +245,11 @@ int adamml_bn_bwd_apply(const void* g, const void* z, const float* bn_vec, int a
                         int groups, hipStream_t stream);
 
 /* nn.MaxPool2d(3, 2, 1) on a lazy input (models/resnet.py:141,202); idx = argmax tap (uint8) for the backward.
- * N = images per group. */
+ * z_sel (NULL or [groups*N, OH, OW, C] bf16) receives the RAW input value at the arg-max tap: with it the BatchNorm backward of
+ * the pool's input takes sum(g'), sum(g' zhat) from adamml_bn_bwd_reduce(g_y, z_sel, ...) over the windows (a quarter of the
+ * pixels) instead of adamml_maxpool2d_bwd_bn_reduce over the input.  N = images per group. */
 int adamml_maxpool2d_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, void* y, uint8_t* idx,
-                         int N, int H, int W, int C, int OH, int OW, int groups, hipStream_t stream);
+                         void* z_sel, int N, int H, int W, int C, int OH, int OW, int groups, hipStream_t stream);
 int adamml_maxpool2d_bwd(const void* g_y, const uint8_t* idx, void* g_x, int N, int H, int W, int C, int OH, int OW,
                          int accumulate, hipStream_t stream);
 /* TemporalPooling (models/common.py:4-33): k3 s2 p1 over the frame axis; mode 0 = max, 1 = avg (zeros counted).

@@ -232,12 +232,12 @@ def test_maxpool_fwd_bwd():
     idx = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=DEV)
     xh = nhwc(x)
     # lazy input: relu(scale*x+shift) is evaluated in fp32 inside the kernel, then pooled
-    call("adamml_maxpool2d_fwd", ptr(xh), ptr(s), ptr(t), 0, 1, ptr(y), ptr(idx), N, H, W, C, OH, OW, 1)
+    call("adamml_maxpool2d_fwd", ptr(xh), ptr(s), ptr(t), 0, 1, ptr(y), ptr(idx), None, N, H, W, C, OH, OW, 1)
     close(nchw(y), F.max_pool2d(F.relu(x * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)), 3, 2, 1), what="maxpool lazy")
     # plain input: identical operand values on both sides -> identical first-arg-max routing
     ar = x.clone().requires_grad_(True)
     ref = F.max_pool2d(ar, 3, 2, 1)
-    call("adamml_maxpool2d_fwd", ptr(xh), None, None, 0, 0, ptr(y), ptr(idx), N, H, W, C, OH, OW, 1)
+    call("adamml_maxpool2d_fwd", ptr(xh), None, None, 0, 0, ptr(y), ptr(idx), None, N, H, W, C, OH, OW, 1)
     assert torch.equal(nchw(y), ref.detach())
     g = rb(torch.randn_like(ref))
     gh = nhwc(g)
@@ -517,9 +517,9 @@ def test_pools_groups_equal_separate_launches():
     OH = OW = 6
     y, y1 = (torch.empty(G * n, OH, OW, C, dtype=torch.bfloat16, device=DEV) for _ in range(2))
     ix, ix1 = (torch.empty(G * n, OH, OW, C, dtype=torch.uint8, device=DEV) for _ in range(2))
-    call("adamml_maxpool2d_fwd", ptr(x), ptr(s), ptr(t), C, 1, ptr(y), ptr(ix), n, H, W, C, OH, OW, G)
+    call("adamml_maxpool2d_fwd", ptr(x), ptr(s), ptr(t), C, 1, ptr(y), ptr(ix), None, n, H, W, C, OH, OW, G)
     for g in range(G):
-        call("adamml_maxpool2d_fwd", ptr(_g(x, G)[g]), ptr(s[g]), ptr(t[g]), 0, 1, ptr(_g(y1, G)[g]), ptr(_g(ix1, G)[g]), n, H, W, C,
+        call("adamml_maxpool2d_fwd", ptr(_g(x, G)[g]), ptr(s[g]), ptr(t[g]), 0, 1, ptr(_g(y1, G)[g]), ptr(_g(ix1, G)[g]), None, n, H, W, C,
              OH, OW, 1)
     assert torch.equal(y, y1) and torch.equal(ix, ix1)
     # temporal pool (max) fwd / bwd
@@ -773,7 +773,19 @@ def test_maxpool_bwd_bn_fused_equals_unfused_sequence(N, H, W, C, G):
     vec[:, 1] -= 1.0                                                   # shift: a good share of ReLU-masked pixels
     y = torch.empty(G * N, OH, OW, C, dtype=torch.bfloat16, device=DEV)
     idx = torch.empty(G * N, OH, OW, C, dtype=torch.uint8, device=DEV)
-    call("adamml_maxpool2d_fwd", ptr(z), ptr(vec[0, 0]), ptr(vec[0, 1]), 4 * C, 1, ptr(y), ptr(idx), N, H, W, C, OH, OW, G)
+    zsel = torch.empty_like(y)
+    call("adamml_maxpool2d_fwd", ptr(z), ptr(vec[0, 0]), ptr(vec[0, 1]), 4 * C, 1, ptr(y), ptr(idx), ptr(zsel), N, H, W, C, OH, OW, G)
+    y0, idx0 = torch.empty_like(y), torch.empty_like(idx)
+    call("adamml_maxpool2d_fwd", ptr(z), ptr(vec[0, 0]), ptr(vec[0, 1]), 4 * C, 1, ptr(y0), ptr(idx0), None, N, H, W, C, OH, OW, G)
+    assert torch.equal(y, y0) and torch.equal(idx, idx0)
+    # z_sel = the raw input at the recorded arg-max tap (gathered here from a zero-padded copy through idx)
+    zp = F.pad(z.float(), (0, 0, 1, 1, 1, 1))
+    oh, ow = torch.meshgrid(torch.arange(OH, device=DEV), torch.arange(OW, device=DEV), indexing="ij")
+    ih = (oh * 2)[None, :, :, None] + (idx // 3).long()
+    iw = (ow * 2)[None, :, :, None] + (idx % 3).long()
+    nn_ = torch.arange(G * N, device=DEV)[:, None, None, None].expand_as(ih)
+    cc = torch.arange(C, device=DEV)[None, None, None, :].expand_as(ih)
+    assert torch.equal(zsel.float(), zp[nn_, ih, iw, cc])
     gy = torch.randn(G * N, OH, OW, C, device=DEV).to(torch.bfloat16)
     P = N * H * W
     # unfused
@@ -792,6 +804,17 @@ def test_maxpool_bwd_bn_fused_equals_unfused_sequence(N, H, W, C, G):
     assert torch.equal(dz, dz_ref)
     a, b = s.sum(1), s_ref.sum(1)
     assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-6
+    # the same two sums over the windows (g_y, z_sel): the unfused reference rounds the routed gradient of a pixel shared by
+    # several windows to bf16 first, this path does not -- equal within that rounding
+    s2 = torch.zeros_like(s_ref)
+    call("adamml_bn_bwd_reduce", ptr(gy), ptr(zsel), ptr(vec), 1, ptr(s2), N * OH * OW, C, G)
+    a2 = s2.sum(1)
+    gw, zw = _g(gy, G).double().reshape(G, -1, C), _g(zsel, G).double().reshape(G, -1, C)
+    keep = ((_g(zsel, G).float().reshape(G, -1, C) * vec[:, 0:1] + vec[:, 1:2]) > 0).double()
+    zhat = (zw - vec[:, 2:3].double()) * vec[:, 3:4].double()
+    want = torch.cat([(gw * keep).sum(1), (gw * keep * zhat).sum(1)], dim=1)
+    assert (a2 - want).abs().max().item() <= 1e-4 * want.abs().max().item() + 1e-6
+    assert (a2 - b).abs().max().item() <= 2e-2 * b.abs().max().item() + 1e-6          # bf16 rounding of ~10^3 routed gradients
 
 
 @pytest.mark.parametrize("N,H,Cin,Cout,G,mode", [(4, 28, 64, 256, 1, "plain"), (6, 14, 128, 512, 3, "bn"), (4, 20, 64, 256, 2, "acc"),
