@@ -2,8 +2,9 @@
 # Whole evidence refresh of a round in ONE gpurun call: parity tests, default bench line, single-stream rocprofv3 kernel stats, PMC
 # traffic passes, non-headline bench lines, per-layer tables.  Usage: bash tools/gpu_round.sh <tag>
 tag=${1:-r02}
-bash tools/gpu_refresh.sh $tag
-bash tools/gpu_pmc.sh ${tag}pmc
+mkdir -p gpurun_out/$tag
+timeout 2700 python -m pytest tests -m gpu -x -q > gpurun_out/$tag/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/$tag/pytest.log; tail -3 gpurun_out/$tag/pytest.log
+bash tools/gpu_final.sh $tag          # PMC passes first, so that the default bench line carries the traffic of THIS build
 out=gpurun_out/${tag}v
 mkdir -p $out
 o="--no-cpu-baseline --no-roofline --steps 6"
