@@ -237,6 +237,84 @@ __global__ __launch_bounds__(NT) void dwconv_bwd_data_kernel(DwP p) {   // p.x =
     }
 }
 
+// Stride 2, pad 1: a thread owns one 8-channel chunk of a 2x2 INPUT quad (rows 2k, 2k+1; columns 2j, 2j+1).  The quad receives from
+// exactly the four dz pixels (k+a, j+b), a, b in {0, 1} -- pixel (0,0) one tap, (0,1) and (1,0) two, (1,1) four -- so the four loads
+// are unconditional (clamped addresses, out-of-range pixels zeroed afterwards) and issued together; the per-pixel kernel above tests
+// the parity of every tap and branches around each load (nine dependent L2 round trips per pixel: 1.6 TB/s).  Taps are accumulated in
+// the same (kh, kw) order as there: results are bit-identical.
+__global__ __launch_bounds__(NT) void dwconv_bwd_data_s2_kernel(DwP p) {   // p.x = dz [N,OH,OW,C], p.y = dx [N,H,W,C]; p.P = quads
+    const unsigned lb = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    p.x += (size_t)(lb / gridDim.x) * p.gx;
+    p.y += (size_t)(lb / gridDim.x) * p.gy;
+    ChanMap m(p.C, threadIdx.x);
+    if (!m.active) return;
+    const size_t qb = (size_t)(lb % gridDim.x) * p.ppb;
+    const size_t qe = qb + p.ppb < p.P ? qb + p.ppb : p.P;
+    const int c = m.chunk * 8;
+    const int QH = (p.H + 1) >> 1, QW = (p.W + 1) >> 1;
+    f32x8 wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = load_f32x8(p.w + (size_t)t * p.C + c);
+    for (size_t qi = qb + m.rslot; qi < qe; qi += m.rows_per_pass) {
+        const int j = (int)(qi % QW);
+        size_t r = qi / QW;
+        const int k = (int)(r % QH);
+        const int n = (int)(r / QH);
+        bf16x8 raw[2][2], prev[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int vh = min(k + a, p.OH - 1), vw = min(j + b, p.OW - 1);
+                raw[a][b] = *reinterpret_cast<const bf16x8*>(p.x + (((size_t)n * p.OH + vh) * p.OW + vw) * p.C + c);
+            }
+        if (p.accumulate) {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int ih = min(2 * k + dy, p.H - 1), iw = min(2 * j + dx, p.W - 1);
+                    prev[dy][dx] = *reinterpret_cast<const bf16x8*>(p.y + (((size_t)n * p.H + ih) * p.W + iw) * p.C + c);
+                }
+        }
+        f32x8 g[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const bool ok = k + a < p.OH && j + b < p.OW;
+                g[a][b] = bf8_to_f32(raw[a][b]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[a][b][i] = ok ? g[a][b][i] : 0.f;
+            }
+        f32x8 acc[2][2];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[dy][dx][i] = 0.f;
+                if (p.accumulate) acc[dy][dx] = bf8_to_f32(prev[dy][dx]);
+            }
+        // input (2k + dy, 2j + dx) <- dz (k + a, j + b) through tap (kh, kw) = (dy + 1 - 2a, dx + 1 - 2b), ascending (kh, kw)
+        acc[0][0] += g[0][0] * wt[4];
+        acc[0][1] += g[0][1] * wt[3];
+        acc[0][1] += g[0][0] * wt[5];
+        acc[1][0] += g[1][0] * wt[1];
+        acc[1][0] += g[0][0] * wt[7];
+        acc[1][1] += g[1][1] * wt[0];
+        acc[1][1] += g[1][0] * wt[2];
+        acc[1][1] += g[0][1] * wt[6];
+        acc[1][1] += g[0][0] * wt[8];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+                if (2 * k + dy < p.H && 2 * j + dx < p.W)
+                    *reinterpret_cast<bf16x8*>(p.y + (((size_t)n * p.H + 2 * k + dy) * p.W + 2 * j + dx) * p.C + c) = f32_to_bf8(acc[dy][dx]);
+    }
+}
+
 struct DwWP {
     const bf16_t* dz;
     const bf16_t* x;
@@ -540,6 +618,13 @@ extern "C" int adamml_dwconv_bwd_data(const adamml_conv_desc_t* d, const void* d
         p.nrb = ceil_div(p.OH, p.rows_per_thread);
         const long threads = (long)p.N * p.nrb * p.nseg * (p.C / 4);
         hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3((unsigned)((threads + NT - 1) / NT), groups), dim3(NT), 0, stream, p);
+        return adamml_check_launch("dwconv_bwd_data");
+    }
+    static const bool quads = !(getenv("ADAMML_DW_S2_QUADS") && atoi(getenv("ADAMML_DW_S2_QUADS")) == 0);       // A/B aid
+    if (d->stride == 2 && d->pad == 1 && quads) {
+        p.P = (size_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+        int nblk = dw_blocks(p.P, p.C, &p.ppb);
+        hipLaunchKernelGGL(dwconv_bwd_data_s2_kernel, dim3(nblk, groups), dim3(NT), 0, stream, p);
         return adamml_check_launch("dwconv_bwd_data");
     }
     int nblk = dw_blocks(p.P, p.C, &p.ppb);

@@ -129,7 +129,8 @@ def test_conv_fwd_bwd(case, lazy):
     close(dw2 - 1, wr.grad, what="conv wgrad (workspace path)")
 
 
-@pytest.mark.parametrize("case", [(2, 40, 40, 32, 1), (2, 41, 41, 96, 2), (1, 20, 20, 144, 2), (2, 10, 10, 960, 1), (1, 16, 16, 576, 2)])
+@pytest.mark.parametrize("case", [(2, 40, 40, 32, 1), (2, 41, 41, 96, 2), (1, 20, 20, 144, 2), (2, 10, 10, 960, 1), (1, 16, 16, 576, 2),
+                                  (3, 13, 18, 24, 2), (2, 1, 7, 16, 2)])
 def test_dwconv(case):
     torch.manual_seed(1)
     N, H, W, C, s = case
@@ -158,6 +159,10 @@ def test_dwconv(case):
     dx = torch.empty(N, H, W, C, dtype=torch.bfloat16, device=DEV)
     call("adamml_dwconv_bwd_data", byref(d), ptr(dz), ptr(wp), ptr(dx), 0)
     close(nchw(dx), xr.grad, what="dw dgrad")
+    base = torch.randn(N, H, W, C, device=DEV).to(torch.bfloat16)                   # accumulate = 1: dx += ...
+    dxa = base.clone()
+    call("adamml_dwconv_bwd_data", byref(d), ptr(dz), ptr(wp), ptr(dxa), 1)
+    close(nchw(dxa), xr.grad + nchw(base), what="dw dgrad (accumulate)")
     dw = torch.zeros_like(w)
     call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(xh), ptr(scale), ptr(shift), ptr(dw), None, 0)
     close(dw, wr.grad, what="dw wgrad (atomic path)")
