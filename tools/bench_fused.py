@@ -57,6 +57,10 @@ for name, N, H, Cm, Cb in [("layer1", B * 8, 56, 64, 256), ("layer2", B * 4, 28,
     coef = torch.rand(G, 3, Cb, device=DEV)
     vin = torch.rand(G, 4, Cm, device=DEV) + 0.5
     sm = torch.zeros(G, STAT_SLOTS, 2 * Cm, dtype=torch.float64, device=DEV)
+    if not hip.load().adamml_conv_bwd_data_dual_supported(byref(d3)):
+        print("%s DUAL dgrad %4d->%4d: not supported by the dual loader (Cout > 512: apply + data gradient is faster, see conv_gemm.hip)" % (name, Cb, Cm))
+        del g, dzs, dx, zin, z3, dz1
+        continue
     t_dual = timeit(lambda: call("adamml_conv_bwd_data_dual", byref(d3), ptr(g), ptr(z3), ptr(aff), ptr(dzs), ptr(wd3), ptr(dx), 0, ptr(zin),
                                  ptr(vin), 1, ptr(sm)))
     t_ap = timeit(lambda: call("adamml_bn_bwd_apply", ptr(g), ptr(z3), ptr(vec), 0, ptr(coef), ptr(dzs), N * H * H, Cb, G))
