@@ -37,6 +37,10 @@ struct DwP {
     size_t P, ppb;
     size_t gx, gy;        // element strides between BatchNorm groups of x / y (blockIdx.y = group)
     int in_gstride;
+    // data gradient w.r.t. a lazily normalised tensor (BNZ kernels): y = g * act'(bn(bn_z)) and stats += sum(y), sum(y zhat)
+    const bf16_t* bn_z;   // raw tensor y is the gradient of (same shape / group stride as y)
+    const float* bn_vec;  // [G][4][C] scale, shift, mean, invstd
+    int bn_act;
 };
 
 // "Column-strip walker": one thread owns 4 channels x SEGW adjacent output columns and walks DOWN `rows_per_thread`
@@ -45,7 +49,11 @@ struct DwP {
 // 31 VALU ops per output element, VALU-bound at ~1 TB/s); the window rotates by compile-time index (rows are processed in
 // groups of 3), the next input row(s) are in flight while the current output row is computed, and the per-channel
 // statistics stay in registers for the whole walk (one LDS fold per thread, one global publication per workgroup).
-template <int S>
+// BNZ (stride-1 data gradient, the walk over dz with reversed taps): the outputs are the gradient w.r.t. the ACTIVATED value of a lazily
+// normalised tensor z -- the mask act'(bn(z)) is applied before the store and the statistics become sum(g'), sum(g' zhat), so the
+// BatchNorm-backward reduction pass over (g, z) disappears (one read of z here instead of a read of g and of z there).  The z rows
+// are requested three output rows ahead (three rotating register rows, like the input window).
+template <int S, bool BNZ = false>
 __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
     constexpr int SEGW = S == 1 ? 4 : 2;                // output columns per thread
     constexpr int NCOL = (SEGW - 1) * S + 3;            // input columns feeding them
@@ -58,6 +66,7 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
         p.y += (size_t)g * p.gy;
         if (p.stats) p.stats += (size_t)g * ADAMML_STAT_SLOTS * 2 * p.C;
         if (p.in_scale) { p.in_scale += (size_t)g * p.in_gstride; p.in_shift += (size_t)g * p.in_gstride; }
+        if (BNZ) { p.bn_z += (size_t)g * p.gy; p.bn_vec += (size_t)g * 4 * p.C; }
     }
     const int nchunk = p.C >> 2;
     const int gid = bx * NT + threadIdx.x;
@@ -88,6 +97,22 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
         for (int j = 0; j < NCOL; ++j) cok[j] = (unsigned)(iw_b + j) < (unsigned)p.W;
         const bf16_t* img = p.x + (size_t)n * p.H * p.W * p.C + c;
         bf16_t* yimg = p.y + (size_t)n * p.OH * p.OW * p.C + c;
+        f32x4 bsc, bsh, bmu, bis;
+        float blo = 0.f, bhi = 0.f;
+        const bf16_t* zimg = nullptr;
+        struct ZRow { bf16x4 v[SEGW]; };
+        ZRow zr[BNZ ? 3 : 1];
+        if (BNZ) {
+            bsc = *reinterpret_cast<const f32x4*>(p.bn_vec + c); bsh = *reinterpret_cast<const f32x4*>(p.bn_vec + p.C + c);
+            bmu = *reinterpret_cast<const f32x4*>(p.bn_vec + 2 * p.C + c); bis = *reinterpret_cast<const f32x4*>(p.bn_vec + 3 * p.C + c);
+            blo = act_lo(p.bn_act); bhi = act_hi(p.bn_act);
+            zimg = p.bn_z + (size_t)n * p.OH * p.OW * p.C + c;
+        }
+        auto load_z = [&](int oh, ZRow& r) {                 // unconditional, clamped (rows / columns past the end are never used)
+            const bf16_t* rp = zimg + (size_t)min(oh, p.OH - 1) * p.OW * p.C;
+#pragma unroll
+            for (int o = 0; o < SEGW; ++o) r.v[o] = *reinterpret_cast<const bf16x4*>(rp + (size_t)min(ow_b + o, p.OW - 1) * p.C);
+        };
 
         struct Raw { bf16x4 v[NCOL]; bool rok; };
         auto load_row = [&](int ih, Raw& r) {
@@ -107,7 +132,7 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
                 dst[j] = v;
             }
         };
-        auto emit = [&](int oh, const f32x4 (&r0)[NCOL], const f32x4 (&r1)[NCOL], const f32x4 (&r2)[NCOL]) {
+        auto emit = [&](int oh, const f32x4 (&r0)[NCOL], const f32x4 (&r1)[NCOL], const f32x4 (&r2)[NCOL], const ZRow& zrow) {
             bf16_t* yrow = yimg + (size_t)oh * p.OW * p.C;
 #pragma unroll
             for (int o = 0; o < SEGW; ++o) {
@@ -121,11 +146,22 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
                     acc += r2[o * S] * wt[6];
                     acc += r2[o * S + 1] * wt[7];
                     acc += r2[o * S + 2] * wt[8];
-                    const bf16x4 ob = f32_to_bf4(acc);
-                    *reinterpret_cast<bf16x4*>(yrow + (size_t)(ow_b + o) * p.C) = ob;
-                    const f32x4 rv = bf4_to_f32(ob);
-                    s += rv;
-                    q += rv * rv;
+                    if (BNZ) {
+                        const f32x4 zv = bf4_to_f32(zrow.v[o]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] *= mask_act(fmaf(zv[i], bsc[i], bsh[i]), blo, bhi);
+                        const bf16x4 ob = f32_to_bf4(acc);
+                        *reinterpret_cast<bf16x4*>(yrow + (size_t)(ow_b + o) * p.C) = ob;
+                        const f32x4 rv = bf4_to_f32(ob);
+                        s += rv;
+                        q += rv * ((zv - bmu) * bis);
+                    } else {
+                        const bf16x4 ob = f32_to_bf4(acc);
+                        *reinterpret_cast<bf16x4*>(yrow + (size_t)(ow_b + o) * p.C) = ob;
+                        const f32x4 rv = bf4_to_f32(ob);
+                        s += rv;
+                        q += rv * rv;
+                    }
                 }
             }
         };
@@ -137,18 +173,22 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
             { Raw r; load_row(oh_b * S - p.pad, r); xform(r, win[0]); }
             { Raw r; load_row(oh_b * S - p.pad + 1, r); xform(r, win[1]); }
             load_row(oh_b - p.pad + 2, nxt[0]);
+            if (BNZ) { load_z(oh_b, zr[0]); load_z(oh_b + 1, zr[BNZ ? 1 : 0]); load_z(oh_b + 2, zr[BNZ ? 2 : 0]); }
             for (int oh = oh_b; oh < oh_e; oh += 3) {
                 xform(nxt[0], win[2]);
                 if (oh + 1 < oh_e) load_row(oh + 1 - p.pad + 2, nxt[0]);
-                emit(oh, win[0], win[1], win[2]);
+                emit(oh, win[0], win[1], win[2], zr[0]);
+                if (BNZ && oh + 3 < oh_e) load_z(oh + 3, zr[0]);
                 if (oh + 1 >= oh_e) break;
                 xform(nxt[0], win[0]);
                 if (oh + 2 < oh_e) load_row(oh + 2 - p.pad + 2, nxt[0]);
-                emit(oh + 1, win[1], win[2], win[0]);
+                emit(oh + 1, win[1], win[2], win[0], zr[BNZ ? 1 : 0]);
+                if (BNZ && oh + 4 < oh_e) load_z(oh + 4, zr[BNZ ? 1 : 0]);
                 if (oh + 2 >= oh_e) break;
                 xform(nxt[0], win[1]);
                 if (oh + 3 < oh_e) load_row(oh + 3 - p.pad + 2, nxt[0]);
-                emit(oh + 2, win[2], win[0], win[1]);
+                emit(oh + 2, win[2], win[0], win[1], zr[BNZ ? 2 : 0]);
+                if (BNZ && oh + 5 < oh_e) load_z(oh + 5, zr[BNZ ? 2 : 0]);
             }
         } else {
             // rows ih = 2oh-1, 2oh, 2oh+1; row 2oh+1 is kept as the top row of output row oh+1
@@ -158,15 +198,15 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
             for (int oh = oh_b; oh < oh_e; oh += 3) {
                 xform(nxt[0], win[1]); xform(nxt[1], win[2]);
                 if (oh + 1 < oh_e) { load_row((oh + 1) * 2 - p.pad + 1, nxt[0]); load_row((oh + 1) * 2 - p.pad + 2, nxt[1]); }
-                emit(oh, win[0], win[1], win[2]);
+                emit(oh, win[0], win[1], win[2], zr[0]);
                 if (oh + 1 >= oh_e) break;
                 xform(nxt[0], win[0]); xform(nxt[1], win[1]);
                 if (oh + 2 < oh_e) { load_row((oh + 2) * 2 - p.pad + 1, nxt[0]); load_row((oh + 2) * 2 - p.pad + 2, nxt[1]); }
-                emit(oh + 1, win[2], win[0], win[1]);
+                emit(oh + 1, win[2], win[0], win[1], zr[0]);
                 if (oh + 2 >= oh_e) break;
                 xform(nxt[0], win[2]); xform(nxt[1], win[0]);
                 if (oh + 3 < oh_e) { load_row((oh + 3) * 2 - p.pad + 1, nxt[0]); load_row((oh + 3) * 2 - p.pad + 2, nxt[1]); }
-                emit(oh + 2, win[1], win[2], win[0]);
+                emit(oh + 2, win[1], win[2], win[0], zr[0]);
             }
         }
     }
@@ -242,76 +282,135 @@ __global__ __launch_bounds__(NT) void dwconv_bwd_data_kernel(DwP p) {   // p.x =
 // are unconditional (clamped addresses, out-of-range pixels zeroed afterwards) and issued together; the per-pixel kernel above tests
 // the parity of every tap and branches around each load (nine dependent L2 round trips per pixel: 1.6 TB/s).  Taps are accumulated in
 // the same (kh, kw) order as there: results are bit-identical.
+template <bool BNZ>
 __global__ __launch_bounds__(NT) void dwconv_bwd_data_s2_kernel(DwP p) {   // p.x = dz [N,OH,OW,C], p.y = dx [N,H,W,C]; p.P = quads
+    __shared__ float smem[BNZ ? 2 * MAXC : 1];
     const unsigned lb = xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    p.x += (size_t)(lb / gridDim.x) * p.gx;
-    p.y += (size_t)(lb / gridDim.x) * p.gy;
+    {
+        const size_t g = lb / gridDim.x;
+        p.x += g * p.gx;
+        p.y += g * p.gy;
+        if (BNZ) { p.bn_z += g * p.gy; p.bn_vec += g * 4 * p.C; p.stats += g * ADAMML_STAT_SLOTS * 2 * p.C; }
+    }
     ChanMap m(p.C, threadIdx.x);
-    if (!m.active) return;
+    if (!BNZ && !m.active) return;
     const size_t qb = (size_t)(lb % gridDim.x) * p.ppb;
     const size_t qe = qb + p.ppb < p.P ? qb + p.ppb : p.P;
     const int c = m.chunk * 8;
     const int QH = (p.H + 1) >> 1, QW = (p.W + 1) >> 1;
-    f32x8 wt[9];
+    float s[8], q[8];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wt[t] = load_f32x8(p.w + (size_t)t * p.C + c);
-    for (size_t qi = qb + m.rslot; qi < qe; qi += m.rows_per_pass) {
-        const int j = (int)(qi % QW);
-        size_t r = qi / QW;
-        const int k = (int)(r % QH);
-        const int n = (int)(r / QH);
-        bf16x8 raw[2][2], prev[2][2];
+    for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+    if (m.active) {
+        f32x8 wt[9];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int t = 0; t < 9; ++t) wt[t] = load_f32x8(p.w + (size_t)t * p.C + c);
+        f32x8 bsc, bsh, bmu, bis;
+        float blo = 0.f, bhi = 0.f;
+        if (BNZ) {
+            bsc = load_f32x8(p.bn_vec + c); bsh = load_f32x8(p.bn_vec + p.C + c);
+            bmu = load_f32x8(p.bn_vec + 2 * p.C + c); bis = load_f32x8(p.bn_vec + 3 * p.C + c);
+            blo = act_lo(p.bn_act); bhi = act_hi(p.bn_act);
+        }
+        for (size_t qi = qb + m.rslot; qi < qe; qi += m.rows_per_pass) {
+            const int j = (int)(qi % QW);
+            size_t r = qi / QW;
+            const int k = (int)(r % QH);
+            const int n = (int)(r / QH);
+            bf16x8 raw[2][2], prev[2][2];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int vh = min(k + a, p.OH - 1), vw = min(j + b, p.OW - 1);
-                raw[a][b] = *reinterpret_cast<const bf16x8*>(p.x + (((size_t)n * p.OH + vh) * p.OW + vw) * p.C + c);
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int vh = min(k + a, p.OH - 1), vw = min(j + b, p.OW - 1);
+                    raw[a][b] = *reinterpret_cast<const bf16x8*>(p.x + (((size_t)n * p.OH + vh) * p.OW + vw) * p.C + c);
+                }
+            if (BNZ || p.accumulate) {                       // BNZ: the z values of the four pixels; accumulate: their previous gradient
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int ih = min(2 * k + dy, p.H - 1), iw = min(2 * j + dx, p.W - 1);
+                        prev[dy][dx] = *reinterpret_cast<const bf16x8*>((BNZ ? p.bn_z : p.y) + (((size_t)n * p.H + ih) * p.W + iw) * p.C + c);
+                    }
             }
-        if (p.accumulate) {
+            f32x8 g[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const bool ok = k + a < p.OH && j + b < p.OW;
+                    g[a][b] = bf8_to_f32(raw[a][b]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) g[a][b][i] = ok ? g[a][b][i] : 0.f;
+                }
+            f32x8 acc[2][2];
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
-                    const int ih = min(2 * k + dy, p.H - 1), iw = min(2 * j + dx, p.W - 1);
-                    prev[dy][dx] = *reinterpret_cast<const bf16x8*>(p.y + (((size_t)n * p.H + ih) * p.W + iw) * p.C + c);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[dy][dx][i] = 0.f;
+                    if (!BNZ && p.accumulate) acc[dy][dx] = bf8_to_f32(prev[dy][dx]);
+                }
+            // input (2k + dy, 2j + dx) <- dz (k + a, j + b) through tap (kh, kw) = (dy + 1 - 2a, dx + 1 - 2b), ascending (kh, kw)
+            acc[0][0] += g[0][0] * wt[4];
+            acc[0][1] += g[0][1] * wt[3];
+            acc[0][1] += g[0][0] * wt[5];
+            acc[1][0] += g[1][0] * wt[1];
+            acc[1][0] += g[0][0] * wt[7];
+            acc[1][1] += g[1][1] * wt[0];
+            acc[1][1] += g[1][0] * wt[2];
+            acc[1][1] += g[0][1] * wt[6];
+            acc[1][1] += g[0][0] * wt[8];
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const bool ok = 2 * k + dy < p.H && 2 * j + dx < p.W;
+                    bf16x8 ob;
+                    if (BNZ) {
+                        const f32x8 zv = bf8_to_f32(prev[dy][dx]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[dy][dx][i] *= mask_act(fmaf(zv[i], bsc[i], bsh[i]), blo, bhi);
+                        ob = f32_to_bf8(acc[dy][dx]);
+                        const f32x8 rv = bf8_to_f32(ob);
+                        const float keep = ok ? 1.f : 0.f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float gp = keep * rv[i];
+                            s[i] += gp;
+                            q[i] += gp * ((zv[i] - bmu[i]) * bis[i]);
+                        }
+                    } else ob = f32_to_bf8(acc[dy][dx]);
+                    if (ok) *reinterpret_cast<bf16x8*>(p.y + (((size_t)n * p.H + 2 * k + dy) * p.W + 2 * j + dx) * p.C + c) = ob;
                 }
         }
-        f32x8 g[2][2];
+    }
+    if (BNZ) {
+        for (int i = threadIdx.x; i < 2 * p.C; i += NT) smem[i] = 0.f;
+        __syncthreads();
+        if (det_mode()) {                                   // exact integer bins instead of float atomics (common.h)
+            if (m.active) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const bool ok = k + a < p.OH && j + b < p.OW;
-                g[a][b] = bf8_to_f32(raw[a][b]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) g[a][b][i] = ok ? g[a][b][i] : 0.f;
+                for (int i = 0; i < 8; ++i) {
+                    det_add(p.stats + c + i, 2 * (size_t)p.C, s[i]);
+                    det_add(p.stats + p.C + c + i, 2 * (size_t)p.C, q[i]);
+                }
             }
-        f32x8 acc[2][2];
+            return;
+        }
+        if (m.active) {
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[dy][dx][i] = 0.f;
-                if (p.accumulate) acc[dy][dx] = bf8_to_f32(prev[dy][dx]);
+            for (int i = 0; i < 8; ++i) {
+                atomicAdd(&smem[c + i], s[i]);
+                atomicAdd(&smem[p.C + c + i], q[i]);
             }
-        // input (2k + dy, 2j + dx) <- dz (k + a, j + b) through tap (kh, kw) = (dy + 1 - 2a, dx + 1 - 2b), ascending (kh, kw)
-        acc[0][0] += g[0][0] * wt[4];
-        acc[0][1] += g[0][1] * wt[3];
-        acc[0][1] += g[0][0] * wt[5];
-        acc[1][0] += g[1][0] * wt[1];
-        acc[1][0] += g[0][0] * wt[7];
-        acc[1][1] += g[1][1] * wt[0];
-        acc[1][1] += g[1][0] * wt[2];
-        acc[1][1] += g[0][1] * wt[6];
-        acc[1][1] += g[0][0] * wt[8];
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx)
-                if (2 * k + dy < p.H && 2 * j + dx < p.W)
-                    *reinterpret_cast<bf16x8*>(p.y + (((size_t)n * p.H + 2 * k + dy) * p.W + 2 * j + dx) * p.C + c) = f32_to_bf8(acc[dy][dx]);
+        }
+        __syncthreads();
+        double* slot = p.stats + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * p.C;
+        for (int i = threadIdx.x; i < 2 * p.C; i += NT)
+            if (smem[i] != 0.f) atomicAdd(&slot[i], (double)smem[i]);
     }
 }
 
@@ -573,6 +672,7 @@ extern "C" int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, con
     int rc = check_dw(d, "dwconv_fwd");
     if (rc) return rc;
     DwP p;
+    p.bn_z = nullptr; p.bn_vec = nullptr; p.bn_act = 0;
     p.x = (const bf16_t*)x; p.w = w; p.in_scale = in_scale; p.in_shift = in_shift; p.y = (bf16_t*)y; p.stats = stats;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.pad = d->pad;
     p.act = d->act; p.accumulate = 0;
@@ -596,12 +696,13 @@ extern "C" int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, con
     return adamml_check_launch("dwconv_fwd");
 }
 
-extern "C" int adamml_dwconv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const float* w, void* dx, int accumulate,
-                                      hipStream_t stream) {
+static int dw_bwd_data_launch(const adamml_conv_desc_t* d, const void* dz, const float* w, void* dx, int accumulate, const void* bn_z,
+                              const float* bn_vec, int bn_act, double* sums, hipStream_t stream) {
     int rc = check_dw(d, "dwconv_bwd_data");
     if (rc) return rc;
     DwP p;
-    p.x = (const bf16_t*)dz; p.w = w; p.in_scale = nullptr; p.in_shift = nullptr; p.y = (bf16_t*)dx; p.stats = nullptr;
+    p.x = (const bf16_t*)dz; p.w = w; p.in_scale = nullptr; p.in_shift = nullptr; p.y = (bf16_t*)dx; p.stats = sums;
+    p.bn_z = (const bf16_t*)bn_z; p.bn_vec = bn_vec; p.bn_act = bn_act;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.pad = d->pad;
     p.act = 0; p.accumulate = accumulate; p.nseg = 1; p.seglen = 0; p.flip = 0;
     p.P = (size_t)d->N * d->H * d->W;
@@ -617,19 +718,40 @@ extern "C" int adamml_dwconv_bwd_data(const adamml_conv_desc_t* d, const void* d
         while (p.rows_per_thread > 3 && (long)groups * p.N * ceil_div(p.OH, p.rows_per_thread) * p.nseg * (p.C / 4) < 4096L * NT) p.rows_per_thread -= 3;
         p.nrb = ceil_div(p.OH, p.rows_per_thread);
         const long threads = (long)p.N * p.nrb * p.nseg * (p.C / 4);
-        hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3((unsigned)((threads + NT - 1) / NT), groups), dim3(NT), 0, stream, p);
+        if (bn_z) hipLaunchKernelGGL((dwconv_fwd_kernel<1, true>), dim3((unsigned)((threads + NT - 1) / NT), groups), dim3(NT), 0, stream, p);
+        else hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3((unsigned)((threads + NT - 1) / NT), groups), dim3(NT), 0, stream, p);
         return adamml_check_launch("dwconv_bwd_data");
     }
     static const bool quads = !(getenv("ADAMML_DW_S2_QUADS") && atoi(getenv("ADAMML_DW_S2_QUADS")) == 0);       // A/B aid
-    if (d->stride == 2 && d->pad == 1 && quads) {
+    if (d->stride == 2 && d->pad == 1 && (quads || bn_z)) {
         p.P = (size_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
         int nblk = dw_blocks(p.P, p.C, &p.ppb);
-        hipLaunchKernelGGL(dwconv_bwd_data_s2_kernel, dim3(nblk, groups), dim3(NT), 0, stream, p);
+        if (bn_z) hipLaunchKernelGGL(dwconv_bwd_data_s2_kernel<true>, dim3(nblk, groups), dim3(NT), 0, stream, p);
+        else hipLaunchKernelGGL(dwconv_bwd_data_s2_kernel<false>, dim3(nblk, groups), dim3(NT), 0, stream, p);
         return adamml_check_launch("dwconv_bwd_data");
     }
+    if (bn_z) return adamml_set_error(ADAMML_EUNSUPPORTED, "dwconv_bwd_data_bn: needs pad 1 and stride 1 (no accumulate) or stride 2");
     int nblk = dw_blocks(p.P, p.C, &p.ppb);
     hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(nblk, groups), dim3(NT), 0, stream, p);
     return adamml_check_launch("dwconv_bwd_data");
+}
+
+extern "C" int adamml_dwconv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const float* w, void* dx, int accumulate,
+                                      hipStream_t stream) {
+    return dw_bwd_data_launch(d, dz, w, dx, accumulate, nullptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int adamml_dwconv_bwd_data_bn_supported(const adamml_conv_desc_t* d) {
+    return d && d->KH == 3 && d->KW == 3 && d->Cin == d->Cout && d->Cin % 8 == 0 && d->Cin <= MAXC && d->pad == 1 &&
+           (d->stride == 1 || d->stride == 2) ? 1 : 0;
+}
+
+extern "C" int adamml_dwconv_bwd_data_bn(const adamml_conv_desc_t* d, const void* dz, const float* w, void* dx, const void* z_in,
+                                         const float* bn_vec, int act, double* sums, hipStream_t stream) {
+    if (!z_in || !bn_vec || !sums) return adamml_set_error(ADAMML_EINVAL, "dwconv_bwd_data_bn: null BatchNorm epilogue operand");
+    if (!adamml_dwconv_bwd_data_bn_supported(d))
+        return adamml_set_error(ADAMML_EUNSUPPORTED, "dwconv_bwd_data_bn: 3x3 depthwise, pad 1, stride 1 / 2, C %% 8 == 0");
+    return dw_bwd_data_launch(d, dz, w, dx, 0, z_in, bn_vec, act, sums, stream);
 }
 
 static int dw_wgrad_blocks(const adamml_conv_desc_t* d, int* rows_per_thread, int* nseg, int* nrb) {

@@ -57,6 +57,7 @@ SIGNATURES = {
     "adamml_conv_stem_bwd_weight": [_DESC, _P, _P, _P, _I, _P, _Z, _P],
     "adamml_dwconv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "adamml_dwconv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
+    "adamml_dwconv_bwd_data_bn": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
     "adamml_dwconv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _P, _Z, _P],
     "adamml_stats_collapse": [_P, _P, _I, _I, _P],
     "adamml_bn_finalize": [_P, _I, _I, _D, _P, _P, _P, _P, _F, _F, _P, _I, _P],
@@ -132,6 +133,8 @@ def load():
     lib.adamml_conv_bwd_data_res_supported.restype = c_int
     lib.adamml_temporal_pool_bwd_res_supported.argtypes = [_I, _I, _I]
     lib.adamml_temporal_pool_bwd_res_supported.restype = c_int
+    lib.adamml_dwconv_bwd_data_bn_supported.argtypes = [_DESC]
+    lib.adamml_dwconv_bwd_data_bn_supported.restype = c_int
     lib.adamml_conv_stem_supported.argtypes = [_DESC]
     lib.adamml_conv_stem_supported.restype = c_int
     lib.adamml_pack_block_elems.restype = c_int

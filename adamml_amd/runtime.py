@@ -412,7 +412,13 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                     acc = 0
                 hip.next_meta = (2 * macs, in_b * (1 + acc) + out_b + w_b, kern)
                 tgt = x.src if x.src is not None else x
-                if cs.depthwise:
+                if cs.depthwise and DW_BNZ and sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None \
+                        and hip.load().adamml_dwconv_bwd_data_bn_supported(byref(d)):
+                    # the expansion's BatchNorm-backward sums come out of this data gradient (mask applied here): no reduction pass
+                    sums = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS)
+                    call("adamml_dwconv_bwd_data_bn", byref(d), ptr(dz), ptr(cs.w_fwd), ptr(x.grad), ptr(tgt.data), ptr(tgt.vec), tgt.act, ptr(sums))
+                    tgt.pre_sums = sums
+                elif cs.depthwise:
                     call("adamml_dwconv_bwd_data", byref(d), ptr(dz), ptr(cs.w_fwd), ptr(x.grad), acc)
                 elif last_consumer and _residual_fusable(x, d):
                     z, idn, ract, idn_sole, rmask = x.res
@@ -520,6 +526,7 @@ def _gram_colsum(rt, x, d):
 
 RES_PROD = os.environ.get("ADAMML_RES_PROD", "1") != "0"     # g'^T a accumulated inside the residual-backward data gradient (A/B aid)
 POOL_ZSEL = os.environ.get("ADAMML_POOL_ZSEL", "1") != "0"   # stem BatchNorm-backward sums over the pool windows (g_y, z_sel) (A/B aid)
+DW_BNZ = os.environ.get("ADAMML_DW_BNZ", "1") != "0"         # BatchNorm-backward sums of the expansion inside the depthwise data gradient (A/B aid)
 GRAM_KERNEL = os.environ.get("ADAMML_GRAM_KERNEL", "1") != "0"     # dedicated Gram + column-sum kernel (A/B aid)
 ALG_BN = os.environ.get("ADAMML_ALG_BN", "1") != "0"     # algebraic BatchNorm backward through expanding 1x1 convs (A/B aid)
 ALG_MAX_COUT = int(os.environ.get("ADAMML_ALG_MAX_COUT", "512"))     # measured: at Cout = 1024 (layer 3) the small per-group products cost more than the saved passes (146.1 vs 144.6 ms)

@@ -194,6 +194,13 @@ int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, const float* w
                       const float* in_shift, void* y, double* stats, hipStream_t stream);
 int adamml_dwconv_bwd_data(const adamml_conv_desc_t* d, const void* dz, const float* w_tapmajor, void* dx,
                            int accumulate, hipStream_t stream);
+/* adamml_dwconv_bwd_data whose output is the gradient w.r.t. the ACTIVATED value of a lazily normalised tensor z_in (the expansion
+ * conv's BatchNorm + ReLU6 output, sound_mobilenet_v2.py:52-57 / policy_net.py:72-79): the mask act'(bn(z_in)) is applied before the
+ * store and sum(g'), sum(g' zhat) are accumulated into sums [groups][SLOTS][2C] -- replaces adamml_bn_bwd_reduce over (g, z_in).
+ * pad 1, stride 1 or 2, no accumulation. */
+int adamml_dwconv_bwd_data_bn_supported(const adamml_conv_desc_t* d);
+int adamml_dwconv_bwd_data_bn(const adamml_conv_desc_t* d, const void* dz, const float* w_tapmajor, void* dx, const void* z_in,
+                              const float* bn_vec, int act, double* sums, hipStream_t stream);
 size_t adamml_dwconv_bwd_weight_workspace(const adamml_conv_desc_t* d);
 int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
                              const float* in_shift, float* dw, void* workspace, size_t workspace_bytes, hipStream_t stream);

@@ -415,6 +415,41 @@ def test_conv_groups_equal_separate_launches(case):
         close(dw, dw1, rtol=1e-3, atol_frac=1e-4, what="grouped wgrad (ws=%s)" % use_ws)
 
 
+@pytest.mark.parametrize("N,H,W,C,s,G", [(2, 20, 20, 96, 1, 1), (2, 21, 19, 144, 2, 2), (1, 16, 16, 32, 2, 3), (3, 9, 14, 24, 1, 2),
+                                         (2, 1, 5, 16, 2, 1), (1, 40, 40, 192, 1, 5), (2, 7, 7, 960, 1, 1)])
+def test_dwconv_bwd_data_bn_equals_dgrad_then_reduce(N, H, W, C, s, G):
+    """adamml_dwconv_bwd_data_bn (activation mask + BatchNorm-backward sums inside the depthwise data gradient) against
+    adamml_dwconv_bwd_data followed by the mask (adamml_bn_bwd_apply with coefficients 1, 0, 0) and adamml_bn_bwd_reduce:
+    g' bit-identical, sums equal up to summation order."""
+    torch.manual_seed(N * 7 + H)
+    OH, OW = (H - 1) // s + 1, (W - 1) // s + 1
+    w = torch.randn(C, 1, 3, 3, device=DEV) * 0.4
+    wp = pack(w, C, 2)
+    d = ConvDesc(N, H, W, C, OH, OW, C, 3, 3, s, 1, 1, 2, 0, G, C)
+    assert hip.load().adamml_dwconv_bwd_data_bn_supported(byref(d)) == 1
+    dz = nhwc(torch.randn(G * N, C, OH, OW, device=DEV))
+    z = torch.randn(G * N, H, W, C, device=DEV).to(torch.bfloat16) * 2
+    vec = torch.rand(G, 4, C, device=DEV) + 0.5
+    vec[:, 1] += 1.0                                                   # ReLU6: a share of pixels below 0 and above 6
+    P = N * H * W
+    g = torch.empty_like(z)
+    call("adamml_dwconv_bwd_data", byref(d), ptr(dz), ptr(wp), ptr(g), 0)
+    s_ref = torch.zeros(G, STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
+    call("adamml_bn_bwd_reduce", ptr(g), ptr(z), ptr(vec), 2, ptr(s_ref), P, C, G)
+    one = torch.zeros(G, 3, C, device=DEV)
+    one[:, 0] = 1.0
+    gp_ref = torch.empty_like(z)
+    call("adamml_bn_bwd_apply", ptr(g), ptr(z), ptr(vec), 2, ptr(one), ptr(gp_ref), P, C, G)
+    gp = torch.full_like(z, 7.0)
+    sums = torch.zeros_like(s_ref)
+    call("adamml_dwconv_bwd_data_bn", byref(d), ptr(dz), ptr(wp), ptr(gp), ptr(z), ptr(vec), 2, ptr(sums))
+    assert torch.equal(gp, gp_ref)
+    frac = (gp_ref == 0).float().mean().item()
+    assert 0.02 < frac < 0.98                                          # the mask is exercised both ways
+    a, b = sums.sum(1), s_ref.sum(1)
+    assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-5
+
+
 @pytest.mark.parametrize("case", [(2, 20, 20, 96, 1), (2, 21, 21, 144, 2)])
 def test_dwconv_groups_equal_separate_launches(case):
     torch.manual_seed(11)
