@@ -19,7 +19,8 @@ def run_blocks(rt, h, plans):
         y = x
         if bp.pw is not None:
             # the expansion conv is recorded before the block's own residual add, so it is reversed after it: last consumer
-            y = conv_bn(rt, y, bp.pw[0], bp.pw[1], ACT_RELU6, last_consumer=True)
+            # (without a residual add the block input feeds nothing else: its BatchNorm-backward sums come from this conv's data gradient)
+            y = conv_bn(rt, y, bp.pw[0], bp.pw[1], ACT_RELU6, last_consumer=True, sole_consumer=not bp.residual)
         # the expansion output feeds only the depthwise conv (without an expansion the block input may also feed the residual add)
         y = conv_bn(rt, y, bp.dw[0], bp.dw[1], ACT_RELU6, sole_consumer=bp.pw is not None or not bp.residual)
         if bp.residual and conv_bn_add_supported(rt, y, bp.pwl[0], rt.tape.need_grad):
