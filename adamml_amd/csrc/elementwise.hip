@@ -482,6 +482,105 @@ __global__ void maxpool_fwd_kernel(const bf16_t* x, const float* scale, const fl
     }
 }
 
+// Column walker of the same pool: a thread owns one 8-channel chunk of one output COLUMN and walks down `rows` output rows.  Input row
+// 2oh+1 is both the bottom row of window oh and the top row of window oh+1, so its three transformed taps are carried over: six new
+// loads per output instead of nine (the per-output form is bound by its nine L1 requests per 16 bytes of output, not by HBM), and the
+// two rows of the next window are in flight while the current one is reduced.  Same scan order (kh, kw ascending, strict >): same
+// arg-max taps.
+template <bool ZSEL>
+__global__ __launch_bounds__(NT) void maxpool_fwd_walk_kernel(const bf16_t* x, const float* scale, const float* shift, int gs, int act, bf16_t* y,
+                                                              uint8_t* idx, bf16_t* zsel, int N, int H, int W, int C, int OH, int OW, int rows,
+                                                              int nrb) {
+    x += (size_t)blockIdx.y * N * H * W * C;
+    y += (size_t)blockIdx.y * N * OH * OW * C;
+    idx += (size_t)blockIdx.y * N * OH * OW * C;
+    if (ZSEL) zsel += (size_t)blockIdx.y * N * OH * OW * C;
+    if (scale) { scale += (size_t)blockIdx.y * gs; shift += (size_t)blockIdx.y * gs; }
+    const int cpr = C >> 3;
+    const size_t total = (size_t)N * nrb * OW * cpr;
+    const size_t e = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (e >= total) return;
+    const int ch = (int)(e % cpr);
+    size_t r = e / cpr;
+    const int ow = (int)(r % OW);
+    r /= OW;
+    const int rb = (int)(r % nrb);
+    const int n = (int)(r / nrb);
+    f32x8 tsc, tsh;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { tsc[i] = 1.f; tsh[i] = 0.f; }
+    if (scale) { tsc = load_f32x8(scale + ch * 8); tsh = load_f32x8(shift + ch * 8); }
+    const float tlo = scale ? act_lo(act) : -INFINITY, thi = scale ? act_hi(act) : INFINITY;
+    const bf16_t* img = x + (size_t)n * H * W * C + ch * 8;
+    int iwc[3];
+    bool cok[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow * 2 - 1 + kw;
+        cok[kw] = (unsigned)iw < (unsigned)W;
+        iwc[kw] = min(max(iw, 0), W - 1);
+    }
+    struct Row { bf16x8 v[3]; };
+    auto load_row = [&](int ih, Row& rw) {                   // unconditional, clamped
+        const bf16_t* rp = img + (size_t)min(max(ih, 0), H - 1) * W * C;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) rw.v[kw] = *reinterpret_cast<const bf16x8*>(rp + (size_t)iwc[kw] * C);
+    };
+    auto xform = [&](const Row& rw, int ih, f32x8 (&t)[3]) {
+        const bool rok = (unsigned)ih < (unsigned)H;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const f32x8 v = bf8_to_f32(rw.v[kw]);
+            const bool ok = rok && cok[kw];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[kw][i] = ok ? clamp_act(fmaf(v[i], tsc[i], tsh[i]), tlo, thi) : -INFINITY;
+        }
+    };
+    const int oh_b = rb * rows, oh_e = min(OH, oh_b + rows);
+    Row top, mid, bot, nmid, nbot;
+    f32x8 ttop[3], tmid[3], tbot[3];
+    load_row(oh_b * 2 - 1, top);
+    load_row(oh_b * 2, nmid);
+    load_row(oh_b * 2 + 1, nbot);
+    xform(top, oh_b * 2 - 1, ttop);
+    for (int oh = oh_b; oh < oh_e; ++oh) {
+        mid = nmid; bot = nbot;
+        if (oh + 1 < oh_e) { load_row(oh * 2 + 2, nmid); load_row(oh * 2 + 3, nbot); }
+        xform(mid, oh * 2, tmid);
+        xform(bot, oh * 2 + 1, tbot);
+        f32x8 best;
+        int bi[8];
+        bf16x8 zs;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bi[i] = 0; zs[i] = 0; }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (ttop[kw][i] > best[i]) { best[i] = ttop[kw][i]; bi[i] = kw; if (ZSEL) zs[i] = top.v[kw][i]; }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (tmid[kw][i] > best[i]) { best[i] = tmid[kw][i]; bi[i] = 3 + kw; if (ZSEL) zs[i] = mid.v[kw][i]; }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (tbot[kw][i] > best[i]) { best[i] = tbot[kw][i]; bi[i] = 6 + kw; if (ZSEL) zs[i] = bot.v[kw][i]; }
+        const size_t o = ((((size_t)n * OH + oh) * OW + ow) * cpr + ch) * 8;
+        *reinterpret_cast<bf16x8*>(y + o) = f32_to_bf8(best);
+        if (ZSEL) *reinterpret_cast<bf16x8*>(zsel + o) = zs;
+        uint64_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) packed |= (uint64_t)bi[i] << (8 * i);
+        *reinterpret_cast<uint64_t*>(idx + o) = packed;
+        top = bot;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) ttop[kw] = tbot[kw];
+    }
+}
+
 __global__ void maxpool_bwd_kernel(const bf16_t* gy, const uint8_t* idx, bf16_t* gx, int N, int H, int W, int C, int OH,
                                    int OW, int accumulate) {
     const int cpr = C >> 3;
@@ -1336,6 +1435,17 @@ extern "C" int adamml_maxpool2d_fwd(const void* x, const float* scale, const flo
     const size_t n = (size_t)N * OH * OW * (C / 8);
     if (!n) return ADAMML_OK;
     if (groups < 1) groups = 1;
+    static const int walk = getenv("ADAMML_MAXPOOL_WALK") ? atoi(getenv("ADAMML_MAXPOOL_WALK")) : 8;          // output rows per thread; 0: per-output kernel (A/B aid)
+    if (walk > 0 && OH >= 2 * walk) {
+        const int nrb = (OH + walk - 1) / walk;
+        const size_t nth = (size_t)N * nrb * OW * (C / 8);
+        const dim3 grid((unsigned)((nth + NT - 1) / NT), groups);
+        if (z_sel) hipLaunchKernelGGL(maxpool_fwd_walk_kernel<true>, grid, dim3(NT), 0, stream, (const bf16_t*)x, scale, shift, gstride, act, (bf16_t*)y,
+                                      idx, (bf16_t*)z_sel, N, H, W, C, OH, OW, walk, nrb);
+        else hipLaunchKernelGGL(maxpool_fwd_walk_kernel<false>, grid, dim3(NT), 0, stream, (const bf16_t*)x, scale, shift, gstride, act, (bf16_t*)y,
+                                idx, nullptr, N, H, W, C, OH, OW, walk, nrb);
+        return adamml_check_launch("maxpool2d_fwd");
+    }
     if (z_sel)
         hipLaunchKernelGGL(maxpool_fwd_kernel<true>, dim3(grid_for(n, NT, 4096 / groups + 1), groups), dim3(NT), 0, stream, (const bf16_t*)x,
                            scale, shift, gstride, act, (bf16_t*)y, idx, (bf16_t*)z_sel, N, H, W, C, OH, OW);
