@@ -75,49 +75,76 @@ __global__ void stats_collapse_kernel(const double* stats, double* out, int C, i
     out[i] = s;
 }
 
-// one 32-lane group per channel: lane k reads slot k, the group folds with xor-shuffles (slot-parallel loads)
-__device__ __forceinline__ void slot_sums(const double* stats, int nslots, int C, int c, int k, double& s1, double& s2) {
-    s1 = 0.0; s2 = 0.0;
-    if (c < C && k < nslots) {
-        if (det_mode() && nslots == ADAMML_STAT_SLOTS) {       // integer bins (nslots == 1: already collapsed to plain doubles)
-            s1 = det_bin_value(stats + c, 2 * (size_t)C, k);
-            s2 = det_bin_value(stats + C + c, 2 * (size_t)C, k);
-        } else {
-            s1 = stats[(size_t)k * 2 * C + c];
-            s2 = stats[(size_t)k * 2 * C + C + c];
-        }
-    }
+// one 32-lane group per channel: lane k reads slot k, the group folds with xor-shuffles (slot-parallel loads).
+// Slot sums of up to 32 groups at once: the loads of all groups are in flight together (four groups per batch), every lane of the
+// 32-lane channel group ends up holding the sums of group g0 + k in (m1, m2): the per-group arithmetic that follows (fp64 divisions,
+// square root) then runs one group per lane instead of one after the other on the lead lane.
+__device__ __forceinline__ void slot_sums_groups(const double* stats, int nslots, int C, int c, int k, int g0, int groups, double& m1, double& m2) {
+    m1 = 0.0; m2 = 0.0;
+    const int ge = groups - g0 < 32 ? groups : g0 + 32;
+    for (int g = g0; g < ge; g += 4) {
+        double a1[4], a2[4];
 #pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) {
-        s1 += __shfl_xor(s1, off, 64);
-        s2 += __shfl_xor(s2, off, 64);
+        for (int j = 0; j < 4; ++j) {
+            a1[j] = 0.0; a2[j] = 0.0;
+            if (g + j < ge && c < C && k < nslots) {
+                const double* st = stats + (size_t)(g + j) * nslots * 2 * C;
+                if (det_mode() && nslots == ADAMML_STAT_SLOTS) {
+                    a1[j] = det_bin_value(st + c, 2 * (size_t)C, k);
+                    a2[j] = det_bin_value(st + C + c, 2 * (size_t)C, k);
+                } else {
+                    a1[j] = st[(size_t)k * 2 * C + c];
+                    a2[j] = st[(size_t)k * 2 * C + C + c];
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a1[j] += __shfl_xor(a1[j], off, 64);
+                a2[j] += __shfl_xor(a2[j], off, 64);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k == g + j - g0) { m1 = a1[j]; m2 = a2[j]; }
     }
 }
 
-// The running statistics see the groups IN ORDER (the reference updates them once per segment call).
+// The running statistics see the groups IN ORDER (the reference updates them once per segment call): lane g of a channel's
+// 32-lane group finalises group g, the lead lane then folds the groups' (mean, unbiased variance) in order.
 __global__ void bn_finalize_kernel(const double* stats, int nslots, int groups, double count, const float* gamma, const float* beta,
                                    float* rm, float* rv, float momentum, float eps, float* vec, int C) {
     const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), k = threadIdx.x & 31;
     float rmean = 0.f, rvar = 0.f;
     const bool lead = c < C && k == 0;
     if (lead && rm) { rmean = rm[c]; rvar = rv[c]; }
-    for (int g = 0; g < groups; ++g) {
+    float ga = 0.f, be = 0.f;
+    if (c < C) { ga = gamma[c]; be = beta[c]; }
+    for (int g0 = 0; g0 < groups; g0 += 32) {
         double s1, s2;
-        slot_sums(stats + (size_t)g * nslots * 2 * C, nslots, C, c, k, s1, s2);
-        if (!lead) continue;
+        slot_sums_groups(stats, nslots, C, c, k, g0, groups, s1, s2);
+        const int g = g0 + k;
         double mu = s1 / count;
         double var = s2 / count - mu * mu;
         if (var < 0.0) var = 0.0;
         float is = (float)(1.0 / sqrt(var + (double)eps));
-        float sc = gamma[c] * is;
-        float* v = vec + (size_t)g * 4 * C;
-        v[c] = sc;
-        v[C + c] = beta[c] - (float)mu * sc;
-        v[2 * C + c] = (float)mu;
-        v[3 * C + c] = is;
+        float sc = ga * is;
+        if (c < C && g < groups) {
+            float* v = vec + (size_t)g * 4 * C;
+            v[c] = sc;
+            v[C + c] = be - (float)mu * sc;
+            v[2 * C + c] = (float)mu;
+            v[3 * C + c] = is;
+        }
         double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        rmean = (1.f - momentum) * rmean + momentum * (float)mu;
-        rvar = (1.f - momentum) * rvar + momentum * (float)unbiased;
+        const float muf = (float)mu, unf = (float)unbiased;
+        const int ng = groups - g0 < 32 ? groups - g0 : 32, base = threadIdx.x & 32;
+        for (int j = 0; j < ng; ++j) {
+            rmean = (1.f - momentum) * rmean + momentum * __shfl(muf, base + j, 64);
+            rvar = (1.f - momentum) * rvar + momentum * __shfl(unf, base + j, 64);
+        }
     }
     if (lead && rm) { rm[c] = rmean; rv[c] = rvar; }
 }
@@ -286,16 +313,22 @@ __global__ void bn_bwd_finalize_kernel(const double* sums, int nslots, int group
     const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), k = threadIdx.x & 31;
     const bool lead = c < C && k == 0;
     float dg = 0.f, db = 0.f;
-    for (int g = 0; g < groups; ++g) {
+    for (int g0 = 0; g0 < groups; g0 += 32) {           // lane g: coefficients of group g; lead lane: dgamma / dbeta over the groups in order
         double sg, sgz;
-        slot_sums(sums + (size_t)g * nslots * 2 * C, nslots, C, c, k, sg, sgz);
-        if (!lead) continue;
-        dg += (float)sgz;
-        db += (float)sg;
-        float* cf = coef + (size_t)g * 3 * C;
-        cf[c] = gamma[c] * vec[(size_t)g * 4 * C + 3 * C + c];
-        cf[C + c] = (float)(sg / count);
-        cf[2 * C + c] = (float)(sgz / count);
+        slot_sums_groups(sums, nslots, C, c, k, g0, groups, sg, sgz);
+        const int g = g0 + k;
+        if (c < C && g < groups) {
+            float* cf = coef + (size_t)g * 3 * C;
+            cf[c] = gamma[c] * vec[(size_t)g * 4 * C + 3 * C + c];
+            cf[C + c] = (float)(sg / count);
+            cf[2 * C + c] = (float)(sgz / count);
+        }
+        const float sgf = (float)sg, sgzf = (float)sgz;
+        const int ng = groups - g0 < 32 ? groups - g0 : 32, base = threadIdx.x & 32;
+        for (int j = 0; j < ng; ++j) {
+            dg += __shfl(sgzf, base + j, 64);
+            db += __shfl(sgf, base + j, 64);
+        }
     }
     if (lead) {
         if (dgamma) dgamma[c] += dg * grad_scale;
