@@ -34,6 +34,7 @@ struct DwP {
     int N, H, W, C, OH, OW, stride, pad, act, accumulate, nseg, seglen;
     int nrb, rows_per_thread;   // forward: row blocks per image / output rows walked by one thread
     int flip;                   // forward kernel used as the stride-1 data gradient: taps read in reverse order
+    int cw, tpb, nct;           // walker workgroup = cw channel chunks x tpb strips (dw_walk_grid); nct = (C / 4) / cw chunk tiles
     size_t P, ppb;
     size_t gx, gy;        // element strides between BatchNorm groups of x / y (blockIdx.y = group)
     int in_gstride;
@@ -68,14 +69,15 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
         if (p.in_scale) { p.in_scale += (size_t)g * p.in_gstride; p.in_shift += (size_t)g * p.in_gstride; }
         if (BNZ) { p.bn_z += (size_t)g * p.gy; p.bn_vec += (size_t)g * 4 * p.C; }
     }
-    const int nchunk = p.C >> 2;
-    const int gid = bx * NT + threadIdx.x;
-    const int chunk = gid % nchunk;
-    int tsk = gid / nchunk;
+    // workgroup = one tile of cw channel chunks x tpb strips: the tpb strips fold their statistics in LDS, so a workgroup publishes
+    // 8 cw sums instead of (with chunk-major thread ids and C / 4 close to NT) one per thread
+    const int ct = bx % p.nct, cl = threadIdx.x % p.cw, tl = threadIdx.x / p.cw;
+    const int chunk = ct * p.cw + cl;
+    int tsk = (bx / p.nct) * p.tpb + tl;
     const int seg = tsk % p.nseg;
     tsk /= p.nseg;
     const int rb = tsk % p.nrb, n = tsk / p.nrb;
-    const bool active = n < p.N;
+    const bool active = tl < p.tpb && n < p.N;
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     if (active) {
         const int c = chunk * 4;
@@ -211,7 +213,8 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
         }
     }
     if (p.stats) {
-        for (int i = threadIdx.x; i < 2 * p.C; i += NT) smem[i] = 0.f;
+        const int nch = 4 * p.cw;                           // channels of this workgroup's tile
+        for (int i = threadIdx.x; i < 2 * nch; i += NT) smem[i] = 0.f;
         __syncthreads();
         if (det_mode()) {                                   // exact integer bins instead of float atomics (common.h)
             if (active) {
@@ -226,14 +229,14 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
         if (active) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                atomicAdd(&smem[chunk * 4 + i], s[i]);
-                atomicAdd(&smem[p.C + chunk * 4 + i], q[i]);
+                atomicAdd(&smem[cl * 4 + i], s[i]);
+                atomicAdd(&smem[nch + cl * 4 + i], q[i]);
             }
         }
         __syncthreads();
-        double* slot = p.stats + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * p.C;
-        for (int i = threadIdx.x; i < 2 * p.C; i += NT)
-            if (smem[i] != 0.f) atomicAdd(&slot[i], (double)smem[i]);
+        double* slot = p.stats + (size_t)((bx / p.nct) & (ADAMML_STAT_SLOTS - 1)) * 2 * p.C + ct * nch;
+        for (int i = threadIdx.x; i < 2 * nch; i += NT)
+            if (smem[i] != 0.f) atomicAdd(&slot[i < nch ? i : p.C + i - nch], (double)smem[i]);
     }
 }
 
@@ -659,6 +662,35 @@ static int dw_blocks(size_t P, int C, size_t* ppb_out) {
 
 }  // namespace
 
+// Grid of the column-strip walker (dwconv_fwd_kernel): rows walked per thread, the workgroup's channel-chunk tile and strip count.
+// cw = a divisor of C / 4 (>= 16 lanes = one 128-byte line per strip when C allows) that leaves the fewest idle threads.
+static unsigned dw_walk_grid(DwP& p, int segw, int groups) {
+    p.seglen = segw;
+    p.nseg = (p.OW + segw - 1) / segw;
+    // rows walked per thread: long walks amortise the 2-row window prologue and the statistics epilogue (a workgroup of 3-row walks
+    // spends as long publishing its sums as computing; the late 16^2 / 8^2 layers ran at half their no-statistics rate), whole image
+    // columns where OH <= 24, equal row blocks otherwise; split further only while the grid is below one workgroup per CU
+    static const long min_blocks = getenv("ADAMML_DW_MIN_BLOCKS") ? atol(getenv("ADAMML_DW_MIN_BLOCKS")) : 256;     // A/B aids
+    static const int max_rows = getenv("ADAMML_DW_MAX_ROWS") ? atoi(getenv("ADAMML_DW_MAX_ROWS")) : 24;
+    p.nrb = ceil_div(p.OH, max_rows);
+    while (ceil_div(p.OH, p.nrb) > 3 && (long)groups * p.N * p.nrb * p.nseg * (p.C / 4) < min_blocks * NT) ++p.nrb;
+    p.rows_per_thread = ceil_div(p.OH, p.nrb);
+    p.nrb = ceil_div(p.OH, p.rows_per_thread);
+    const int nchunk = p.C / 4;
+    static const int cw_min = getenv("ADAMML_DW_CW_MIN") ? atoi(getenv("ADAMML_DW_CW_MIN")) : 16;         // A/B aid (1024: whole channel rows)
+    int best = 0, best_active = 0;
+    for (int pass = 0; pass < 2 && !best; ++pass)           // pass 0: divisors in [cw_min, 64], fewest idle threads; pass 1: the largest divisor <= 64
+        for (int cw = pass ? 1 : cw_min; cw <= 64 && cw <= nchunk; ++cw) {
+            if (nchunk % cw) continue;
+            const int act = pass ? cw : cw * (NT / cw);
+            if (act > best_active || (act == best_active && cw > best)) { best = cw; best_active = act; }
+        }
+    if (cw_min >= 1024 && nchunk <= NT) best = nchunk;
+    p.cw = best; p.tpb = NT / best > 0 ? NT / best : 1; p.nct = nchunk / best;
+    const long strips = (long)p.N * p.nrb * p.nseg;
+    return (unsigned)(p.nct * ((strips + p.tpb - 1) / p.tpb));
+}
+
 static int check_dw(const adamml_conv_desc_t* d, const char* name) {
     if (!d) return adamml_set_error(ADAMML_EINVAL, "%s: null desc", name);
     if (d->KH != 3 || d->KW != 3 || d->Cin != d->Cout || d->Cin % 8 || d->Cin > MAXC || (d->stride != 1 && d->stride != 2))
@@ -682,15 +714,7 @@ extern "C" int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, con
     p.gx = (size_t)d->N * d->H * d->W * d->Cin; p.gy = p.P * d->Cin; p.in_gstride = d->in_gstride;
     p.ppb = 0;
     p.flip = 0;
-    p.seglen = d->stride == 1 ? 4 : 2;          // == SEGW of dwconv_fwd_kernel<S>
-    p.nseg = (d->OW + p.seglen - 1) / p.seglen;
-    // rows walked per thread: long walks amortise the 2-row window prologue, but the grid must still fill the chip
-    p.rows_per_thread = 12;
-    while (p.rows_per_thread > 3 &&
-           (long)groups * d->N * ceil_div(d->OH, p.rows_per_thread) * p.nseg * (p.C / 4) < 4096L * NT) p.rows_per_thread -= 3;
-    p.nrb = ceil_div(d->OH, p.rows_per_thread);
-    const long threads = (long)d->N * p.nrb * p.nseg * (p.C / 4);
-    const int nblk = (int)((threads + NT - 1) / NT);
+    const unsigned nblk = dw_walk_grid(p, d->stride == 1 ? 4 : 2, groups);          // segw == SEGW of dwconv_fwd_kernel<S>
     if (d->stride == 1) hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3(nblk, groups), dim3(NT), 0, stream, p);
     else hipLaunchKernelGGL(dwconv_fwd_kernel<2>, dim3(nblk, groups), dim3(NT), 0, stream, p);
     return adamml_check_launch("dwconv_fwd");
@@ -712,14 +736,9 @@ static int dw_bwd_data_launch(const adamml_conv_desc_t* d, const void* dz, const
     if (d->stride == 1 && !accumulate && d->pad == 1) {
         // stride 1: the data gradient IS the forward walk over dz with the taps reversed (no transform, no statistics)
         p.H = d->OH; p.W = d->OW; p.OH = d->H; p.OW = d->W; p.flip = 1;
-        p.seglen = 4;
-        p.nseg = (p.OW + 3) / 4;
-        p.rows_per_thread = 12;
-        while (p.rows_per_thread > 3 && (long)groups * p.N * ceil_div(p.OH, p.rows_per_thread) * p.nseg * (p.C / 4) < 4096L * NT) p.rows_per_thread -= 3;
-        p.nrb = ceil_div(p.OH, p.rows_per_thread);
-        const long threads = (long)p.N * p.nrb * p.nseg * (p.C / 4);
-        if (bn_z) hipLaunchKernelGGL((dwconv_fwd_kernel<1, true>), dim3((unsigned)((threads + NT - 1) / NT), groups), dim3(NT), 0, stream, p);
-        else hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3((unsigned)((threads + NT - 1) / NT), groups), dim3(NT), 0, stream, p);
+        const unsigned nblk = dw_walk_grid(p, 4, groups);
+        if (bn_z) hipLaunchKernelGGL((dwconv_fwd_kernel<1, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
+        else hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3(nblk, groups), dim3(NT), 0, stream, p);
         return adamml_check_launch("dwconv_bwd_data");
     }
     static const bool quads = !(getenv("ADAMML_DW_S2_QUADS") && atoi(getenv("ADAMML_DW_S2_QUADS")) == 0);       // A/B aid
@@ -759,8 +778,12 @@ static int dw_wgrad_blocks(const adamml_conv_desc_t* d, int* rows_per_thread, in
     const int segw = d->stride == 1 ? 4 : 2;           // == SEGW of dwconv_bwd_weight_kernel<S>
     *nseg = (d->OW + segw - 1) / segw;
     const int groups = d->groups < 1 ? 1 : d->groups;
-    int rpt = 12;
-    while (rpt > 3 && (long)groups * d->N * ceil_div(d->OH, rpt) * *nseg * nchunk < 2048L * NT) rpt -= 3;
+    // equal row blocks of at most max_rows rows, split further only while the grid is short of threads (as dw_walk_grid)
+    static const long min_blocks = getenv("ADAMML_DWW_MIN_BLOCKS") ? atol(getenv("ADAMML_DWW_MIN_BLOCKS")) : 256;      // A/B aids
+    static const int max_rows = getenv("ADAMML_DWW_MAX_ROWS") ? atoi(getenv("ADAMML_DWW_MAX_ROWS")) : 24;
+    int nb_rows = ceil_div(d->OH, max_rows);
+    while (ceil_div(d->OH, nb_rows) > 3 && (long)groups * d->N * nb_rows * *nseg * nchunk < min_blocks * NT) ++nb_rows;
+    const int rpt = ceil_div(d->OH, nb_rows);
     *rows_per_thread = rpt;
     *nrb = ceil_div(d->OH, rpt);
     const long threads = (long)d->N * *nrb * *nseg * nchunk;
