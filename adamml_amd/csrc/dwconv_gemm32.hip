@@ -744,7 +744,7 @@ static int dw_bwd_data_launch(const adamml_conv_desc_t* d, const void* dz, const
     static const bool quads = !(getenv("ADAMML_DW_S2_QUADS") && atoi(getenv("ADAMML_DW_S2_QUADS")) == 0);       // A/B aid
     if (d->stride == 2 && d->pad == 1 && (quads || bn_z)) {
         p.P = (size_t)d->N * ((d->H + 1) / 2) * ((d->W + 1) / 2);
-        int nblk = dw_blocks(p.P, p.C, &p.ppb);
+        int nblk = dw_blocks(p.P, p.C, &p.ppb);           // (16 / 32 / 64 passes per thread instead of 8: no gain, 4.2-4.7 TB/s incl. the z read)
         if (bn_z) hipLaunchKernelGGL(dwconv_bwd_data_s2_kernel<true>, dim3(nblk, groups), dim3(NT), 0, stream, p);
         else hipLaunchKernelGGL(dwconv_bwd_data_s2_kernel<false>, dim3(nblk, groups), dim3(NT), 0, stream, p);
         return adamml_check_launch("dwconv_bwd_data");
