@@ -130,7 +130,7 @@ def test_conv_fwd_bwd(case, lazy):
 
 
 @pytest.mark.parametrize("case", [(2, 40, 40, 32, 1), (2, 41, 41, 96, 2), (1, 20, 20, 144, 2), (2, 10, 10, 960, 1), (1, 16, 16, 576, 2),
-                                  (3, 13, 18, 24, 2), (2, 1, 7, 16, 2)])
+                                  (3, 13, 18, 24, 2), (2, 1, 7, 16, 2), (1, 50, 22, 384, 1), (1, 53, 9, 192, 2)])
 def test_dwconv(case):
     torch.manual_seed(1)
     N, H, W, C, s = case
@@ -416,7 +416,7 @@ def test_conv_groups_equal_separate_launches(case):
 
 
 @pytest.mark.parametrize("N,H,W,C,s,G", [(2, 20, 20, 96, 1, 1), (2, 21, 19, 144, 2, 2), (1, 16, 16, 32, 2, 3), (3, 9, 14, 24, 1, 2),
-                                         (2, 1, 5, 16, 2, 1), (1, 40, 40, 192, 1, 5), (2, 7, 7, 960, 1, 1)])
+                                         (2, 1, 5, 16, 2, 1), (1, 40, 40, 192, 1, 5), (2, 7, 7, 960, 1, 1), (1, 50, 22, 384, 1, 2)])
 def test_dwconv_bwd_data_bn_equals_dgrad_then_reduce(N, H, W, C, s, G):
     """adamml_dwconv_bwd_data_bn (activation mask + BatchNorm-backward sums inside the depthwise data gradient) against
     adamml_dwconv_bwd_data followed by the mask (adamml_bn_bwd_apply with coefficients 1, 0, 0) and adamml_bn_bwd_reduce:
