@@ -180,12 +180,10 @@ __global__ __launch_bounds__(NT) void bn_act_add_kernel(const bf16_t* z, const f
     const float lo = act_lo(act), hi = act_hi(act);
     const size_t pb = (size_t)blockIdx.x * ppb;
     const size_t pe = pb + ppb < P ? pb + ppb : P;
-    for (size_t p = pb + m.rslot; p < pe; p += m.rows_per_pass) {
-        f32x8 v = bf8_to_f32(STREAM ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(z + p * C + c))
-                                    : *reinterpret_cast<const bf16x8*>(z + p * C + c));
+    auto row = [&](size_t p, bf16x8 zraw, bf16x8 iraw) {
+        f32x8 v = bf8_to_f32(zraw);
         if (idn) {
-            const f32x8 w = bf8_to_f32(STREAM ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(idn + p * C + c))
-                                              : *reinterpret_cast<const bf16x8*>(idn + p * C + c));
+            const f32x8 w = bf8_to_f32(iraw);
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = clamp_act(fmaf(v[i], sc[i], sh[i]) + fmaf(w[i], isc[i], ish[i]), lo, hi);
         } else {
@@ -203,7 +201,24 @@ __global__ __launch_bounds__(NT) void bn_act_add_kernel(const bf16_t* z, const f
             for (int i = 0; i < 8; ++i) bits |= (r[i] > lo && r[i] < hi) ? (1u << i) : 0u;
             mask_out[(p * C + c) >> 3] = (uint8_t)bits;
         }
+    };
+    auto ld = [&](const bf16_t* base, size_t p) {
+        return STREAM ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + p * C + c)) : *reinterpret_cast<const bf16x8*>(base + p * C + c);
+    };
+    constexpr int U = 4;                                  // rows in flight per thread (one-shot workgroups: see adamml_bn_bwd_apply)
+    const size_t step = m.rows_per_pass;
+    size_t p = pb + m.rslot;
+    for (; p + (U - 1) * step < pe; p += U * step) {
+        bf16x8 zr[U], ir[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            zr[u] = ld(z, p + u * step);
+            ir[u] = idn ? ld(idn, p + u * step) : zr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) row(p + u * step, zr[u], ir[u]);
     }
+    for (; p < pe; p += step) row(p, ld(z, p), idn ? ld(idn, p) : bf16x8{});
 }
 
 __global__ void act_bwd_from_output_kernel(const bf16_t* g_out, const bf16_t* out, int act, bf16_t* g, size_t nchunks) {
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(NT) void lazy_colsum_kernel(const bf16_t* x, const 
 
 // STREAM: the tensors are larger than the 256 MB Infinity Cache -> non-temporal accesses (nothing is re-used from cache);
 // smaller tensors keep default caching so that the consumers of dz (data / weight gradient) still find it in L2 / MALL.
-template <bool STREAM>
+template <bool STREAM, int U>
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const bf16_t* g, const bf16_t* z, const float* vec, int act, const float* coef,
                                                           bf16_t* dz, size_t P, int C, size_t ppb) {
     {
@@ -427,25 +442,24 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const bf16_t* g, const
     };
     const size_t step = m.rows_per_pass;
     size_t p = pb + m.rslot;
-    for (; p + step < pe; p += 2 * step) {            // two rows in flight per thread
-        const bf16x8* gp0 = reinterpret_cast<const bf16x8*>(g + p * C + c);
-        const bf16x8* gp1 = reinterpret_cast<const bf16x8*>(g + (p + step) * C + c);
-        const bf16x8* zp0 = reinterpret_cast<const bf16x8*>(z + p * C + c);
-        const bf16x8* zp1 = reinterpret_cast<const bf16x8*>(z + (p + step) * C + c);
-        bf16x8 g0, g1, z0, z1;
-        if (STREAM) {
-            g0 = __builtin_nontemporal_load(gp0); g1 = __builtin_nontemporal_load(gp1);
-            z0 = __builtin_nontemporal_load(zp0); z1 = __builtin_nontemporal_load(zp1);
-            __builtin_nontemporal_store(one(g0, z0), reinterpret_cast<bf16x8*>(dz + p * C + c));
-            __builtin_nontemporal_store(one(g1, z1), reinterpret_cast<bf16x8*>(dz + (p + step) * C + c));
-        } else {
-            g0 = *gp0; g1 = *gp1; z0 = *zp0; z1 = *zp1;
-            *reinterpret_cast<bf16x8*>(dz + p * C + c) = one(g0, z0);
-            *reinterpret_cast<bf16x8*>(dz + (p + step) * C + c) = one(g1, z1);
+    for (; p + (U - 1) * step < pe; p += U * step) {            // U rows (2 U loads) in flight per thread
+        bf16x8 gr[U], zr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bf16x8* gp = reinterpret_cast<const bf16x8*>(g + (p + u * step) * C + c);
+            const bf16x8* zp = reinterpret_cast<const bf16x8*>(z + (p + u * step) * C + c);
+            if (STREAM) { gr[u] = __builtin_nontemporal_load(gp); zr[u] = __builtin_nontemporal_load(zp); }
+            else { gr[u] = *gp; zr[u] = *zp; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bf16x8* op = reinterpret_cast<bf16x8*>(dz + (p + u * step) * C + c);
+            if (STREAM) __builtin_nontemporal_store(one(gr[u], zr[u]), op);
+            else *op = one(gr[u], zr[u]);
         }
     }
-    if (p < pe) *reinterpret_cast<bf16x8*>(dz + p * C + c) = one(*reinterpret_cast<const bf16x8*>(g + p * C + c),
-                                                                *reinterpret_cast<const bf16x8*>(z + p * C + c));
+    for (; p < pe; p += step) *reinterpret_cast<bf16x8*>(dz + p * C + c) = one(*reinterpret_cast<const bf16x8*>(g + p * C + c),
+                                                                                 *reinterpret_cast<const bf16x8*>(z + p * C + c));
 }
 
 // ------------------------------------------------------------------------------------------------ pooling
@@ -1354,7 +1368,11 @@ static int bn_act_add_launch(const void* z, const float* scale, const float* shi
     if (!P) return ADAMML_OK;
     if (groups < 1) groups = 1;
     size_t ppb, nblk;
-    rowwalk_grid(P, C, groups, 8192, &ppb, &nblk);
+    static const int aa_passes = getenv("ADAMML_ACTADD_PASSES") ? atoi(getenv("ADAMML_ACTADD_PASSES")) : 0;          // A/B aid (16: the row walk)
+    const int rows = NT / (C / 8) > 0 ? NT / (C / 8) : 1;
+    ppb = (size_t)rows * (aa_passes > 0 ? aa_passes : (idn && (size_t)groups * P * C * 2 > ((size_t)512 << 20) ? 4 : 8));      // one-shot workgroups (two-pass form: 8 rows)
+    nblk = (P + ppb - 1) / ppb;
+    if (aa_passes >= 16) rowwalk_grid(P, C, groups, 8192, &ppb, &nblk);
     if ((size_t)groups * P * C * 2 > ((size_t)256 << 20))
         hipLaunchKernelGGL(bn_act_add_kernel<true>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)z, scale, shift, z_gstride,
                            act, (const bf16_t*)idn, id_scale, id_shift, id_gstride, (bf16_t*)out, mask_out, P, C, ppb);
@@ -1452,12 +1470,21 @@ extern "C" int adamml_bn_bwd_apply(const void* g, const void* z, const float* ve
     if (!P) return ADAMML_OK;
     if (groups < 1) groups = 1;
     size_t ppb, nblk;
-    rowwalk_grid(P, C, groups, 8192, &ppb, &nblk);
+    // One-shot workgroups: every thread loads U = 4 rows of (g, z), stores them and (for tensors beyond 512 MB) retires -- 6.2-6.4 TB/s
+    // against 5.3-5.5 for the long row walk (>= 16 rows per thread, <= 8192 workgroups) and 6.05 for torch's add on the same tensors:
+    // with nothing to amortise (the 7 per-channel vectors are 28 cached loads per thread) the short-lived form keeps more requests
+    // in flight across workgroup turnover.  Measured (tools/bench_elementwise.py): U / rows per thread 2/2 5.0, 4/4 6.2, 4/8 5.9-6.4,
+    // 8/8 5.8-6.3, 8/16 5.1-5.7 TB/s; default caching instead of non-temporal accesses: -4 %.
+    const int rows = NT / (C / 8) > 0 ? NT / (C / 8) : 1;
+    ppb = (size_t)rows * ((size_t)groups * P * C * 2 > ((size_t)512 << 20) ? 4 : 8);
+    nblk = (P + ppb - 1) / ppb;
+    static const bool walk = getenv("ADAMML_BNAPPLY_WALK") && atoi(getenv("ADAMML_BNAPPLY_WALK"));          // A/B aid: the long row walk
+    if (walk) rowwalk_grid(P, C, groups, 8192, &ppb, &nblk);
     if ((size_t)groups * P * C * 2 > ((size_t)256 << 20))
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g, (const bf16_t*)z,
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<true, 4>), dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g, (const bf16_t*)z,
                            vec, act, coef, (bf16_t*)dz, P, C, ppb);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g, (const bf16_t*)z,
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<false, 4>), dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g, (const bf16_t*)z,
                            vec, act, coef, (bf16_t*)dz, P, C, ppb);
     return adamml_check_launch("bn_bwd_apply");
 }
