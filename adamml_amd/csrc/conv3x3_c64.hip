@@ -11,6 +11,7 @@
 // ds_read_b128 -- no per-tap staging, no gathers.  Output strips are contiguous in HBM (full rows), staged through the
 // dead patch buffer and stored 16 B per lane; forward statistics come from the matrix cores, the data-gradient variant
 // applies the activation mask and accumulates the BatchNorm-backward sums (conv_gemm.hip epilogue semantics).
+#include <type_traits>
 #include "common.h"
 #include "../../include/adamml_hip.h"
 
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
             // loads and stores retire in order through vmcnt and the compiler cannot move a z load above a store to y, so the
             // row-at-a-time loop exposed one HBM round trip per row (7 per tile: the data gradient ran 1.33 ms against 0.89 ms forward)
             constexpr int MAXE = MAXPX3 * 8 / NT3, EBZ = 4;
+            auto rows = [&](auto relu_c) {
 #pragma unroll 1
             for (int b0 = 0; b0 < MAXE; b0 += EBZ) {                // (not unrolled: eight rows of address arithmetic hoisted at once spill)
                 if ((b0 * NT3) >= npx * 8) break;                  // (uniform)
@@ -313,17 +315,29 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
                         u.s.a = lo; u.s.b = hi;
                         f32x8 f = bf8_to_f32(u.v);
                         const f32x8 zv = bf8_to_f32(zr[k]);
+                        // (the VALU work of this epilogue is 2.8 of the kernel's 6.3 VALU instructions per MFMA, profiles/r02_pmc_mfma_*:
+                        // ReLU as one compare + select instead of the generic two-sided mask and its multiply; the rounded value is
+                        // unpacked from the packed words the store uses -- the vector conversion re-converted every element)
+                        if constexpr (decltype(relu_c)::value) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) f[i] *= act_mask(fmaf(zv[i], bsc[i], bsh[i]), p.bn_act);
-                        const bf16x8 v = f32_to_bf8(f);
-                        *reinterpret_cast<bf16x8*>(p.y + obase + (size_t)q * C64 + ech * 8) = v;
-                        f = bf8_to_f32(v);
+                            for (int i = 0; i < 8; ++i) f[i] = fmaf(zv[i], bsc[i], bsh[i]) > 0.f ? f[i] : 0.f;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) f[i] *= act_mask(fmaf(zv[i], bsc[i], bsh[i]), p.bn_act);
+                        }
+                        union { bf16x8 v; unsigned w[4]; } o;
+                        o.v = f32_to_bf8(f);
+                        *reinterpret_cast<bf16x8*>(p.y + obase + (size_t)q * C64 + ech * 8) = o.v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(o.w[i] << 16); f[2 * i + 1] = __uint_as_float(o.w[i] & 0xffff0000u); }
                         esum += f;
 #pragma unroll
                         for (int i = 0; i < 8; ++i) esq[i] += f[i] * (zv[i] - mu[i]) * is[i];
                     }
                 }
             }
+            };
+            if (p.bn_act == ADAMML_ACT_RELU) rows(std::true_type{}); else rows(std::false_type{});      // (uniform)
             if (p.stats) fold16_to_cs(esum, esq, cs, lane, ech, det_mode() ? p.stats + (size_t)g * ADAMML_STAT_SLOTS * 128 : nullptr);
         }
         __syncthreads();                                     // staging consumed before the next patch lands
