@@ -20,6 +20,7 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
     def __init__(self, policy_net, main_net, num_frames, num_segments, modality, rng_policy, rng_threshold, num_classes,
                  input_channels=None):
         super().__init__()
+        self._install_ddp_probe()
         self.rng_policy = rng_policy
         self.policy_net = policy_net
         self.main_net = main_net
@@ -269,7 +270,7 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
             nets += list(self.policy_net.joint_net.nets)
         return nets
 
-    def enable_sync_bn(self, group=None):
+    def enable_sync_bn(self, group=None, force=False):
         """SyncBatchNorm (train_adamml.py:126-127): BN statistic sums are all-reduced over RCCL.
         By default every backbone uses the caller's process group, i.e. ONE RCCL communicator: torch serialises all its
         collectives on one internal stream, so the side-stream backbones' exchanges queue behind the ResNet's.
@@ -286,7 +287,7 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
         if per_net and group is not None:
             ranks = dist.get_process_group_ranks(group)
         for net in self.backbones():
-            net.rt.sync = SyncCtx(dist.new_group(ranks) if per_net else group, True)
+            net.rt.sync = SyncCtx(dist.new_group(ranks) if per_net else group, True, force)
 
     def flat_grad_buffers(self):
         """Flat fp32 gradient buffers of the TRAINABLE sub-networks (one RCCL all-reduce each)."""

@@ -147,7 +147,7 @@ def enable_autograd_param_grads(module, on=True):
     """Deliver the backbones' parameter gradients through autograd instead of writing them into the flat .grad views behind
     its back: what stock torch.nn.parallel.DistributedDataParallel (its hooks sit on the AccumulateGrad nodes) and
     torch.optim on `model.module.*.parameters()` need -- the reference's own loop (train_adamml.py:126-129, 250-257).  Switched
-    on automatically when DistributedDataParallel wraps a model (StockDDPAware)."""
+    on by the first forward that arrives through a DistributedDataParallel wrapper (StockDDPAware), or explicitly by the caller."""
     for m in module.modules():
         if isinstance(m, HipBackbone):
             m.expose_param_grads = on
@@ -157,14 +157,33 @@ def enable_autograd_param_grads(module, on=True):
 
 
 class StockDDPAware:
-    """Mixin of the modules a caller may wrap in torch's DistributedDataParallel.  DDP's constructor probes the wrapped module
-    for `_ddp_params_and_buffers_to_ignore`; that probe is the (only) moment the module learns it is being wrapped: it switches
-    to autograd-delivered parameter gradients and then answers "no such attribute", so DDP proceeds normally."""
+    """Mixin of the modules a caller may wrap in torch's DistributedDataParallel (train_adamml.py:129).  Stock DDP hangs its
+    reduction hooks on the parameters' AccumulateGrad nodes, so the parameter gradients have to travel through autograd instead
+    of being written into the flat .grad views behind its back.  The switch is made where the wrap becomes a FACT, not where it is
+    probed: the first forward that arrives through a DistributedDataParallel parent (`_adopt_stock_ddp`, called from `forward`
+    via the module's `_ddp_parent_probe` forward-pre-hook) calls enable_autograd_param_grads(self, True).  Attribute probes
+    (hasattr / inspect.getmembers / dir()-based tools) have no side effect."""
 
-    @property
-    def _ddp_params_and_buffers_to_ignore(self):
-        enable_autograd_param_grads(self, True)
-        raise AttributeError("_ddp_params_and_buffers_to_ignore")
+    def _install_ddp_probe(self):
+        self._under_stock_ddp = False
+        self.register_forward_pre_hook(StockDDPAware._ddp_parent_probe)
+
+    @staticmethod
+    def _ddp_parent_probe(module, args):
+        if module._under_stock_ddp:
+            return
+        # DistributedDataParallel.forward runs `self.module(*inputs)` from inside its own forward: look for it on the call stack
+        # (a dozen frames per forward until the wrap is seen; nothing afterwards)
+        import sys
+        from torch.nn.parallel import DistributedDataParallel
+        f = sys._getframe(1)
+        while f is not None:
+            owner = f.f_locals.get("self")
+            if isinstance(owner, DistributedDataParallel) and getattr(owner, "module", None) is module:
+                module._under_stock_ddp = True
+                enable_autograd_param_grads(module, True)
+                return
+            f = f.f_back
 
 
 class HipBackbone(nn.Module):

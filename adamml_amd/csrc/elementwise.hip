@@ -69,10 +69,18 @@ __global__ void stats_collapse_kernel(const double* stats, double* out, int C, i
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * C * groups) return;
     const int g = i / (2 * C), j = i - g * 2 * C;
-    double s = 0.0;
-    if (det_mode()) s = det_decode(stats + (size_t)g * ADAMML_STAT_SLOTS * 2 * C + j, 2 * (size_t)C);
-    else for (int k = 0; k < ADAMML_STAT_SLOTS; ++k) s += stats[((size_t)g * ADAMML_STAT_SLOTS + k) * 2 * C + j];
-    out[i] = s;
+    // the 32 slot (or deterministic-bin) values are folded in the order of the xor-butterfly of slot_sums_groups (16, 8, 4, 2, 1):
+    // a collapsed vector fed to the finalize kernels with nslots = 1 then yields bit for bit what they compute from the 32 slots
+    // themselves -- a SyncBatchNorm step over ONE rank equals the plain step exactly (tests/test_rccl_gpu.py)
+    double v[ADAMML_STAT_SLOTS];
+    const double* st = stats + (size_t)g * ADAMML_STAT_SLOTS * 2 * C + j;
+#pragma unroll
+    for (int k = 0; k < ADAMML_STAT_SLOTS; ++k) v[k] = det_mode() ? det_bin_value(st, 2 * (size_t)C, k) : st[(size_t)k * 2 * C];
+#pragma unroll
+    for (int off = ADAMML_STAT_SLOTS / 2; off >= 1; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < off; ++k) v[k] += v[k + off];
+    out[i] = v[0];
 }
 
 // one 32-lane group per channel: lane k reads slot k, the group folds with xor-shuffles (slot-parallel loads).
@@ -1050,7 +1058,8 @@ __global__ __launch_bounds__(NT) void head_bwd_kernel(const float* g, const uint
     const size_t n = row / T;
     const int cpr = C >> 3;
     const float sc = 1.f / ((float)T * (float)HW);
-    if (gy && threadIdx.x < K) gy[row * K + threadIdx.x] = g[n * K + threadIdx.x] / (float)T;
+    if (gy)
+        for (int k = threadIdx.x; k < K; k += NT) gy[row * K + k] = g[n * K + k] / (float)T;      // (any class count: K = 400 / 1000 heads)
     for (int ch = threadIdx.x; ch < cpr; ch += NT) {
         f32x8 acc;
 #pragma unroll
@@ -1645,7 +1654,7 @@ extern "C" int adamml_head_bwd(const float* g, const uint8_t* keep_mask, float i
                                int T, int HW, int C, int K, hipStream_t stream) {
     CHECK_C(C, "head_bwd");
     if (!g || !weight || !g_x) return adamml_set_error(ADAMML_EINVAL, "head_bwd: null argument");
-    if (K > NT) return adamml_set_error(ADAMML_EUNSUPPORTED, "head_bwd: K=%d > %d", K, NT);
+    if (K < 1 || T < 1 || HW < 1) return adamml_set_error(ADAMML_EINVAL, "head_bwd: T=%d HW=%d K=%d", T, HW, K);
     if (!clips) return ADAMML_OK;
     hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)clips * T), dim3(NT), 0, stream, g, keep_mask, inv_keep, weight, (bf16_t*)g_x, g_rows, T, HW, C, K);
     return adamml_check_launch("head_bwd");

@@ -14,18 +14,23 @@ class HipDDP(nn.Module):
     """DistributedDataParallel-shaped wrapper: exposes `.module`, forwards calls, averages gradients on demand.
     Call `reduce_gradients()` after `loss.backward()` (the restated train loop does)."""
 
-    def __init__(self, module, process_group=None, sync_bn=False, overlap=True):
+    def __init__(self, module, process_group=None, sync_bn=False, overlap=True, force_collectives=False):
+        """force_collectives=True issues every collective of the N > 1 path on a ONE-rank group as well (each is an identity
+        there): the bucketed asynchronous all-reduce from inside backward, the coalesced SyncBatchNorm exchange and their
+        stream / event ordering then run against the real RCCL backend on a single GPU (tests/test_rccl_gpu.py)."""
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force_collectives and dist.is_initialized())
         self.overlap = overlap
         self._pending = []
-        if self.world > 1 and hasattr(module, "backbones"):
+        self.stats = {"bucket_all_reduces": 0, "gap_all_reduces": 0}
+        if self.active and hasattr(module, "backbones"):
             for net in module.backbones():
                 net.grad_hook = self._on_grads_ready
-        if sync_bn and self.world > 1 and hasattr(module, "enable_sync_bn"):
-            module.enable_sync_bn(process_group)
+        if sync_bn and self.active and hasattr(module, "enable_sync_bn"):
+            module.enable_sync_bn(process_group, force=force_collectives)
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
@@ -33,7 +38,7 @@ class HipDDP(nn.Module):
     def broadcast_parameters(self, src=0):
         """Rank `src`'s parameters and buffers to every rank, as torch's DistributedDataParallel does at construction
         (train_adamml.py:129).  The writes go through .data: the backbones re-pack their bf16 operands afterwards."""
-        if self.world == 1:
+        if not self.active:
             return
         for t in list(self.module.parameters()) + list(self.module.buffers()):
             dist.broadcast(t.data, src, group=self.group)
@@ -43,13 +48,18 @@ class HipDDP(nn.Module):
 
     # -- overlapped bucket exchange --------------------------------------------------------------------------------
     def _flat_buffers(self):
+        for name in ("_flat_main", "_flat_policy", "flat_owner"):
+            fb = getattr(self.module, name, None)
+            if fb is not None and getattr(fb, "detached", False):
+                raise RuntimeError("HipDDP: the parameter gradients of this model are delivered through autograd (it went through a stock "
+                                   "DistributedDataParallel wrap / enable_autograd_param_grads): there is no flat gradient buffer to reduce")
         return self.module.flat_grad_buffers() if hasattr(self.module, "flat_grad_buffers") else []
 
     def _on_grads_ready(self, params):
         """Called by a backbone from inside backward when the gradients of `params` are final (the kernels writing them
         are already enqueued on the current stream).  Starts an asynchronous all-reduce of the slice of the flat gradient
         buffer they occupy; non-contiguous or non-flat gradients are left to reduce_gradients()."""
-        if self.world == 1 or not self.overlap:
+        if not self.active or not self.overlap:
             return
         grads = [p.grad for p in params if p.grad is not None]
         if not grads:
@@ -63,13 +73,14 @@ class HipDDP(nn.Module):
             if base <= lo and hi <= base + fg.numel() * 4:
                 piece = fg[(lo - base) // 4:(hi - base) // 4]
                 work = dist.all_reduce(piece, group=self.group, async_op=True)
+                self.stats["bucket_all_reduces"] += 1
                 self._pending.append((base, (lo - base) // 4, (hi - base) // 4, work))
                 return
 
     def reduce_gradients(self):
         """Average the gradients over the ranks: waits for the slices already in flight, all-reduces the remaining gaps
         of each flat buffer (and any parameter living outside the flat buffers), then scales by 1/world once."""
-        if self.world == 1:
+        if not self.active:
             return
         pending, self._pending = self._pending, []
         for _, _, _, work in pending:
@@ -82,8 +93,10 @@ class HipDDP(nn.Module):
             for a, b in done + [(n, n)]:
                 if a > pos:
                     dist.all_reduce(fg[pos:a], group=self.group)
+                    self.stats["gap_all_reduces"] += 1
                 pos = max(pos, b)
-            fg.div_(self.world)
+            if self.world > 1:
+                fg.div_(self.world)
             covered.add((base, base + n * 4))
         for p in self.module.parameters():        # stragglers not living in a flat buffer
             if p.grad is None:
@@ -91,7 +104,8 @@ class HipDDP(nn.Module):
             if any(lo <= p.grad.data_ptr() < hi for lo, hi in covered):
                 continue
             dist.all_reduce(p.grad, group=self.group)
-            p.grad.div_(self.world)
+            if self.world > 1:
+                p.grad.div_(self.world)
 
 
 def shard_batch(tensors, rank, world):

@@ -23,7 +23,7 @@ def run_blocks(rt, h, plans):
             y = conv_bn(rt, y, bp.pw[0], bp.pw[1], ACT_RELU6, last_consumer=True, sole_consumer=not bp.residual)
         # the expansion output feeds only the depthwise conv (without an expansion the block input may also feed the residual add)
         y = conv_bn(rt, y, bp.dw[0], bp.dw[1], ACT_RELU6, sole_consumer=bp.pw is not None or not bp.residual)
-        if bp.residual and conv_bn_add_supported(rt, y, bp.pwl[0], rt.tape.need_grad):
+        if bp.residual and conv_bn_add_supported(rt, y, bp.pwl[0], rt.tape.need_grad, x):
             h = conv_bn_add(rt, y, bp.pwl[0], bp.pwl[1], x, ACT_NONE)               # inference: projection + BatchNorm + add in one kernel
             continue
         y = conv_bn(rt, y, bp.pwl[0], bp.pwl[1], ACT_NONE, sole_consumer=True)      # the dw output feeds only this conv

@@ -14,6 +14,7 @@ class FlatSGD:
 
     def step(self):
         fb = self.fb
+        _check_attached(fb, "FlatSGD")
         if fb.flat_grad is None:
             return
         if self.mom is None or self.mom.numel() != fb.flat.numel():
@@ -54,6 +55,7 @@ class FlatAdam:
 
     def step(self):
         fb = self.fb
+        _check_attached(fb, "FlatAdam")
         if fb.flat_grad is None:
             return
         if self.m is None or self.m.numel() != fb.flat.numel():
@@ -101,19 +103,39 @@ def _split_like(flat, params):
     return out
 
 
-def _join_state(state, key, fb):
-    """Flat device buffer from torch's per-parameter optimizer state; None when the state is absent or does not match."""
+def _check_attached(fb, who):
+    """The flat optimizers update from the flat gradient buffer; once the parameter gradients are delivered through autograd
+    (backbone.enable_autograd_param_grads: stock DistributedDataParallel / torch.optim own .grad) that buffer does not exist and a
+    silent return would leave the weights untouched for the whole run."""
+    if fb.detached:
+        raise RuntimeError("%s.step(): this sub-network's parameter gradients are delivered through autograd "
+                           "(enable_autograd_param_grads / a DistributedDataParallel wrap): use torch.optim on its parameters, or call "
+                           "adamml_amd.backbone.enable_autograd_param_grads(model, False) to return to the flat buffers" % who)
+
+
+def _join_state(state, key, fb, log=None):
+    """Flat device buffer from torch's per-parameter optimizer state.  torch.optim creates an entry only for parameters that have
+    received a gradient, so entries may be MISSING (a never-updated parameter of a reference checkpoint): those stay zero, as a
+    fresh torch buffer would be.  None only when there is no state at all, or when an entry's size does not match its parameter
+    (a checkpoint of another architecture) -- the latter is reported."""
     params = fb.params
-    if fb.flat is None or len(state) != len(params):
+    if fb.flat is None or not state:
         return None
     flat = torch.zeros_like(fb.flat)
-    off = 0
+    off, missing = 0, 0
     for i, p in enumerate(params):
         e = state.get(i, state.get(str(i)))
-        if e is None or key not in e or e[key].numel() != p.numel():
+        if e is None or key not in e:
+            missing += 1
+        elif e[key].numel() != p.numel():
+            (log or print)("optimizer state: entry %d ('%s') has %d elements, parameter has %d -- state discarded"
+                           % (i, key, e[key].numel(), p.numel()))
             return None
-        flat[off:off + p.numel()].copy_(e[key].reshape(-1))
+        else:
+            flat[off:off + p.numel()].copy_(e[key].reshape(-1))
         off += p.numel()
+    if missing == len(params):
+        return None
     return flat
 
 

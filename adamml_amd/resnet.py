@@ -43,6 +43,7 @@ class ResNet(HipBackbone, MeanStdMixin, StockDDPAware):
     def __init__(self, depth, num_frames, num_classes=1000, dropout=0.5, zero_init_residual=False,
                  without_t_stride=False, pooling_method='max', input_channels=3):
         super().__init__()
+        self._install_ddp_probe()
         if depth not in _BLOCKS:
             raise ValueError("adamml_amd.ResNet: the HIP path implements the Bottleneck depths 50/101/152 "
                              "(the AdaMML hot path uses 50); got depth=%r" % (depth,))
@@ -113,7 +114,7 @@ class ResNet(HipBackbone, MeanStdMixin, StockDDPAware):
                 # the add is reversed first): its data-gradient epilogue finishes the previous block's residual backward
                 o = conv_bn(rt, h, b._cs1, b.bn1, ACT_RELU, last_consumer=b._csd is None)
                 o = conv_bn(rt, o, b._cs2, b.bn2, ACT_RELU, sole_consumer=True)
-                if conv_bn_add_supported(rt, o, b._cs3, need_grad):
+                if conv_bn_add_supported(rt, o, b._cs3, need_grad, idn):
                     # conv3 + bn3 + residual add + ReLU in one kernel (statistics from the Gram matrix of conv3's input in train mode)
                     h = conv_bn_add(rt, o, b._cs3, b.bn3, idn, ACT_RELU, idn_sole=b._csd is not None)
                 else:

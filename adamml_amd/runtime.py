@@ -104,12 +104,15 @@ class Arena:
 
 
 class SyncCtx:
-    """SyncBatchNorm plumbing (train_adamml.py:126-127): statistic sums are all-reduced over RCCL."""
+    """SyncBatchNorm plumbing (train_adamml.py:126-127): statistic sums are all-reduced over RCCL.
+    force=True keeps the exchange on for a ONE-rank group too (the collectives are identities then): how the communication-stream
+    / event ordering of the SyncBN path is exercised against a stream-asynchronous backend on a single GPU (tests/test_rccl_gpu.py)."""
 
-    def __init__(self, group=None, enabled=False):
+    def __init__(self, group=None, enabled=False, force=False):
         self.group = group
-        self.enabled = enabled and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-        self.world = dist.get_world_size(group) if self.enabled else 1
+        ok = enabled and dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if ok else 1
+        self.enabled = bool(ok and (self.world > 1 or force))
 
     def reduce(self, t, C, groups):
         """t: [groups][STAT_SLOTS][2C] slot-interleaved sums.  Returns (sums, nslots) for the finalize kernel: under
@@ -729,13 +732,15 @@ def _add_backward(rt, out, out_t, z, idn, act, idn_sole, P, C):
 FUSE_ADD = os.environ.get("ADAMML_FUSE_ADD", "1") != "0"     # conv3 + BatchNorm + residual add in one kernel (A/B aid)
 
 
-def conv_bn_add_supported(rt, x, cs, need_grad):
+def conv_bn_add_supported(rt, x, cs, need_grad, idn=None):
     """Can `conv (1x1) -> BatchNorm -> (+ identity) -> activation` run as conv_bn_add?  Eval mode: every 1x1 / stride-1 conv (the
     BatchNorm is a known affine map).  Train mode: the statistics must come from the Gram matrix of the conv INPUT, which only
     pays for expanding convs (bottleneck conv3 of layers 1-2: same shapes as the algebraic BatchNorm backward, whose products it
     shares), and the backward must be the algebraic one (it never reads the raw conv output)."""
     if not FUSE_ADD or cs.depthwise or cs.stem or x.shape[3] != cs.cin:
         return False
+    if idn is not None and idn.act != ACT_NONE:
+        return False             # the epilogue applies the identity's scale / shift only: a pending activation needs add_act's check
     d = cs.desc(x.shape, x.act, rt.groups, x.gs)
     if not hip.load().adamml_conv_fwd_bn_add_supported(byref(d)):
         return False
@@ -754,6 +759,8 @@ def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False):
     G and s are exactly the products the algebraic BatchNorm backward needs (_conv1x1_backward_alg), so computing them here
     only moves work from backward to forward.  Caller checks conv_bn_add_supported()."""
     G = rt.groups
+    if idn is not None and idn.act != ACT_NONE:
+        raise RuntimeError("conv_bn_add: the identity operand must be linear (no pending activation)")
     d = cs.desc(x.shape, x.act, G, x.gs)
     dev = x.data.device
     C, Cin = d.Cout, d.Cin

@@ -52,6 +52,7 @@ class MobileNetV2(HipBackbone, MeanStdMixin, StockDDPAware):
     def __init__(self, num_classes=1000, width_mult=1.0, inverted_residual_setting=None, round_nearest=8, block=None,
                  input_channels=3, dropout=0.5):
         super().__init__()
+        self._install_ddp_probe()
         if width_mult != 1.0 or inverted_residual_setting is not None or block is not None:
             raise ValueError("adamml_amd sound MobileNetV2: only the default width/setting of the AdaMML hot path is built")
         input_channel = _make_divisible(32 * width_mult, round_nearest)

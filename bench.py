@@ -280,10 +280,13 @@ def run_rank(args):
     # wall clock over exactly K steps (the contract), plus one HIP event per step boundary on the caller's stream -- every
     # side stream is joined into it before a step's optimizer runs -- for the per-step median
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    issue_ms = []
     t0 = time.time()
     marks[0].record()
     for i in range(args.steps):
+        ti = time.perf_counter()
         loss = step()
+        issue_ms.append((time.perf_counter() - ti) * 1e3)     # host time to ISSUE the step (nothing in step() synchronises)
         marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
@@ -364,6 +367,9 @@ def run_rank(args):
                       "clips/sec (inference fwd, policy-gated) AdaMML @224^2, 5 seg", "value": round(value, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
             "ms_per_step_median_hipevent": round(med_ms, 2),
+            # host side: median wall time step() takes to return (Python + ctypes issue of ~1300 launches, no device sync inside);
+            # when it approaches ms_per_step the step is host-bound
+            "host_issue_ms": round(statistics.median(issue_ms), 2), "deterministic": bool(hip.deterministic()),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("AdaMML %s (non-headline), eval-mode forward with decision-driven skipping of the main nets, "
                                     "%d segments x 8 frames" % ("+".join(args.modalities), args.segments)) if args.stage == "infer" else

@@ -178,7 +178,8 @@ def test_fusion_matches_reference_formula(M, learnable, gated):
 
 
 @pytest.mark.parametrize("N,T,HW,C,K,p,groups,lazy", [(6, 1, 49, 2048, 31, 0.5, 3, False), (4, 2, 16, 512, 31, 0.0, 2, False),
-                                                       (5, 1, 64, 1280, 31, 0.5, 5, True), (3, 4, 9, 256, 7, 0.25, 1, True)])
+                                                       (5, 1, 64, 1280, 31, 0.5, 5, True), (3, 4, 9, 256, 7, 0.25, 1, True),
+                                                       (2, 2, 9, 512, 400, 0.5, 1, False), (2, 1, 4, 2048, 1000, 0.0, 2, True)])
 def test_fused_classifier_head(N, T, HW, C, K, p, groups, lazy):
     """adamml_head_fwd / adamml_head_bwd (+ adamml_colsum_f32) == AdaptiveAvgPool2d(1) -> Dropout(explicit keep mask) -> Linear ->
     mean over the T frames of a clip (models/resnet.py:212-221, models/sound_mobilenet_v2.py:155-158) in torch fp32 on the same

@@ -263,14 +263,40 @@ def test_torch_library_ops_are_registered_with_fake_implementations():
         torch.ops.adamml.gemm_f32(torch.zeros(2, 2), torch.zeros(2, 2), None, 0, False, True)
 
 
-def test_stock_ddp_probe_switches_to_autograd_delivered_gradients():
-    """torch's DistributedDataParallel probes `_ddp_params_and_buffers_to_ignore` on the module it wraps: that switches the
-    backbones to delivering parameter gradients through autograd (so DDP's hooks fire) and detaches the flat .grad views."""
+def test_stock_ddp_wrap_switches_to_autograd_delivered_gradients():
+    """The first forward that arrives THROUGH torch's DistributedDataParallel switches the backbones to delivering parameter
+    gradients through autograd (so DDP's AccumulateGrad hooks fire) and detaches the flat .grad views; attribute probes
+    (hasattr / dir / inspect.getmembers -- loggers, tracing tools) have no such side effect, a direct forward neither, and the
+    flat optimizers refuse to step on a detached sub-network instead of silently leaving the weights untouched."""
+    import inspect
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    from adamml_amd.optim import FlatSGD, FlatAdam
     m = _build(CASES["adamml_rgb_sound"])
-    assert not any(n.expose_param_grads for n in m.backbones())
-    assert not hasattr(m, "_ddp_params_and_buffers_to_ignore")      # DDP sees "no such attribute" and proceeds normally
-    assert all(n.expose_param_grads for n in m.backbones())
-    assert m._flat_main.detached and m._flat_policy.detached
+    assert not hasattr(m, "_ddp_params_and_buffers_to_ignore")
+    dir(m)
+    inspect.getmembers(m)
+    assert not any(n.expose_param_grads for n in m.backbones()) and not m._flat_main.detached
+    x = [torch.zeros(1, 2 * 8 * 3, 64, 64), torch.zeros(1, 2, 64, 64)]
+    with pytest.raises(RuntimeError):
+        m(x)                                             # direct call: CPU tensors are refused, nothing switched
+    assert not any(n.expose_param_grads for n in m.backbones()) and not m._flat_main.detached
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        ddp = DistributedDataParallel(m, find_unused_parameters=True)       # train_adamml.py:129
+        assert not any(n.expose_param_grads for n in m.backbones())      # construction alone does not switch either
+        with pytest.raises(RuntimeError):
+            ddp(x)                                       # the forward reaches the module (and is refused: CPU tensors) ...
+        assert all(n.expose_param_grads for n in m.backbones())          # ... through DDP: switched
+        assert m._flat_main.detached and m._flat_policy.detached
+        with pytest.raises(RuntimeError, match="delivered through autograd"):
+            FlatSGD(m._flat_main, lr=0.1).step()
+        with pytest.raises(RuntimeError, match="delivered through autograd"):
+            FlatAdam(m._flat_policy, lr=0.1).step()
+    finally:
+        dist.destroy_process_group()
 
 
 def test_lr_schedules_match_torch_schedulers():
@@ -302,3 +328,66 @@ def test_lr_schedules_match_torch_schedulers():
         m2 = LRSchedule(o2, kind, base, epochs, steps)
         m2.load_state_dict(mine.state_dict())
         assert o2.lr == o.lr
+
+
+def test_readme_commands_parse():
+    """The five `python3 train_adamml.py ...` command lines of the reference's README (README.md:68,89,100,111,161; fixture
+    tests/golden/readme_train_adamml_commands.txt) parse VERBATIM with the restated launcher's parser, every flag of opts.py:5-149
+    exists with the reference's destination name, and the three concrete recipes resolve to the model configuration the reference
+    derives from them (train_adamml.py:70-95)."""
+    import shlex
+    from adamml_amd import train
+    lines = [l for l in open(os.path.join(ROOT, "tests", "golden", "readme_train_adamml_commands.txt")).read().splitlines()
+             if l and not l.startswith("#")]
+    assert len(lines) == 5
+    parsed = []
+    for l in lines:
+        argv = shlex.split(l)
+        assert argv[:2] == ["python3", "train_adamml.py"]
+        parsed.append(train.arg_parser().parse_args(argv[2:]))
+    tmpl, rgb_audio, rgb_flow, four, evaluate = parsed
+    assert tmpl.multiprocessing_distributed and tmpl.workers == 96 and tmpl.datadir == ["/PATH/TO/MODALITY1", "/PATH/TO/MODALITY2"]
+    assert rgb_audio.modality == ["rgb", "sound"] and rgb_audio.cost_weights == [1.0, 0.05] and rgb_audio.sync_bn
+    assert rgb_audio.lr == 0.001 and rgb_audio.p_lr == 0.01 and rgb_audio.lr_scheduler == "multisteps" and rgb_audio.lr_steps == [10, 15]
+    assert rgb_flow.modality == ["rgb", "flow", "rgbdiff"] and len(rgb_flow.datadir) == 3 and len(rgb_flow.unimodality_pretrained) == 2
+    assert four.modality == ["rgb", "sound", "flow", "rgbdiff"] and four.cost_weights == [0.5, 0.05, 0.8]
+    assert evaluate.evaluate and evaluate.pretrained == "/PATH/TO/ADAMML_MODEL" and not evaluate.multiprocessing_distributed
+    # the placeholders of the template lines are rejected where the reference's argparse `choices` would reject them
+    with pytest.raises(SystemExit):
+        train.resolve_args(tmpl, log=lambda *_: None)
+    notes = []
+    for a, chans in ((rgb_audio, [3, 1]), (rgb_flow, [3, 10, 15]), (four, [3, 1, 10, 15])):
+        a.dataset = "kinetics-sounds"                        # (README placeholder DATASET)
+        train.resolve_args(a, log=notes.append)
+        assert a.num_classes == 31 and a.input_channels == chans and a.groups == 8 and a.num_segments == 5 and a.depth == 50
+    assert notes and "--workers" in notes[0] and "--dense_sampling" in notes[0]     # inert flags are reported, not rejected
+    # every destination of the reference's parser exists here (names read off opts.py:5-149)
+    dests = ("backbone_net depth dropout groups num_segments frames_per_group without_t_stride pooling_method fusion_point prefix "
+             "learnable_lf_weights causality_modeling cost_weights rng_policy rng_threshold gammas penalty_type gpu gpu_id cudnn_benchmark "
+             "batch_size lr p_lr lr_scheduler lr_steps momentum nesterov weight_decay epochs warmup_epochs finetune_epochs resume auto_resume "
+             "pretrained unimodality_pretrained start_epoch clip_gradient curr_stage workers datadir dataset threed_data input_size "
+             "disable_scaleup random_sampling dense_sampling augmentor_ver scale_range modality mean std skip_normalization fps audio_length "
+             "resampling_rate logdir print_freq show_model evaluate num_crops num_clips val_num_clips pred_files pred_weights after_softmax "
+             "lazy_eval sync_bn world_size rank dist_url hostfile dist_backend multiprocessing_distributed").split()
+    ns = vars(train.arg_parser().parse_args([]))
+    assert [d for d in dests if d not in ns] == []
+
+
+def test_plateau_schedule_follows_torch():
+    """train.LRSchedule('plateau') stepped with validation losses == torch.optim.lr_scheduler.ReduceLROnPlateau('min') defaults
+    (train_adamml.py:268-269,460-462)."""
+    from adamml_amd import train
+
+    class _Opt:
+        lr = 0.1
+    o = _Opt()
+    s = train.LRSchedule(o, "plateau", 0.1, 50, [15])
+    p = torch.nn.Parameter(torch.zeros(1))
+    topt = torch.optim.SGD([p], lr=0.1)
+    ts = torch.optim.lr_scheduler.ReduceLROnPlateau(topt, "min")
+    losses = [1.0, 0.9, 0.8] + [0.8] * 12 + [0.7] + [0.75] * 13
+    for e, v in enumerate(losses):
+        s.step(e + 1, v)
+        ts.step(v)
+        assert abs(o.lr - topt.param_groups[0]["lr"]) < 1e-12, (e, o.lr, topt.param_groups[0]["lr"])
+    assert o.lr < 0.0011

@@ -65,8 +65,9 @@ def nets_of(model):
     return model.backbones() if hasattr(model, "backbones") else [model]
 
 
-def hip_train_step(model, c, mode, sd):
-    """One train-mode forward + backward through the HIP path with the conv outputs captured (test hook NetRT.capture)."""
+def hip_train_step(model, c, mode, sd, after_backward=None):
+    """One train-mode forward + backward through the HIP path with the conv outputs captured (test hook NetRT.capture).
+    after_backward: optional callable run between loss.backward() and the device synchronisation (data-parallel reduction)."""
     xs, target = case_inputs(c)
     model.load_state_dict(sd)
     model.to(DEV)
@@ -91,6 +92,8 @@ def hip_train_step(model, c, mode, sd):
             loss = loss + O.policy_loss("blockdrop", sel, torch.ones(sel.shape[-1], device=DEV), torch.tensor(10.0, device=DEV), logits,
                                         target.to(DEV))
         loss.backward()
+        if after_backward is not None:
+            after_backward()
         torch.cuda.synchronize()
     finally:
         for n in nets_of(model):

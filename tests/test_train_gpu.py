@@ -34,8 +34,7 @@ def test_three_stage_schedule_checkpoints_and_resume(tmp_path):
     assert "module.policy_net.lstm.weight_ih" in ck["state_dict"] and "module.main_net.nets.0.layer4.2.conv3.weight" in ck["state_dict"]
     # interchange: load it into a fresh model through the reference-checkpoint path, names and values identical
     args = train.arg_parser().parse_args(ARGS)
-    args.input_channels = [3, 1]
-    args.imagenet_pretrained = False
+    train.resolve_args(args, log=lambda *_: None)
     model, _ = train.build_model(args)
     train.load_reference_checkpoint(model, os.path.join(folder, "checkpoint.pth.tar"))
     sd = model.state_dict()
@@ -46,6 +45,30 @@ def test_three_stage_schedule_checkpoints_and_resume(tmp_path):
     # resume: the saved stage is 'finetune' at epoch 1 of 1 -> nothing left to train, state restored
     res2 = train.main(ARGS + ["--logdir", str(tmp_path), "--auto_resume"], log=lines.append)
     assert res2["history"] == [] and abs(res2["temperature"] - res["temperature"]) < 1e-9
+
+
+def test_multiprocessing_distributed_spawns_its_own_ranks(tmp_path, monkeypatch):
+    """`--multiprocessing-distributed` (train_adamml.py:52-63): the launcher itself starts one process per GPU and joins them over
+    --dist-url.  One MI355X here, so two ranks share it over gloo (ADAMML_SPAWN_RANKS / --dist-backend gloo are the test aids);
+    each rank trains on its half of the global batch with SyncBatchNorm, rank 0 writes the reference-format checkpoints."""
+    import socket
+    from adamml_amd import train
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    monkeypatch.setenv("ADAMML_SPAWN_RANKS", "2")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    argv = ["--multiprocessing-distributed", "--backbone_net", "adamml", "-d", "50", "--groups", "8", "--num_segments", "2", "--modality", "rgb",
+            "sound", "--causality_modeling", "lstm", "--learnable_lf_weights", "-b", "2", "-j", "4", "--input_size", "64", "--epochs", "1",
+            "--warmup_epochs", "0", "--finetune_epochs", "0", "--val_num_clips", "2", "--cost_weights", "1.0", "0.05", "--synthetic", "1",
+            "--sync-bn", "--dist-backend", "gloo", "--dist-url", "tcp://127.0.0.1:%d" % port, "--logdir", str(tmp_path)]
+    assert train.main(argv) is None
+    folder = os.path.join(str(tmp_path), os.listdir(str(tmp_path))[0])
+    ck = torch.load(os.path.join(folder, "checkpoint_main_01.pth.tar"), map_location="cpu")
+    assert ck["stage"] == "alternative_training" and ck["epoch"] == 1
+    assert all(torch.isfinite(v).all() for v in ck["state_dict"].values() if v.is_floating_point())
 
 
 def test_eval_after_training_steps_sees_the_updated_weights_and_statistics():

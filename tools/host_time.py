@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 import torch.nn.functional as F
 from adamml_amd import adamml, synth
 from adamml_amd.optim import FlatSGD
-B, S = 72, 5
+B, S = (int(sys.argv[1]) if len(sys.argv) > 1 else 72), 5
 dev = torch.device("cuda")
 m = adamml(groups=8, modality=["rgb", "sound"], input_channels=[3, 1], num_segments=S, rng_policy=False, rng_threshold=0.5,
            causality_modeling="lstm", num_classes=31, depth=50, without_t_stride=False, dropout=0.5, pooling_method="max",
