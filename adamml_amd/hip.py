@@ -181,11 +181,17 @@ class LaunchProfiler:
     def __init__(self):
         self.records = []
 
-    def summary(self):
+    def summary(self, by_role=False):
+        """by_role=False: launches grouped by device kernel (entry point where the caller does not name one).
+        by_role=True: the MFMA launches grouped by their roofline role (meta[3], runtime.R_*); launches without a role are left out."""
         torch.cuda.synchronize()
         agg = {}
         for name, s, e, meta in self.records:
-            if len(meta) > 2 and meta[2]:
+            if by_role:
+                if len(meta) < 4 or not meta[3]:
+                    continue
+                name = meta[3]
+            elif len(meta) > 2 and meta[2]:
                 name = meta[2]
             a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             a["launches"] += 1

@@ -19,6 +19,12 @@ from ctypes import byref
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+# roles of the MFMA launches in bench.py's per-role roofline (4th element of hip.next_meta): each role has ONE bounding roof
+R_1X1 = "conv1x1_streaming"            # plain 1x1 forward / data gradient (conv_gemm_kernel MODE 0): HBM-bound
+R_FUSED = "conv1x1_fused_streaming"    # 1x1 with a fused BatchNorm / residual / algebraic epilogue or loader (FADD, RES, DUAL, CAT, stream)
+R_KXK = "convKxK_mfma"                 # 3x3 / 7x7 / strided data gradients (MODE 1-3, conv3x3_c64, conv_stem): MFMA-bound
+R_WGRAD = "weight_gradient"            # contractions over the pixel axis: weight gradients, g'^T a products, Gram matrices
+
 
 def pad8(c):
     return (c + 7) // 8 * 8
@@ -357,7 +363,10 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
     kern = None
     if not cs.depthwise:
         kern = "conv3x3_c64_kernel" if hip.load().adamml_conv_fused_input_supported(byref(d)) else "conv_gemm_kernel"
-    hip.next_meta = (2 * macs, in_b + out_b + w_b, "conv_stem_kernel" if stem else kern)
+    role_f = None if cs.depthwise else (R_KXK if cs.kh * cs.kw > 1 else R_1X1)
+    role_b = None if cs.depthwise else (R_KXK if (cs.kh * cs.kw > 1 or cs.stride > 1) else R_1X1)
+    role_bf = role_b if role_b != R_1X1 else R_FUSED          # data gradient with a fused BatchNorm-backward / residual epilogue
+    hip.next_meta = (2 * macs, in_b + out_b + w_b, "conv_stem_kernel" if stem else kern, role_f)
     if rt.training:
         stats = rt.fwd_arena.take(G * 2 * C * STAT_SLOTS)
         if stem:
@@ -395,7 +404,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
             dz = _bn_backward(rt, out, y, vec, bn, act, count)
             if cs.weight.requires_grad:
                 with _on_wgrad_stream(rt, (dz, x.data, x.scale)):
-                    hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b)
+                    hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b, None, None if cs.depthwise else R_WGRAD)
                     if cs.depthwise:
                         ws = hip.wgrad_workspace(d, 0, dz.device, depthwise=True)
                         call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(cs.weight.grad),
@@ -413,7 +422,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                 if x.grad is None:
                     x.grad = torch.empty_like(x.data)
                     acc = 0
-                hip.next_meta = (2 * macs, in_b * (1 + acc) + out_b + w_b, kern)
+                hip.next_meta = (2 * macs, in_b * (1 + acc) + out_b + w_b, kern, role_b)
                 tgt = x.src if x.src is not None else x
                 if cs.depthwise and DW_BNZ and sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None \
                         and hip.load().adamml_dwconv_bwd_data_bn_supported(byref(d)):
@@ -430,7 +439,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                     sb = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS) if fb else None
                     fb_alg = fb and idn.alg               # the downsample BatchNorm shares sum(g'); its second moment comes from g'^T a too
                     hip.next_meta = (2 * macs, in_b * ((1.0625 if rmask is not None else 2) + (0 if z.alg else 1) + acc
-                                                       + (1 if (fb and not (fb and idn.alg)) else 0)) + out_b + w_b, kern)
+                                                       + (1 if (fb and not (fb and idn.alg)) else 0)) + out_b + w_b, kern, R_FUSED)
                     fbk = fb and not fb_alg
                     ain = z.alg_in
                     if (RES_PROD and z.alg and ain is not None and (not fb or fb_alg) and acc == 1 and rmask is not None and ain[0].data is not None
@@ -441,7 +450,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                         z.prod = torch.empty(G, d.Cin, ain[1].Cin, dtype=torch.float32, device=dz.device)
                         need = hip.load().adamml_conv_bwd_data_res_prod_workspace(byref(d))
                         wsp = hip.scratch(need, dz.device)
-                        hip.next_meta = (2 * macs + 2.0 * G * d.N * d.H * d.W * d.Cin * ain[1].Cin, in_b * 2.0625 + out_b + w_b + 2.0 * G * d.N * d.H * d.W * ain[1].Cin, kern)
+                        hip.next_meta = (2 * macs + 2.0 * G * d.N * d.H * d.W * d.Cin * ain[1].Cin, in_b * 2.0625 + out_b + w_b + 2.0 * G * d.N * d.H * d.W * ain[1].Cin, kern, R_FUSED)
                         call("adamml_conv_bwd_data_res_prod", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), ptr(rmask), ract, ptr(sa), ptr(xa.data),
                              ptr(xa.scale), ptr(xa.shift), xa.act, xa.gs, ain[1].Cin, ptr(z.prod), ptr(wsp), wsp.numel() * 4)
                     else:
@@ -458,7 +467,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                     x.res_done = True
                 elif sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None:
                     sums = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS)
-                    hip.next_meta = (2 * macs, 2 * in_b + out_b + w_b, kern)
+                    hip.next_meta = (2 * macs, 2 * in_b + out_b + w_b, kern, role_bf)
                     call("adamml_conv_bwd_data_bn", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), ptr(tgt.data), ptr(tgt.vec),
                          tgt.act, ptr(sums))
                     tgt.pre_sums = sums
@@ -515,12 +524,12 @@ def _gram_colsum(rt, x, d):
         # one streaming pass (csrc/gram.hip) instead of the generic weight-gradient kernel with dz = x plus a column-sum pass
         P = n // G * h * w_
         wsg = hip.scratch(hip.load().adamml_gram_colsum_workspace(P, Cin, G), dev)
-        hip.next_meta = (2.0 * G * P * Cin * Cin, 2.0 * G * P * Cin)
+        hip.next_meta = (2.0 * G * P * Cin * Cin, 2.0 * G * P * Cin, None, R_WGRAD)
         call("adamml_gram_colsum", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(Gm), ptr(sv), P, Cin, G, ptr(wsg), wsg.numel() * 4)
         return Gm, sv
     dg = ConvDesc(d.N, d.H, d.W, Cin, d.H, d.W, Cin, 1, 1, 1, 0, 1, d.act, 0, G, d.in_gstride)
     wsg = hip.wgrad_workspace(dg, Cin, dev)
-    hip.next_meta = (2.0 * G * d.N * d.H * d.W * Cin * Cin, 2.0 * G * d.N * d.H * d.W * Cin)
+    hip.next_meta = (2.0 * G * d.N * d.H * d.W * Cin * Cin, 2.0 * G * d.N * d.H * d.W * Cin, None, R_WGRAD)
     call("adamml_conv_bwd_weight_grouped", byref(dg), ptr(x.data), ptr(x.scale), ptr(x.shift), x.act, x.gs, ptr(x.data), ptr(x.scale),
          ptr(x.shift), ptr(Gm), Cin, ptr(wsg), wsg.numel() * 4)
     call("adamml_lazy_colsum", ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act, ptr(sv), n // G * h * w_, Cin, G)
@@ -559,7 +568,7 @@ def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, m
 
     def products():
         ws = hip.wgrad_workspace(d, Cin, dev)
-        hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b)
+        hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b, None, R_WGRAD)
         call("adamml_conv_bwd_weight_grouped", byref(d), ptr(g0), None, None, 0, 0, ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(P), Cin,
              ptr(ws), ws.numel() * 4)
     if out.sums_partial:
@@ -596,12 +605,12 @@ def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, m
         kern = "alg_stream_kernel"            # csrc/conv1x1_stream.hip serves this shape (bench.py groups launches by device kernel)
     if sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None:
         sums = rt.bwd_arena.take(G * 2 * Cin * STAT_SLOTS)
-        hip.next_meta = (2 * macs, 3 * in_b + out_b + w_b, kern)
+        hip.next_meta = (2 * macs, 3 * in_b + out_b + w_b, kern, R_FUSED)
         call("adamml_conv_bwd_data_alg", byref(d), ptr(g), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(w_alg), ptr(cadd), ptr(x.grad), 0,
              ptr(tgt.data), ptr(tgt.vec), tgt.act, ptr(sums))
         tgt.pre_sums = sums
     else:
-        hip.next_meta = (2 * macs, in_b * (2 + acc) + out_b + w_b, kern)
+        hip.next_meta = (2 * macs, in_b * (2 + acc) + out_b + w_b, kern, R_FUSED)
         call("adamml_conv_bwd_data_alg", byref(d), ptr(g), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(w_alg), ptr(cadd), ptr(x.grad), acc,
              None, None, 0, None)
     # ---- weight gradient (weight-gradient stream): products over the pixels, then the per-group combination
@@ -637,17 +646,17 @@ def _conv1x1_backward_dual(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, 
     tgt = x.src if x.src is not None else x
     if sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None:
         sums = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS)
-        hip.next_meta = (2 * macs, 2 * in_b + (3 if need_w else 2) * out_b + w_b, kern)
+        hip.next_meta = (2 * macs, 2 * in_b + (3 if need_w else 2) * out_b + w_b, kern, R_FUSED)
         call("adamml_conv_bwd_data_dual", byref(d), ptr(g), ptr(y), ptr(aff), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), 0, ptr(tgt.data),
              ptr(tgt.vec), tgt.act, ptr(sums))
         tgt.pre_sums = sums
     else:
-        hip.next_meta = (2 * macs, in_b * (1 + acc) + (3 if need_w else 2) * out_b + w_b, kern)
+        hip.next_meta = (2 * macs, in_b * (1 + acc) + (3 if need_w else 2) * out_b + w_b, kern, R_FUSED)
         call("adamml_conv_bwd_data_dual", byref(d), ptr(g), ptr(y), ptr(aff), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc, None, None, 0,
              None)
     if need_w:
         with _on_wgrad_stream(rt, (dz, x.data, x.scale)):
-            hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b)
+            hip.next_meta = (2 * macs, in_b + out_b + 2 * w_b, None, R_WGRAD)
             ws = hip.wgrad_workspace(d, cs.cin_true, dz.device)
             call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(cs.weight.grad), cs.cin_true,
                  ptr(ws), ws.numel() * 4)
@@ -786,7 +795,7 @@ def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False):
         vec[:, 0], vec[:, 1] = ev[0], ev[1]
     out_t = torch.empty(G * d.N, d.OH, d.OW, C, dtype=torch.bfloat16, device=dev)
     mask_t = torch.empty(G * d.N, d.OH, d.OW, C // 8, dtype=torch.uint8, device=dev) if (need_grad and act != ACT_NONE) else None
-    hip.next_meta = (2 * macs, in_b + (2 if idn is not None else 1) * out_b + w_b + (out_b / 16 if mask_t is not None else 0), kern)
+    hip.next_meta = (2 * macs, in_b + (2 if idn is not None else 1) * out_b + w_b + (out_b / 16 if mask_t is not None else 0), kern, R_FUSED)
     call("adamml_conv_fwd_bn_add", byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(vec),
          ptr(idn.data) if idn is not None else None, ptr(idn.scale) if idn is not None else None,
          ptr(idn.shift) if idn is not None else None, idn.gs if idn is not None else 0, act, ptr(out_t), ptr(mask_t))

@@ -36,7 +36,9 @@ PEAK_HBM_GBS = 8000.0          # HBM3E spec peak, same table
 CLIP_GFLOP_MAIN_STAGE = 86.7   # algorithmic GFLOP per clip, main-net stage (BASELINE.md section 3 / SURVEY.md section 8d)
 CLIP_GB_MAIN_STAGE = 1.12      # algorithmic GB per clip, fwd + bwd, bf16, BN/ReLU/residual fused (same sections)
 CHANNELS = {"rgb": 3, "sound": 1, "flow": 10, "rgbdiff": 15}      # per frame (train_adamml.py:86-95)
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+# newest round's PMC summary (tools/gpu_pmc.sh); accepted only when its kernel-source stamp equals the running build
+PMC_TRAFFIC_FILE = (sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_hbm_traffic.json"))) or
+                    [os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")])[-1]
 
 
 def parse():
@@ -56,6 +58,9 @@ def parse():
     ap.add_argument("--no-sync-bn", action="store_true")
     ap.add_argument("--modalities", nargs="+", default=["rgb", "sound"], choices=["rgb", "sound", "flow", "rgbdiff"],
                     help="non-default: BASELINE.json configs[3] (rgb flow rgbdiff) / configs[4] (rgb sound flow rgbdiff)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1 only: a ONE-rank RCCL communicator with SyncBN and the bucketed gradient all-reduce forced on (every "
+                         "collective is an identity): the host / stream choreography of configs[2] measured on one GPU (non-headline)")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: no side streams, so per-kernel durations "
                     "in a rocprofv3 trace are not inflated by concurrently running kernels")
     return ap.parse_args()
@@ -212,6 +217,13 @@ def run_rank(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)     # "nccl" == RCCL on ROCm
+    elif args.force_collectives:
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port_ = s_.getsockname()[1]
+        s_.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port_, rank=0, world_size=1)
 
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(ge.LIB):
@@ -233,7 +245,8 @@ def run_rank(args):
     else:
         per_gpu = args.batch
     model = build(args, device)
-    ddp = HipDDP(model, sync_bn=(world > 1 and not args.no_sync_bn))
+    forced = args.force_collectives and world == 1
+    ddp = HipDDP(model, sync_bn=((world > 1 or forced) and not args.no_sync_bn), force_collectives=forced)
     if args.stage == "main":
         model.freeze_policy_net()
     else:
@@ -319,6 +332,7 @@ def run_rank(args):
         hip.profiler = hip.LaunchProfiler()
         step()
         agg = hip.profiler.summary()
+        role_agg = hip.profiler.summary(by_role=True)
         hip.profiler = None
         model.use_side_stream = not args.single_stream
         # launches are grouped by DEVICE kernel where the runtime names it: the forward conv and the data gradient of the
@@ -350,7 +364,25 @@ def run_rank(args):
                 traffic = round(t["per_launch_bytes"] / 1e9, 4)                     # GB per launch (average), as `achieved` is
                 tsrc = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH_SIZE x2 gfx950 correction) of this build "
                         "(source stamp %s), %s" % (tj["_source_stamp"], os.path.relpath(PMC_TRAFFIC_FILE, ROOT)))
-        roof.update({"traffic": traffic, "traffic_unit": "GB of HBM traffic per launch (PMC, average over this kernel's launches)",
+        # the "dominant kernel" is a template family that spans regimes (HBM-bound 1x1 layers, MFMA-bound 3x3 layers): the same
+        # measurement split by ROLE, each against the roof that bounds it (PMC traffic per role from the same summary file)
+        pmc_roles = tj.get("_roles", {}) if (os.path.exists(PMC_TRAFFIC_FILE) and traffic is not None) else {}
+        per_role = {}
+        for rname, ra in sorted(role_agg.items(), key=lambda kv: -kv[1]["ms"]):
+            r_tfl, r_gbs = ra["flops"] / (ra["ms"] * 1e9), ra["bytes"] / (ra["ms"] * 1e6)
+            rm, rh = r_tfl / PEAK_BF16_TFLOPS, r_gbs / PEAK_HBM_GBS
+            pr = pmc_roles.get(rname)
+            per_role[rname] = {"bound": "hbm" if rh >= rm else "mfma", "frac": round(max(rh, rm), 4),
+                               "achieved": round(r_gbs if rh >= rm else r_tfl, 1), "peak": PEAK_HBM_GBS if rh >= rm else PEAK_BF16_TFLOPS,
+                               "unit": "GB/s" if rh >= rm else "TFLOP/s", "hbm_frac": round(rh, 4), "mfma_frac": round(rm, 4),
+                               "c_abi_launches_per_step": ra["launches"], "ms_per_step": round(ra["ms"], 3),
+                               "algorithmic_gb_per_step": round(ra["bytes"] / 1e9, 2), "algorithmic_tflop_per_step": round(ra["flops"] / 1e12, 3),
+                               "traffic_gb_per_step": round(pr["hbm_bytes_per_step"] / 1e9, 2) if pr else None,
+                               "traffic_over_algorithmic": round(pr["hbm_bytes_per_step"] / ra["bytes"], 3) if pr and ra["bytes"] else None}
+        roof.update({"per_role": per_role,
+                     "launch_count_note": "launches_per_step counts C-ABI calls; a stride-2 data gradient is ONE call that launches its four "
+                                          "parity classes (rocprofv3 / PMC count those: +9 device launches per step for ResNet-50)",
+                     "traffic": traffic, "traffic_unit": "GB of HBM traffic per launch (PMC, average over this kernel's launches)",
                      "traffic_source": tsrc, "algorithmic_gb_per_launch": round(a["bytes"] / a["launches"] / 1e9, 4),
                      "traffic_gb_per_step": round(traffic * a["launches"], 2) if traffic is not None else None,
                      "algorithmic_gb_per_step": round(a["bytes"] / 1e9, 2), "kernel": name, "launches_per_step": a["launches"],
@@ -378,7 +410,8 @@ def run_rank(args):
                        if args.modalities == ["rgb", "sound"] else
                        ("AdaMML %s (non-headline config), %s-net stage train step, %d segments x 8 frames" % ("+".join(args.modalities), args.stage, args.segments)),
                        "videos_per_gpu": per_gpu, "global_batch_videos": per_gpu * world, "clips_per_step": clips, "segments": args.segments,
-                       "parallelism": "dp%d%s" % (world, "+syncbn" if (world > 1 and not args.no_sync_bn) else ""),
+                       "parallelism": "dp%d%s%s" % (world, "+syncbn" if ((world > 1 or forced) and not args.no_sync_bn) else "",
+                                                    " (one-rank RCCL communicator, collectives forced on)" if forced else ""),
                        "dist_backend": (backend if world > 1 else None), "communicator_ranks": comm_ranks,
                        "optimizer": "fused flat SGD(momentum 0.9, wd 5e-4)" if args.stage != "infer" else None,
                        "executed_clips_per_modality": getattr(model, "last_skip_stats", None)},
@@ -392,7 +425,7 @@ def run_rank(args):
             "roofline": roof, "cpu_baseline": cpu, "kernel_breakdown": breakdown,
         }
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Copies the evidence of one tools/gpu_round.sh call (gpurun_out/<tag>, <tag>pmc, <tag>v) into profiles/ under the round's names and
 # regenerates profiles/README.md.  Usage (in the build container): bash tools/install_profiles.sh <tag> <round, e.g. r02>
-tag=$1; r=${2:-r02}; g=gpurun_out
+tag=$1; r=${2:-r03}; g=gpurun_out
 cp $g/$tag/bench_default.json profiles/${r}_bench_default.json
 cp $g/$tag/bench_ss.json profiles/${r}_bench_single_stream_under_rocprof.json
 cp $g/$tag/kernel_stats.csv profiles/${r}_bench_single_stream_kernel_stats.csv
 [ -f $g/$tag/pytest.log ] && cp $g/$tag/pytest.log profiles/${r}_gpu_tests.txt
-cp $g/${tag}pmc/r02_pmc_hbm_traffic.json profiles/${r}_pmc_hbm_traffic.json
+cp $g/${tag}pmc/r03_pmc_hbm_traffic.json profiles/${r}_pmc_hbm_traffic.json
 v=$g/${tag}v
 if [ -d $v ]; then
   for n in policy_stage inference_skipping c4_rgb_flow_rgbdiff_b72 c5_four_modalities_b48; do cp $v/bench_$n.json profiles/${r}_bench_$n.json; done

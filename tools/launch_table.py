@@ -38,11 +38,25 @@ else:
 
 
 step(); step(); torch.cuda.synchronize()
+# shape of every launch that takes a conv descriptor (first argument), recorded beside the profiler's records
+from adamml_amd import runtime as _rt
+shapes = []
+_orig_call = hip.call
+
+
+def _call(name, *args):
+    d = getattr(args[0], "_obj", None) if args else None
+    shapes.append("%dx%dx%d %d->%d k%d s%d g%d" % (d.N, d.H, d.W, d.Cin, d.Cout, d.KH, max(d.stride, d.up), d.groups) if isinstance(d, hip.ConvDesc) else "")
+    return _orig_call(name, *args)
+
+
+_rt.call = hip.call = _call
 hip.profiler = hip.LaunchProfiler()
 step()
 torch.cuda.synchronize()
 recs = hip.profiler.records
 hip.profiler = None
+_rt.call = hip.call = _orig_call
 rows = []
 for i, (name, s, e, meta) in enumerate(recs):
     ms = s.elapsed_time(e)
@@ -54,3 +68,19 @@ tot = sum(r[4] for r in rows)
 print("%s: %d launches, %.1f ms of launch time; top %d by excess over the 5.3 TB/s / 800 TFLOP/s floor (no figure: caller supplies no bytes)" % (which, len(rows), tot, TOP))
 for ex, i, name, kern, ms, gbs, tfs, gb in sorted(rows, reverse=True)[:TOP]:
     print("#%4d %-28s %-18s %7.3f ms %6.0f GB/s %5.0f TF/s %6.2f GB  excess %6.3f" % (i, name[:28], kern[:18], ms, gbs, tfs, gb, ex))
+
+if len(sys.argv) > 4 and sys.argv[4] == "all":
+    import collections
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for name, s_, e, meta in recs:
+        a = agg[name.replace("adamml_", "")]
+        a[0] += 1
+        a[1] += s_.elapsed_time(e)
+    print("per entry point:")
+    for k, (c, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("  %-32s %4d launches %8.3f ms" % (k, c, ms))
+    print("chronological:")
+    for i, (name, s_, e, meta) in enumerate(recs):
+        ms = s_.elapsed_time(e)
+        print("@%4d %-28s %-26s %7.3f ms %6.2f GB %6.0f GB/s" % (i, name.replace("adamml_", "")[:28], shapes[i] if i < len(shapes) else "", ms, meta[1] / 1e9,
+                                                             meta[1] / ms / 1e6 if ms and meta[1] else 0))
