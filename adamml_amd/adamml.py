@@ -136,10 +136,12 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
         if side is not None and interleave.ENABLED and any(n.rt.sync.enabled for n in self.backbones()):
             # SyncBatchNorm on one communicator: issue the backbones round-robin, one statistics exchange per turn, so that the
             # side-stream nets' exchanges do not queue behind all of the ResNet's (interleave.py)
-            jobs = []
+            jobs, calls = [], []
             for m_i in range(self.num_modality):
                 net, xin = self.main_net.nets[m_i], m_x[m_i].flatten(0, 1)
-                jobs.append(((lambda net=net, xin=xin: net.forward_nhwc(xin, S)), side if self.main_net.modality[m_i] == 'sound' else main))
+                st = side if self.main_net.modality[m_i] == 'sound' else main
+                jobs.append(((lambda net=net, xin=xin: net.run_raw(xin, S)), st))
+                calls.append((net, xin, st))
             if not self.rng_policy:
                 # one job per policy backbone (each on its own stream): the lock-step rounds then carry the statistics of ALL
                 # backbones of a BatchNorm depth in one collective, 53 rounds per direction instead of 53 + 2 x 52
@@ -147,8 +149,15 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
                 for ps in pstreams[1:]:
                     ps.wait_stream(main)
                 for k, net in enumerate(self.policy_net.joint_net.nets):
-                    jobs.append(((lambda net=net, xin=p_x[k].flatten(0, 1): net.feature_extraction(xin, S)), pstreams[k]))
-            res = interleave.run_interleaved(jobs, dev)
+                    xin = p_x[k].flatten(0, 1)
+                    jobs.append(((lambda net=net, xin=xin: net.run_raw(xin, S)), pstreams[k]))
+                    calls.append((net, xin, pstreams[k]))
+            raw = interleave.run_interleaved(jobs, dev, phase="fwd")
+            # the launch sequences are issued; attach each to autograd (adamml::backbone_call with the precomputed result) on its stream
+            res = []
+            for (net, xin, st), pre in zip(calls, raw):
+                with torch.cuda.stream(st):
+                    res.append(net.call(xin, S, precomputed=pre))
             stacked = res[:self.num_modality]
             if not self.rng_policy:
                 with torch.cuda.stream(pside):

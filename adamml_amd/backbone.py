@@ -138,7 +138,7 @@ def _run_deferred():
     _in_deferred_run[0] = True
     try:
         jobs = [((lambda t=t, g=g, n=n: run_tape(t, g, n)), s) for (t, g, n, s) in pend]
-        interleave.run_interleaved(jobs, dev)
+        interleave.run_interleaved(jobs, dev, phase="bwd")
     finally:
         _in_deferred_run[0] = False
 
@@ -200,6 +200,7 @@ class HipBackbone(nn.Module):
         self.expose_param_grads = False      # deliver parameter gradients through autograd (enable_autograd_param_grads)
         self._handle = ops.register_net(self)
         self._pending_tape = None
+        self._precomputed = None
         self._bn_probe = None
 
     # -- weight packs ------------------------------------------------------------------------------
@@ -254,11 +255,12 @@ class HipBackbone(nn.Module):
     def _trainable(self):
         return any(p.requires_grad for p in self.parameters())
 
-    def call(self, x, groups=1):
+    def call(self, x, groups=1, precomputed=None):
         """x: NHWC bf16 frames tensor on the GPU, `groups` independent module calls stacked along dim 0 (group-major):
         each group gets its own train-mode BatchNorm statistics and running-stat update, exactly as `groups` successive
         calls of the reference module would (models/adamml.py:151-160 loops the segments).  Returns the fp32 head output
-        of all groups stacked the same way."""
+        of all groups stacked the same way.  precomputed: the (output, tape) of run_raw() on the same x -- the launch sequence has
+        already been issued (as a coroutine of interleave.run_interleaved) and is only attached to autograd here."""
         hip.require_gpu(x)
         if groups < 1 or x.shape[0] % groups:
             raise RuntimeError("backbone call: %d images do not split into %d groups" % (x.shape[0], groups))
@@ -268,7 +270,20 @@ class HipBackbone(nn.Module):
             self._anchor = torch.zeros(1, device=x.device)
         anchor = self._anchor.detach().requires_grad_(need_grad)
         params = [p for p in self.parameters() if p.requires_grad] if (need_grad and self.expose_param_grads) else []
-        return torch.ops.adamml.backbone_call(anchor, x, params, self._handle, groups, need_grad)
+        self._precomputed = precomputed
+        try:
+            return torch.ops.adamml.backbone_call(anchor, x, params, self._handle, groups, need_grad)
+        finally:
+            self._precomputed = None
+
+    def run_raw(self, x, groups=1):
+        """The launch sequence of call() WITHOUT the operator around it: returns (output, tape) for call(x, groups, precomputed=...).
+        What a job of interleave.run_interleaved runs: a coroutine must not park inside a torch dispatcher call."""
+        hip.require_gpu(x)
+        if groups < 1 or x.shape[0] % groups:
+            raise RuntimeError("backbone call: %d images do not split into %d groups" % (x.shape[0], groups))
+        self._adopt_sync_batchnorm()
+        return self._run(x, groups, need_grad=torch.is_grad_enabled() and self._trainable())
 
     def _adopt_sync_batchnorm(self):
         """nn.SyncBatchNorm.convert_sync_batchnorm(model) (train_adamml.py:126-127) replaces the BatchNorm2d containers by

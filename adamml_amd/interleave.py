@@ -5,119 +5,117 @@ next layer of that backbone cannot start before the result is back: 209 exchange
 (RGB+Audio), each latency-bound.  Issued backbone after backbone on one communicator they would also serialise the backbones
 (torch orders a process group's collectives on one internal stream in host issue order).
 
-Here the host runs the backbones as ROUNDS: every job (one backbone's forward or backward, on its own HIP stream) runs in
-its own thread -- torch's current stream and grad mode are thread-local -- but only ONE job runs at any time, and it runs
-until it needs an exchange (`exchange()`), where it parks.  When every unfinished job is parked, the scheduler concatenates
-the parked vectors into one flat buffer, issues ONE all-reduce for the round on a communication stream that waits for the
-jobs' streams, hands each job its slice of the result and resumes them.  The sequence of collectives is a pure function of
-the program (identical on every rank, which is all RCCL needs), there is one communicator, and the count per step drops from
-the SUM of the backbones' BatchNorm layers to their MAXIMUM per direction: 53 + 53 for ResNet-50 + MobileNetV2s instead of
-314 -- each carrying all backbones' vectors of that depth (a few tens of KB: still one latency-bound message on xGMI).
+Here the host runs the backbones as ROUNDS: every job (one backbone's forward or backward, on its own HIP stream) is a
+COROUTINE (greenlet) of the calling thread; it runs until it needs an exchange (`exchange()` / `exchange_stats()`), where it
+parks.  When every unfinished job is parked, the scheduler gives each parked vector a slice of the round's persistent flat
+buffer (the statistics are collapsed straight into their slice: no concatenation), issues ONE all-reduce for the round on a
+communication stream that waits for the jobs' streams, hands each job its slice and resumes them.  The sequence of collectives
+is a pure function of the program (identical on every rank, which is all RCCL needs), there is one communicator, and the
+count per step drops from the SUM of the backbones' BatchNorm layers to their MAXIMUM per direction: 53 + 53 for ResNet-50 +
+MobileNetV2s instead of 314 -- each carrying all backbones' vectors of that depth (a few tens of KB: still one latency-bound
+message on xGMI).
+
+Round 3: coroutines instead of threads.  The first form parked every job in its own Python thread behind semaphores; at the
+per-GPU share of the reference recipe (B = 9 of a global 72, train_adamml.py:122) the 848 thread hand-overs, the per-round
+torch.cat / record_stream / wait_stream bookkeeping and the GIL traffic made the step HOST-bound: 77 ms per step against 21 ms
+without SyncBatchNorm (profiles/r03_bench_b9_*.json).  A greenlet switch costs ~1 us, needs no lock, and a job that raises
+simply ends -- nothing stays parked.  torch's current stream and grad mode are thread-local, i.e. shared by the coroutines of
+one thread: the scheduler swaps them at every switch.  A coroutine must not park INSIDE a torch dispatcher call (the
+dispatcher's key guards are thread-local too): the jobs therefore call the backbones' launch sequences directly
+(HipBackbone.run_raw), and the results are attached to autograd afterwards (HipBackbone.call(..., precomputed=...)).
 """
 import os
-import threading
 
+import greenlet
 import torch
 import torch.distributed as dist
 
-_local = threading.local()
+from . import hip
+
 ENABLED = os.environ.get("ADAMML_INTERLEAVE", "1") != "0"      # A/B aid; only ever used when SyncBatchNorm is on
 stats = {"collectives": 0, "coalesced_vectors": 0}            # counters (tests, design notes)
+_current = [None]                                             # the job whose coroutine is running (None: plain code)
+
+
+def active():
+    """True while the caller runs inside a job of run_interleaved()."""
+    return _current[0] is not None
 
 
 def yield_point():
     """Hand the turn to the next job without an exchange; a no-op outside run_interleaved()."""
-    job = getattr(_local, "job", None)
+    job = _current[0]
     if job is not None:
-        job.handoff()
+        job.park()
 
 
 def exchange(t, group=None):
     """All-reduce(sum) of the statistic vector t over `group`; returns the reduced tensor (t itself, or a slice of the round's
     flat buffer).  Inside run_interleaved() the call parks the job until the round's coalesced collective has been issued."""
-    job = getattr(_local, "job", None)
+    job = _current[0]
     if job is None:
         dist.all_reduce(t, group=group)
         stats["collectives"] += 1
         stats["coalesced_vectors"] += 1
         return t
-    job.pending = (t, group)
-    job.handoff()
+    job.pending = ("vec", t, group, 0, 0)
+    job.park()
+    out, job.reduced = job.reduced, None
+    return out
+
+
+def exchange_stats(acc, C, groups, group=None):
+    """acc: [groups][STAT_SLOTS][2C] slot-interleaved fp64 accumulators of one BatchNorm.  Returns the all-reduced collapsed sums
+    [groups * 2C] (fp64; the finalize kernels read them with nslots = 1).  Inside run_interleaved() the collapse kernel writes
+    straight into this job's slice of the round's flat buffer."""
+    job = _current[0]
+    if job is None:
+        out = torch.empty(groups * 2 * C, dtype=torch.float64, device=acc.device)
+        hip.call("adamml_stats_collapse", hip.ptr(acc), hip.ptr(out), C, groups)
+        dist.all_reduce(out, group=group)
+        stats["collectives"] += 1
+        stats["coalesced_vectors"] += 1
+        return out
+    job.pending = ("stats", acc, group, C, groups)
+    job.park()
     out, job.reduced = job.reduced, None
     return out
 
 
 class _Job:
-    def __init__(self, fn, stream, device, grad_enabled, back):
-        self.fn, self.stream, self.device, self.grad_enabled, self.back = fn, stream, device, grad_enabled, back
-        self.go = threading.Semaphore(0)
+    def __init__(self, fn, stream, grad_enabled, sched):
+        self.fn, self.stream, self.grad, self.sched = fn, stream, grad_enabled, sched
         self.done = False
         self.result = None
         self.error = None
-        self.pending = None                 # (tensor, group) parked at exchange()
+        self.pending = None                 # ("vec" | "stats", tensor, group, C, groups) parked at an exchange
         self.reduced = None
-        self.thread = threading.Thread(target=self._main, daemon=True)
+        self.g = greenlet.greenlet(self._main, parent=sched)
 
     def _main(self):
-        self.go.acquire()
-        _local.job = self
         try:
-            if self.device is not None and torch.device(self.device).type == "cuda":
-                torch.cuda.set_device(self.device)
-            with torch.set_grad_enabled(self.grad_enabled):
-                if self.stream is not None:
-                    with torch.cuda.stream(self.stream):
-                        self.result = self.fn()
-                else:
-                    self.result = self.fn()
-        except BaseException as e:          # re-raised in the caller's thread
+            self.result = self.fn()
+        except BaseException as e:          # re-raised by the scheduler
             self.error = e
-        finally:
-            _local.job = None
-            self.done = True
-            self.back.release()
+        self.done = True                    # returning switches to the parent (the scheduler)
 
-    def handoff(self):
-        self.back.release()                 # give the turn back to the scheduler ...
-        self.go.acquire()                   # ... and wait for the next one
+    def park(self):
+        self.sched.switch()                 # back to the scheduler; returns when the scheduler resumes this job
 
 
-def _coalesced_all_reduce(parked, device):
-    """ONE collective for the vectors parked in this round (all on `device`, one process group)."""
-    group = parked[0].pending[1]
-    tensors = [j.pending[0] for j in parked]
-    on_gpu = tensors[0].is_cuda
-    if any(j.pending[1] is not group for j in parked) or len({t.dtype for t in tensors}) > 1:
-        for j in parked:                    # mixed groups / dtypes: no coalescing (not used by the hot path)
-            dist.all_reduce(j.pending[0], group=j.pending[1])
-            stats["collectives"] += 1
-            stats["coalesced_vectors"] += 1
-            j.reduced, j.pending = j.pending[0], None
-        return
-    if on_gpu:
-        comm = _comm_stream(tensors[0].device)
-        for j in parked:
-            comm.wait_stream(j.stream if j.stream is not None else torch.cuda.current_stream(tensors[0].device))
-        ctx = torch.cuda.stream(comm)
-    else:
-        comm, ctx = None, _Null()
-    with ctx:
-        flat = torch.cat([t.reshape(-1) for t in tensors]) if len(tensors) > 1 else tensors[0].reshape(-1)
-        dist.all_reduce(flat, group=group)
-    stats["collectives"] += 1
-    stats["coalesced_vectors"] += len(tensors)
-    off = 0
-    for j, t in zip(parked, tensors):
-        n = t.numel()
-        j.reduced = flat[off:off + n].view(t.shape)
-        off += n
-        if on_gpu:
-            s = j.stream if j.stream is not None else torch.cuda.current_stream(t.device)
-            s.wait_stream(comm)             # the job's next launch reads its slice of the reduced buffer
-            flat.record_stream(s)           # (a few KB: the cross-stream bookkeeping of the caching allocator is harmless here)
-        j.pending = None
+class _Round:
+    """Persistent per-round state: the flat exchange buffer and the events of its stream choreography (reused every step:
+    the sizes are a function of the model, and a round's buffer is consumed -- stream-ordered -- long before the same round of
+    the next step is produced)."""
+    __slots__ = ("flat", "done", "ready")
+
+    def __init__(self):
+        self.flat = None
+        self.done = torch.cuda.Event()
+        self.ready = []
 
 
+_rounds = {}
 _comm = {}
 
 
@@ -128,35 +126,123 @@ def _comm_stream(device):
     return s
 
 
-class _Null:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False
+def _vec_dtype(p):
+    return torch.float64 if p[0] == "stats" else p[1].dtype
 
 
-def run_interleaved(jobs, device):
+def _coalesced_all_reduce(parked, device, phase, ridx):
+    """ONE collective for the vectors parked in this round (all on `device`, one process group)."""
+    group = parked[0].pending[2]
+    on_gpu = parked[0].pending[1].is_cuda
+    dtype = _vec_dtype(parked[0].pending)
+    if any(j.pending[2] is not group or _vec_dtype(j.pending) != dtype for j in parked):
+        for j in parked:                    # mixed groups / dtypes: no coalescing (not used by the hot path)
+            kind, t, grp, C, G = j.pending
+            prev = torch.cuda.current_stream(device) if on_gpu else None
+            if on_gpu:
+                torch.cuda.set_stream(j.stream)
+            try:
+                if kind == "stats":
+                    out = torch.empty(G * 2 * C, dtype=torch.float64, device=t.device)
+                    hip.call("adamml_stats_collapse", hip.ptr(t), hip.ptr(out), C, G)
+                    t = out
+                dist.all_reduce(t, group=grp)
+            finally:
+                if on_gpu:
+                    torch.cuda.set_stream(prev)
+            stats["collectives"] += 1
+            stats["coalesced_vectors"] += 1
+            j.reduced, j.pending = t, None
+        return
+    if not on_gpu:                          # host tensors (the gloo tests of the scheduling logic): concatenate
+        tensors = [j.pending[1] for j in parked]
+        flat = torch.cat([t.reshape(-1) for t in tensors]) if len(tensors) > 1 else tensors[0].reshape(-1)
+        dist.all_reduce(flat, group=group)
+        stats["collectives"] += 1
+        stats["coalesced_vectors"] += len(tensors)
+        off = 0
+        for j, t in zip(parked, tensors):
+            j.reduced, j.pending = flat[off:off + t.numel()].view(t.shape), None
+            off += t.numel()
+        return
+    sizes = [(j.pending[1].numel() if j.pending[0] == "vec" else j.pending[4] * 2 * j.pending[3]) for j in parked]
+    total = sum(sizes)
+    rd = _rounds.get((device, phase, ridx, dtype))
+    if rd is None:
+        rd = _rounds[(device, phase, ridx, dtype)] = _Round()
+    if rd.flat is None or rd.flat.numel() < total:
+        rd.flat = torch.empty(max(total, 1024), dtype=dtype, device=device)
+    while len(rd.ready) < len(parked):
+        rd.ready.append(torch.cuda.Event())
+    comm = _comm_stream(device)
+    for j, ev in zip(parked, rd.ready):
+        ev.record(j.stream)                 # the job's accumulators are complete ...
+        comm.wait_event(ev)                 # ... before the communication stream collapses / reads them
+    flat = rd.flat[:total]
+    prev = torch.cuda.current_stream(device)
+    torch.cuda.set_stream(comm)
+    try:
+        off = 0
+        for j, n in zip(parked, sizes):
+            kind, t, _, C, G = j.pending
+            if kind == "stats":
+                hip.call("adamml_stats_collapse", hip.ptr(t), hip.ptr(flat[off:off + n]), C, G)
+            else:
+                flat[off:off + n].copy_(t.reshape(-1))
+            off += n
+        dist.all_reduce(flat, group=group)
+        rd.done.record(comm)
+    finally:
+        torch.cuda.set_stream(prev)
+    stats["collectives"] += 1
+    stats["coalesced_vectors"] += len(parked)
+    off = 0
+    for j, n in zip(parked, sizes):
+        t = j.pending[1]
+        j.reduced = flat[off:off + n] if j.pending[0] == "stats" else flat[off:off + n].view(t.shape)
+        off += n
+        j.stream.wait_event(rd.done)        # the job's next launch reads its slice of the reduced buffer
+        j.pending = None
+
+
+def run_interleaved(jobs, device, phase="fwd"):
     """jobs: list of (callable, stream or None).  Runs them to completion in rounds: every unfinished job gets one turn per round,
-    in fixed order, and runs until it parks at exchange() / yield_point() or finishes; the exchanges parked in a round are
-    all-reduced as ONE collective.  Returns the list of results; the first exception is re-raised."""
-    back = threading.Semaphore(0)
+    in fixed order, and runs until it parks at an exchange / yield_point() or finishes; the exchanges parked in a round are
+    all-reduced as ONE collective.  Returns the list of results; the first exception is re-raised (the other jobs' coroutines are
+    dropped: nothing stays parked).  `phase` names the persistent round buffers ("fwd" / "bwd")."""
+    if _current[0] is not None:
+        raise RuntimeError("run_interleaved: nested call from inside a job")
+    sched = greenlet.getcurrent()
     ge = torch.is_grad_enabled()
-    js = [_Job(fn, stream, device, ge, back) for fn, stream in jobs]
-    for j in js:
-        j.thread.start()
-    active = list(js)
-    while active:
-        for j in list(active):
-            j.go.release()
-            back.acquire()
-            if j.done:
-                active.remove(j)
-                if j.error is not None:
-                    raise j.error           # (the other jobs' daemon threads stay parked; the step is lost anyway)
-        parked = [j for j in active if j.pending is not None]
-        if parked:
-            _coalesced_all_reduce(parked, device)
-    for j in js:
-        j.thread.join()
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+    dev = torch.device(device) if on_gpu else None
+    home = torch.cuda.current_stream(dev) if on_gpu else None
+    js = [_Job(fn, (stream if stream is not None else home), ge, sched) for fn, stream in jobs]
+    active_jobs = list(js)
+    ridx = 0
+    try:
+        while active_jobs:
+            for j in list(active_jobs):
+                _current[0] = j
+                if on_gpu:
+                    torch.cuda.set_stream(j.stream)
+                torch.set_grad_enabled(j.grad)
+                try:
+                    j.g.switch()
+                finally:
+                    j.grad = torch.is_grad_enabled()
+                    _current[0] = None
+                    if on_gpu:
+                        torch.cuda.set_stream(home)
+                    torch.set_grad_enabled(ge)
+                if j.done:
+                    active_jobs.remove(j)
+                    if j.error is not None:
+                        raise j.error
+            parked = [j for j in active_jobs if j.pending is not None]
+            if parked:
+                _coalesced_all_reduce(parked, dev, phase, ridx)
+                ridx += 1
+    finally:
+        _current[0] = None
     return [j.result for j in js]

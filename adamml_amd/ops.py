@@ -47,7 +47,12 @@ def backbone_call(anchor: torch.Tensor, x: torch.Tensor, params: List[torch.Tens
     then accumulate straight into the pre-attached flat .grad views).  BatchNorm running statistics of the backbone are
     updated in place as a side effect, exactly like nn.BatchNorm2d in train mode."""
     net = _net(handle)
-    out, tape = net._run(x, groups, need_grad=need_grad)
+    pre, net._precomputed = net._precomputed, None
+    if pre is not None:            # the launch sequence already ran as a coroutine of interleave.run_interleaved (HipBackbone.run_raw)
+        out, tape = pre
+        out = out.clone()          # (an operator may not return its argument; [clips, classes] fp32)
+    else:
+        out, tape = net._run(x, groups, need_grad=need_grad)
     net._pending_tape = tape
     return out
 

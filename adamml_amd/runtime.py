@@ -122,14 +122,12 @@ class SyncCtx:
 
     def reduce(self, t, C, groups):
         """t: [groups][STAT_SLOTS][2C] slot-interleaved sums.  Returns (sums, nslots) for the finalize kernel: under
-        SyncBN the slots are collapsed first so that only groups*2C doubles cross xGMI, in ONE all-reduce."""
+        SyncBN the slots are collapsed first so that only groups*2C doubles cross xGMI, in ONE all-reduce -- coalesced with the
+        exchanges the other backbones have pending in this round when the backbones are issued in lock-step (interleave.py):
+        one collective per BatchNorm DEPTH instead of one per BatchNorm."""
         if not self.enabled:
             return t, STAT_SLOTS
-        out = torch.empty(groups * 2 * C, dtype=torch.float64, device=t.device)
-        call("adamml_stats_collapse", ptr(t), ptr(out), C, groups)
-        # one all-reduce -- coalesced with the exchanges the other backbones have pending in this round when the backbones are
-        # issued in lock-step (interleave.py): one collective per BatchNorm DEPTH instead of one per BatchNorm
-        return interleave.exchange(out, self.group), 1
+        return interleave.exchange_stats(t, C, groups, self.group), 1
 
 
 class NetRT:
