@@ -83,6 +83,14 @@ struct ConvP {
     int cls_nt;                  // taps of this class (0..4)
     unsigned cls_code;           // per tap, 8 bits: dh | dw << 1 | weight-pack tap index << 2
     int oH, oW, o_ph, o_pw;      // output rows are scattered: pixel (i, j) of the class grid -> (2i + o_ph, 2j + o_pw) of [oH, oW]
+    // TP (FADD kernels): the block output feeds ONLY a temporal max-pool (models/common.py:4-33 after the last block of a ResNet stage,
+    // models/resnet.py:205-209).  A pixel tile then holds the TP frames of a clip for BP / TP pixels (row r = frame r / (BP / TP), pixel
+    // r % (BP / TP) of block tp_blk), the epilogue pools over the frames and writes the POOLED tensor tp_y [clips * TP / 2][Q][Cout] and
+    // 2 bits per pooled element (tp_code, one uint16 per 8-channel chunk: window tap 0..2 of the first maximum, 3 = maximum <= 0, i.e.
+    // no gradient passes the ReLU) -- the full-rate block output, its activation mask and the pool's own pass never touch HBM
+    int tp_nblk, tp_Q;           // pixel blocks per clip (ceil(Q / (BP / TP))), pixels per frame
+    bf16_t* tp_y;
+    uint16_t* tp_code;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -149,8 +157,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
 // the forward instances carry no dead epilogue state and the data-gradient ones can request a batch of rows ahead of their stores.
 // PF: see ConvP::pf_a (BC = 128, 64 channels of a; RES + GLDS + EID only).
 template <int BC, int MODE, int PD, bool RES = false, bool DUAL = false, bool CAT = false, bool FADD = false, bool GLDS = false, int EID = 0,
-          bool LZF = false, int EPI = -1, bool PF = false>
+          bool LZF = false, int EPI = -1, bool PF = false, int TP = 0>
 __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
+    static_assert(TP == 0 || (FADD && EID && MODE == 0 && BC == 128 && (TP == 2 || TP == 4 || TP == 8)), "TP: FADD + EID, 128-wide cout tiles");
+    constexpr int PPF = TP ? BP / TP : BP;  // TP: pixels of one frame in a tile
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
     constexpr int WROWS = BC / 64;          // weight rows staged per thread
     constexpr int TILE_BYTES = (BP + BC) * 64;
@@ -191,6 +201,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
             if (p.res_out) p.res_out += (size_t)g * p.gy;
             if (p.mask_out) p.mask_out += ((size_t)g * p.gy) >> 3;
             if (p.id_scale) { p.id_scale += (size_t)g * p.id_gstride; p.id_shift += (size_t)g * p.id_gstride; }
+            if (TP) { p.tp_y += (size_t)g * (p.gy >> 1); if (p.tp_code) p.tp_code += ((size_t)g * (p.gy >> 1)) >> 3; }
         }
         if (PF) {
             p.pf_a += (size_t)g * p.P * PF_C;
@@ -307,6 +318,14 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
     const int ptile = pgrp * p.tpb + it;
     if (ptile >= p.n_ptiles) break;
     const int p0 = ptile * BP;
+    // TP: tile = (clip, pixel block); tile row r -> pixel (clip * TP + r / PPF) * Q + blk * PPF + r % PPF, valid while the pixel exists
+    const int tp_clip = TP ? ptile / p.tp_nblk : 0;
+    const int tp_q0 = TP ? (ptile - tp_clip * p.tp_nblk) * PPF : 0;
+    auto tp_row = [&](int r, bool& ok) -> int {
+        const int q = tp_q0 + (r % PPF);
+        ok = q < p.tp_Q;
+        return (tp_clip * TP + r / PPF) * p.tp_Q + (ok ? q : 0);
+    };
 
     // ---- per-thread staging coordinates -------------------------------------------------------
     int a_n[2], a_h0[2], a_w0[2], a_base[2];
@@ -317,6 +336,11 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
         int pp = p0 + row_a + r * 64;
         a_ok[r] = pp < p.P;
         int ppc = a_ok[r] ? pp : 0;
+        if constexpr (TP != 0) {
+            bool ok;
+            ppc = tp_row(row_a + r * 64, ok);
+            a_ok[r] = ok;
+        }
         if (MODE == 0 && p.stride == 1 && p.pad == 0) {
             // 1x1 / stride 1 (pad 0): the input pixel IS the output pixel -- none of the two integer divisions below (~80 VALU
             // instructions per row, executed per tile AHEAD of the tile's first load)
@@ -388,7 +412,11 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
 #pragma unroll
             for (int j = 0; j < NRE; ++j) {
                 const int r = erow0 + j * RSTEP;
-                const size_t pre = (size_t)(p0 + r < p.P ? p0 + r : p0) * p.Cout + ecoc;
+                size_t pre = (size_t)(p0 + r < p.P ? p0 + r : p0) * p.Cout + ecoc;
+                if constexpr (TP != 0) {
+                    bool ok;
+                    pre = (size_t)tp_row(r, ok) * p.Cout + ecoc;
+                }
                 if (FADD) eid[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.res_out + pre));
                 else {
                     eid[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.y + pre));
@@ -513,7 +541,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
-    const bool tail_rows = p0 + BP > p.P;                     // (uniform) this tile has rows past the last pixel
+    const bool tail_rows = TP ? tp_q0 + PPF > p.tp_Q : p0 + BP > p.P;      // (uniform) this tile has rows without a pixel
     auto compute = [&](int buf, int kt = 0) {
         const char* base = smem + buf * TILE_BYTES;
         bf16x8 fa[4], fw[WCT];
@@ -533,8 +561,10 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
             }
             if (tail_rows) {                              // zero-filled rows must stay zero (statistics, never-stored outputs)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (p0 + wp * 64 + t * 16 + li >= p.P) fa[t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                for (int t = 0; t < 4; ++t) {
+                    const int r = wp * 64 + t * 16 + li;
+                    if (TP ? tp_q0 + (r % PPF) >= p.tp_Q : p0 + r >= p.P) fa[t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
             }
         }
 #pragma unroll
@@ -645,6 +675,48 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
             if (p.id_scale) { isc = load_f32x8(p.id_scale + eco); ish = load_f32x8(p.id_shift + eco); }
             const float rlo = act_lo(p.res_act), rhi = act_hi(p.res_act);
             constexpr int NR = BP / RSTEP, EB = EID ? NR : (NR < 4 ? NR : 4);
+            if constexpr (TP != 0) {
+                // this thread's NR = 8 rows are rows erow0 + 16 j: NPX = PPF / 16 pixels x TP frames (frame t of pixel s at j = t * NPX + s)
+                static_assert(RSTEP == 16 && NR == 8, "TP epilogue mapping");
+                constexpr int NPX = PPF / 16, To = TP / 2;
+                bf16x8 vb[NR];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int r = erow0 + j * RSTEP;
+                    f32x8 f = bf8_to_f32(*reinterpret_cast<const bf16x8*>(smem + r * CROW + ech * 16));
+                    const f32x8 w = bf8_to_f32(eid[j]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) f[i] = clamp_act(fmaf(f[i], sc[i], sh[i]) + fmaf(w[i], isc[i], ish[i]), rlo, rhi);
+                    vb[j] = f32_to_bf8(f);                                  // the value the unfused path stores and the pool re-reads
+                }
+#pragma unroll
+                for (int s = 0; s < NPX; ++s) {
+                    const int q = tp_q0 + erow0 + 16 * s;
+                    if (q >= p.tp_Q) continue;
+#pragma unroll
+                    for (int to = 0; to < To; ++to) {
+                        f32x8 best;
+                        unsigned code = 0;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) best[i] = -INFINITY;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const int tt = 2 * to - 1 + k;
+                            if (tt < 0 || tt >= TP) continue;
+                            const f32x8 v = bf8_to_f32(vb[tt * NPX + s]);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i)
+                                if (v[i] > best[i]) { best[i] = v[i]; code = (code & ~(3u << (2 * i))) | ((unsigned)k << (2 * i)); }   // first maximum in scan order
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (!(best[i] > rlo && best[i] < rhi)) code |= 3u << (2 * i);       // act'(maximum) == 0: no gradient through this window
+                        const size_t po = ((size_t)(tp_clip * To + to) * p.tp_Q + q) * p.Cout + eco;
+                        *reinterpret_cast<bf16x8*>(p.tp_y + po) = f32_to_bf8(best);
+                        if (p.tp_code) p.tp_code[po >> 3] = (uint16_t)code;
+                    }
+                }
+            } else
 #pragma unroll
             for (int b0 = 0; b0 < NR; b0 += EB) {
                 bf16x8 ir[EB];
@@ -1618,7 +1690,8 @@ struct CatIn { const void* xb; int C2; size_t gw; const float* epi_add; };
 // forward BatchNorm + residual-add epilogue (ConvP::id_scale ..)
 // product with a second tensor accumulated from the gradient tile (ConvP::pf_a ..); ws: partial workspace, nsplit: out
 struct PfIn { const void* a; const float* scale; const float* shift; int act, gs, C; float* out; void* ws; size_t ws_bytes; };
-struct FaddEpi { const float* vec; const void* idn; const float* id_scale; const float* id_shift; int id_gstride; int act; uint8_t* mask_out; };
+struct FaddEpi { const float* vec; const void* idn; const float* id_scale; const float* id_shift; int id_gstride; int act; uint8_t* mask_out;
+                 int tp_frames; void* tp_y; uint16_t* tp_code; };      // tp_frames > 0: temporal max-pool in the epilogue (ConvP::tp_y ..)
 
 static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
                        const float* in_shift, void* y, double* stats, const void* bn_z, const float* bn_vec, int bn_act,
@@ -1640,6 +1713,7 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     p.epi_add = cat ? cat->epi_add : nullptr;
     p.id_scale = fadd ? fadd->id_scale : nullptr; p.id_shift = fadd ? fadd->id_shift : nullptr; p.id_gstride = fadd ? fadd->id_gstride : 0;
     p.mask_out = fadd ? fadd->mask_out : nullptr;
+    p.tp_nblk = p.tp_Q = 0; p.tp_y = nullptr; p.tp_code = nullptr;
     p.pf_a = nullptr; p.pf_scale = p.pf_shift = nullptr; p.pf_ws = nullptr; p.pf_act = p.pf_gs = p.pf_nsplit = 0;
     if (fadd) { p.bn_vec = fadd->vec; p.res_out = (const bf16_t*)fadd->idn; p.res_act = fadd->act; }
     const int groups = d->groups < 1 ? 1 : d->groups;
@@ -1675,8 +1749,17 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     bool narrow = d->Cout <= 64 || (d->Cout % 128 != 0 && d->Cout < 256);
     // small problems: halve the cout tile so that at least ~2 workgroups per CU exist
     if (!narrow && (long)ceil_div(p.P, BP) * ceil_div(d->Cout, 128) * groups < 512) narrow = true;
+    const int tp = fadd ? fadd->tp_frames : 0;
+    if (tp) narrow = false;
     const int BC = narrow ? 64 : 128;
     p.n_ptiles = ceil_div(p.P, BP);
+    if (tp) {
+        // tiles = (clip, block of BP / tp pixels); all frames of a clip's pixel block sit in one tile
+        p.tp_Q = d->OH * d->OW;
+        p.tp_nblk = ceil_div(p.tp_Q, BP / tp);
+        p.n_ptiles = (d->N / tp) * p.tp_nblk;
+        p.tp_y = (bf16_t*)fadd->tp_y; p.tp_code = fadd->tp_code;
+    }
     p.n_ctiles = ceil_div(d->Cout, BC);
     // consecutive pixel tiles per workgroup (amortises the statistics publication), keeping >= ~2048 workgroups
     p.tpb = (int)((long)p.n_ptiles * p.n_ctiles * groups / 2048);
@@ -1708,6 +1791,16 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
             // operands by LDS-DMA (a lazily normalised input is transformed at the fragment: LZF); with an identity operand, that one is
             // requested at the start of each tile (EID)
             const bool eid = fadd_glds > 1 && p.res_out;
+            if (tp) {
+#define LAUNCH_TP(TV)                                                                                                                                        \
+                do {                                                                                                                                         \
+                    if (in_scale) hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, false, false, false, true, true, 1, true, -1, false, TV>), grid, block, 0, stream, p);  \
+                    else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, false, false, false, true, true, 1, false, -1, false, TV>), grid, block, 0, stream, p);         \
+                } while (0)
+                if (tp == 8) LAUNCH_TP(8); else if (tp == 4) LAUNCH_TP(4); else LAUNCH_TP(2);
+#undef LAUNCH_TP
+                return adamml_check_launch("conv_fwd_bn_add_tpool");
+            }
 #define LAUNCH_FADD(BCV)                                                                                                                   \
             do {                                                                                                                           \
                 if (in_scale) {                                                                                                            \
@@ -1721,6 +1814,8 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
             if (BC == 64) LAUNCH_FADD(64); else LAUNCH_FADD(128);
 #undef LAUNCH_FADD
         } else
+        if (tp) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd_bn_add_tpool: needs the LDS-DMA kernel (K <= 512 for a lazy input)");
+        else
         if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, false, false, false, true>), grid, block, 0, stream, p);
         else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, false, false, false, true>), grid, block, 0, stream, p);
         return adamml_check_launch("conv_fwd_bn_add");
@@ -1824,8 +1919,29 @@ extern "C" int adamml_conv_fwd_bn_add(const adamml_conv_desc_t* d, const void* x
                                       const float* id_shift, int id_gstride, int act, void* out, uint8_t* mask_out, hipStream_t stream) {
     if (!adamml_conv_fwd_bn_add_supported(d)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd_bn_add: 1x1 / stride-1 convs only");
     if (!bn_vec) return adamml_set_error(ADAMML_EINVAL, "conv_fwd_bn_add: null BatchNorm vectors");
-    FaddEpi f{bn_vec, idn, id_scale, id_shift, id_gstride, act, mask_out};
+    FaddEpi f{bn_vec, idn, id_scale, id_shift, id_gstride, act, mask_out, 0, nullptr, nullptr};
     return conv_launch(d, x, w_packed, in_scale, in_shift, out, nullptr, nullptr, nullptr, 0, stream, nullptr, nullptr, nullptr, nullptr, &f);
+}
+
+extern "C" int adamml_conv_fwd_bn_add_tpool_supported(const adamml_conv_desc_t* d, int frames, int act, int lazy_input) {
+    if (!adamml_conv_fwd_bn_add_supported(d)) return 0;
+    if (!(frames == 2 || frames == 4 || frames == 8) || d->N % frames || d->Cout % 128 || act != ADAMML_ACT_RELU) return 0;
+    if (lazy_input && d->Cin > 512) return 0;                         // (the fragment-side lazy transform keeps its vectors in LDS)
+    static const bool on = !(getenv("ADAMML_FADD_TPOOL") && getenv("ADAMML_FADD_TPOOL")[0] == '0') &&
+                           !(getenv("ADAMML_FADD_GLDS") && atoi(getenv("ADAMML_FADD_GLDS")) < 2);
+    return on ? 1 : 0;
+}
+
+extern "C" int adamml_conv_fwd_bn_add_tpool(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
+                                            const float* in_shift, const float* bn_vec, const void* idn, const float* id_scale,
+                                            const float* id_shift, int id_gstride, int act, int frames, void* pooled, uint16_t* code,
+                                            hipStream_t stream) {
+    if (!adamml_conv_fwd_bn_add_tpool_supported(d, frames, act, in_scale != nullptr))
+        return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd_bn_add_tpool: 1x1 / stride-1 conv, Cout %% 128 == 0, ReLU, 2 / 4 / 8 frames per clip");
+    if (!bn_vec || !idn || !pooled) return adamml_set_error(ADAMML_EINVAL, "conv_fwd_bn_add_tpool: null argument");
+    FaddEpi f{bn_vec, idn, id_scale, id_shift, id_gstride, act, nullptr, frames, pooled, code};
+    // (`pooled` doubles as the kernel's y pointer: the full-rate output is never written)
+    return conv_launch(d, x, w_packed, in_scale, in_shift, pooled, nullptr, nullptr, nullptr, 0, stream, nullptr, nullptr, nullptr, nullptr, &f);
 }
 
 // Per-channel sum / sum of squares of z = W a over the pixels of each group WITHOUT z: sum z[co] = W[co,:] . s and

@@ -42,6 +42,10 @@ struct DwP {
     const bf16_t* bn_z;   // raw tensor y is the gradient of (same shape / group stride as y)
     const float* bn_vec;  // [G][4][C] scale, shift, mean, invstd
     int bn_act;
+    // X1 kernels (3x3 stem of a ONE-channel fp32 image, models/sound_mobilenet_v2.py:96 / models/policy_net.py:108 on a spectrogram): the
+    // input is x1 [.. H, W] fp32 -- image n of group g at x1 + g * x1_g + n * x1_n floats -- broadcast over the C output channels
+    const float* x1;
+    size_t x1_g, x1_n;
 };
 
 // "Column-strip walker": one thread owns 4 channels x SEGW adjacent output columns and walks DOWN `rows_per_thread`
@@ -54,7 +58,7 @@ struct DwP {
 // normalised tensor z -- the mask act'(bn(z)) is applied before the store and the statistics become sum(g'), sum(g' zhat), so the
 // BatchNorm-backward reduction pass over (g, z) disappears (one read of z here instead of a read of g and of z there).  The z rows
 // are requested three output rows ahead (three rotating register rows, like the input window).
-template <int S, bool BNZ = false>
+template <int S, bool BNZ = false, bool X1 = false>
 __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
     constexpr int SEGW = S == 1 ? 4 : 2;                // output columns per thread
     constexpr int NCOL = (SEGW - 1) * S + 3;            // input columns feeding them
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
     const unsigned bx = lb % gridDim.x;
     {
         const int g = lb / gridDim.x;
-        p.x += (size_t)g * p.gx;
+        if (X1) p.x1 += (size_t)g * p.x1_g; else p.x += (size_t)g * p.gx;
         p.y += (size_t)g * p.gy;
         if (p.stats) p.stats += (size_t)g * ADAMML_STAT_SLOTS * 2 * p.C;
         if (p.in_scale) { p.in_scale += (size_t)g * p.in_gstride; p.in_shift += (size_t)g * p.in_gstride; }
@@ -97,7 +101,8 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
         bool cok[NCOL];
 #pragma unroll
         for (int j = 0; j < NCOL; ++j) cok[j] = (unsigned)(iw_b + j) < (unsigned)p.W;
-        const bf16_t* img = p.x + (size_t)n * p.H * p.W * p.C + c;
+        const bf16_t* img = X1 ? nullptr : p.x + (size_t)n * p.H * p.W * p.C + c;
+        const float* img1 = X1 ? p.x1 + (size_t)n * p.x1_n : nullptr;
         bf16_t* yimg = p.y + (size_t)n * p.OH * p.OW * p.C + c;
         f32x4 bsc, bsh, bmu, bis;
         float blo = 0.f, bhi = 0.f;
@@ -116,22 +121,33 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
             for (int o = 0; o < SEGW; ++o) r.v[o] = *reinterpret_cast<const bf16x4*>(rp + (size_t)min(ow_b + o, p.OW - 1) * p.C);
         };
 
-        struct Raw { bf16x4 v[NCOL]; bool rok; };
+        struct Raw { bf16x4 v[X1 ? 1 : NCOL]; float f[X1 ? NCOL : 1]; bool rok; };
         auto load_row = [&](int ih, Raw& r) {
             r.rok = (unsigned)ih < (unsigned)p.H;
+            if constexpr (X1) {
+                const float* rp = img1 + (size_t)(r.rok ? ih : 0) * p.W;
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j) r.f[j] = rp[cok[j] ? iw_b + j : 0];
+            } else {
             const bf16_t* rp = img + (size_t)(r.rok ? ih : 0) * p.W * p.C;
 #pragma unroll
             for (int j = 0; j < NCOL; ++j)          // unconditional loads from clamped addresses; xform() zeroes the invalid ones
                 r.v[j] = *reinterpret_cast<const bf16x4*>(rp + (size_t)(cok[j] ? iw_b + j : 0) * p.C);
+            }
         };
         auto xform = [&](const Raw& r, f32x4 (&dst)[NCOL]) {
 #pragma unroll
             for (int j = 0; j < NCOL; ++j) {
-                f32x4 v = bf4_to_f32(r.v[j]);
                 const bool ok = r.rok && cok[j];
+                if constexpr (X1) {                 // the fp32 pixel itself, for every output channel (no input BatchNorm: first layer)
+                    const float v = ok ? r.f[j] : 0.f;
+                    dst[j] = f32x4{v, v, v, v};
+                } else {
+                f32x4 v = bf4_to_f32(r.v[j]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? clamp_act(fmaf(v[i], sc[i], sh[i]), lo, hi) : 0.f;
                 dst[j] = v;
+                }
             }
         };
         auto emit = [&](int oh, const f32x4 (&r0)[NCOL], const f32x4 (&r1)[NCOL], const f32x4 (&r2)[NCOL], const ZRow& zrow) {
@@ -427,6 +443,8 @@ struct DwWP {
     int N, H, W, C, OH, OW, stride, pad, act, rows_per_thread, nseg, nrb;
     size_t gdz, gx;
     int in_gstride;
+    const float* x1;      // X1 kernels: one-channel fp32 input (DwP::x1)
+    size_t x1_g, x1_n;
 };
 
 // Weight gradient with the forward kernel's column-strip walk: dw[c][kh][kw] = sum_p dz[p][c] * a[p@(kh,kw)][c] over a
@@ -434,13 +452,13 @@ struct DwWP {
 // accumulators per thread.  The grid is capped (thread count a multiple of every channel-group count of MobileNetV2) with
 // a task loop: a thread keeps its 4-channel group, publishes its accumulators once, and a workgroup writes ONE partial
 // [9*C] tile (plain stores into the workspace, summed by adamml_launch_split_reduce; fp32 atomics without a workspace).
-template <int S>
+template <int S, bool X1 = false>
 __global__ __launch_bounds__(NT, 2) void dwconv_bwd_weight_kernel(DwWP p) {
     constexpr int SEGW = S == 1 ? 4 : 2;
     constexpr int NCOL = (SEGW - 1) * S + 3;
     extern __shared__ float dsm[];        // [9][C]
     p.dz += (size_t)blockIdx.y * p.gdz;
-    p.x += (size_t)blockIdx.y * p.gx;
+    if (X1) p.x1 += (size_t)blockIdx.y * p.x1_g; else p.x += (size_t)blockIdx.y * p.gx;
     if (p.in_scale) { p.in_scale += (size_t)blockIdx.y * p.in_gstride; p.in_shift += (size_t)blockIdx.y * p.in_gstride; }
     const int nchunk = p.C >> 2;
     for (int i = threadIdx.x; i < 9 * p.C; i += NT) dsm[i] = 0.f;
@@ -475,17 +493,24 @@ __global__ __launch_bounds__(NT, 2) void dwconv_bwd_weight_kernel(DwWP p) {
         for (int j = 0; j < NCOL; ++j) cok[j] = (unsigned)(iw_b + j) < (unsigned)p.W;
 #pragma unroll
         for (int o = 0; o < SEGW; ++o) ook[o] = ow_b + o < p.OW;
-        const bf16_t* img = p.x + (size_t)n * p.H * p.W * p.C + c;
+        const bf16_t* img = X1 ? nullptr : p.x + (size_t)n * p.H * p.W * p.C + c;
+        const float* img1 = X1 ? p.x1 + (size_t)n * p.x1_n : nullptr;
         const bf16_t* gimg = p.dz + ((size_t)n * p.OH * p.OW + ow_b) * p.C + c;
 
-        struct Raw { bf16x4 v[NCOL]; bool rok; };
+        struct Raw { bf16x4 v[X1 ? 1 : NCOL]; float f[X1 ? NCOL : 1]; bool rok; };
         struct GRow { bf16x4 v[SEGW]; };
         auto load_row = [&](int ih, Raw& r) {
             r.rok = (unsigned)ih < (unsigned)p.H;
+            if constexpr (X1) {
+                const float* rp = img1 + (size_t)(r.rok ? ih : 0) * p.W;
+#pragma unroll
+                for (int j = 0; j < NCOL; ++j) r.f[j] = rp[cok[j] ? iw_b + j : 0];
+            } else {
             const bf16_t* rp = img + (size_t)(r.rok ? ih : 0) * p.W * p.C;
 #pragma unroll
             for (int j = 0; j < NCOL; ++j)          // unconditional loads from clamped addresses; xform() zeroes the invalid ones
                 r.v[j] = *reinterpret_cast<const bf16x4*>(rp + (size_t)(cok[j] ? iw_b + j : 0) * p.C);
+            }
         };
         auto load_g = [&](int oh, GRow& gr) {
             const bf16_t* rp = gimg + (size_t)oh * p.OW * p.C;
@@ -499,11 +524,16 @@ __global__ __launch_bounds__(NT, 2) void dwconv_bwd_weight_kernel(DwWP p) {
         auto xform = [&](const Raw& r, f32x4 (&dst)[NCOL]) {
 #pragma unroll
             for (int j = 0; j < NCOL; ++j) {
-                f32x4 v = bf4_to_f32(r.v[j]);
                 const bool ok = r.rok && cok[j];
+                if constexpr (X1) {
+                    const float v = ok ? r.f[j] : 0.f;
+                    dst[j] = f32x4{v, v, v, v};
+                } else {
+                f32x4 v = bf4_to_f32(r.v[j]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? clamp_act(fmaf(v[i], sc[i], sh[i]), lo, hi) : 0.f;
                 dst[j] = v;
+                }
             }
         };
         auto emit = [&](const GRow& gr, const f32x4 (&r0)[NCOL], const f32x4 (&r1)[NCOL], const f32x4 (&r2)[NCOL]) {
@@ -704,7 +734,7 @@ extern "C" int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, con
     int rc = check_dw(d, "dwconv_fwd");
     if (rc) return rc;
     DwP p;
-    p.bn_z = nullptr; p.bn_vec = nullptr; p.bn_act = 0;
+    p.bn_z = nullptr; p.bn_vec = nullptr; p.bn_act = 0; p.x1 = nullptr; p.x1_g = p.x1_n = 0;
     p.x = (const bf16_t*)x; p.w = w; p.in_scale = in_scale; p.in_shift = in_shift; p.y = (bf16_t*)y; p.stats = stats;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.pad = d->pad;
     p.act = d->act; p.accumulate = 0;
@@ -725,6 +755,7 @@ static int dw_bwd_data_launch(const adamml_conv_desc_t* d, const void* dz, const
     int rc = check_dw(d, "dwconv_bwd_data");
     if (rc) return rc;
     DwP p;
+    p.x1 = nullptr; p.x1_g = p.x1_n = 0;
     p.x = (const bf16_t*)dz; p.w = w; p.in_scale = nullptr; p.in_shift = nullptr; p.y = (bf16_t*)dx; p.stats = sums;
     p.bn_z = (const bf16_t*)bn_z; p.bn_vec = bn_vec; p.bn_act = bn_act;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.pad = d->pad;
@@ -813,6 +844,7 @@ extern "C" int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void*
     int rc = check_dw(d, "dwconv_bwd_weight");
     if (rc) return rc;
     DwWP p;
+    p.x1 = nullptr; p.x1_g = p.x1_n = 0;
     p.dz = (const bf16_t*)dz; p.x = (const bf16_t*)x; p.in_scale = in_scale; p.in_shift = in_shift; p.dw = dw;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.OH = d->OH; p.OW = d->OW; p.stride = d->stride; p.pad = d->pad; p.act = d->act;
     const size_t P = (size_t)d->N * d->OH * d->OW;
@@ -829,6 +861,79 @@ extern "C" int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void*
         return adamml_launch_split_reduce(p.ws, dw, (size_t)9 * p.C, groups * nblk, stream);
     }
     return adamml_check_launch("dwconv_bwd_weight");
+}
+
+// ---- 3x3 / stride-2 stem of a ONE-channel fp32 image (spectrogram): the depthwise walkers with the pixel broadcast over the output
+// channels.  d: N images per group of H x W, Cin ignored (1), Cout = C (multiple of 8, <= 64), KH = KW = 3, stride 2, pad 1.
+static int check_stem1(const adamml_conv_desc_t* d, const char* name) {
+    if (!d) return adamml_set_error(ADAMML_EINVAL, "%s: null desc", name);
+    if (d->KH != 3 || d->KW != 3 || d->stride != 2 || d->pad != 1 || d->Cout % 8 || d->Cout > 64 || d->Cout < 8)
+        return adamml_set_error(ADAMML_EUNSUPPORTED, "%s: 3x3 / stride 2 / pad 1 stem with 8..64 output channels (Cout=%d k=%d s=%d)", name, d->Cout,
+                                d->KH, d->stride);
+    return ADAMML_OK;
+}
+
+extern "C" int adamml_conv_stem1_supported(const adamml_conv_desc_t* d) {
+    return d && d->KH == 3 && d->KW == 3 && d->stride == 2 && d->pad == 1 && d->Cout % 8 == 0 && d->Cout >= 8 && d->Cout <= 64 ? 1 : 0;
+}
+
+extern "C" int adamml_conv_stem1_fwd(const adamml_conv_desc_t* d, const float* x, size_t image_stride, size_t group_stride, const float* w,
+                                     void* y, double* stats, hipStream_t stream) {
+    int rc = check_stem1(d, "conv_stem1_fwd");
+    if (rc) return rc;
+    if (!x || !w || !y) return adamml_set_error(ADAMML_EINVAL, "conv_stem1_fwd: null argument");
+    DwP p;
+    p.bn_z = nullptr; p.bn_vec = nullptr; p.bn_act = 0;
+    p.x = nullptr; p.x1 = x; p.x1_g = group_stride; p.x1_n = image_stride;
+    p.w = w; p.in_scale = nullptr; p.in_shift = nullptr; p.y = (bf16_t*)y; p.stats = stats;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cout; p.OH = d->OH; p.OW = d->OW; p.stride = 2; p.pad = 1;
+    p.act = 0; p.accumulate = 0;
+    p.P = (size_t)d->N * d->OH * d->OW;
+    if (!p.P) return ADAMML_OK;
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    p.gx = 0; p.gy = p.P * d->Cout; p.in_gstride = 0;
+    p.ppb = 0;
+    p.flip = 0;
+    const unsigned nblk = dw_walk_grid(p, 2, groups);
+    hipLaunchKernelGGL((dwconv_fwd_kernel<2, false, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
+    return adamml_check_launch("conv_stem1_fwd");
+}
+
+static adamml_conv_desc_t stem1_as_dw(const adamml_conv_desc_t* d) {
+    adamml_conv_desc_t e = *d;
+    e.Cin = d->Cout;
+    return e;
+}
+
+extern "C" size_t adamml_conv_stem1_bwd_weight_workspace(const adamml_conv_desc_t* d) {
+    if (!adamml_conv_stem1_supported(d)) return 0;
+    const adamml_conv_desc_t e = stem1_as_dw(d);
+    return adamml_dwconv_bwd_weight_workspace(&e);
+}
+
+extern "C" int adamml_conv_stem1_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const float* x, size_t image_stride, size_t group_stride,
+                                            float* dw, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    int rc = check_stem1(d, "conv_stem1_bwd_weight");
+    if (rc) return rc;
+    if (!dz || !x || !dw) return adamml_set_error(ADAMML_EINVAL, "conv_stem1_bwd_weight: null argument");
+    const adamml_conv_desc_t e = stem1_as_dw(d);
+    DwWP p;
+    p.dz = (const bf16_t*)dz; p.x = nullptr; p.x1 = x; p.x1_g = group_stride; p.x1_n = image_stride;
+    p.in_scale = nullptr; p.in_shift = nullptr; p.dw = dw;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cout; p.OH = d->OH; p.OW = d->OW; p.stride = 2; p.pad = 1; p.act = 0;
+    const size_t P = (size_t)d->N * d->OH * d->OW;
+    if (!P) return ADAMML_OK;
+    const int nblk = dw_wgrad_blocks(&e, &p.rows_per_thread, &p.nseg, &p.nrb);
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    p.gdz = P * d->Cout; p.gx = 0; p.in_gstride = 0;
+    p.ws = (workspace && workspace_bytes >= (size_t)groups * nblk * 9 * p.C * sizeof(float)) ? (float*)workspace : nullptr;
+    hipLaunchKernelGGL((dwconv_bwd_weight_kernel<2, true>), dim3(nblk, groups), dim3(NT), 9 * p.C * sizeof(float), stream, p);
+    if (p.ws) {
+        rc = adamml_check_launch("conv_stem1_bwd_weight");
+        if (rc) return rc;
+        return adamml_launch_split_reduce(p.ws, dw, (size_t)9 * p.C, groups * nblk, stream);
+    }
+    return adamml_check_launch("conv_stem1_bwd_weight");
 }
 
 extern "C" int adamml_gemm_f32(const float* a, int64_t a_sm, int64_t a_sk, const float* b, int64_t b_sn, int64_t b_sk, float* c,

@@ -1013,6 +1013,67 @@ __global__ __launch_bounds__(NT) void temporal_pool_residual_bwd_kernel(const bf
     block_channel_publish(sa, qa, m, smem, C, sumsa);
 }
 
+// The same backward when the forward fused the pool into the producing conv (adamml_conv_fwd_bn_add_tpool): the block output was never
+// stored; 2 bits per pooled element say which window tap held the first maximum (3: the maximum did not pass the ReLU).  One thread
+// owns the T frames of one (clip, pixel, 8-channel chunk) column: To gradient rows + To code words in, T gradient rows out.
+template <int T>
+__global__ __launch_bounds__(NT) void temporal_pool_code_bwd_kernel(const bf16_t* gy, const uint16_t* code, bf16_t* g2, double* sumsa,
+                                                                    size_t NBHW, int HW, int C, size_t cpb) {
+    constexpr int To = T / 2;
+    __shared__ float smem[2 * MAXC];
+    const int NB = (int)(NBHW / HW);
+    {
+        const size_t poff = (size_t)blockIdx.y * NB * To * HW * C;
+        gy += poff;
+        code += poff >> 3;
+        g2 += (size_t)blockIdx.y * NB * T * HW * C;
+        sumsa += (size_t)blockIdx.y * ADAMML_STAT_SLOTS * 2 * C;
+    }
+    ChanMap m(C, threadIdx.x);
+    float sa[8], qa[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sa[i] = qa[i] = 0.f;
+    const size_t cb = (size_t)blockIdx.x * cpb;
+    const size_t ce = cb + cpb < NBHW ? cb + cpb : NBHW;
+    if (m.active) {
+        const int c = m.chunk * 8;
+        const size_t fstride = (size_t)HW * C;
+        for (size_t col = cb + m.rslot; col < ce; col += m.rows_per_pass) {
+            const size_t nb = col / HW, hw = col - nb * HW;
+            const size_t base = (nb * T * HW + hw) * C + c, gbase = (nb * To * HW + hw) * C + c;
+            bf16x8 gv[To];
+            unsigned cw[To];
+#pragma unroll
+            for (int t = 0; t < To; ++t) {
+                gv[t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(gy + gbase + t * fstride));
+                cw[t] = code[(gbase + t * fstride) >> 3];
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                // frame t is tap (t - (2 to - 1)) of window to: tap 1 of window t / 2 for even t; for odd t, tap 2 of window (t - 1) / 2 and tap 0 of
+                // window (t + 1) / 2 (when that window exists)
+                f32x8 acc;
+                const int w0 = t >> 1, k0 = t - (2 * w0 - 1);
+                const f32x8 g0 = bf8_to_f32(gv[w0]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = ((cw[w0] >> (2 * i)) & 3u) == (unsigned)k0 ? g0[i] : 0.f;
+                if ((t & 1) && ((t + 1) >> 1) < To) {
+                    const int w1 = (t + 1) >> 1;
+                    const f32x8 g1 = bf8_to_f32(gv[w1 < To ? w1 : 0]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += ((cw[w1 < To ? w1 : 0] >> (2 * i)) & 3u) == 0u ? g1[i] : 0.f;
+                }
+                const bf16x8 gb = f32_to_bf8(acc);
+                __builtin_nontemporal_store(gb, reinterpret_cast<bf16x8*>(g2 + base + t * fstride));
+                const f32x8 gq = bf8_to_f32(gb);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sa[i] += gq[i];
+            }
+        }
+    }
+    block_channel_publish(sa, qa, m, smem, C, sumsa);
+}
+
 // ------------------------------------------------------------------------------------------------ fused classifier head
 // models/resnet.py:212-221 / models/sound_mobilenet_v2.py:155-158: AdaptiveAvgPool2d(1) -> Dropout -> Linear -> mean over the
 // remaining frames of a clip, one workgroup per clip.  feat (the pooled, dropout-masked features) is kept for the backward.
@@ -1616,6 +1677,24 @@ extern "C" int adamml_temporal_pool_bwd_res(const void* g_y, const void* out, in
     if (T == 8) LAUNCH_TPR(8); else if (T == 4) LAUNCH_TPR(4); else LAUNCH_TPR(2);
 #undef LAUNCH_TPR
     return adamml_check_launch("temporal_pool_bwd_res");
+}
+
+extern "C" int adamml_temporal_pool_bwd_code(const void* g_y, const uint16_t* code, void* g2, double* sums_a, int NB, int T, int HW, int C,
+                                             int groups, hipStream_t stream) {
+    CHECK_C(C, "temporal_pool_bwd_code");
+    if (!adamml_temporal_pool_bwd_res_supported(T, C, 0)) return adamml_set_error(ADAMML_EUNSUPPORTED, "temporal_pool_bwd_code: T=%d C=%d", T, C);
+    if (!g_y || !code || !g2 || !sums_a) return adamml_set_error(ADAMML_EINVAL, "temporal_pool_bwd_code: null argument");
+    const size_t cols = (size_t)NB * HW;
+    if (!cols) return ADAMML_OK;
+    if (groups < 1) groups = 1;
+    size_t cpb, nblk;
+    reduce_grid(cols, C, groups, &cpb, &nblk);
+#define LAUNCH_TPC(TV)                                                                                                          \
+    hipLaunchKernelGGL(temporal_pool_code_bwd_kernel<TV>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g_y, \
+                       code, (bf16_t*)g2, sums_a, cols, HW, C, cpb)
+    if (T == 8) LAUNCH_TPC(8); else if (T == 4) LAUNCH_TPC(4); else LAUNCH_TPC(2);
+#undef LAUNCH_TPC
+    return adamml_check_launch("temporal_pool_bwd_code");
 }
 
 extern "C" int adamml_gap_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, float* out, int N, int HW,

@@ -34,6 +34,8 @@ SIGNATURES = {
     "adamml_conv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "adamml_conv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
     "adamml_conv_fwd_bn_add": [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "adamml_conv_fwd_bn_add_tpool": [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "adamml_temporal_pool_bwd_code": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "adamml_gram_stats": [_P, _P, _P, _P, _I, _I, _I, _P],
     "adamml_gram_colsum": [_P, _P, _P, _I, _I, _P, _P, _Z, _I, _I, _P, _Z, _P],
     "adamml_conv_bwd_data_bn": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
@@ -56,6 +58,8 @@ SIGNATURES = {
     "adamml_conv_stem_fwd": [_DESC, _P, _P, _P, _P, _P],
     "adamml_conv_stem_bwd_weight": [_DESC, _P, _P, _P, _I, _P, _Z, _P],
     "adamml_dwconv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
+    "adamml_conv_stem1_fwd": [_DESC, _P, _Z, _Z, _P, _P, _P, _P],
+    "adamml_conv_stem1_bwd_weight": [_DESC, _P, _P, _Z, _Z, _P, _P, _Z, _P],
     "adamml_dwconv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
     "adamml_dwconv_bwd_data_bn": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
     "adamml_dwconv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _P, _Z, _P],
@@ -115,6 +119,10 @@ def load():
     lib.adamml_conv_stem_bwd_weight_workspace.restype = c_size_t
     lib.adamml_dwconv_bwd_weight_workspace.argtypes = [_DESC]
     lib.adamml_dwconv_bwd_weight_workspace.restype = c_size_t
+    lib.adamml_conv_stem1_bwd_weight_workspace.argtypes = [_DESC]
+    lib.adamml_conv_stem1_bwd_weight_workspace.restype = c_size_t
+    lib.adamml_conv_stem1_supported.argtypes = [_DESC]
+    lib.adamml_conv_stem1_supported.restype = c_int
     lib.adamml_gram_colsum_workspace.argtypes = [_Z, _I, _I]
     lib.adamml_gram_colsum_workspace.restype = c_size_t
     lib.adamml_gram_colsum_supported.argtypes = [_I]
@@ -127,6 +135,8 @@ def load():
     lib.adamml_conv_fused_input_supported.restype = c_int
     lib.adamml_conv_fwd_bn_add_supported.argtypes = [_DESC]
     lib.adamml_conv_fwd_bn_add_supported.restype = c_int
+    lib.adamml_conv_fwd_bn_add_tpool_supported.argtypes = [_DESC, _I, _I, _I]
+    lib.adamml_conv_fwd_bn_add_tpool_supported.restype = c_int
     lib.adamml_conv_bwd_data_dual_supported.argtypes = [_DESC]
     lib.adamml_conv_bwd_data_dual_supported.restype = c_int
     lib.adamml_conv_bwd_data_res_supported.argtypes = [_DESC]
@@ -164,7 +174,14 @@ def deterministic():
     return bool((_lib if _lib is not None else load()).adamml_get_deterministic())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (the raw accessor: no Stream object per launch -- the Python-side
+    cost of ~1000 launches per step is what bounds the step at the per-GPU batch of the reference recipe, B = 9)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -205,20 +222,25 @@ profiler = None
 next_meta = (0.0, 0.0)
 
 
+_fns = {}
+
+
 def call(name, *args):
     global next_meta
-    lib = load()
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
     if profiler is not None:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        rc = getattr(lib, name)(*args, _stream())
+        rc = fn(*args, _stream())
         e.record()
         profiler.records.append((name, s, e, next_meta))
         next_meta = (0.0, 0.0)
     else:
-        rc = getattr(lib, name)(*args, _stream())
+        rc = fn(*args, _stream())
     if rc != 0:
-        raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.adamml_last_error_string().decode()))
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, load().adamml_last_error_string().decode()))
 
 
 _wgrad_ws = {}
@@ -232,7 +254,7 @@ def wgrad_workspace(desc, cin_true, device, depthwise=False, stem=False):
         need = load().adamml_dwconv_bwd_weight_workspace(ctypes.byref(desc))
     else:
         need = load().adamml_conv_bwd_weight_workspace(ctypes.byref(desc), cin_true)
-    key = (device, torch.cuda.current_stream().cuda_stream)      # one scratch per stream: backbones run concurrently
+    key = (device, _stream())      # one scratch per stream: backbones run concurrently
     buf = _wgrad_ws.get(key)
     if buf is None or buf.numel() * 4 < need:
         buf = torch.empty(max(need // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
@@ -242,7 +264,7 @@ def wgrad_workspace(desc, cin_true, device, depthwise=False, stem=False):
 
 def scratch(nbytes, device):
     """The per-stream scratch buffer of wgrad_workspace(), grown to at least nbytes."""
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    key = (device, _stream())
     buf = _wgrad_ws.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty(max(nbytes // 4 + 1, 1 << 20), dtype=torch.float32, device=device)

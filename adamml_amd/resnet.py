@@ -11,7 +11,7 @@ import torch.nn as nn
 from . import hip
 from .backbone import HipBackbone, FlatBuffers, StockDDPAware
 from .common import MeanStdMixin
-from .runtime import (Lazy, conv_bn, conv_bn_add, conv_bn_add_supported, add_act, maxpool3x3s2, temporal_pool, head, clip_to_nhwc, pad8,
+from .runtime import (Lazy, conv_bn, conv_bn_add, conv_bn_add_supported, conv_bn_add_tpool_supported, add_act, maxpool3x3s2, temporal_pool, head, clip_to_nhwc, pad8,
                       ACT_NONE, ACT_RELU)
 
 __all__ = ['ResNet', 'resnet']
@@ -114,14 +114,19 @@ class ResNet(HipBackbone, MeanStdMixin, StockDDPAware):
                 # the add is reversed first): its data-gradient epilogue finishes the previous block's residual backward
                 o = conv_bn(rt, h, b._cs1, b.bn1, ACT_RELU, last_consumer=b._csd is None)
                 o = conv_bn(rt, o, b._cs2, b.bn2, ACT_RELU, sole_consumer=True)
+                pooled = False
                 if conv_bn_add_supported(rt, o, b._cs3, need_grad, idn):
-                    # conv3 + bn3 + residual add + ReLU in one kernel (statistics from the Gram matrix of conv3's input in train mode)
-                    h = conv_bn_add(rt, o, b._cs3, b.bn3, idn, ACT_RELU, idn_sole=b._csd is not None)
+                    # conv3 + bn3 + residual add + ReLU in one kernel (statistics from the Gram matrix of conv3's input in train mode);
+                    # behind the last block of a stage the temporal max-pool runs in that kernel's epilogue as well
+                    pooled = (b is layer[-1] and li < 3 and not self.without_t_stride and
+                              conv_bn_add_tpool_supported(rt, o, b._cs3, idn, ACT_RELU, frames, self.pooling_method))
+                    h = conv_bn_add(rt, o, b._cs3, b.bn3, idn, ACT_RELU, idn_sole=b._csd is not None, tpool=frames if pooled else 0)
                 else:
                     o = conv_bn(rt, o, b._cs3, b.bn3, ACT_NONE, sole_consumer=True)
                     h = add_act(rt, o, idn, ACT_RELU, idn_sole=b._csd is not None)
             if li < 3 and not self.without_t_stride:
-                h = temporal_pool(rt, h, frames, self.pooling_method, sole_consumer=True)
+                if not pooled:
+                    h = temporal_pool(rt, h, frames, self.pooling_method, sole_consumer=True)
                 frames = max(1, frames // 2)
         # GAP -> dropout -> fc -> mean over the remaining frames (models/resnet.py:212-221): one fused launch per direction
         out, head_backward = head(rt, h, self.fc, frames, self.dropout_p if self.training else 0.0, getattr(self, "_dropout_keep_mask", None))

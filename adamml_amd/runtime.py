@@ -475,6 +475,61 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
     return out
 
 
+STEM1_F32 = os.environ.get("ADAMML_STEM1_F32", "1") != "0"     # fp32 spectrogram straight into the MobileNetV2 stems (A/B aid)
+
+
+def stem1_supported(cs, x):
+    """x: the fp32 one-channel input [B, G, H, W] as the caller supplies it (models/adamml.py:49-53: G = segments).  True when the
+    3x3 / stride-2 stem described by cs can read it directly (adamml_conv_stem1_fwd)."""
+    if not STEM1_F32 or x.dtype != torch.float32 or x.dim() != 4 or cs.kh != 3 or cs.stride != 2 or cs.pad != 1 or cs.weight.shape[1] != 1:
+        return False
+    d = ConvDesc(x.shape[0], x.shape[2], x.shape[3], 8, (x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1, cs.cout, 3, 3, 2, 1, 1, 0, 0,
+                 x.shape[1], 0)
+    return bool(hip.load().adamml_conv_stem1_supported(byref(d)))
+
+
+def conv_stem1_bn(rt, x1, cs, bn, act):
+    """First conv of a MobileNetV2 on a one-channel fp32 image + train/eval BatchNorm + activation, as one lazy tensor: the kernel reads
+    the caller's [B, G, H, W] fp32 tensor (group = dim 1) -- no re-layout pass, no bf16 rounding of the spectrogram or of the 3x3
+    weights.  cs: a ConvState registered with depthwise=True (tap-major fp32 pack [9][Cout]).  The network input takes no gradient."""
+    B, G, H, W = x1.shape
+    if G != rt.groups:
+        raise RuntimeError("conv_stem1_bn: input has %d groups (dim 1), the call %d" % (G, rt.groups))
+    x1 = x1.contiguous()
+    C = cs.cout
+    d = ConvDesc(B, H, W, 8, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C, 3, 3, 2, 1, 1, 0, 0, G, 0)
+    dev = x1.device
+    y = torch.empty(G * B, d.OH, d.OW, C, dtype=torch.bfloat16, device=dev)
+    count = B * d.OH * d.OW
+    istr, gstr = G * H * W, H * W
+    hip.next_meta = (2.0 * count * G * C * 9, 4.0 * G * B * H * W + 2.0 * G * count * C)
+    if rt.training:
+        stats = rt.fwd_arena.take(G * 2 * C * STAT_SLOTS)
+        call("adamml_conv_stem1_fwd", byref(d), ptr(x1), istr, gstr, ptr(cs.w_fwd), ptr(y), ptr(stats))
+        vec = _bn_vectors(rt, bn, stats, count, C, dev)
+        rt.touched_bns.append(bn)
+        out = Lazy(y, vec[0, 0], vec[0, 1], act, gs=4 * C)
+        out.vec = vec
+    else:
+        call("adamml_conv_stem1_fwd", byref(d), ptr(x1), istr, gstr, ptr(cs.w_fwd), ptr(y), None)
+        vec = _bn_eval_vectors(rt, bn, C, dev)
+        out = Lazy(y, vec[0], vec[1], act)
+    if rt.capture is not None:
+        rt.capture.setdefault(id(cs.weight), []).append(y)
+    if rt.tape.need_grad:
+        def bwd():
+            if out.grad is None and out.pool_grad is None:
+                return
+            dz = _bn_backward(rt, out, y, vec, bn, act, count)
+            if cs.weight.requires_grad:
+                with _on_wgrad_stream(rt, (dz, x1)):
+                    need = hip.load().adamml_conv_stem1_bwd_weight_workspace(byref(d))
+                    ws = hip.scratch(need, dev)
+                    call("adamml_conv_stem1_bwd_weight", byref(d), ptr(dz), ptr(x1), istr, gstr, ptr(cs.weight.grad), ptr(ws), ws.numel() * 4)
+        rt.tape.record(bwd)
+    return out
+
+
 class _on_wgrad_stream:
     """Weight gradients are leaves of the backward dataflow: nothing downstream of a conv's backward needs dW, only dz.
     With rt.wgrad_stream set they are enqueued on that stream (after the kernels that produced their operands) and run
@@ -737,6 +792,7 @@ def _add_backward(rt, out, out_t, z, idn, act, idn_sole, P, C):
 
 
 FUSE_ADD = os.environ.get("ADAMML_FUSE_ADD", "1") != "0"     # conv3 + BatchNorm + residual add in one kernel (A/B aid)
+FUSE_TPOOL = os.environ.get("ADAMML_FUSE_TPOOL", "1") != "0"     # ... and the temporal max-pool behind the last block of a stage (A/B aid)
 
 
 def conv_bn_add_supported(rt, x, cs, need_grad, idn=None):
@@ -758,9 +814,21 @@ def conv_bn_add_supported(rt, x, cs, need_grad, idn=None):
     return (not need_grad) or (x.requires_grad and cs.weight.requires_grad)
 
 
-def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False):
+def conv_bn_add_tpool_supported(rt, x, cs, idn, act, frames, mode):
+    """Can conv_bn_add additionally run the temporal max-pool that is the block output's ONLY consumer in its epilogue
+    (adamml_conv_fwd_bn_add_tpool)?  The identity must be a plain tensor (the last block of a stage has no downsample branch)."""
+    if not FUSE_TPOOL or mode != "max" or idn is None or idn.scale is not None or frames not in (2, 4, 8) or x.shape[0] % (rt.groups * frames):
+        return False
+    d = cs.desc(x.shape, x.act, rt.groups, x.gs)
+    return bool(hip.load().adamml_conv_fwd_bn_add_tpool_supported(byref(d), frames, act, 1 if x.scale is not None else 0))
+
+
+def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False, tpool=0):
     """out = act(BatchNorm(conv1x1(x)) + value(idn)) in ONE kernel whose epilogue normalises, adds and activates
     (adamml_conv_fwd_bn_add): the raw conv output is never written to HBM nor re-read by a separate add pass.
+    tpool = T > 0 (caller checked conv_bn_add_tpool_supported): the block output feeds only TemporalPooling(max) over the T frames of a
+    clip (models/resnet.py:205-209); the epilogue pools too and the POOLED tensor is returned -- the full-rate block output, its mask and
+    the pool's pass never reach HBM; the backward routes the pooled gradient with the 2-bit codes the forward stored.
     Train mode: BatchNorm needs the batch statistics BEFORE that epilogue runs; for z = W a they follow from the Gram matrix
     G = a^T a and the column sums s of the (4x narrower) conv input: sum z = W s, sum z^2 = diag(W G W^T) (adamml_gram_stats).
     G and s are exactly the products the algebraic BatchNorm backward needs (_conv1x1_backward_alg), so computing them here
@@ -791,38 +859,66 @@ def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False):
         ev = _bn_eval_vectors(rt, bn, C, dev)
         vec = torch.zeros(G, 4, C, dtype=torch.float32, device=dev)
         vec[:, 0], vec[:, 1] = ev[0], ev[1]
-    out_t = torch.empty(G * d.N, d.OH, d.OW, C, dtype=torch.bfloat16, device=dev)
-    mask_t = torch.empty(G * d.N, d.OH, d.OW, C // 8, dtype=torch.uint8, device=dev) if (need_grad and act != ACT_NONE) else None
-    hip.next_meta = (2 * macs, in_b + (2 if idn is not None else 1) * out_b + w_b + (out_b / 16 if mask_t is not None else 0), kern, R_FUSED)
-    call("adamml_conv_fwd_bn_add", byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(vec),
-         ptr(idn.data) if idn is not None else None, ptr(idn.scale) if idn is not None else None,
-         ptr(idn.shift) if idn is not None else None, idn.gs if idn is not None else 0, act, ptr(out_t), ptr(mask_t))
+    if tpool:
+        to = tpool // 2
+        out_t = torch.empty(G * d.N // tpool * to, d.OH, d.OW, C, dtype=torch.bfloat16, device=dev)        # POOLED block output
+        code_t = torch.empty(G * d.N // tpool * to, d.OH, d.OW, C // 8, dtype=torch.int16, device=dev) if need_grad else None
+        mask_t = None
+        hip.next_meta = (2 * macs, in_b + 1.5 * out_b + w_b + (out_b / 16 if code_t is not None else 0), kern, R_FUSED)
+        call("adamml_conv_fwd_bn_add_tpool", byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(vec), ptr(idn.data), None, None, 0,
+             act, tpool, ptr(out_t), ptr(code_t))
+        full_shape = (G * d.N, d.OH, d.OW, C)
+    else:
+        out_t = torch.empty(G * d.N, d.OH, d.OW, C, dtype=torch.bfloat16, device=dev)
+        mask_t = torch.empty(G * d.N, d.OH, d.OW, C // 8, dtype=torch.uint8, device=dev) if (need_grad and act != ACT_NONE) else None
+        hip.next_meta = (2 * macs, in_b + (2 if idn is not None else 1) * out_b + w_b + (out_b / 16 if mask_t is not None else 0), kern, R_FUSED)
+        call("adamml_conv_fwd_bn_add", byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(vec),
+             ptr(idn.data) if idn is not None else None, ptr(idn.scale) if idn is not None else None,
+             ptr(idn.shift) if idn is not None else None, idn.gs if idn is not None else 0, act, ptr(out_t), ptr(mask_t))
+        full_shape = tuple(out_t.shape)
     out = Lazy(out_t)
     if not need_grad:
         return out
     # the raw conv output as a (never materialised) lazy tensor: the generic residual machinery only needs its BatchNorm vectors
     z = Lazy(None, vec[0, 0], vec[0, 1], ACT_NONE, gs=4 * C)
-    z._shape = out_t.shape
+    z._shape = torch.Size(full_shape)
     z.vec = vec
     z.alg = True
 
     def recompute():
-        y = torch.empty_like(out_t)
+        y = torch.empty(full_shape, dtype=torch.bfloat16, device=dev)
         call("adamml_conv_fwd", byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(y), None)
         return y
     z.recompute = recompute
     z.alg_in = (x, d)
-    out.res = (z, idn, act, idn_sole, mask_t)
+    # `blk` = the full-rate block output as the residual machinery sees it; with the pool fused it is never materialised (data None):
+    # its gradient arrives from the pool's backward below, already masked, with the sum(g') of bn3 accumulated (res_done)
+    blk = out if not tpool else Lazy(None)
+    if tpool:
+        blk._shape = torch.Size(full_shape)
+    blk.res = (z, idn, act, idn_sole, mask_t)
 
     def conv_bwd():
         if z.grad is None:
             return
         if z.pre_sums is None:
             z.ensure_data()              # the producer of g' could not fuse the BatchNorm-backward sums: the reduction pass reads z
-        y = z.data if z.data is not None else _Meta(out_t.shape, dev)
+        y = z.data if z.data is not None else _Meta(full_shape, dev)
         _conv1x1_backward_alg(rt, z, x, y, vec, bn, cs, d, count, True, macs, in_b, out_b, w_b, kern, Gm=Gm, sv=sv)
     rt.tape.record(conv_bwd)
-    rt.tape.record(lambda: _add_backward(rt, out, out_t, z, idn, act, idn_sole, count, C))
+    rt.tape.record(lambda: _add_backward(rt, blk, out_t if not tpool else None, z, idn, act, idn_sole, count, C))
+    if tpool:
+        def pool_bwd():
+            g, out.grad = out.grad, None
+            if g is None:
+                return
+            gx = torch.empty(full_shape, dtype=torch.bfloat16, device=dev)
+            sa = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS)
+            call("adamml_temporal_pool_bwd_code", ptr(g), ptr(code_t), ptr(gx), ptr(sa), d.N // tpool, tpool, d.OH * d.OW, C, G)
+            z.pre_sums, z.sums_partial = sa, True
+            blk.res_done = True
+            blk.grad = gx
+        rt.tape.record(pool_bwd)
     return out
 
 

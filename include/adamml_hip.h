@@ -75,6 +75,16 @@ int adamml_conv_fwd_bn_add_supported(const adamml_conv_desc_t* d);
 int adamml_conv_fwd_bn_add(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
                            const float* bn_vec, const void* idn, const float* id_scale, const float* id_shift, int id_gstride, int act,
                            void* out, uint8_t* mask_out, hipStream_t stream);
+/* The same conv + BatchNorm + add + ReLU when the block output feeds ONLY a temporal max-pool (the last block of a ResNet stage:
+ * models/resnet.py:205-209 -> models/common.py:4-33, kernel 3 / stride 2 / pad 1 over the `frames` frames of a clip; d->N = clips * frames
+ * per group): the epilogue pools over the frames and writes pooled [groups * clips * frames / 2][OH*OW][Cout] and, when `code` is given,
+ * 2 bits per pooled element (one uint16 per 8 channels: window tap 0..2 of the FIRST maximum, as nn.MaxPool3d, or 3 when the maximum
+ * is <= 0, i.e. the ReLU passes no gradient) for adamml_temporal_pool_bwd_code.  The full-rate block output, its activation mask and the
+ * pool's own pass (adamml_temporal_pool_fwd) never touch HBM.  frames in {2, 4, 8}, Cout % 128 == 0, act = ReLU, idn required. */
+int adamml_conv_fwd_bn_add_tpool_supported(const adamml_conv_desc_t* d, int frames, int act, int lazy_input);
+int adamml_conv_fwd_bn_add_tpool(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
+                                 const float* bn_vec, const void* idn, const float* id_scale, const float* id_shift, int id_gstride, int act,
+                                 int frames, void* pooled, uint16_t* code, hipStream_t stream);
 /* Train-mode BatchNorm statistics of z = W a without z: sums[g][co] = W[co,:] . s_g, sums[g][Cout+co] = W[co,:] G_g W[co,:]^T from
  * the Gram matrix G [groups][Cin][Cin] = a^T a and the column sums s [groups][Cin] of the conv INPUT (fp32), W = the bf16
  * forward pack [Cout][Cin].  sums [groups][2*Cout] doubles: pass to adamml_bn_finalize with nslots = 1. */
@@ -202,6 +212,19 @@ int adamml_dwconv_bwd_data_bn_supported(const adamml_conv_desc_t* d);
 int adamml_dwconv_bwd_data_bn(const adamml_conv_desc_t* d, const void* dz, const float* w_tapmajor, void* dx, const void* z_in,
                               const float* bn_vec, int act, double* sums, hipStream_t stream);
 size_t adamml_dwconv_bwd_weight_workspace(const adamml_conv_desc_t* d);
+/* 3x3 / stride-2 / pad-1 stem of a ONE-channel fp32 image -- the first conv of the Sound-MobileNetV2 and of the policy MobileNetV2 on a
+ * log-spectrogram (models/sound_mobilenet_v2.py:96, models/policy_net.py:108 with input_channels = 1) -- reading the caller's fp32 tensor
+ * directly: image n of BatchNorm group g at x + g * group_stride + n * image_stride floats (for the [B, S, H, W] input of
+ * models/adamml.py:49-53 with the segment as the group: image_stride = S*H*W, group_stride = H*W).  The spectrogram's range (-5 +- 3)
+ * costs bf16 two to three bits; here neither the input nor the 3x3 weights (w_tapmajor [9][Cout] fp32, adamml_pack_conv_weight mode 2)
+ * are rounded, only the output y [groups*N][OH][OW][Cout] bf16; stats as adamml_conv_fwd.  No data gradient (network input). */
+int adamml_conv_stem1_supported(const adamml_conv_desc_t* d);
+int adamml_conv_stem1_fwd(const adamml_conv_desc_t* d, const float* x, size_t image_stride, size_t group_stride, const float* w_tapmajor,
+                          void* y, double* stats, hipStream_t stream);
+size_t adamml_conv_stem1_bwd_weight_workspace(const adamml_conv_desc_t* d);
+int adamml_conv_stem1_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const float* x, size_t image_stride, size_t group_stride,
+                                 float* dw /* [Cout][3][3], overwritten when a workspace is given, else accumulated */, void* workspace,
+                                 size_t workspace_bytes, hipStream_t stream);
 int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
                              const float* in_shift, float* dw, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
@@ -282,6 +305,12 @@ int adamml_maxpool2d_bwd_bn_apply(const void* g_y, const uint8_t* idx, const voi
 int adamml_temporal_pool_bwd_res_supported(int T, int C, int mode);
 int adamml_temporal_pool_bwd_res(const void* g_y, const void* out, int act, void* g2, const void* z_a, const float* vec_a,
                                  double* sums_a, int NB, int T, int HW, int C, int groups, hipStream_t stream);
+/* The same backward from the 2-bit codes adamml_conv_fwd_bn_add_tpool stored instead of the block output:
+ *   g2[n,t] = sum over the windows `to` containing frame t of (code[n,to] == tap of t ? g_y[n,to] : 0)   (code 3 routes nothing),
+ * rounded to bf16 as the unfused pair does, and sums_a += sum g2 per channel and group (second moment 0: the algebraic BatchNorm
+ * backward derives it, adamml_alg_sumfix).  Bit-identical to adamml_temporal_pool_bwd_res(z_a = NULL) on the block output. */
+int adamml_temporal_pool_bwd_code(const void* g_y, const uint16_t* code, void* g2, double* sums_a, int NB, int T, int HW, int C, int groups,
+                                  hipStream_t stream);
 
 /* AdaptiveAvgPool2d(1) on a lazy input -> fp32 [groups*N,C] (resnet.py:212, sound_mobilenet_v2.py:157, policy_net.py:147) */
 int adamml_gap_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, float* out, int N, int HW,

@@ -1160,3 +1160,54 @@ def test_conv_bwd_data_res_prod_equals_res_then_grouped_product():
     # reference forms a = act(scale x + shift) with a separate multiply and add, the kernels with one fma -- a few bf16 roundings flip)
     e64, ekern = (Pf.double() - P64).abs().max().item() / scale, (Pf - P_ref).abs().max().item() / scale
     assert e64 <= 2e-4 and ekern <= 2e-5, (e64, ekern)
+
+
+@pytest.mark.parametrize("T,clips,H,Cin,Cout,G,lazy", [(8, 3, 56, 64, 256, 2, True), (4, 5, 28, 128, 512, 3, True), (2, 7, 14, 256, 1024, 2, True),
+                                                        (8, 2, 13, 64, 128, 1, False), (4, 3, 9, 64, 256, 2, False)])
+def test_conv_fwd_bn_add_tpool_equals_add_then_pool(T, clips, H, Cin, Cout, G, lazy):
+    """adamml_conv_fwd_bn_add_tpool (conv3 + bn3 + identity + ReLU + TemporalPooling(max) in ONE kernel: models/resnet.py:104-112 then
+    :205-209 -> models/common.py:4-33) == adamml_conv_fwd_bn_add followed by adamml_temporal_pool_fwd, BIT FOR BIT, at the three
+    stage boundaries' shapes (56^2 x 8 frames, 28^2 x 4: 784 pixels do not fill 32-pixel blocks, 14^2 x 2: 196 pixels / 64) and two odd
+    ones; and adamml_temporal_pool_bwd_code on the 2-bit codes it stores == adamml_temporal_pool_bwd_res(z = NULL) on the block
+    output it no longer stores: routed + masked gradient bit-identical, sum(g') equal."""
+    from adamml_amd.runtime import ACT_RELU
+    torch.manual_seed(T * 100 + H)
+    N = clips * T
+    Q = H * H
+    x = (torch.randn(G * N, H, H, Cin, device=DEV) * 1.5).to(torch.bfloat16)
+    xvec = torch.rand(G, 4, Cin, device=DEV) + 0.5
+    xvec[:, 1] -= 0.7
+    w = torch.randn(Cout, Cin, 1, 1, device=DEV) * (2.0 / Cin) ** 0.5
+    wp = pack(w, Cin, 0)
+    d = ConvDesc(N, H, H, Cin, H, H, Cout, 1, 1, 1, 0, 1, ACT_RELU if lazy else 0, 0, G, 4 * Cin if lazy else 0)
+    assert hip.load().adamml_conv_fwd_bn_add_tpool_supported(byref(d), T, ACT_RELU, 1 if lazy else 0)
+    vec = torch.rand(G, 4, Cout, device=DEV) * 0.5 + 0.25
+    vec[:, 1] = torch.randn(G, Cout, device=DEV) * 0.3 - 0.2
+    idn = torch.relu(torch.randn(G * N, H, H, Cout, device=DEV)).to(torch.bfloat16)
+    sc, sh = (ptr(xvec[0, 0]), ptr(xvec[0, 1])) if lazy else (None, None)
+    # reference: fused add, then the pool kernel
+    full = torch.empty(G * N, H, H, Cout, dtype=torch.bfloat16, device=DEV)
+    call("adamml_conv_fwd_bn_add", byref(d), ptr(x), ptr(wp), sc, sh, ptr(vec), ptr(idn), None, None, 0, ACT_RELU, ptr(full), None)
+    To = T // 2
+    ref = torch.empty(G * clips * To, H, H, Cout, dtype=torch.bfloat16, device=DEV)
+    call("adamml_temporal_pool_fwd", ptr(full), None, None, 0, 0, ptr(ref), clips, T, Q * Cout, Cout, 0, G)
+    pooled = torch.full_like(ref, float("nan"))
+    code = torch.full((G * clips * To, H, H, Cout // 8), -1, dtype=torch.int16, device=DEV)
+    call("adamml_conv_fwd_bn_add_tpool", byref(d), ptr(x), ptr(wp), sc, sh, ptr(vec), ptr(idn), None, None, 0, ACT_RELU, T, ptr(pooled), ptr(code))
+    assert torch.equal(pooled, ref)
+    # inference form: no codes
+    p2 = torch.empty_like(ref)
+    call("adamml_conv_fwd_bn_add_tpool", byref(d), ptr(x), ptr(wp), sc, sh, ptr(vec), ptr(idn), None, None, 0, ACT_RELU, T, ptr(p2), None)
+    assert torch.equal(p2, ref)
+    # backward from the codes vs the backward that re-reads the block output
+    g = torch.randn(G * clips * To, H, H, Cout, device=DEV).to(torch.bfloat16)
+    gx_ref, gx = torch.empty_like(full), torch.full_like(full, float("nan"))
+    s_ref = torch.zeros(G, STAT_SLOTS, 2 * Cout, dtype=torch.float64, device=DEV)
+    s = torch.zeros_like(s_ref)
+    call("adamml_temporal_pool_bwd_res", ptr(g), ptr(full), ACT_RELU, ptr(gx_ref), None, ptr(vec), ptr(s_ref), clips, T, Q, Cout, G)
+    call("adamml_temporal_pool_bwd_code", ptr(g), ptr(code), ptr(gx), ptr(s), clips, T, Q, Cout, G)
+    assert torch.equal(gx, gx_ref)
+    cs, cr = torch.empty(G, 2 * Cout, dtype=torch.float64, device=DEV), torch.empty(G, 2 * Cout, dtype=torch.float64, device=DEV)
+    call("adamml_stats_collapse", ptr(s), ptr(cs), Cout, G)
+    call("adamml_stats_collapse", ptr(s_ref), ptr(cr), Cout, G)
+    assert torch.allclose(cs[:, :Cout], cr[:, :Cout], rtol=1e-6, atol=1e-6 * cr.abs().max().item())

@@ -5,7 +5,16 @@ fused flat SGD (adamml_sgd_step) and must follow the reference's loss curve step
 gradients are USEFUL, not merely plausible: every step's gradients feed the next step's weights, BatchNorm running statistics and
 momentum buffers, so an error in any of them compounds over the 20 steps instead of averaging out.
 
-Measured on MI355X (deterministic mode, printed by the test): see the asserts' comments."""
+Two comparators:
+  (1) the fp32 reference curve itself.  Training in bf16 STORAGE converges slightly more slowly on this 4-video batch: the loss falls
+      3.49 -> 0.37 in the reference and 3.49 -> 0.43 here, a lag of about one step in twenty; relative to the (exponentially falling)
+      reference loss that is 0.1 % at step 0, 3 % at step 8, 18 % at step 19.
+  (2) the curve of the ORACLE WITH ITS bf16-STORAGE EMULATION (tests/golden/adamml_c2_traj_bf16emu.npz, tools/traj_study.py: every
+      tensor the HIP path keeps in bf16 is rounded, all arithmetic fp32, same 20 steps on the CPU).  That curve shows the same lag
+      (18.2 % at step 19): the distance in (1) is the price of bf16 activations / gradients, not of the kernels.  The HIP path must
+      follow THIS curve tightly at every step.
+Measured on MI355X (printed by the test): vs the emulation max 0.9 % / mean 0.3 % per step; vs the fp32 reference max 18.3 % (step
+19) / mean 6.0 %; final logits 5.1e-2 of scale vs the reference; ResNet fc weight update over the 20 steps 3.2e-2 rel L2."""
 import numpy as np
 import pytest
 import torch
@@ -57,16 +66,21 @@ def test_twenty_steps_follow_the_reference_loss_curve(deterministic):
     finally:
         hip.set_deterministic(False)
     ref = traj["loss"]
+    emu = load_golden("adamml_c2_traj_bf16emu")["loss"]
     rel = np.abs(np.array(losses) - ref) / ref
+    rel_emu = np.abs(np.array(losses) - emu) / emu
     e_final = rel_max(final_logits.cpu().numpy(), traj["final_logits"])
     e_fc = float(np.linalg.norm(model.main_net.nets[0].fc.weight.detach().cpu().numpy() - traj["final_fc_weight"]) /
                  np.linalg.norm(traj["final_fc_weight"] - synth.synth_state_dict(manifest(c), seed=1234)["main_net.nets.0.fc.weight"].numpy()))
     print("adamml_c2 trajectory (%s): loss HIP  %s" % ("deterministic" if deterministic else "default mode", np.round(losses, 4)))
     print("                               loss ref  %s" % np.round(ref, 4))
+    print("                          loss bf16-emu  %s" % np.round(emu, 4))
+    print("  per-step |loss - bf16-storage emulation| / emulation: max %.4f (step %d), mean %.4f" % (rel_emu.max(), int(rel_emu.argmax()), rel_emu.mean()))
     print("  per-step |loss - reference| / reference: max %.4f (step %d), mean %.4f; logits along the way max %.4f of scale; after the "
           "last update: logits %.4f of scale, ResNet fc weight UPDATE (w20 - w0) rel L2 %.4f" % (rel.max(), int(rel.argmax()), rel.mean(),
                                                                                                worst_logit, e_final, e_fc))
     assert losses[-1] < 0.2 * losses[0]                   # it trains: 3.49 -> 0.37 in the reference
-    assert rel.max() <= 0.05, (int(rel.argmax()), rel.max())
-    assert e_final <= 0.2, e_final
-    assert e_fc <= 0.25, e_fc
+    assert rel_emu.max() <= 0.02, (int(rel_emu.argmax()), rel_emu.max())          # the curve bf16 storage allows, every step
+    assert rel.max() <= 0.24 and rel.mean() <= 0.08, (int(rel.argmax()), rel.max(), rel.mean())      # 1.3 x measured vs the fp32 reference
+    assert e_final <= 0.07, e_final                       # 1.3 x measured (the one-step bound of test_parity_fullsize_gpu is 1e-1)
+    assert e_fc <= 0.05, e_fc
