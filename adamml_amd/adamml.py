@@ -15,6 +15,12 @@ from .runtime import clip_to_nhwc, clip_u8_to_nhwc, clip_u8_rgbdiff_to_nhwc, Syn
 __all__ = ['adamml']
 
 
+def _frames(t):
+    """Input of one backbone call over all segments: [S, B*F, H, W, C] bf16 -> [S*B*F, H, W, C] (group-major); the fp32 one-channel
+    form [B, S, H, W] (data_layer) is passed through as it is."""
+    return t if t.dtype == torch.float32 else t.flatten(0, 1)
+
+
 class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
 
     def __init__(self, policy_net, main_net, num_frames, num_segments, modality, rng_policy, rng_threshold, num_classes,
@@ -64,7 +70,12 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
                     x_ = torch.stack(x_.chunk(num_segments, dim=-1), dim=1).reshape(x_.size(0), -1, x_.size(-2),
                                                                                     x_.size(-1) // num_segments)
                 c = x_.size(1) // num_segments
-                t = clip_to_nhwc(x_, num_segments, 1, c)
+                if c == 1 and self._sound_f32_ok(idx, x_):
+                    # one-channel spectrograms go to the MobileNetV2 stems AS THEY ARE: [B, S, H, W] fp32, segment = BatchNorm group
+                    # (runtime.conv_stem1_bn) -- no re-layout pass, and the -5 +- 3 log-power range is not rounded to bf16
+                    t = x_.float().contiguous()
+                else:
+                    t = clip_to_nhwc(x_, num_segments, 1, c)
                 p_x.append(t)
                 m_x.append(t)
                 continue
@@ -91,6 +102,15 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
             if idx in self.m_data_idx:
                 m_x.append(clip_to_nhwc(x_, num_segments, f, c, cpad=self._main_cpad(m, x_.size(-2), x_.size(-1))))
         return p_x, m_x, num_segments
+
+    def _sound_f32_ok(self, idx, x_):
+        """Every consumer of modality `idx` (its main net, its policy backbone) reads a [B, S, H, W] fp32 tensor directly."""
+        nets = []
+        if idx in self.m_data_idx:
+            nets.append(self.main_net.nets[self.m_data_idx.index(idx)])
+        if idx in self.p_data_idx and hasattr(self.policy_net, "joint_net"):
+            nets.append(self.policy_net.joint_net.nets[self.p_data_idx.index(idx)])
+        return bool(nets) and all(hasattr(n, "accepts_f32") and n.accepts_f32(x_) for n in nets)
 
     def forward(self, x, num_segments=None, gumbel_exponential=None):
         """x: list over modality of [N, S*F*C, H, W] fp32 GPU tensors.  Returns (logits [N, classes], decisions [N,S,M]).
@@ -138,7 +158,7 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
             # side-stream nets' exchanges do not queue behind all of the ResNet's (interleave.py)
             jobs, calls = [], []
             for m_i in range(self.num_modality):
-                net, xin = self.main_net.nets[m_i], m_x[m_i].flatten(0, 1)
+                net, xin = self.main_net.nets[m_i], _frames(m_x[m_i])
                 st = side if self.main_net.modality[m_i] == 'sound' else main
                 jobs.append(((lambda net=net, xin=xin: net.run_raw(xin, S)), st))
                 calls.append((net, xin, st))
@@ -149,7 +169,7 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
                 for ps in pstreams[1:]:
                     ps.wait_stream(main)
                 for k, net in enumerate(self.policy_net.joint_net.nets):
-                    xin = p_x[k].flatten(0, 1)
+                    xin = _frames(p_x[k])
                     jobs.append(((lambda net=net, xin=xin: net.run_raw(xin, S)), pstreams[k]))
                     calls.append((net, xin, pstreams[k]))
             raw = interleave.run_interleaved(jobs, dev, phase="fwd")
@@ -177,7 +197,7 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
                 t.record_stream(main)
             final_logits = self.main_net.fuse_segments(stacked, decisions, num_segments)
             return final_logits, decisions.permute((2, 0, 1))
-        stacked = self.main_net.backbone_logits([m_x[m_i].flatten(0, 1) for m_i in range(self.num_modality)], side, groups=S)
+        stacked = self.main_net.backbone_logits([_frames(m_x[m_i]) for m_i in range(self.num_modality)], side, groups=S)
         if not self.rng_policy:
             if side is not None:
                 with torch.cuda.stream(pside):
@@ -211,15 +231,19 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
         stacked, ran = [], []
         for m_i in range(self.num_modality):
             net = self.main_net.nets[m_i]
-            frames = m_x[m_i].flatten(0, 1)                                   # [S*B*F, H, W, C], clips contiguous
-            fpc = frames.shape[0] // (S * B)
+            raw32 = m_x[m_i].dtype == torch.float32                           # one-channel fp32 input [B, S, H, W] (data_layer)
+            frames = _frames(m_x[m_i])                                        # [S*B*F, H, W, C], clips contiguous
+            fpc = 1 if raw32 else frames.shape[0] // (S * B)
             idx = (decisions[:, m_i, :].reshape(-1) > 0.5).nonzero().flatten()      # host sync: the launch sizes depend on it
             ncls = net.fc.out_features if hasattr(net, "fc") else net.classifier[1].out_features
             out = torch.zeros(S * B, ncls, dtype=torch.float32, device=dev)
             if idx.numel() == S * B:
-                out = net.forward_nhwc(frames, 1)
+                out = net.forward_nhwc(frames, S if raw32 else 1)             # (eval BatchNorm: the grouping is immaterial)
             elif idx.numel() > 0:
-                sel = frames.view(S * B, fpc, *frames.shape[1:]).index_select(0, idx).flatten(0, 1)
+                if raw32:
+                    sel = frames.transpose(0, 1).reshape(S * B, 1, *frames.shape[2:]).index_select(0, idx)      # [n, 1, H, W]: one group
+                else:
+                    sel = frames.view(S * B, fpc, *frames.shape[1:]).index_select(0, idx).flatten(0, 1)
                 out.index_copy_(0, idx, net.forward_nhwc(sel, 1))
             stacked.append(out)
             ran.append(int(idx.numel()))

@@ -186,6 +186,16 @@ class StockDDPAware:
             f = f.f_back
 
 
+def _check_groups(x, groups):
+    """x: NHWC bf16 frames [groups * N, H, W, C] (group-major), or -- one-channel fp32 input of the MobileNetV2 stems, handed over as the
+    caller has it -- [B, groups, H, W] fp32 (group = dim 1, runtime.conv_stem1_bn)."""
+    if x.dtype == torch.float32:
+        if x.dim() != 4 or x.shape[1] != groups:
+            raise RuntimeError("backbone call: fp32 input must be [B, groups, H, W] (got %s for %d groups)" % (tuple(x.shape), groups))
+    elif groups < 1 or x.shape[0] % groups:
+        raise RuntimeError("backbone call: %d images do not split into %d groups" % (x.shape[0], groups))
+
+
 class HipBackbone(nn.Module):
     """Base of ResNet / MobileNetV2 backbones executed by libadamml_hip."""
 
@@ -262,8 +272,7 @@ class HipBackbone(nn.Module):
         of all groups stacked the same way.  precomputed: the (output, tape) of run_raw() on the same x -- the launch sequence has
         already been issued (as a coroutine of interleave.run_interleaved) and is only attached to autograd here."""
         hip.require_gpu(x)
-        if groups < 1 or x.shape[0] % groups:
-            raise RuntimeError("backbone call: %d images do not split into %d groups" % (x.shape[0], groups))
+        _check_groups(x, groups)
         need_grad = torch.is_grad_enabled() and self._trainable()
         self._adopt_sync_batchnorm()
         if self._anchor is None or self._anchor.device != x.device:
@@ -280,8 +289,7 @@ class HipBackbone(nn.Module):
         """The launch sequence of call() WITHOUT the operator around it: returns (output, tape) for call(x, groups, precomputed=...).
         What a job of interleave.run_interleaved runs: a coroutine must not park inside a torch dispatcher call."""
         hip.require_gpu(x)
-        if groups < 1 or x.shape[0] % groups:
-            raise RuntimeError("backbone call: %d images do not split into %d groups" % (x.shape[0], groups))
+        _check_groups(x, groups)
         self._adopt_sync_batchnorm()
         return self._run(x, groups, need_grad=torch.is_grad_enabled() and self._trainable())
 

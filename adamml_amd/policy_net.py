@@ -9,7 +9,7 @@ from .backbone import HipBackbone
 from .common import MeanStdMixin
 from .functional import hip_linear, policy_head, gumbel_gate
 from .mobilenet_common import BlockPlan, run_blocks
-from .runtime import Lazy, conv_bn, gap, ACT_NONE, ACT_RELU, ACT_RELU6
+from .runtime import Lazy, conv_bn, conv_stem1_bn, stem1_supported, gap, ACT_NONE, ACT_RELU, ACT_RELU6
 
 _CFGS = [[1, 16, 1, 1], [6, 24, 2, 2], [6, 32, 3, 2], [6, 64, 4, 2], [6, 96, 3, 1], [6, 160, 3, 2], [6, 320, 1, 1]]
 
@@ -69,6 +69,8 @@ class MobileNetV2(HipBackbone, MeanStdMixin):
 
         f0 = self.features[0]
         self._stem = (self._register_conv(f0[0]), f0[1])
+        # one-channel input (spectrogram): the stem can read the fp32 tensor directly (runtime.conv_stem1_bn)
+        self._stem1 = self._register_conv(f0[0], depthwise=True) if input_channels == 1 else None
         self._plans = []
         for blk in self.features[1:]:
             seq = blk.conv
@@ -101,7 +103,10 @@ class MobileNetV2(HipBackbone, MeanStdMixin):
         tape = rt.begin_forward(x.device, self.training, need_grad, groups)
         self._repack(need_grad)
         self._mark_grads_ready_after(tape, [self])        # one gradient bucket: exchanged as soon as this net's backward is enqueued
-        h = conv_bn(rt, Lazy(x, requires_grad=False), self._stem[0], self._stem[1], ACT_RELU6)
+        if x.dtype == torch.float32:
+            h = conv_stem1_bn(rt, x, self._stem1, self._stem[1], ACT_RELU6)
+        else:
+            h = conv_bn(rt, Lazy(x, requires_grad=False), self._stem[0], self._stem[1], ACT_RELU6)
         h = run_blocks(rt, h, self._plans)
         h = conv_bn(rt, h, self._last[0], self._last[1], ACT_RELU6)
         feat, push = gap(rt, h)
@@ -111,7 +116,12 @@ class MobileNetV2(HipBackbone, MeanStdMixin):
         return feat, tape
 
     def out_shape(self, x_shape, groups):
-        return (x_shape[0] // self.orig_num_frames * self.out_frames, self.last_channel)
+        n = x_shape[0] * x_shape[1] if (len(x_shape) == 4 and x_shape[1] == groups and x_shape[-1] != 8 and self._stem1 is not None) else x_shape[0]
+        return (n // self.orig_num_frames * self.out_frames, self.last_channel)
+
+    def accepts_f32(self, x):
+        """Can the stem read this [B, G, H, W] one-channel-per-group fp32 tensor directly?"""
+        return self._stem1 is not None and x.dim() == 4 and stem1_supported(self._stem1, x)
 
     def feature_extraction(self, frames_nhwc, groups=1):
         return self.call(frames_nhwc, groups)
@@ -189,7 +199,7 @@ class PolicyNet(nn.Module):
         """Joint features of ALL segments in one batched pass (per-segment BatchNorm statistics are kept by the
         `groups` mechanism of the backbones; the joint FCs have no batch statistics).  -> list of S tensors [B, 2048]."""
         S = x[0].shape[0]
-        out = self.joint_net.features([x[m_i].flatten(0, 1) for m_i in range(self.num_modality)], groups=S)
+        out = self.joint_net.features([(x[m_i] if x[m_i].dtype == torch.float32 else x[m_i].flatten(0, 1)) for m_i in range(self.num_modality)], groups=S)
         return list(out.view(S, -1, out.shape[-1]).unbind(0))
 
     def forward(self, x, gumbel_exponential=None):

@@ -7,7 +7,7 @@ from . import hip
 from .backbone import HipBackbone, FlatBuffers, StockDDPAware
 from .common import MeanStdMixin
 from .mobilenet_common import BlockPlan, run_blocks
-from .runtime import Lazy, conv_bn, head, clip_to_nhwc, ACT_RELU6
+from .runtime import Lazy, conv_bn, conv_stem1_bn, stem1_supported, head, clip_to_nhwc, ACT_RELU6
 
 __all__ = ['MobileNetV2', 'sound_mobilenet_v2']
 
@@ -80,6 +80,8 @@ class MobileNetV2(HipBackbone, MeanStdMixin, StockDDPAware):
 
         f0 = self.features[0]
         self._stem = (self._register_conv(f0[0]), f0[1])
+        # one-channel input: the stem can read the fp32 spectrogram directly (runtime.conv_stem1_bn; tap-major fp32 weight pack)
+        self._stem1 = self._register_conv(f0[0], depthwise=True) if input_channels == 1 else None
         self._plans = []
         for blk in self.features[1:-1]:
             seq = list(blk.conv)
@@ -96,12 +98,15 @@ class MobileNetV2(HipBackbone, MeanStdMixin, StockDDPAware):
         self.flat_owner = FlatBuffers(self)
 
     def _run(self, x, groups, need_grad):
-        """x: [G*B, H, W, 8] bf16 (1 real channel).  Returns fp32 logits [G*B, num_classes]."""
+        """x: [G*B, H, W, 8] bf16 (1 real channel), or the fp32 spectrograms [B, G, H, W] themselves.  Returns fp32 logits [G*B, num_classes]."""
         rt = self.rt
         tape = rt.begin_forward(x.device, self.training, need_grad, groups)
         self._repack(need_grad)
         self._mark_grads_ready_after(tape, [self])        # one gradient bucket: exchanged as soon as this net's backward is enqueued
-        h = conv_bn(rt, Lazy(x, requires_grad=False), self._stem[0], self._stem[1], ACT_RELU6)
+        if x.dtype == torch.float32:
+            h = conv_stem1_bn(rt, x, self._stem1, self._stem[1], ACT_RELU6)
+        else:
+            h = conv_bn(rt, Lazy(x, requires_grad=False), self._stem[0], self._stem[1], ACT_RELU6)
         h = run_blocks(rt, h, self._plans)
         h = conv_bn(rt, h, self._last[0], self._last[1], ACT_RELU6)
         # GAP -> dropout -> classifier (models/sound_mobilenet_v2.py:155-158): one fused launch per direction
@@ -118,14 +123,20 @@ class MobileNetV2(HipBackbone, MeanStdMixin, StockDDPAware):
         self.flat_owner.ensure(x.device)
         if self.training and torch.is_grad_enabled():
             self.flat_owner.ensure_grads()
+        if self.accepts_f32(x):
+            return self.call(x.float().contiguous(), 1)           # [B, 1, H, W]: one BatchNorm group
         xs = clip_to_nhwc(x, 1, 1, x.shape[1])[0]
         return self.call(xs)
+
+    def accepts_f32(self, x):
+        """Can the stem read this [B, G, H, W] one-channel-per-group fp32 tensor directly?"""
+        return self._stem1 is not None and x.dim() == 4 and stem1_supported(self._stem1, x.float() if x.dtype != torch.float32 else x)
 
     def forward_nhwc(self, frames_nhwc, groups=1):
         return self.call(frames_nhwc, groups)
 
     def out_shape(self, x_shape, groups):
-        return (x_shape[0], self.classifier[1].out_features)
+        return (x_shape[0] * x_shape[1] if len(x_shape) == 4 and x_shape[1] == groups and x_shape[-1] != 8 else x_shape[0], self.classifier[1].out_features)
 
 
 def sound_mobilenet_v2(num_classes, input_channels, dropout, imagenet_pretrained=True, **kwargs):

@@ -223,7 +223,7 @@ int adamml_conv_stem1_fwd(const adamml_conv_desc_t* d, const float* x, size_t im
                           void* y, double* stats, hipStream_t stream);
 size_t adamml_conv_stem1_bwd_weight_workspace(const adamml_conv_desc_t* d);
 int adamml_conv_stem1_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const float* x, size_t image_stride, size_t group_stride,
-                                 float* dw /* [Cout][3][3], overwritten when a workspace is given, else accumulated */, void* workspace,
+                                 float* dw /* [Cout][3][3], accumulated */, void* workspace,
                                  size_t workspace_bytes, hipStream_t stream);
 int adamml_dwconv_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale,
                              const float* in_shift, float* dw, void* workspace, size_t workspace_bytes, hipStream_t stream);

@@ -1211,3 +1211,37 @@ def test_conv_fwd_bn_add_tpool_equals_add_then_pool(T, clips, H, Cin, Cout, G, l
     call("adamml_stats_collapse", ptr(s), ptr(cs), Cout, G)
     call("adamml_stats_collapse", ptr(s_ref), ptr(cr), Cout, G)
     assert torch.allclose(cs[:, :Cout], cr[:, :Cout], rtol=1e-6, atol=1e-6 * cr.abs().max().item())
+
+
+@pytest.mark.parametrize("B,G,H,W,C", [(3, 2, 64, 64, 32), (2, 5, 96, 80, 32), (1, 1, 33, 47, 32), (4, 3, 256, 256, 32)])
+def test_conv_stem1_reads_the_fp32_spectrogram_directly(B, G, H, W, C):
+    """adamml_conv_stem1_fwd / adamml_conv_stem1_bwd_weight: the 3x3 / stride-2 / pad-1 stem of the MobileNetV2s on a one-channel input
+    (models/sound_mobilenet_v2.py:96; models/policy_net.py:108 with input_channels = 1) reading the caller's [B, G, H, W] fp32 tensor
+    (group = segment, models/adamml.py:49-53) -- against F.conv2d in fp32 on the UNROUNDED input and weights (only the output is bf16),
+    statistics of the stored values, weight gradient against torch autograd; odd sizes and the full 256^2."""
+    torch.manual_seed(B * 10 + G)
+    x = torch.randn(B, G, H, W, device=DEV) * 3.0 - 5.0
+    w = torch.randn(C, 1, 3, 3, device=DEV) * 0.4
+    wp = pack(w, 1, 2)                                                 # tap-major fp32 [9][C]
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    d = ConvDesc(B, H, W, 8, OH, OW, C, 3, 3, 2, 1, 1, 0, 0, G, 0)
+    assert hip.load().adamml_conv_stem1_supported(byref(d))
+    y = torch.empty(G * B, OH, OW, C, dtype=torch.bfloat16, device=DEV)
+    st = torch.zeros(G, STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
+    call("adamml_conv_stem1_fwd", byref(d), ptr(x), G * H * W, H * W, ptr(wp), ptr(y), ptr(st))
+    xg = x.transpose(0, 1).reshape(G * B, 1, H, W)                     # group-major images
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(xg, wr, stride=2, padding=1)
+    got = nchw(y)
+    assert (got - ref.detach()).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-6       # one bf16 rounding of the output
+    cs = torch.empty(G, 2 * C, dtype=torch.float64, device=DEV)
+    call("adamml_stats_collapse", ptr(st), ptr(cs), C, G)
+    yq = y.double().view(G, -1, C)
+    assert torch.allclose(cs[:, :C], yq.sum(1), rtol=1e-6, atol=1e-3) and torch.allclose(cs[:, C:], (yq * yq).sum(1), rtol=1e-6, atol=1e-3)
+    dz = (torch.randn(G * B, OH, OW, C, device=DEV) * 0.1).to(torch.bfloat16)
+    ref.backward(nchw(dz))
+    dw = torch.zeros(C, 1, 3, 3, device=DEV)
+    need = hip.load().adamml_conv_stem1_bwd_weight_workspace(byref(d))
+    ws = torch.empty(need // 4 + 1, device=DEV)
+    call("adamml_conv_stem1_bwd_weight", byref(d), ptr(dz), ptr(x), G * H * W, H * W, ptr(dw), ptr(ws), ws.numel() * 4)
+    assert (dw - wr.grad).abs().max().item() <= 2e-4 * wr.grad.abs().max().item()

@@ -3,6 +3,7 @@ forward+backward for the trainable main nets -- shows how the step's device time
 import sys, time, torch
 sys.path.insert(0, ".")
 from adamml_amd import adamml, synth, hip
+from adamml_amd.adamml import _frames
 from adamml_amd.runtime import clip_to_nhwc
 B, S = int(sys.argv[1]) if len(sys.argv) > 1 else 72, 5
 dev = torch.device("cuda")
@@ -41,17 +42,17 @@ def fwd(net, x):
 
 
 res, sound = m.main_net.nets
-print("ResNet-50 main      fwd+bwd %.1f ms" % timed(fwd_bwd(res, m_x[0].flatten(0, 1))))
-print("Sound-MBv2 main     fwd+bwd %.1f ms" % timed(fwd_bwd(sound, m_x[1].flatten(0, 1))))
+print("ResNet-50 main      fwd+bwd %.1f ms" % timed(fwd_bwd(res, _frames(m_x[0]))))
+print("Sound-MBv2 main     fwd+bwd %.1f ms" % timed(fwd_bwd(sound, _frames(m_x[1]))))
 m.freeze_policy_net()
 pr, ps = m.policy_net.joint_net.nets
 for net in (pr, ps):
     net.train()
-print("policy MBv2 rgb     fwd     %.1f ms" % timed(fwd(pr, p_x[0].flatten(0, 1))))
-print("policy MBv2 sound   fwd     %.1f ms" % timed(fwd(ps, p_x[1].flatten(0, 1))))
+print("policy MBv2 rgb     fwd     %.1f ms" % timed(fwd(pr, _frames(p_x[0]))))
+print("policy MBv2 sound   fwd     %.1f ms" % timed(fwd(ps, _frames(p_x[1]))))
 
 if len(sys.argv) > 2 and sys.argv[2] == "profile-sound":
-    f = fwd_bwd(sound, m_x[1].flatten(0, 1))
+    f = fwd_bwd(sound, _frames(m_x[1]))
     f(); torch.cuda.synchronize()
     hip.profiler = hip.LaunchProfiler()
     f()

@@ -4,6 +4,7 @@ above the roofs sits.  Usage: python tools/launch_table.py [resnet|sound] [B] [t
 import sys, torch
 sys.path.insert(0, ".")
 from adamml_amd import adamml, synth, hip
+from adamml_amd.adamml import _frames
 which = sys.argv[1] if len(sys.argv) > 1 else "resnet"
 B, S = int(sys.argv[2]) if len(sys.argv) > 2 else 72, 5
 TOP = int(sys.argv[3]) if len(sys.argv) > 3 else 45
@@ -23,14 +24,14 @@ os.environ["ADAMML_WGRAD_STREAM"] = "0"
 if which in ("policy_rgb", "policy_sound"):                # frozen policy backbones of the main-net stage: forward only, train-mode BatchNorm
     m.freeze_policy_net()
     pr, ps = m.policy_net.joint_net.nets
-    net, x = (pr, p_x[0].flatten(0, 1)) if which == "policy_rgb" else (ps, p_x[1].flatten(0, 1))
+    net, x = (pr, _frames(p_x[0])) if which == "policy_rgb" else (ps, _frames(p_x[1]))
     net.train()
 
     def step():
         with torch.no_grad():
             net.call(x, S)
 else:
-    net, x = (res, m_x[0].flatten(0, 1)) if which == "resnet" else (sound, m_x[1].flatten(0, 1))
+    net, x = (res, _frames(m_x[0])) if which == "resnet" else (sound, _frames(m_x[1]))
 
     def step():
         out = net.forward_nhwc(x, S)
