@@ -70,4 +70,4 @@ def run_smoke():
     e2 = np.abs(logits.detach().cpu().numpy() - g2).max() / np.abs(g2).max()
     ep = np.abs(model.last_policy_logits.detach().cpu().numpy() - gold2["train_main.policy_logits"]).max() / np.abs(gold2["train_main.policy_logits"]).max()
     print("smoke: full size (B=4, S=5, 224^2 / 256^2) logits |HIP-reference| %.4f, policy logits %.4f of scale | decisions match" % (e2, ep))
-    assert e2 <= 1e-1 and ep <= 1e-1
+    assert e2 <= 5e-2 and ep <= 7.5e-2            # 1.3 x the measured 3.9e-2 / 5.8e-2 (tests/test_parity_fullsize_gpu.py)
