@@ -81,7 +81,11 @@ __device__ __forceinline__ void fold16_to_cs(const f32x8& esum, const f32x8& esq
 
 // BNZ: the data-gradient form (activation mask + BatchNorm-backward sums in the epilogue, p.bn_z != null) is its own instantiation, so
 // that its epilogue -- which keeps a batch of z rows in flight -- does not weigh on the register allocation of the forward kernel.
-template <bool BNZ>
+// PP = patch pixel pitch in bytes.  144 (9 x 16 B) lets 8 output rows of a 56-wide image fit beside the weights, but an odd pitch in
+// 16-byte units cannot be conflict-free for the gfx950 ds_read_b128 service groups (rows {0-3, 12-15} at chunk c with rows {4-11} at
+// chunk c + 1: for ANY pixel order one of the two complementary groups collides -- the groups cover all 16 residues and one half is
+// shifted by one).  160 (10 units) is conflict-free for every pixel offset; it costs one output row per strip (7 instead of 8 at W = 56).
+template <bool BNZ, int PP>
 __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_w = smem;                                              // [64][WROW3]
@@ -92,7 +96,10 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
 
     for (int e = tid; e < C64 * (KT3 / 8); e += NT3) {
         const int co = e / (KT3 / 8), ch = e - co * (KT3 / 8);
-        *reinterpret_cast<bf16x8*>(s_w + co * WROW3 + ch * 16) = *reinterpret_cast<const bf16x8*>(p.w + (size_t)co * KT3 + ch * 8);
+        // 16-byte chunk ch of row co sits at position ch ^ wswz(co): with the 73-chunk row pitch the 16 lanes of a gfx950 ds_read_b128 service
+        // group (rows {0-3, 12-15} at chunk c and rows {4-11} at chunk c + 1, or the complement) then touch 16 distinct 16-byte bank units;
+        // unswizzled they touched 9 (2-way conflicts on every weight fragment read: SQ_LDS_BANK_CONFLICT 34-41 % of the LDS cycles, round 2)
+        *reinterpret_cast<bf16x8*>(s_w + co * WROW3 + (ch ^ (((co >> 2) ^ (co >> 3)) & 1)) * 16) = *reinterpret_cast<const bf16x8*>(p.w + (size_t)co * KT3 + ch * 8);
     }
     if (tid < 128) cs[tid] = 0.f;
 
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
                         for (int i = 0; i < 8; ++i) f[i] = clamp_act(fmaf(f[i], sc[i], sh[i]), lo, hi);
                         v = f32_to_bf8(f);
                     }
-                    *reinterpret_cast<bf16x8*>(s_patch + (e >> 3) * PPIX + ech * 16) = v;
+                    *reinterpret_cast<bf16x8*>(s_patch + (e >> 3) * PP + ech * 16) = v;
                 }
             }
         }
@@ -193,16 +200,16 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
             int q = (wave + 8 * j) * 16 + li;
             if (q >= npx) q = 0;
             const int r = q / p.W, c = q - r * p.W;
-            pixoff[j] = (r * p.PW + c) * PPIX + lg * 16;
+            pixoff[j] = (r * p.PW + c) * PP + lg * 16;
         }
-        const char* wbase = s_w + li * WROW3 + lg * 16;
+        const char* wbase = s_w + li * WROW3 + (lg ^ (((li >> 2) ^ (li >> 3)) & 1)) * 16;
         const bool last_live = (wave + 24) * 16 < npx;
 #pragma unroll 1
         for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk) {                 // (kw, 32-channel half)
                 const int ks = kh * 6 + kk;
-                const int aoff = (kh * p.PW + (kk >> 1)) * PPIX + (kk & 1) * 64;
+                const int aoff = (kh * p.PW + (kk >> 1)) * PP + (kk & 1) * 64;
                 bf16x8 fw[4];
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) fw[ct] = *reinterpret_cast<const bf16x8*>(wbase + ct * 16 * WROW3 + ks * 64);
@@ -518,20 +525,35 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_wgrad_kernel(C3WP p) {
 }  // namespace
 
 // d: the FORWARD-shaped descriptor of the conv that is executed (for a data gradient: H/W of dz == H/W of dx).
+static int c3_pitch() {
+    static const int pp = getenv("ADAMML_C64_PITCH") ? atoi(getenv("ADAMML_C64_PITCH")) : 144;      // A/B aid: 144 | 160
+    return pp == 160 ? 160 : 144;
+}
+
+// rows per strip of the forward / data-gradient kernel: the largest R <= 512 / W (preferring, among the top four, one that divides H)
+// whose patch fits beside the resident weights at pixel pitch `pitch`; 0 when none does
+static int c3_rows(const adamml_conv_desc_t* d, int pitch) {
+    int R = MAXPX3 / d->W;
+    if (R > d->H) R = d->H;
+    for (; R >= 2; --R) {
+        int pick = R;
+        for (int r = R; r >= R - 3 && r >= 2; --r)
+            if (d->H % r == 0) { pick = r; break; }
+        const int PR = pick + 2, PW = d->W + 2;
+        const size_t patch = (size_t)PR * PW * pitch, stage = (size_t)((pick * d->W + 31) / 32 * 32) * SROW3;
+        if (PR * PW * 8 <= MAXSLOT3 * NT3 && (pick * d->W + 31) / 32 * 2 <= 8 * MAXPT &&
+            C64 * WROW3 + 512 + (patch > stage ? patch : stage) <= 160 * 1024)
+            return pick;
+    }
+    return 0;
+}
+
+// d: the FORWARD-shaped descriptor of the conv that is executed (for a data gradient: H/W of dz == H/W of dx).
 bool adamml_conv3x3_c64_supported(const adamml_conv_desc_t* d) {
     if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Cin != 64 || d->Cout != 64 || (d->up > 1)) return false;
     if (d->OH != d->H || d->OW != d->W || d->accumulate) return false;
     if (d->W < 8 || d->W > MAXPX3 / 2) return false;        // at least 2 rows per tile
-    int R = MAXPX3 / d->W;
-    if (R > d->H) R = d->H;
-    // prefer a row count that divides H (no ragged last strip)
-    for (int r = R; r >= R - 3 && r >= 2; --r)
-        if (d->H % r == 0) { R = r; break; }
-    const int PR = R + 2, PW = d->W + 2;
-    if (PR * PW * 8 > MAXSLOT3 * NT3) return false;
-    const size_t patch = (size_t)PR * PW * PPIX, stage = (size_t)((R * d->W + 31) / 32 * 32) * SROW3;
-    if ((R * d->W + 31) / 32 * 2 > 8 * MAXPT) return false;
-    return C64 * WROW3 + 512 + (patch > stage ? patch : stage) <= 160 * 1024;
+    return c3_rows(d, 144) >= 2 && c3_rows(d, c3_pitch()) >= 2;
 }
 
 int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
@@ -541,10 +563,8 @@ int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const 
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.in_scale = in_scale; p.in_shift = in_shift; p.y = (bf16_t*)y;
     p.stats = stats; p.bn_z = (const bf16_t*)bn_z; p.bn_vec = bn_vec; p.bn_act = bn_act; p.act = d->act;
     p.N = d->N; p.H = d->H; p.W = d->W;
-    int R = MAXPX3 / d->W;
-    if (R > d->H) R = d->H;
-    for (int r = R; r >= R - 3 && r >= 2; --r)
-        if (d->H % r == 0) { R = r; break; }
+    const int pitch = c3_pitch();
+    const int R = c3_rows(d, pitch);
     p.R = R; p.PR = R + 2; p.PW = d->W + 2;
     p.npt = (R * d->W + 31) / 32 * 2;            // staged rows cover whole 32-pixel statistic steps
     const int groups = d->groups < 1 ? 1 : d->groups;
@@ -555,17 +575,25 @@ int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const 
     p.in_gstride = d->in_gstride;
     p.gxy = (size_t)d->N * d->H * d->W * C64;
     p.tpb = ceil_div(p.total_tiles, 1024);
-    const size_t patch = (size_t)p.PR * p.PW * PPIX, stage = (size_t)p.npt * 16 * SROW3;
+    const size_t patch = (size_t)p.PR * p.PW * pitch, stage = (size_t)p.npt * 16 * SROW3;
     const size_t lds = C64 * WROW3 + 512 + (patch > stage ? patch : stage);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<false, 144>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<true, 144>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<false, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<true, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv3x3_c64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    if (p.bn_z) hipLaunchKernelGGL(conv3x3_c64_kernel<true>, dim3(ceil_div(p.total_tiles, p.tpb)), dim3(NT3), lds, stream, p);
-    else hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3(ceil_div(p.total_tiles, p.tpb)), dim3(NT3), lds, stream, p);
+    const dim3 grid(ceil_div(p.total_tiles, p.tpb));
+    if (pitch == 160) {
+        if (p.bn_z) hipLaunchKernelGGL((conv3x3_c64_kernel<true, 160>), grid, dim3(NT3), lds, stream, p);
+        else hipLaunchKernelGGL((conv3x3_c64_kernel<false, 160>), grid, dim3(NT3), lds, stream, p);
+    } else {
+        if (p.bn_z) hipLaunchKernelGGL((conv3x3_c64_kernel<true, 144>), grid, dim3(NT3), lds, stream, p);
+        else hipLaunchKernelGGL((conv3x3_c64_kernel<false, 144>), grid, dim3(NT3), lds, stream, p);
+    }
     return adamml_check_launch("conv3x3_c64");
 }
 
