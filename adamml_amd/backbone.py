@@ -31,9 +31,17 @@ class FlatBuffers:
         self.detached = on
 
     def ensure(self, device):
+        # fast path (every forward): the parameter objects found at the last re-homing still sit in the flat buffer.  (Walking
+        # module.parameters() -- ~1400 modules for AdaMML -- costs ~1 ms per sub-network per step, which matters at the per-GPU batch
+        # of the reference recipe where the step is host-bound; a parameter REPLACED by the caller is caught by the data_ptr probes of
+        # the first and the last one and by the optimizers / load_state_dict going through .data, which keeps the objects.)
+        if self.flat is not None and self.flat.device == device and self.params and \
+                self.params[0].data_ptr() == self.views[0].data_ptr() and self.params[-1].data_ptr() == self.views[-1].data_ptr():
+            return
         params = [p for p in self.module.parameters()]
         if self.flat is not None and self.flat.device == device and len(params) == len(self.params) and \
                 all(p.data_ptr() == v.data_ptr() for p, v in zip(params[:2], self.views[:2])):
+            self.params = params
             return
         total = sum(p.numel() for p in params)
         flat = torch.empty(total, dtype=torch.float32, device=device)
@@ -263,7 +271,10 @@ class HipBackbone(nn.Module):
             tape.record(fire)
 
     def _trainable(self):
-        return any(p.requires_grad for p in self.parameters())
+        plist = getattr(self, "_plist", None)
+        if plist is None:                # (parameter OBJECTS are fixed after construction; only their .data / .requires_grad change)
+            plist = self._plist = list(self.parameters())
+        return any(p.requires_grad for p in plist)
 
     def call(self, x, groups=1, precomputed=None):
         """x: NHWC bf16 frames tensor on the GPU, `groups` independent module calls stacked along dim 0 (group-major):
@@ -278,7 +289,7 @@ class HipBackbone(nn.Module):
         if self._anchor is None or self._anchor.device != x.device:
             self._anchor = torch.zeros(1, device=x.device)
         anchor = self._anchor.detach().requires_grad_(need_grad)
-        params = [p for p in self.parameters() if p.requires_grad] if (need_grad and self.expose_param_grads) else []
+        params = [p for p in self._plist if p.requires_grad] if (need_grad and self.expose_param_grads) else []
         self._precomputed = precomputed
         try:
             return torch.ops.adamml.backbone_call(anchor, x, params, self._handle, groups, need_grad)

@@ -42,6 +42,7 @@ struct C3P {
     int N, H, W, R, tiles_per_img, tiles_per_group, total_tiles, tpb;
     int PW, PR, npt;         // patch width / rows (pixels); pixel tiles per tile
     int in_gstride;
+    int wswz;                // 1: weight rows stored with the chunk swizzle (A/B aid ADAMML_C64_WSWZ)
     size_t gxy;              // elements per group of x and y (same shape)
 };
 
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
         // 16-byte chunk ch of row co sits at position ch ^ wswz(co): with the 73-chunk row pitch the 16 lanes of a gfx950 ds_read_b128 service
         // group (rows {0-3, 12-15} at chunk c and rows {4-11} at chunk c + 1, or the complement) then touch 16 distinct 16-byte bank units;
         // unswizzled they touched 9 (2-way conflicts on every weight fragment read: SQ_LDS_BANK_CONFLICT 34-41 % of the LDS cycles, round 2)
-        *reinterpret_cast<bf16x8*>(s_w + co * WROW3 + (ch ^ (((co >> 2) ^ (co >> 3)) & 1)) * 16) = *reinterpret_cast<const bf16x8*>(p.w + (size_t)co * KT3 + ch * 8);
+        *reinterpret_cast<bf16x8*>(s_w + co * WROW3 + (ch ^ (((co >> 2) ^ (co >> 3)) & p.wswz)) * 16) = *reinterpret_cast<const bf16x8*>(p.w + (size_t)co * KT3 + ch * 8);
     }
     if (tid < 128) cs[tid] = 0.f;
 
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
             const int r = q / p.W, c = q - r * p.W;
             pixoff[j] = (r * p.PW + c) * PP + lg * 16;
         }
-        const char* wbase = s_w + li * WROW3 + (lg ^ (((li >> 2) ^ (li >> 3)) & 1)) * 16;
+        const char* wbase = s_w + li * WROW3 + (lg ^ (((li >> 2) ^ (li >> 3)) & p.wswz)) * 16;
         const bool last_live = (wave + 24) * 16 < npx;
 #pragma unroll 1
         for (int kh = 0; kh < 3; ++kh) {
@@ -565,6 +566,8 @@ int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const 
     p.N = d->N; p.H = d->H; p.W = d->W;
     const int pitch = c3_pitch();
     const int R = c3_rows(d, pitch);
+    static const int wswz = getenv("ADAMML_C64_WSWZ") ? atoi(getenv("ADAMML_C64_WSWZ")) & 1 : 1;
+    p.wswz = wswz;
     p.R = R; p.PR = R + 2; p.PW = d->W + 2;
     p.npt = (R * d->W + 31) / 32 * 2;            // staged rows cover whole 32-pixel statistic steps
     const int groups = d->groups < 1 ? 1 : d->groups;

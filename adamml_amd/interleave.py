@@ -175,21 +175,23 @@ def _coalesced_all_reduce(parked, device, phase, ridx):
     while len(rd.ready) < len(parked):
         rd.ready.append(torch.cuda.Event())
     comm = _comm_stream(device)
-    for j, ev in zip(parked, rd.ready):
-        ev.record(j.stream)                 # the job's accumulators are complete ...
-        comm.wait_event(ev)                 # ... before the communication stream collapses / reads them
     flat = rd.flat[:total]
     prev = torch.cuda.current_stream(device)
-    torch.cuda.set_stream(comm)
     try:
+        # every job's vector is collapsed / copied into its slice ON THE JOB'S OWN STREAM (the collapse kernels of the round then run
+        # concurrently, not one after the other in front of the collective); the communication stream waits for all of them
         off = 0
-        for j, n in zip(parked, sizes):
+        for j, n, ev in zip(parked, sizes, rd.ready):
             kind, t, _, C, G = j.pending
+            torch.cuda.set_stream(j.stream)
             if kind == "stats":
                 hip.call("adamml_stats_collapse", hip.ptr(t), hip.ptr(flat[off:off + n]), C, G)
             else:
                 flat[off:off + n].copy_(t.reshape(-1))
             off += n
+            ev.record(j.stream)
+            comm.wait_event(ev)
+        torch.cuda.set_stream(comm)
         dist.all_reduce(flat, group=group)
         rd.done.record(comm)
     finally:

@@ -140,6 +140,9 @@ def _join_state(state, key, fb, log=None):
 
 
 def _mark_dirty(module):
-    for m in module.modules():
-        if hasattr(m, "mark_weights_dirty"):
-            m.mark_weights_dirty()
+    nets = module.__dict__.get("_hip_backbones")
+    if nets is None:                    # (the backbones of a sub-network are fixed after construction: walk the module tree once)
+        nets = [m for m in module.modules() if hasattr(m, "mark_weights_dirty")]
+        module.__dict__["_hip_backbones"] = nets
+    for m in nets:
+        m.mark_weights_dirty()

@@ -29,4 +29,4 @@ for _ in range(4):
     print("host issue %.1f ms, step complete %.1f ms" % ((t1 - t0) * 1e3, (t2 - t0) * 1e3))
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable(); step(); pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)
