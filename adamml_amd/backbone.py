@@ -4,7 +4,7 @@ call as a single node (forward = fused HIP launches, backward = the recorded tap
 import torch
 import torch.nn as nn
 
-from . import hip, interleave, ops
+from . import hip, interleave, ops, plan
 from .runtime import NetRT, ConvState, Tape
 
 
@@ -111,21 +111,45 @@ def run_backward(net, tape, g, params):
 
 
 def run_tape(tape, g, net):
-    net.rt.bwd_arena.reset(g.device)
-    tape.grad_out = g.contiguous()
-    tape.backward()
-    side = torch.cuda.current_stream()
-    if net.rt.wgrad_stream is not None:
-        side.wait_stream(net.rt.wgrad_stream)      # the weight gradients are complete before anyone reads .grad
-        net.rt.wgrad_pending.clear()               # later allocations on this stream are ordered behind that wait
-    if side != torch.cuda.default_stream(g.device) and not getattr(net, "_join_queued", False):
+    if isinstance(tape, plan.PlanTape):
+        # replayed call: the recorded reverse tape as one C call per segment (arena memset, launches and stream waits included)
+        tape.grad_out = g
+        tape.backward()
+        _queue_default_stream_join(net, g.device, torch.cuda.current_stream())
+        return
+    rec = getattr(tape, "recorder", None)
+    if rec is not None:                       # this call is being recorded into a launch plan: its backward too
+        g = g.contiguous()
+        rec.begin_backward(g)
+        hip.recorder = rec
+    try:
+        net.rt.bwd_arena.reset(g.device)
+        tape.grad_out = g.contiguous()
+        tape.backward()
+        side = torch.cuda.current_stream()
+        if net.rt.wgrad_stream is not None:
+            side.wait_stream(net.rt.wgrad_stream)      # the weight gradients are complete before anyone reads .grad
+            if hip.recorder is not None:
+                hip.recorder.wait(side.cuda_stream, net.rt.wgrad_stream.cuda_stream)
+            net.rt.wgrad_pending.clear()               # later allocations on this stream are ordered behind that wait
+    finally:
+        if rec is not None:
+            hip.recorder = None
+    if rec is not None:
+        rec.end_backward()
+        net._finish_recording(tape, rec)
+    _queue_default_stream_join(net, g.device, side)
+
+
+def _queue_default_stream_join(net, device, side):
+    if side != torch.cuda.default_stream(device) and not getattr(net, "_join_queued", False):
         # the HIP weight-gradient kernels wrote .grad on a side stream without going through AccumulateGrad: make
         # the default stream wait for them once, when the whole backward pass has been enqueued
         net._join_queued = True
 
         def _join():
             net._join_queued = False
-            torch.cuda.default_stream(g.device).wait_stream(side)
+            torch.cuda.default_stream(device).wait_stream(side)
         if _in_deferred_run[0]:
             _join()                     # already past the engine's callbacks: join right away
         else:
@@ -265,9 +289,21 @@ class HipBackbone(nn.Module):
             def fire():
                 if self.grad_hook is None:
                     return
+                rec = hip.recorder
                 if self.rt.wgrad_stream is not None:       # this bucket's weight gradients run on the side stream
-                    torch.cuda.current_stream().wait_stream(self.rt.wgrad_stream)
-                self.grad_hook(params)
+                    cur = torch.cuda.current_stream()
+                    cur.wait_stream(self.rt.wgrad_stream)
+                    if rec is not None:
+                        rec.wait(cur.cuda_stream, self.rt.wgrad_stream.cuda_stream)
+                if rec is not None:                        # a launch plan calls the hook between two of its segments
+                    hook = self.grad_hook
+                    rec.boundary(lambda: hook(params))
+                    hip.recorder = None
+                try:
+                    self.grad_hook(params)
+                finally:
+                    if rec is not None:
+                        hip.recorder = rec
             tape.record(fire)
 
     def _trainable(self):
@@ -302,7 +338,7 @@ class HipBackbone(nn.Module):
         hip.require_gpu(x)
         _check_groups(x, groups)
         self._adopt_sync_batchnorm()
-        return self._run(x, groups, need_grad=torch.is_grad_enabled() and self._trainable())
+        return self.run_planned(x, groups, torch.is_grad_enabled() and self._trainable())
 
     def _adopt_sync_batchnorm(self):
         """nn.SyncBatchNorm.convert_sync_batchnorm(model) (train_adamml.py:126-127) replaces the BatchNorm2d containers by
@@ -322,6 +358,56 @@ class HipBackbone(nn.Module):
     def out_shape(self, x_shape, groups):
         """Shape of the fp32 head output for an input of shape x_shape (fake / meta implementation of adamml::backbone_call)."""
         raise NotImplementedError
+
+    # -- launch plans (plan.py) ----------------------------------------------------------------------------------------
+    def _plan_key(self, x, groups, need_grad):
+        """Everything the launch sequence of a call depends on; None: this call is not plannable."""
+        rt = self.rt
+        if not (plan.ENABLED and self.training) or hip.profiler is not None or rt.capture is not None or self.expose_param_grads \
+                or getattr(self, "_dropout_keep_mask", None) is not None or (rt.sync.enabled and not interleave.active()):
+            return None
+        ws = rt.wgrad_stream.cuda_stream if rt.wgrad_stream is not None else 0
+        return (tuple(x.shape), x.dtype, groups, need_grad, hip.deterministic(), rt.sync.enabled, ws, hip._stream(),
+                tuple(p.requires_grad for p in self._plist), self.flat_owner.flat.data_ptr() if (self.flat_owner is not None and
+                self.flat_owner.flat is not None) else self._plist[0].data_ptr(), self.grad_hook is not None)
+
+    def run_planned(self, x, groups, need_grad):
+        """_run(), or the replay of its launch plan once the same call has been seen WARMUP_CALLS times."""
+        key = self._plan_key(x, groups, need_grad)
+        if key is None:
+            return self._run(x, groups, need_grad=need_grad)
+        plans = self.__dict__.setdefault("_plans", {})
+        entry = plans.get(key)
+        if isinstance(entry, plan.Plan):
+            return entry.forward(x)
+        seen = entry or 0
+        if seen < plan.WARMUP_CALLS or hip.recorder is not None:
+            plans[key] = seen + 1
+            return self._run(x, groups, need_grad=need_grad)
+        # record this (ordinary, eager) call
+        rec = plan.Recorder(x)
+        self._packed_version = None                # the plan re-packs the bf16 operands every step (the weights change every step)
+        hip.recorder = rec
+        try:
+            out, tape = self._run(x, groups, need_grad=need_grad)
+        finally:
+            hip.recorder = None
+        rec.end_forward()
+        rec.key = key
+        if need_grad:
+            tape.recorder = rec                    # the reverse tape is recorded when autograd runs it (run_tape)
+            rec.out = out
+        else:
+            self._finish_recording(None, rec, out)
+        return out, tape
+
+    def _finish_recording(self, tape, rec, out=None):
+        plans = self.__dict__.setdefault("_plans", {})
+        if rec.failed:
+            plans[rec.key] = -(10 ** 9)            # never try again for this key
+            return
+        plans[rec.key] = plan.Plan(rec, out if out is not None else rec.out)
+        plan.stats["recorded"] += 1
 
     def _run(self, x, groups, need_grad):
         raise NotImplementedError

@@ -36,6 +36,7 @@ SIGNATURES = {
     "adamml_conv_fwd_bn_add": [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "adamml_conv_fwd_bn_add_tpool": [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "adamml_temporal_pool_bwd_code": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "adamml_copy2d": [_P, _Z, _P, _Z, _Z, _Z, _P],
     "adamml_gram_stats": [_P, _P, _P, _P, _I, _I, _I, _P],
     "adamml_gram_colsum": [_P, _P, _P, _I, _I, _P, _P, _Z, _I, _I, _P, _Z, _P],
     "adamml_conv_bwd_data_bn": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
@@ -147,6 +148,13 @@ def load():
     lib.adamml_dwconv_bwd_data_bn_supported.restype = c_int
     lib.adamml_conv_stem_supported.argtypes = [_DESC]
     lib.adamml_conv_stem_supported.restype = c_int
+    lib.adamml_plan_run.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int]
+    lib.adamml_plan_run.restype = c_int
+    lib.adamml_plan_events_create.argtypes = [c_void_p, c_int]
+    lib.adamml_plan_events_create.restype = c_int
+    lib.adamml_plan_events_destroy.argtypes = [c_void_p, c_int]
+    lib.adamml_plan_events_destroy.restype = c_int
+    lib.adamml_plan_num_entry_points.restype = c_int
     lib.adamml_pack_block_elems.restype = c_int
     lib.adamml_version.restype = c_int
     lib.adamml_last_error_string.restype = c_char_p
@@ -185,8 +193,15 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+recorder = None          # plan.Recorder listening to the launches of one backbone call (plan.py), else None
+
+
 def ptr(t):
-    return None if t is None else t.data_ptr()
+    if t is None:
+        return None
+    if recorder is not None:
+        recorder.keep.append(t)          # the plan owns every tensor whose address one of its records holds
+    return t.data_ptr()
 
 
 class LaunchProfiler:
@@ -238,7 +253,10 @@ def call(name, *args):
         profiler.records.append((name, s, e, next_meta))
         next_meta = (0.0, 0.0)
     else:
-        rc = fn(*args, _stream())
+        st = _stream()
+        rc = fn(*args, st)
+        if recorder is not None:
+            recorder.call(name, args, st)
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (name, rc, load().adamml_last_error_string().decode()))
 

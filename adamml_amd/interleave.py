@@ -53,14 +53,26 @@ def exchange(t, group=None):
     """All-reduce(sum) of the statistic vector t over `group`; returns the reduced tensor (t itself, or a slice of the round's
     flat buffer).  Inside run_interleaved() the call parks the job until the round's coalesced collective has been issued."""
     job = _current[0]
+    rec = hip.recorder
+    if rec is not None:
+        # a launch plan is being recorded: the exchange ends a segment and is repeated, with these very tensors, at every replay
+        if job is None:
+            rec.failed = "SyncBatchNorm exchange outside the lock-step scheduler (no persistent round buffer)"
+        rec.keep.append(t)
+        hip.recorder = None
+        rec.boundary(lambda: exchange(t, group))
     if job is None:
         dist.all_reduce(t, group=group)
         stats["collectives"] += 1
         stats["coalesced_vectors"] += 1
-        return t
-    job.pending = ("vec", t, group, 0, 0)
-    job.park()
-    out, job.reduced = job.reduced, None
+        out = t
+    else:
+        job.pending = ("vec", t, group, 0, 0)
+        job.park()
+        out, job.reduced = job.reduced, None
+    if rec is not None:
+        rec.keep.append(out)
+        hip.recorder = rec
     return out
 
 
@@ -69,16 +81,26 @@ def exchange_stats(acc, C, groups, group=None):
     [groups * 2C] (fp64; the finalize kernels read them with nslots = 1).  Inside run_interleaved() the collapse kernel writes
     straight into this job's slice of the round's flat buffer."""
     job = _current[0]
+    rec = hip.recorder
+    if rec is not None:
+        if job is None:
+            rec.failed = "SyncBatchNorm exchange outside the lock-step scheduler (no persistent round buffer)"
+        rec.keep.append(acc)
+        hip.recorder = None
+        rec.boundary(lambda: exchange_stats(acc, C, groups, group))
     if job is None:
         out = torch.empty(groups * 2 * C, dtype=torch.float64, device=acc.device)
         hip.call("adamml_stats_collapse", hip.ptr(acc), hip.ptr(out), C, groups)
         dist.all_reduce(out, group=group)
         stats["collectives"] += 1
         stats["coalesced_vectors"] += 1
-        return out
-    job.pending = ("stats", acc, group, C, groups)
-    job.park()
-    out, job.reduced = job.reduced, None
+    else:
+        job.pending = ("stats", acc, group, C, groups)
+        job.park()
+        out, job.reduced = job.reduced, None
+    if rec is not None:
+        rec.keep.append(out)
+        hip.recorder = rec
     return out
 
 
@@ -90,6 +112,7 @@ class _Job:
         self.error = None
         self.pending = None                 # ("vec" | "stats", tensor, group, C, groups) parked at an exchange
         self.reduced = None
+        self.recorder = None                # hip.recorder of this coroutine while it is parked
         self.g = greenlet.greenlet(self._main, parent=sched)
 
     def _main(self):
@@ -229,9 +252,11 @@ def run_interleaved(jobs, device, phase="fwd"):
                 if on_gpu:
                     torch.cuda.set_stream(j.stream)
                 torch.set_grad_enabled(j.grad)
+                hip.recorder = j.recorder                  # (a job may be recording a launch plan: per coroutine, like the stream)
                 try:
                     j.g.switch()
                 finally:
+                    j.recorder, hip.recorder = hip.recorder, None
                     j.grad = torch.is_grad_enabled()
                     _current[0] = None
                     if on_gpu:

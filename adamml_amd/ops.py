@@ -52,7 +52,9 @@ def backbone_call(anchor: torch.Tensor, x: torch.Tensor, params: List[torch.Tens
         out, tape = pre
         out = out.clone()          # (an operator may not return its argument; [clips, classes] fp32)
     else:
-        out, tape = net._run(x, groups, need_grad=need_grad)
+        out, tape = net.run_planned(x, groups, need_grad)
+        if tape.__class__.__name__ == "PlanTape":
+            out = out.clone()      # (the plan's output buffer is rewritten by the next replay)
     net._pending_tape = tape
     return out
 

@@ -96,6 +96,8 @@ class Arena:
             self.buf = torch.zeros(need, dtype=torch.float64, device=device)
         else:
             self.buf[:need].zero_()
+            if hip.recorder is not None:                 # (a launch plan repeats the memset; the buffer has its final size after warm-up)
+                hip.recorder.zero(self.buf[:need], hip._stream())
         self.off = 0
 
     def take(self, n):
@@ -162,6 +164,13 @@ class NetRT:
         if self.training and self.touched_bns:
             torch._foreach_add_([b.num_batches_tracked for b in self.touched_bns], self.groups)
             self.state_gen += 1      # adamml_bn_finalize rewrote running_mean / running_var through raw pointers
+            if hip.recorder is not None:
+                nbt, grp = [b.num_batches_tracked for b in self.touched_bns], self.groups
+
+                def bump():
+                    torch._foreach_add_(nbt, grp)
+                    self.state_gen += 1
+                hip.recorder.post_fwd.append(bump)
         self.touched_bns = []
 
 
@@ -459,7 +468,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                     z.sums_partial = z.alg
                     if fb:
                         if fb_alg:
-                            sb.view(G, STAT_SLOTS, 2 * d.Cin)[:, :, :d.Cin].copy_(sa.view(G, STAT_SLOTS, 2 * d.Cin)[:, :, :d.Cin])
+                            call("adamml_copy2d", ptr(sb), 2 * d.Cin * 8, ptr(sa), 2 * d.Cin * 8, d.Cin * 8, G * STAT_SLOTS)       # the sum(g') columns
                             idn.sums_partial = True
                         idn.pre_sums = sb
                     x.res_done = True
@@ -548,7 +557,10 @@ class _on_wgrad_stream:
 
     def __enter__(self):
         if self.ws is not None:
-            self.ws.wait_stream(torch.cuda.current_stream())
+            cur = torch.cuda.current_stream()
+            self.ws.wait_stream(cur)
+            if hip.recorder is not None:
+                hip.recorder.wait(self.ws.cuda_stream, cur.cuda_stream)
             self.ctx = torch.cuda.stream(self.ws)
             self.ctx.__enter__()
         return self
@@ -1028,6 +1040,11 @@ def head(rt, x, fc, frames, dropout_p, keep_mask=None):
     inv_keep = 1.0
     if keep_mask is None and rt.training and dropout_p > 0:
         keep_mask = torch.rand(nt, C, device=dev) < (1.0 - dropout_p)
+        if hip.recorder is not None:        # a launch plan re-draws the mask into this very buffer before every replay
+            km = keep_mask
+            hip.recorder.pre_fwd.append(lambda: km.copy_(torch.rand(nt, C, device=dev) < (1.0 - dropout_p)))
+    elif keep_mask is not None and hip.recorder is not None:
+        hip.recorder.failed = "caller-supplied dropout mask"
     if keep_mask is not None:
         inv_keep = 1.0 / (1.0 - dropout_p)
         keep_mask = keep_mask.contiguous()

@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--force-collectives", action="store_true",
                     help="N = 1 only: a ONE-rank RCCL communicator with SyncBN and the bucketed gradient all-reduce forced on (every "
                          "collective is an identity): the host / stream choreography of configs[2] measured on one GPU (non-headline)")
+    ap.add_argument("--launch-plan", action="store_true",
+                    help="replay the static launch sequence of every backbone call from C (adamml_amd/plan.py): for small per-GPU batches, "
+                         "where the Python issue of ~1300 launches per step bounds the step (non-headline)")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: no side streams, so per-kernel durations "
                     "in a rocprofv3 trace are not inflated by concurrently running kernels")
     return ap.parse_args()
@@ -245,6 +248,9 @@ def run_rank(args):
     else:
         per_gpu = args.batch
     model = build(args, device)
+    if args.launch_plan:
+        from adamml_amd import plan as _plan
+        _plan.ENABLED = True
     forced = args.force_collectives and world == 1
     ddp = HipDDP(model, sync_bn=((world > 1 or forced) and not args.no_sync_bn), force_collectives=forced)
     if args.stage == "main":
@@ -402,6 +408,7 @@ def run_rank(args):
             # host side: median wall time step() takes to return (Python + ctypes issue of ~1300 launches, no device sync inside);
             # when it approaches ms_per_step the step is host-bound
             "host_issue_ms": round(statistics.median(issue_ms), 2), "deterministic": bool(hip.deterministic()),
+            "launch_plan": bool(args.launch_plan),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("AdaMML %s (non-headline), eval-mode forward with decision-driven skipping of the main nets, "
                                     "%d segments x 8 frames" % ("+".join(args.modalities), args.segments)) if args.stage == "infer" else

@@ -24,6 +24,7 @@ extern "C" {
 #endif
 
 typedef struct ihipStream_t* hipStream_t;
+typedef struct ihipEvent_t* hipEvent_t;
 
 /* Per-channel reductions (BatchNorm statistics, BatchNorm-backward sums) are accumulated with fp64 atomics into
  * ADAMML_STAT_SLOTS interleaved copies ([slot][2*C], slot = block index mod ADAMML_STAT_SLOTS) so that thousands of
@@ -407,6 +408,32 @@ int adamml_fusion_fwd(const float* const* x, const float* decisions, const float
 int adamml_fusion_bwd(const float* const* x, const float* decisions, const float* lf_weights, const float* g_out,
                       float* const* d_x, float* d_decisions, float* d_lf_part, int S, int B, int C, int M,
                       hipStream_t stream);
+
+/* ---- launch plans (csrc/plan.hip) -------------------------------------------------------------------------------------------
+ * The static launch sequence of one backbone call, recorded once by the host executor and replayed by ONE call: every record is a call
+ * of one of the stream-taking entry points above (`fn` = its index in the alphabetically sorted list of those entry points,
+ * adamml_plan_num_entry_points() of them), a wait of one of the caller's streams on another, or a memset.  Arguments are 8-byte slots:
+ * pointers and integers as they are, float / double arguments as the bits of a double, descriptors as pointers to HOST copies the
+ * caller keeps alive.  A bit of `slot_mask` marks an argument as an index into the `slots` array of adamml_plan_run (the pointers that
+ * change from replay to replay: the call's input, the incoming gradient).  Nothing is allocated or synchronised; an error of a
+ * record ends the replay with that record's code.  The reference has no counterpart: its launches are issued by the PyTorch
+ * dispatcher, one Python call each (utils/utils.py:359-400). */
+#define ADAMML_PLAN_MAX_ARGS 21
+#define ADAMML_PLAN_CALL 0
+#define ADAMML_PLAN_WAIT 1
+#define ADAMML_PLAN_ZERO 2
+typedef struct {
+    int32_t kind, fn, nargs, stream;      /* stream: index into the `streams` array of adamml_plan_run */
+    uint32_t slot_mask, reserved;
+    uint64_t a[ADAMML_PLAN_MAX_ARGS];
+} adamml_plan_op_t;
+int adamml_plan_num_entry_points(void);
+int adamml_plan_run(const adamml_plan_op_t* ops, int n_ops, const hipStream_t* streams, int n_streams, const hipEvent_t* events, int n_events,
+                    const uint64_t* slots, int n_slots);       /* ops / streams / events / slots: HOST arrays */
+int adamml_plan_events_create(hipEvent_t* events, int n);     /* HOST array, filled with timing-less events */
+int adamml_plan_events_destroy(hipEvent_t* events, int n);
+/* Stream-ordered strided device copy (byte pitches): dst[r][0..width) = src[r][0..width), r < rows. */
+int adamml_copy2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width_bytes, size_t rows, hipStream_t stream);
 
 #ifdef __cplusplus
 }
