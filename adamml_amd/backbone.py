@@ -376,7 +376,7 @@ class HipBackbone(nn.Module):
         key = self._plan_key(x, groups, need_grad)
         if key is None:
             return self._run(x, groups, need_grad=need_grad)
-        plans = self.__dict__.setdefault("_plans", {})
+        plans = self.__dict__.setdefault("_launch_plans", {})
         entry = plans.get(key)
         if isinstance(entry, plan.Plan):
             return entry.forward(x)
@@ -402,7 +402,7 @@ class HipBackbone(nn.Module):
         return out, tape
 
     def _finish_recording(self, tape, rec, out=None):
-        plans = self.__dict__.setdefault("_plans", {})
+        plans = self.__dict__.setdefault("_launch_plans", {})
         if rec.failed:
             plans[rec.key] = -(10 ** 9)            # never try again for this key
             return

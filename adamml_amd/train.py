@@ -461,6 +461,11 @@ def main_worker(gpu, ngpus_per_node, args, train_loader=None, val_loader=None, l
     args.distributed = world > 1
     resolve_args(args, log, rank)
     per_rank_batch = max(1, args.batch_size // world)                       # train_adamml.py:122
+    if "ADAMML_LAUNCH_PLAN" not in os.environ and per_rank_batch <= 16:
+        # small per-GPU batches (the README recipe: 72 videos over 8 GPUs) are bound by the Python issue of ~1300 launches per step:
+        # replay the static launch sequences from C (adamml_amd/plan.py; costs the sum instead of the peak of a step's activations)
+        from . import plan as _plan
+        _plan.ENABLED = True
     if args.backbone_net != "adamml":
         raise SystemExit("adamml_amd.train restates train_adamml.py; unimodal training is models.resnet / sound_mobilenet_v2 "
                          "behind the same registry (build_model) with a plain loop")

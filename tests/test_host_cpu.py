@@ -391,3 +391,25 @@ def test_plateau_schedule_follows_torch():
         ts.step(v)
         assert abs(o.lr - topt.param_groups[0]["lr"]) < 1e-12, (e, o.lr, topt.param_groups[0]["lr"])
     assert o.lr < 0.0011
+
+
+def test_launch_plan_thunks_are_in_sync_with_the_c_abi(built):
+    """csrc/plan_thunks.inc (generated by tools/gen_plan_thunks.py) has one case per stream-taking entry point of include/adamml_hip.h,
+    numbered by its position in sorted(hip.SIGNATURES) -- the numbering adamml_amd/plan.py records with -- and the library agrees on the
+    count; the record structure has the size the header declares."""
+    import subprocess
+    import sys
+    from adamml_amd import hip, plan
+    path = os.path.join(ROOT, "adamml_amd", "csrc", "plan_thunks.inc")
+    before = open(path).read()
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_plan_thunks.py")], stdout=subprocess.DEVNULL)
+    assert open(path).read() == before, "plan_thunks.inc is stale: run tools/gen_plan_thunks.py and rebuild"
+    names = sorted(hip.SIGNATURES)
+    for i, n in enumerate(names):
+        assert ("case %d: return %s(" % (i, n)) in before
+        assert plan.fn_id(n) == i
+    lib = ctypes.CDLL(built)
+    assert lib.adamml_plan_num_entry_points() == len(names)
+    assert ctypes.sizeof(plan.PlanOp) == 4 * 4 + 2 * 4 + 8 * plan.MAX_ARGS
+    hdr = open(os.path.join(ROOT, "include", "adamml_hip.h")).read()
+    assert ("#define ADAMML_PLAN_MAX_ARGS %d" % plan.MAX_ARGS) in hdr

@@ -54,7 +54,7 @@ def _steps(c, n, planned, forced, stage, dropout=0.0):
             loss.backward()
             ddp.reduce_gradients()
             if opt is None:
-                opt = FlatSGD(model._flat_main, lr=0.01, momentum=0.9, weight_decay=1e-4) if stage == "main" else \\
+                opt = FlatSGD(model._flat_main, lr=0.01, momentum=0.9, weight_decay=1e-4) if stage == "main" else \
                     FlatAdam(model._flat_policy, lr=1e-3, weight_decay=1e-4)
             opt.step()
             opt.zero_grad()
