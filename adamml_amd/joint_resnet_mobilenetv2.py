@@ -83,17 +83,26 @@ class JointResNetMobileNetV2(nn.Module, MeanStdMixin):
         return self.fuse(self.backbone_logits(multi_modalities), decisions)
 
 
+def _load_unimodal_checkpoints(model, paths):
+    """Contract of models/joint_resnet_mobilenetv2.py:141-155 (--unimodality_pretrained): one train_unimodal.py checkpoint per backbone, in
+    backbone order, each a dict whose 'state_dict' carries DataParallel's `module.` prefix; loaded strictly.  A wrong count is a ValueError
+    with the reference's message.  (fusion_point is always 'logits' here, so no head is dropped.)"""
+    if not paths:
+        return
+    if len(paths) != len(model.nets):
+        raise ValueError("the number of pretrained models is incorrect.")
+    for net, path in zip(model.nets, paths):
+        print("Loading unimodality pretrained model from: {}".format(path))
+        weights = torch.load(path, map_location='cpu')['state_dict']
+        net.load_state_dict({name.replace("module.", ""): t for name, t in weights.items()}, strict=True)
+        if hasattr(net, "mark_weights_dirty"):
+            net.mark_weights_dirty()
+
+
 def joint_resnet_mobilenetv2(depth, num_classes, without_t_stride, groups, dropout, pooling_method, input_channels,
                              fusion_point, modality, unimodality_pretrained, learnable_lf_weights, **kwargs):
     model = JointResNetMobileNetV2(depth, num_frames=groups, num_classes=num_classes, without_t_stride=without_t_stride,
                                    dropout=dropout, pooling_method=pooling_method, input_channels=input_channels,
                                    fusion_point=fusion_point, modality=modality, learnable_lf_weights=learnable_lf_weights)
-    if len(unimodality_pretrained) > 0:
-        if len(unimodality_pretrained) != len(model.nets):
-            raise ValueError("the number of pretrained models is incorrect.")
-        for i, m in enumerate(modality):
-            print("Loading unimodality pretrained model from: {}".format(unimodality_pretrained[i]))
-            state_dict = torch.load(unimodality_pretrained[i], map_location='cpu')['state_dict']
-            new_state_dict = {key.replace("module.", ""): v for key, v in state_dict.items()}
-            model.nets[i].load_state_dict(new_state_dict, strict=True)
+    _load_unimodal_checkpoints(model, list(unimodality_pretrained))
     return model
