@@ -1,13 +1,13 @@
 """Regenerates profiles/README.md from the committed rocprofv3 kernel statistics, PMC traffic and bench lines of a round.
 
-    python tools/profile_readme.py [r02]"""
+    python tools/profile_readme.py [r03]"""
 import collections
 import csv
 import json
 import re
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 P = "profiles/%s_" % R
 
 
@@ -66,17 +66,39 @@ out.append("conv_gemm_kernel %.1f MB per launch = %.1f GB per step measured vs %
 out.append("(round 1: 587 GB, 1.46x).  Largest contributors per step: " + ", ".join(
     "%s %.0f GB" % (k, v["hbm_bytes_corrected"] / 3e9) for k, v in sorted(((k, v) for k, v in tr.items() if not k.startswith("_")),
                                                                           key=lambda kv: -kv[1]["hbm_bytes_corrected"])[:8]) + ".\n")
-out.append("Other bench lines of this round (one MI355X): " + "; ".join(
-    "`%s_%s.json` %.0f clips/s" % (R, n, json.load(open(P + n + ".json"))["value"])
-    for n in ("bench_policy_stage", "bench_inference_skipping", "bench_c4_rgb_flow_rgbdiff_b72", "bench_c5_four_modalities_b48")) + ".")
-out.append("Full-size parity study (HIP vs fp32 oracle vs bf16-storage emulation vs forced-forward replay, per tensor): `%s_parity_study_*.log` (`tools/parity_study.py`)." % R)
-out.append("\nPer-layer tables of the same build (B = 72 shapes): `%s_per_layer_bench_conv.txt` (every ResNet-50 conv: forward / data gradient / weight gradient, GB/s and TFLOP/s;"
+import os
+
+
+def line(n):
+    return json.load(open(P + n + ".json"))
+
+
+if rf.get("per_role"):
+    out.append("The same single-stream measurement split by ROLE (bench.py `roofline.per_role`; each role against the roof that bounds it, PMC traffic per role from the template arguments):\n")
+    out.append("| role | C-ABI launches / step | ms / step | bound | fraction of that roof | HBM fraction | MFMA fraction | PMC / algorithmic bytes |")
+    out.append("|---|---|---|---|---|---|---|---|")
+    for k, v in rf["per_role"].items():
+        out.append("| %s | %d | %.2f | %s | %.3f | %.3f | %.3f | %s |" % (k, v["c_abi_launches_per_step"], v["ms_per_step"], v["bound"], v["frac"], v["hbm_frac"], v["mfma_frac"],
+                                                                        ("%.2f" % v["traffic_over_algorithmic"]) if v.get("traffic_over_algorithmic") else "-"))
+    out.append("")
+others = [n for n in ("bench_policy_stage", "bench_inference_skipping", "bench_c4_rgb_flow_rgbdiff_b72", "bench_c5_four_modalities_b48") if os.path.exists(P + n + ".json")]
+out.append("Other bench lines of this round (one MI355X): " + "; ".join("`%s_%s.json` %.0f clips/s" % (R, n, line(n)["value"]) for n in others) + ".\n")
+b9 = [("bench_b9", "B = 9 (the per-GPU share of the reference recipe: global batch 72 over 8 GPUs, train_adamml.py:122), eager"),
+      ("bench_b9_launch_plan", "B = 9, launch plans (`--launch-plan`)"),
+      ("bench_b9_forced_collectives", "B = 9 with the configs[2] choreography forced on a one-rank RCCL communicator (`--force-collectives`: SyncBN rounds + bucketed all-reduce)"),
+      ("bench_b9_forced_collectives_launch_plan", "the same with launch plans"),
+      ("bench_b72_forced_collectives", "B = 72 with the forced choreography")]
+if all(os.path.exists(P + n + ".json") for n, _ in b9):
+    out.append("configs[2] as far as one GPU allows (host issue time = wall time `step()` takes to return, nothing in it synchronises):\n")
+    out.append("| line | clips/s | ms / step | host issue ms | peak GiB |")
+    out.append("|---|---|---|---|---|")
+    for n, what in b9:
+        d = line(n)
+        out.append("| `%s_%s.json`: %s | %.0f | %.2f | %.2f | %.1f |" % (R, n, what, d["value"], d["ms_per_step"], d["host_issue_ms"], d["peak_mem_gib"]))
+    out.append("")
+out.append("Per-layer tables of the same build (B = 72 shapes): `%s_per_layer_bench_conv.txt` (every ResNet-50 conv: forward / data gradient / weight gradient, GB/s and TFLOP/s;"
            " `tools/bench_conv.py`), `%s_per_layer_bench_fused.txt` (RES / DUAL forms), `%s_per_layer_bench_dw.txt` (depthwise), `%s_bench_elementwise.txt` (BatchNorm / residual passes"
-           " against a plain copy), `%s_streaming_kernels_layer1_2.txt` (FADD, RES, algebraic data gradient, Gram kernel, products in the form the net runs them; `tools/explore_stream.py`),"
-           " `%s_launch_table_resnet.txt` / `%s_launch_table_sound.txt` (every launch of one backbone step with its excess over a 5.3 TB/s / 800 TFLOP/s floor; `tools/launch_table.py`),"
-           " `%s_bench_nets.txt` (each backbone alone)." % ((R,) * 8))
-out.append("Counter studies behind the round's kernel changes: `%s_pmc_streaming_kernels_memory_counters.txt` (reads outstanding at the fabric, TCC / TCP latencies of the layer-1 streaming kernels"
-           " against the elementwise kernels, BEFORE the early identity loads; `tools/gpu_pmc_stream.sh`), `%s_pmc_streaming_kernels_sq_counters_layer2.txt` (instruction mix and stall split of the"
-           " layer-2 kernels: 30-35 %% of the wave time is VALU issue; `tools/gpu_pmc_sq.sh`)." % (R, R))
+           " against a plain copy), `%s_launch_table_resnet.txt` / `%s_launch_table_sound.txt` (every launch of one backbone step with its excess over a 5.3 TB/s / 800 TFLOP/s floor;"
+           " `tools/launch_table.py`), `%s_bench_nets.txt` (each backbone alone), `%s_kernel_resources.txt` (registers / spills / LDS of every kernel instance, `tools/kernel_resources.py`)." % ((R,) * 8))
 open("profiles/README.md", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
