@@ -408,6 +408,10 @@ class HipBackbone(nn.Module):
             return
         plans[rec.key] = plan.Plan(rec, out if out is not None else rec.out)
         plan.stats["recorded"] += 1
+        # a plan pins the activations of its call: keep the most recent few (a ragged last batch, a stage switch), drop the oldest
+        live = [k for k, v in plans.items() if isinstance(v, plan.Plan)]
+        for k in live[:-plan.MAX_PLANS_PER_NET]:
+            del plans[k]
 
     def _run(self, x, groups, need_grad):
         raise NotImplementedError

@@ -25,6 +25,7 @@ from . import hip
 
 ENABLED = os.environ.get("ADAMML_LAUNCH_PLAN", "0") not in ("", "0")
 WARMUP_CALLS = 2               # eager calls of a key before it is recorded (arenas and scratch buffers have reached their sizes)
+MAX_PLANS_PER_NET = 4          # plans kept per backbone (each pins the activations of one call shape / mode)
 MAX_ARGS = 21
 KIND_CALL, KIND_WAIT, KIND_ZERO = 0, 1, 2
 stats = {"recorded": 0, "replayed_segments": 0, "replayed_ops": 0}
