@@ -5,7 +5,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import hip, interleave
+from . import hip, interleave, plan
 from .backbone import FlatBuffers, StockDDPAware
 from .common import MeanStdMixin
 from .joint_resnet_mobilenetv2 import joint_resnet_mobilenetv2
@@ -239,14 +239,19 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
             out = torch.zeros(S * B, ncls, dtype=torch.float32, device=dev)
             if idx.numel() == S * B:
                 out = net.forward_nhwc(frames, S if raw32 else 1)             # (eval BatchNorm: the grouping is immaterial)
-            elif idx.numel() > 0:
+            nsel = int(idx.numel())
+            if 0 < nsel < S * B:
+                if plan.ENABLED and idx.numel() % 8:
+                    # launch plans are per call shape: pad the selected clips to a multiple of 8 (the first one repeated; eval BatchNorm is
+                    # per sample, the duplicates' logits overwrite identical values) so that few distinct shapes occur
+                    idx = torch.cat([idx, idx[:1].expand(8 - idx.numel() % 8)])
                 if raw32:
                     sel = frames.transpose(0, 1).reshape(S * B, 1, *frames.shape[2:]).index_select(0, idx)      # [n, 1, H, W]: one group
                 else:
                     sel = frames.view(S * B, fpc, *frames.shape[1:]).index_select(0, idx).flatten(0, 1)
                 out.index_copy_(0, idx, net.forward_nhwc(sel, 1))
             stacked.append(out)
-            ran.append(int(idx.numel()))
+            ran.append(nsel)
         self.last_skip_stats = {"clips": S * B, "executed_per_modality": ran}
         return self.main_net.fuse_segments(stacked, decisions, S), decisions.permute((2, 0, 1))
 

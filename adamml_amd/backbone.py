@@ -363,11 +363,15 @@ class HipBackbone(nn.Module):
     def _plan_key(self, x, groups, need_grad):
         """Everything the launch sequence of a call depends on; None: this call is not plannable."""
         rt = self.rt
-        if not (plan.ENABLED and self.training) or hip.profiler is not None or rt.capture is not None or self.expose_param_grads \
-                or getattr(self, "_dropout_keep_mask", None) is not None or (rt.sync.enabled and not interleave.active()):
+        if not plan.ENABLED or hip.profiler is not None or rt.capture is not None or self.expose_param_grads \
+                or getattr(self, "_dropout_keep_mask", None) is not None or (rt.sync.enabled and self.training and not interleave.active()):
+            return None
+        if not self.training and (need_grad or x.numel() > plan.MAX_EVAL_ELEMENTS):
+            # inference: a plan pins the activations of its call shape, and the shapes of policy-gated inference vary with the decisions --
+            # worth it for serving-sized calls only
             return None
         ws = rt.wgrad_stream.cuda_stream if rt.wgrad_stream is not None else 0
-        return (tuple(x.shape), x.dtype, groups, need_grad, hip.deterministic(), rt.sync.enabled, ws, hip._stream(),
+        return (tuple(x.shape), x.dtype, groups, need_grad, self.training, hip.deterministic(), rt.sync.enabled, ws, hip._stream(),
                 tuple(p.requires_grad for p in self._plist), self.flat_owner.flat.data_ptr() if (self.flat_owner is not None and
                 self.flat_owner.flat is not None) else self._plist[0].data_ptr(), self.grad_hook is not None)
 
@@ -409,9 +413,10 @@ class HipBackbone(nn.Module):
         plans[rec.key] = plan.Plan(rec, out if out is not None else rec.out)
         plan.stats["recorded"] += 1
         # a plan pins the activations of its call: keep the most recent few (a ragged last batch, a stage switch), drop the oldest
-        live = [k for k, v in plans.items() if isinstance(v, plan.Plan)]
-        for k in live[:-plan.MAX_PLANS_PER_NET]:
-            del plans[k]
+        for mode, cap in ((True, plan.MAX_PLANS_PER_NET), (False, plan.MAX_EVAL_PLANS_PER_NET)):
+            live = [k for k, v in plans.items() if isinstance(v, plan.Plan) and k[4] == mode]
+            for k in live[:-cap]:
+                del plans[k]
 
     def _run(self, x, groups, need_grad):
         raise NotImplementedError

@@ -13,8 +13,9 @@ goes through pointer slots (slot 0: the call's input tensor, slot 1: the incomin
 into its fixed buffer by a pre-replay hook, `num_batches_tracked` is advanced by a post-replay hook.
 
 Opt-in (`ADAMML_LAUNCH_PLAN=1`, `plan.ENABLED = True`, `bench.py --launch-plan`): a plan pins every intermediate tensor of its call, i.e.
-the SUM of the call's allocations instead of their peak -- right for small per-GPU batches, wrong for B = 72.  Training-mode calls only
-(an eval call caches its BatchNorm affines across calls, which a recording would freeze)."""
+the SUM of the call's allocations instead of their peak -- right for small per-GPU batches, wrong for B = 72.  Inference calls are planned
+up to a serving-sized input (MAX_EVAL_ELEMENTS); their eval-mode BatchNorm affines are recomputed inside the plan (the eager path caches
+them per module), and policy-gated inference pads its selected-clip count to a multiple of 8 so that few distinct shapes occur."""
 import ctypes
 import os
 import struct
@@ -25,7 +26,9 @@ from . import hip
 
 ENABLED = os.environ.get("ADAMML_LAUNCH_PLAN", "0") not in ("", "0")
 WARMUP_CALLS = 2               # eager calls of a key before it is recorded (arenas and scratch buffers have reached their sizes)
-MAX_PLANS_PER_NET = 4          # plans kept per backbone (each pins the activations of one call shape / mode)
+MAX_PLANS_PER_NET = 4          # training plans kept per backbone (each pins the activations of one call shape / mode)
+MAX_EVAL_PLANS_PER_NET = 12    # inference plans kept per backbone (policy-gated inference: one per padded clip count)
+MAX_EVAL_ELEMENTS = 40 * 8 * 224 * 224 * 4     # largest inference input planned (40 clips of 8 RGB frames): serving-sized calls
 MAX_ARGS = 21
 KIND_CALL, KIND_WAIT, KIND_ZERO = 0, 1, 2
 stats = {"recorded": 0, "replayed_segments": 0, "replayed_ops": 0}

@@ -264,12 +264,13 @@ def _bn_eval_vectors(rt, bn, C, device):
     key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
            bn.weight.data_ptr(), bn.running_mean.data_ptr(), str(device), rt.state_gen)
     cached = getattr(bn, "_hip_eval_vec", None)
-    if cached is not None and cached[0] == key and not hip.profiler:
+    if cached is not None and cached[0] == key and not hip.profiler and hip.recorder is None:
         return cached[1]
     vec = torch.empty(2, C, dtype=torch.float32, device=device)
     call("adamml_bn_eval_affine", ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), BN_EPS,
          ptr(vec[0]), ptr(vec[1]), C)
-    bn._hip_eval_vec = (key, vec)
+    if hip.recorder is None:           # (a launch plan owns the vectors it recomputes at every replay: not shared through the module)
+        bn._hip_eval_vec = (key, vec)
     return vec
 
 
@@ -868,9 +869,12 @@ def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False, tpool=0):
              ptr(bn.running_var), BN_MOMENTUM, BN_EPS, ptr(vec), C)
         rt.touched_bns.append(bn)
     else:
+        # [G][4][C] with (scale, shift) of the eval-mode affine in rows 0 / 1 of every group (the epilogue reads nothing else): stream-ordered
+        # C-ABI copies, so that a launch plan records them
         ev = _bn_eval_vectors(rt, bn, C, dev)
-        vec = torch.zeros(G, 4, C, dtype=torch.float32, device=dev)
-        vec[:, 0], vec[:, 1] = ev[0], ev[1]
+        vec = torch.empty(G, 4, C, dtype=torch.float32, device=dev)
+        for gi in range(G):
+            call("adamml_copy2d", ptr(vec[gi]), 0, ptr(ev), 0, 2 * C * 4, 1)
     if tpool:
         to = tpool // 2
         out_t = torch.empty(G * d.N // tpool * to, d.OH, d.OW, C, dtype=torch.bfloat16, device=dev)        # POOLED block output

@@ -148,3 +148,46 @@ def test_plans_with_dropout_redraw_the_mask_every_replay():
         assert not torch.equal(outs[4], outs[5]) and not torch.equal(outs[3], outs[4])
     finally:
         plan.ENABLED = False
+
+
+def test_inference_plans_equal_eager_inference():
+    """Policy-gated inference (models/adamml.py:81-86 with decision-driven skipping) at a serving-sized batch: with launch plans the
+    eval-mode calls of the policy backbones and of the main nets (selected-clip count padded to a multiple of 8) are replayed from C; logits
+    and decisions must equal the eager path's exactly, also after the weights changed (the plan recomputes its BatchNorm affines)."""
+    from adamml_amd import plan
+    c = CASES["adamml_rgb_sound"]
+    xs, _ = case_inputs(c)
+    xs = [t.to(DEV) for t in xs]
+    expo = synth.synth_gumbel_exponential(c["S"], 2, c["B"], seed=11).to(DEV)
+    model = _build(c, 0.0)
+    model.load_state_dict(synth.synth_state_dict(manifest(c), seed=1234))
+    model.to(DEV).eval()
+
+    def infer():
+        with torch.no_grad():
+            y, sel = model(xs, gumbel_exponential=expo)
+        return y.clone(), sel.clone(), dict(model.last_skip_stats)
+
+    ref, sel_ref, st_ref = infer()
+    assert 0 < sum(st_ref["executed_per_modality"]) < 2 * st_ref["clips"]          # some clips skipped, some run: the compaction path
+    before = dict(plan.stats)
+    plan.ENABLED = True
+    try:
+        outs = [infer() for _ in range(5)]
+        assert plan.stats["recorded"] - before["recorded"] >= 3 and plan.stats["replayed_ops"] - before["replayed_ops"] > 300
+        for y, sel, st in outs:
+            assert torch.equal(sel, sel_ref) and torch.equal(y, ref) and st == st_ref
+        # new weights / statistics: eager reference from a fresh model, planned result from the replaying one
+        sd2 = synth.synth_state_dict(manifest(c), seed=77)
+        model.load_state_dict(sd2)
+        for n in model.backbones():
+            n.mark_weights_dirty()
+        got, sel_got, _ = infer()
+    finally:
+        plan.ENABLED = False
+    fresh = _build(c, 0.0)
+    fresh.load_state_dict(sd2)
+    fresh.to(DEV).eval()
+    with torch.no_grad():
+        want, sel_want = fresh(xs, gumbel_exponential=expo)
+    assert torch.equal(sel_got, sel_want) and torch.equal(got, want)
