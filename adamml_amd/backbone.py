@@ -306,11 +306,14 @@ class HipBackbone(nn.Module):
                         hip.recorder = rec
             tape.record(fire)
 
-    def _trainable(self):
-        plist = getattr(self, "_plist", None)
+    def _params(self):
+        plist = self.__dict__.get("_plist")
         if plist is None:                # (parameter OBJECTS are fixed after construction; only their .data / .requires_grad change)
-            plist = self._plist = list(self.parameters())
-        return any(p.requires_grad for p in plist)
+            plist = self.__dict__["_plist"] = list(self.parameters())
+        return plist
+
+    def _trainable(self):
+        return any(p.requires_grad for p in self._params())
 
     def call(self, x, groups=1, precomputed=None):
         """x: NHWC bf16 frames tensor on the GPU, `groups` independent module calls stacked along dim 0 (group-major):
@@ -325,7 +328,7 @@ class HipBackbone(nn.Module):
         if self._anchor is None or self._anchor.device != x.device:
             self._anchor = torch.zeros(1, device=x.device)
         anchor = self._anchor.detach().requires_grad_(need_grad)
-        params = [p for p in self._plist if p.requires_grad] if (need_grad and self.expose_param_grads) else []
+        params = [p for p in self._params() if p.requires_grad] if (need_grad and self.expose_param_grads) else []
         self._precomputed = precomputed
         try:
             return torch.ops.adamml.backbone_call(anchor, x, params, self._handle, groups, need_grad)
@@ -372,8 +375,8 @@ class HipBackbone(nn.Module):
             return None
         ws = rt.wgrad_stream.cuda_stream if rt.wgrad_stream is not None else 0
         return (tuple(x.shape), x.dtype, groups, need_grad, self.training, hip.deterministic(), rt.sync.enabled, ws, hip._stream(),
-                tuple(p.requires_grad for p in self._plist), self.flat_owner.flat.data_ptr() if (self.flat_owner is not None and
-                self.flat_owner.flat is not None) else self._plist[0].data_ptr(), self.grad_hook is not None)
+                tuple(p.requires_grad for p in self._params()), self.flat_owner.flat.data_ptr() if (self.flat_owner is not None and
+                self.flat_owner.flat is not None) else self._params()[0].data_ptr(), self.grad_hook is not None)
 
     def run_planned(self, x, groups, need_grad):
         """_run(), or the replay of its launch plan once the same call has been seen WARMUP_CALLS times."""

@@ -874,7 +874,7 @@ def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False, tpool=0):
         ev = _bn_eval_vectors(rt, bn, C, dev)
         vec = torch.empty(G, 4, C, dtype=torch.float32, device=dev)
         for gi in range(G):
-            call("adamml_copy2d", ptr(vec[gi]), 0, ptr(ev), 0, 2 * C * 4, 1)
+            call("adamml_copy2d", ptr(vec[gi]), 2 * C * 4, ptr(ev), 2 * C * 4, 2 * C * 4, 1)
     if tpool:
         to = tpool // 2
         out_t = torch.empty(G * d.N // tpool * to, d.OH, d.OW, C, dtype=torch.bfloat16, device=dev)        # POOLED block output
