@@ -241,7 +241,7 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
                 out = net.forward_nhwc(frames, S if raw32 else 1)             # (eval BatchNorm: the grouping is immaterial)
             nsel = int(idx.numel())
             if 0 < nsel < S * B:
-                if plan.ENABLED and idx.numel() % 8:
+                if plan.ENABLED and plan.EVAL_ENABLED and idx.numel() % 8:
                     # launch plans are per call shape: pad the selected clips to a multiple of 8 (the first one repeated; eval BatchNorm is
                     # per sample, the duplicates' logits overwrite identical values) so that few distinct shapes occur
                     idx = torch.cat([idx, idx[:1].expand(8 - idx.numel() % 8)])

@@ -369,7 +369,7 @@ class HipBackbone(nn.Module):
         if not plan.ENABLED or hip.profiler is not None or rt.capture is not None or self.expose_param_grads \
                 or getattr(self, "_dropout_keep_mask", None) is not None or (rt.sync.enabled and self.training and not interleave.active()):
             return None
-        if not self.training and (need_grad or x.numel() > plan.MAX_EVAL_ELEMENTS):
+        if not self.training and (not plan.EVAL_ENABLED or need_grad or x.numel() > plan.MAX_EVAL_ELEMENTS):
             # inference: a plan pins the activations of its call shape, and the shapes of policy-gated inference vary with the decisions --
             # worth it for serving-sized calls only
             return None

@@ -13,9 +13,10 @@ goes through pointer slots (slot 0: the call's input tensor, slot 1: the incomin
 into its fixed buffer by a pre-replay hook, `num_batches_tracked` is advanced by a post-replay hook.
 
 Opt-in (`ADAMML_LAUNCH_PLAN=1`, `plan.ENABLED = True`, `bench.py --launch-plan`): a plan pins every intermediate tensor of its call, i.e.
-the SUM of the call's allocations instead of their peak -- right for small per-GPU batches, wrong for B = 72.  Inference calls are planned
-up to a serving-sized input (MAX_EVAL_ELEMENTS); their eval-mode BatchNorm affines are recomputed inside the plan (the eager path caches
-them per module), and policy-gated inference pads its selected-clip count to a multiple of 8 so that few distinct shapes occur."""
+the SUM of the call's allocations instead of their peak -- right for small per-GPU batches, wrong for B = 72.  Inference calls can be
+planned too (EVAL_ENABLED, serving-sized inputs up to MAX_EVAL_ELEMENTS: their eval-mode BatchNorm affines are recomputed inside the plan,
+policy-gated inference pads its selected-clip count to a multiple of 8 so that few distinct shapes occur) -- correct, but measured to gain
+nothing: see EVAL_ENABLED."""
 import ctypes
 import os
 import struct
@@ -25,6 +26,10 @@ import torch
 from . import hip
 
 ENABLED = os.environ.get("ADAMML_LAUNCH_PLAN", "0") not in ("", "0")
+# inference calls as well (serving-sized inputs only).  Off by default: measured on MI355X, policy-gated inference at B = 1 / 4 / 8 videos
+# takes 5.5 / 5.9 / 6.7 ms per batch eagerly and 5.2 / 6.0 / 7.6 ms with plans -- it is bound by the DEVICE-side chain of ~330 dependent tiny
+# launches of the two policy backbones and by the host sync on the decisions, not by the host's issue rate
+EVAL_ENABLED = os.environ.get("ADAMML_LAUNCH_PLAN_EVAL", "0") not in ("", "0")
 WARMUP_CALLS = 2               # eager calls of a key before it is recorded (arenas and scratch buffers have reached their sizes)
 MAX_PLANS_PER_NET = 4          # training plans kept per backbone (each pins the activations of one call shape / mode)
 MAX_EVAL_PLANS_PER_NET = 12    # inference plans kept per backbone (policy-gated inference: one per padded clip count)

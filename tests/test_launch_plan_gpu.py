@@ -171,7 +171,7 @@ def test_inference_plans_equal_eager_inference():
     ref, sel_ref, st_ref = infer()
     assert 0 < sum(st_ref["executed_per_modality"]) < 2 * st_ref["clips"]          # some clips skipped, some run: the compaction path
     before = dict(plan.stats)
-    plan.ENABLED = True
+    plan.ENABLED = plan.EVAL_ENABLED = True
     try:
         outs = [infer() for _ in range(5)]
         assert plan.stats["recorded"] - before["recorded"] >= 3 and plan.stats["replayed_ops"] - before["replayed_ops"] > 300
@@ -184,7 +184,7 @@ def test_inference_plans_equal_eager_inference():
             n.mark_weights_dirty()
         got, sel_got, _ = infer()
     finally:
-        plan.ENABLED = False
+        plan.ENABLED = plan.EVAL_ENABLED = False
     fresh = _build(c, 0.0)
     fresh.load_state_dict(sd2)
     fresh.to(DEV).eval()
