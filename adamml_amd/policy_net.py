@@ -190,11 +190,6 @@ class PolicyNet(nn.Module):
             self.temperature *= decay_ratio
         print("Current temperature: {}".format(self.temperature), flush=True)
 
-    def segment_features(self, x, i):
-        """Joint feature [B, 2048] of segment i (models/policy_net.py:323-326); lets the caller interleave the policy
-        backbones of segment i with the main nets of segment i on different HIP streams."""
-        return self.joint_net.features([x[m_i][i] for m_i in range(self.num_modality)])
-
     def all_segment_features(self, x):
         """Joint features of ALL segments in one batched pass (per-segment BatchNorm statistics are kept by the
         `groups` mechanism of the backbones; the joint FCs have no batch statistics).  -> list of S tensors [B, 2048]."""

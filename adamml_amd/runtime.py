@@ -872,9 +872,15 @@ def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False, tpool=0):
         # [G][4][C] with (scale, shift) of the eval-mode affine in rows 0 / 1 of every group (the epilogue reads nothing else): stream-ordered
         # C-ABI copies, so that a launch plan records them
         ev = _bn_eval_vectors(rt, bn, C, dev)
-        vec = torch.empty(G, 4, C, dtype=torch.float32, device=dev)
-        for gi in range(G):
-            call("adamml_copy2d", ptr(vec[gi]), 2 * C * 4, ptr(ev), 2 * C * 4, 2 * C * 4, 1)
+        c4 = getattr(bn, "_hip_eval_vec4", None)
+        if c4 is not None and c4[0] is ev and c4[1].shape[0] == G and hip.recorder is None:
+            vec = c4[1]                      # (built from this very eval-affine tensor: valid as long as that cache entry is)
+        else:
+            vec = torch.empty(G, 4, C, dtype=torch.float32, device=dev)
+            for gi in range(G):
+                call("adamml_copy2d", ptr(vec[gi]), 2 * C * 4, ptr(ev), 2 * C * 4, 2 * C * 4, 1)
+            if hip.recorder is None:
+                bn._hip_eval_vec4 = (ev, vec)
     if tpool:
         to = tpool // 2
         out_t = torch.empty(G * d.N // tpool * to, d.OH, d.OW, C, dtype=torch.bfloat16, device=dev)        # POOLED block output

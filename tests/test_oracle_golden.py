@@ -56,5 +56,6 @@ def test_oracle_training_trajectory_follows_the_reference():
         loss.backward()
         opt.step()
         assert np.array_equal(np.round(sel.detach().numpy()), np.round(traj["decisions"]))
-        assert abs(float(loss) - float(traj["loss"][it])) <= 2e-4 * float(traj["loss"][it]), (it, float(loss), float(traj["loss"][it]))
+        lv = float(loss.detach())
+        assert abs(lv - float(traj["loss"][it])) <= 2e-4 * float(traj["loss"][it]), (it, lv, float(traj["loss"][it]))
         np.testing.assert_allclose(logits.detach().numpy(), traj["logits"][it], rtol=2e-3, atol=2e-4)
