@@ -17,6 +17,27 @@
 
 ADAMML_DET_SETTER(conv3x3_c64)
 
+// Phase timing (tools/c64_phase_probe.py builds this file alone with -DC64_PHASE_TIMING; never part of the shipped library): every wave of
+// one workgroup stamps the shader clock at the phase boundaries of its first tiles.
+#ifdef C64_PHASE_TIMING
+// (stamps go to a small LDS area and are flushed to global memory once per tile: a global store per stamp would make every stamp wait for
+// the prefetched patch loads -- vmcnt is shared)
+__device__ unsigned* c64_dbg = nullptr;
+#define C64_TS_ON (dbg_on && it < 16)
+#define C64_TS(k) do { if (C64_TS_ON && lane == 0) s_dbg[wave * 16 + (k)] = (unsigned)__builtin_readcyclecounter(); } while (0)
+#define C64_TS_DECL unsigned* s_dbg = reinterpret_cast<unsigned*>(smem + 160 * 1024 - 1024); unsigned* g_dbg = c64_dbg; const bool dbg_on = g_dbg && blockIdx.x == 8;
+#define C64_TS_FLUSH do { if (C64_TS_ON) { __syncthreads(); if (tid < 128) g_dbg[it * 128 + tid] = s_dbg[tid]; __syncthreads(); } } while (0)
+#define C64_LDS(x) (160 * 1024)
+extern "C" int adamml_c64_set_phase_buffer(unsigned* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(c64_dbg), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#else
+#define C64_TS(k) do { } while (0)
+#define C64_TS_DECL
+#define C64_TS_FLUSH do { } while (0)
+#define C64_LDS(x) (x)
+#endif
+
 namespace {
 
 constexpr int NT3 = 512;
@@ -24,7 +45,17 @@ constexpr int C64 = 64;
 constexpr int KT3 = 9 * C64;             // 576
 constexpr int WROW3 = KT3 * 2 + 16;      // LDS bytes per weight row (+16 B skew): 1168
 constexpr int PPIX = C64 * 2 + 16;       // patch pixel pitch: 144 B
-constexpr int SROW3 = C64 * 2 + 8;       // staging row: 136 B
+// Start stagger.  Every workgroup runs the same phases on same-sized tiles, and the CUs stay in step: all of them request their next patch
+// (36 MB chip-wide) within the same few microseconds, then all of them compute while HBM idles.  The first workgroup of each CU (the
+// later ones inherit its phase) therefore starts 0..3 quarter-tile times late, by its position within the XCD: forward 0.95 -> 0.90 ms,
+// weight gradient 0.89 -> 0.84 ms at the layer-1 shape (tools/c64_ab.py; two / eight / sixteen phases and longer delays measured the same).
+// Only for launches whose workgroups own >= 8 tiles each: the delay (<= 18 000 cycles) must stay small against the workgroup's life.
+#ifndef C64_STAGGER
+#define C64_STAGGER 94                   // s_sleep units (64 cycles) per phase step; 0 = off (A/B aid)
+#endif
+#define C64_STAGGER_PH 4
+#define C64_STAGGER_START do { if (C64_STAGGER && p.tpb >= 8 && blockIdx.x < 256) { const int ph = (blockIdx.x >> 3) & (C64_STAGGER_PH - 1); for (int i = 0; i < ph; ++i) __builtin_amdgcn_s_sleep(C64_STAGGER); } } while (0)
+constexpr int SROW3 = C64 * 2 + 8;       // staging row: 136 B (144 measured the same)
 constexpr int MAXPT = 4;                 // pixel tiles (16 px) per wave
 constexpr int MAXPX3 = 8 * MAXPT * 16;   // 512 output pixels per tile at most
 constexpr int MAXSLOT3 = 10;             // 16-byte patch slots per thread
@@ -45,6 +76,29 @@ struct C3P {
     int wswz;                // 1: weight rows stored with the chunk swizzle (A/B aid ADAMML_C64_WSWZ)
     size_t gxy;              // elements per group of x and y (same shape)
 };
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+
+// relu(scale * z + shift) of 8 bf16 values, rounded to bf16.  The generic form (unpack, fma, max, min, convert: 43 VALU instructions per
+// 16-byte slot) made the patch staging the second-longest phase of a tile (tools/c64_phase_probe.py: 3500 of 24000 cycles with two waves
+// per SIMD); here the FMAs are packed-fp32 and ReLU is one signed 16-bit max per PAIR on the rounded result -- round-to-nearest-even is
+// monotonic and keeps the sign, so max(round(v), 0) == round(max(v, 0)) bit for bit (and -0 becomes +0 either way).
+__device__ __forceinline__ bf16x8 bn_relu8(bf16x8 raw, const f32x8& sc, const f32x8& sh) {
+    union { bf16x8 v; unsigned w[4]; } in;
+    union { bf16x8 v; s16x2 h[4]; bf16x2 b[4]; } out;
+    in.v = raw;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 z = {__uint_as_float(in.w[i] << 16), __uint_as_float(in.w[i] & 0xffff0000u)};
+        const f32x2 a = {sc[2 * i], sc[2 * i + 1]}, b = {sh[2 * i], sh[2 * i + 1]};
+        const f32x2 r = __builtin_elementwise_fma(z, a, b);
+        out.b[i] = __builtin_convertvector(r, bf16x2);
+        out.h[i] = __builtin_elementwise_max(out.h[i], s16x2{0, 0});
+    }
+    return out.v;
+}
 
 __device__ __forceinline__ void fold16_to_cs(const f32x8& esum, const f32x8& esq, float* cs, int lane, int ech, double* gdst) {
     // lanes l, l+8, .., l+56 of a wave hold partial sums of channel chunk `ech` (8 channels): DPP + lane-swap fold
@@ -93,7 +147,9 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
     float* cs = reinterpret_cast<float*>(smem + C64 * WROW3);      // [128]
     char* s_patch = smem + C64 * WROW3 + 512;                      // patch, later the staging tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    C64_TS_DECL
     const int li = lane & 15, lg = lane >> 4;
+    C64_STAGGER_START;
 
     for (int e = tid; e < C64 * (KT3 / 8); e += NT3) {
         const int co = e / (KT3 / 8), ch = e - co * (KT3 / 8);
@@ -104,35 +160,46 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
     }
     if (tid < 128) cs[tid] = 0.f;
 
-    // ---- patch slots: slot e -> (patch pixel e >> 3, 16-byte chunk e & 7 == tid & 7); tile-invariant --------------------
+    // ---- patch slots: slot e -> (patch pixel e >> 3, 16-byte chunk e & 7 == tid & 7) -------------------------------------------
+    // slot l of this thread is patch pixel (tid >> 3) + 64 l: its (row, column) is carried from slot to slot (the slots of a tile are always
+    // loaded in order) instead of a 10-register table
     const int nslots = p.PR * p.PW * 8;
     const int ech = tid & 7;
-    int s_rc[MAXSLOT3];                  // patch (row << 16 | column) of each slot; dead slots get row 0x7fff
-#pragma unroll
-    for (int l = 0; l < MAXSLOT3; ++l) {
-        const int e = tid + l * NT3;
-        const int ppix = e >> 3;
-        const int pr = ppix / p.PW;
-        s_rc[l] = ((e < nslots ? pr : 0x7fff) << 16) | (ppix - pr * p.PW);
-    }
+    const int pstep_r = 64 / p.PW, pstep_c = 64 - pstep_r * p.PW;
+    const int pr0 = (tid >> 3) / p.PW, pc0 = (tid >> 3) - pr0 * p.PW;
+    int cpr = pr0, cpc = pc0;
     bf16x8 rp[MAXSLOT3];
     unsigned rok = 0;
-    auto load_patch = [&](int tile) {
+    const char* nimg = nullptr;          // (uniform) image base / first input row of the tile being prefetched
+    int nih0 = 0;
+    auto load_begin = [&](int tile) {
         const int g = tile / p.tiles_per_group, tg = tile - g * p.tiles_per_group;
         const int n = tg / p.tiles_per_img, tr = tg - n * p.tiles_per_img;
-        const int ih0 = tr * p.R - 1;
-        const bf16_t* img = p.x + (size_t)g * p.gxy + (size_t)n * p.H * p.W * C64 + ech * 8;
+        nih0 = tr * p.R - 1;
+        nimg = reinterpret_cast<const char*>(p.x + (size_t)g * p.gxy + (size_t)n * p.H * p.W * C64);
         rok = 0;
+        cpr = pr0; cpc = pc0;
+        asm volatile("" : "+v"(cpr), "+v"(cpc));      // (opaque: the whole carry chain is tile-invariant and would be hoisted out of the tile loop as a 20-register table)
+    };
+    auto load_slot = [&](int l) {
+        // UNCONDITIONAL loads from clamped (always valid) addresses, zeroed at the LDS write: a branch per slot makes
+        // the compiler wait for each load before the next one is issued (one HBM round trip per slot)
+        const int ih = nih0 + cpr, iw = cpc - 1;
+        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && tid + l * NT3 < nslots;
+        rok |= (ok ? 1u : 0u) << l;
+        const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
+        // uniform 64-bit base + 32-bit lane offset (data gradient 1.13 -> 1.08 ms against per-lane 64-bit addresses, tools/c64_ab.py)
+        const unsigned off = (unsigned)(ihc * p.W + iwc) * (C64 * 2) + ech * 16;
+        rp[l] = *reinterpret_cast<const bf16x8*>(nimg + off);
+        cpc += pstep_c;
+        const bool wrap = cpc >= p.PW;
+        cpc -= wrap ? p.PW : 0;
+        cpr += pstep_r + (wrap ? 1 : 0);
+    };
+    auto load_patch = [&](int tile) {
+        load_begin(tile);
 #pragma unroll
-        for (int l = 0; l < MAXSLOT3; ++l) {
-            // UNCONDITIONAL loads from clamped (always valid) addresses, zeroed at the LDS write: a branch per slot makes
-            // the compiler wait for each load before the next one is issued (one HBM round trip per slot)
-            const int ih = ih0 + (s_rc[l] >> 16), iw = (s_rc[l] & 0xffff) - 1;
-            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            rok |= (ok ? 1u : 0u) << l;
-            const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
-            rp[l] = *reinterpret_cast<const bf16x8*>(img + ((size_t)ihc * p.W + iwc) * C64);
-        }
+        for (int l = 0; l < MAXSLOT3; ++l) load_slot(l);
     };
     const int tile0 = blockIdx.x * p.tpb;
     if (tile0 < p.total_tiles) load_patch(tile0);
@@ -155,6 +222,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
             cur_group = g;
         }
         // ---- prefetched patch -> LDS (BatchNorm + activation of the producer applied here, once per element) ------------
+        C64_TS(0);
         {
             const float lo = act_lo(p.act), hi = act_hi(p.act);
             f32x8 sc, sh;                          // (re-read per tile from L1/L2: not held across the MFMA loop)
@@ -164,23 +232,27 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
                 sc = load_f32x8(p.in_scale + (size_t)g * p.in_gstride + ech * 8);
                 sh = load_f32x8(p.in_shift + (size_t)g * p.in_gstride + ech * 8);
             }
+            const bool relu_bn = p.in_scale && p.act == ACT_RELU;
 #pragma unroll
             for (int l = 0; l < MAXSLOT3; ++l) {
                 const int e = tid + l * NT3;
                 if (e < nslots) {
                     bf16x8 v = rp[l];
-                    if (!((rok >> l) & 1u)) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (relu_bn) v = bn_relu8(v, sc, sh);                       // (uniform)
                     else if (p.in_scale) {
                         f32x8 f = bf8_to_f32(v);
 #pragma unroll
                         for (int i = 0; i < 8; ++i) f[i] = clamp_act(fmaf(f[i], sc[i], sh[i]), lo, hi);
                         v = f32_to_bf8(f);
                     }
+                    if (!((rok >> l) & 1u)) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
                     *reinterpret_cast<bf16x8*>(s_patch + (e >> 3) * PP + ech * 16) = v;
                 }
             }
         }
+        C64_TS(1);
         __syncthreads();
+        C64_TS(2);
         if (it + 1 < p.tpb && tile + 1 < p.total_tiles) load_patch(tile + 1);
         // BNZ: the epilogue reads the z rows of this strip (one 128-byte line per pixel, contiguous) with nothing to overlap them with --
         // one 8-wave workgroup per CU, every register and all of the LDS taken.  One dword per line requested HERE, ahead of the ~14 us
@@ -205,36 +277,38 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
         }
         const char* wbase = s_w + li * WROW3 + (lg ^ (((li >> 2) ^ (li >> 3)) & p.wswz)) * 16;
         const bool last_live = (wave + 24) * 16 < npx;
-#pragma unroll 1
-        for (int kh = 0; kh < 3; ++kh) {
+        C64_TS(3);
+        // Two copies of the loop, for waves with 4 and with 3 live pixel tiles (dead ones of a short strip read valid patch addresses and are
+        // zeroed at staging; full strips have >= 24 live tiles): with the 4th tile behind a branch INSIDE the K step every K step was its own
+        // basic block -- five ds_reads, a full LDS round trip, then MFMAs (tools/c64_phase_probe.py: 10 700 cycles for 8 064 of MFMA) --
+        // straight-line K steps let the scheduler run the next step's reads under this step's MFMAs.
+        auto mfma_loop = [&](auto npt_c) {
+            constexpr int NPT = decltype(npt_c)::value;
+#pragma unroll 1                              // (all 18 K steps unrolled: 0.86 -> 1.02 ms, measured)
+            for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
-            for (int kk = 0; kk < 6; ++kk) {                 // (kw, 32-channel half)
-                const int ks = kh * 6 + kk;
-                const int aoff = (kh * p.PW + (kk >> 1)) * PP + (kk & 1) * 64;
-                bf16x8 fw[4];
+                for (int kk = 0; kk < 6; ++kk) {             // (kw, 32-channel half)
+                    const int ks = kh * 6 + kk;
+                    const int aoff = (kh * p.PW + (kk >> 1)) * PP + (kk & 1) * 64;
+                    bf16x8 fw[4], fa[NPT];
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) fw[ct] = *reinterpret_cast<const bf16x8*>(wbase + ct * 16 * WROW3 + ks * 64);
-                // pixel tiles 0..2 of a wave are computed unconditionally (dead ones of a short strip read valid patch addresses and
-                // are zeroed at staging; full strips have >= 24 live tiles); only the 4th is guarded, so the
-                // bulk is straight-line code whose ds_reads the compiler can run ahead of the MFMAs
-                bf16x8 fa[3];
+                    for (int ct = 0; ct < 4; ++ct) fw[ct] = *reinterpret_cast<const bf16x8*>(wbase + ct * 16 * WROW3 + ks * 64);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) fa[j] = *reinterpret_cast<const bf16x8*>(s_patch + pixoff[j] + aoff);
+                    for (int j = 0; j < NPT; ++j) fa[j] = *reinterpret_cast<const bf16x8*>(s_patch + pixoff[j] + aoff);
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
+                    for (int j = 0; j < NPT; ++j)
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
-                        acc[ct][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ct], fa[j], acc[ct][j], 0, 0, 0);
-                if (last_live) {                             // wave-uniform
-                    const bf16x8 f3 = *reinterpret_cast<const bf16x8*>(s_patch + pixoff[3] + aoff);
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
-                        acc[ct][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ct], f3, acc[ct][3], 0, 0, 0);
+                        for (int ct = 0; ct < 4; ++ct)
+                            acc[ct][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ct], fa[j], acc[ct][j], 0, 0, 0);
                 }
             }
-        }
+        };
+        if (__builtin_amdgcn_readfirstlane(last_live ? 1 : 0)) mfma_loop(std::integral_constant<int, 4>{});
+        else mfma_loop(std::integral_constant<int, 3>{});
         if constexpr (BNZ) asm volatile("" ::"v"(ztouch));   // (keeps the touch load's destination allocated until it has landed)
+        C64_TS(4);
         __syncthreads();                                     // patch consumed: its LDS becomes the staging tile
+        C64_TS(5);
 
         // ---- stage [npt*16][64] bf16 (rows >= npx zero) ---------------------------------------------------------------
 #pragma unroll
@@ -250,7 +324,9 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
                 }
             }
         }
+        C64_TS(6);
         __syncthreads();
+        C64_TS(7);
         const size_t obase = (size_t)g * p.gxy + ((size_t)n * p.H + oh0) * p.W * C64;
         if constexpr (!BNZ) {
             for (int e = tid; e < npx * 8; e += NT3) {
@@ -348,7 +424,10 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
             if (p.bn_act == ADAMML_ACT_RELU) rows(std::true_type{}); else rows(std::false_type{});      // (uniform)
             if (p.stats) fold16_to_cs(esum, esq, cs, lane, ech, det_mode() ? p.stats + (size_t)g * ADAMML_STAT_SLOTS * 128 : nullptr);
         }
+        C64_TS(8);
         __syncthreads();                                     // staging consumed before the next patch lands
+        C64_TS(9);
+        C64_TS_FLUSH;
     }
     if (p.stats && cur_group >= 0) {
         __syncthreads();
@@ -382,48 +461,63 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_wgrad_kernel(C3WP p) {
     char* s_dz = smem + p.PR * p.PW * PPIX;                          // [MAXPX3][SROW3]
     int* s_poff = reinterpret_cast<int*>(s_dz + MAXPX3 * SROW3);     // patch byte offset of each strip pixel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    C64_TS_DECL
     const int li = lane & 15, lg = lane >> 4;
     const int ech = tid & 7;
     const int nslots = p.PR * p.PW * 8;
+    C64_STAGGER_START;
     for (int q = tid; q < MAXPX3; q += NT3) {
         const int qq = q < p.R * p.W ? q : 0;
         const int r = qq / p.W, c = qq - r * p.W;
         s_poff[q] = (r * p.PW + c) * PPIX;
     }
-    int s_rc[MAXSLOT3];
-#pragma unroll
-    for (int l = 0; l < MAXSLOT3; ++l) {
-        const int e = tid + l * NT3;
-        const int ppix = e >> 3;
-        const int pr = ppix / p.PW;
-        s_rc[l] = ((e < nslots ? pr : 0x7fff) << 16) | (ppix - pr * p.PW);
-    }
+    // patch slot l of this thread is patch pixel (tid >> 3) + 64 l: its (row, column) is carried from slot to slot (the slots of a tile are
+    // always loaded in order) instead of a 10-register table
+    const int pstep_r = 64 / p.PW, pstep_c = 64 - pstep_r * p.PW;
+    const int pr0 = (tid >> 3) / p.PW, pc0 = (tid >> 3) - pr0 * p.PW;
+    int cpr = pr0, cpc = pc0;
     bf16x8 rp[MAXSLOT3], rz[MAXDZ3];
     unsigned rok = 0;                    // bits 0..9: patch slots valid; bits 16..23: dz slots valid
-    auto load_tile = [&](int tile) {
+    // the tile being prefetched: uniform image / strip bases, first input row, live dz elements
+    const char* nimg = nullptr;
+    const char* nzb = nullptr;
+    int nih0 = 0, nnpx8 = 0;
+    auto load_begin = [&](int tile) {
         const int g = tile / p.tiles_per_group, tg = tile - g * p.tiles_per_group;
         const int n = tg / p.tiles_per_img, tr = tg - n * p.tiles_per_img;
-        const int ih0 = tr * p.R - 1;
+        nih0 = tr * p.R - 1;
         const size_t ibase = (size_t)g * p.gxy + (size_t)n * p.H * p.W * C64;
-        const bf16_t* img = p.x + ibase + ech * 8;
-        rok = 0;
-#pragma unroll
-        for (int l = 0; l < MAXSLOT3; ++l) {
-            const int ih = ih0 + (s_rc[l] >> 16), iw = (s_rc[l] & 0xffff) - 1;
-            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            rok |= (ok ? 1u : 0u) << l;
-            const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
-            rp[l] = *reinterpret_cast<const bf16x8*>(img + ((size_t)ihc * p.W + iwc) * C64);
-        }
+        nimg = reinterpret_cast<const char*>(p.x + ibase);
         const int oh0 = tr * p.R;
-        const int npx = min(p.R, p.H - oh0) * p.W;
-        const bf16_t* zb = p.dz + ibase + (size_t)oh0 * p.W * C64;
+        nnpx8 = min(p.R, p.H - oh0) * p.W * 8;
+        nzb = reinterpret_cast<const char*>(p.dz + ibase + (size_t)oh0 * p.W * C64);
+        rok = 0;
+        cpr = pr0; cpc = pc0;
+        asm volatile("" : "+v"(cpr), "+v"(cpc));      // (opaque: the whole carry chain is tile-invariant and would be hoisted out of the tile loop as a 20-register table)
+    };
+    auto load_p = [&](int l) {           // patch slot l: unconditional load from a clamped (valid) address, zeroed at the LDS write
+        const int ih = nih0 + cpr, iw = cpc - 1;
+        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && tid + l * NT3 < nslots;
+        rok |= (ok ? 1u : 0u) << l;
+        const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
+        const unsigned off = (unsigned)(ihc * p.W + iwc) * (C64 * 2) + ech * 16;       // (uniform 64-bit base + 32-bit lane offset)
+        rp[l] = *reinterpret_cast<const bf16x8*>(nimg + off);
+        cpc += pstep_c;
+        const bool wrap = cpc >= p.PW;
+        cpc -= wrap ? p.PW : 0;
+        cpr += pstep_r + (wrap ? 1 : 0);
+    };
+    auto load_z = [&](int l) {
+        const int e = tid + l * NT3;
+        rz[l] = *reinterpret_cast<const bf16x8*>(nzb + (unsigned)(e < nnpx8 ? e : 0) * 16u);
+        rok |= (e < nnpx8 ? 1u : 0u) << (16 + l);
+    };
+    auto load_tile = [&](int tile) {
+        load_begin(tile);
 #pragma unroll
-        for (int l = 0; l < MAXDZ3; ++l) {
-            const int e = tid + l * NT3;
-            rz[l] = *reinterpret_cast<const bf16x8*>(zb + (size_t)(e < npx * 8 ? e : 0) * 8);
-            rok |= (e < npx * 8 ? 1u : 0u) << (16 + l);
-        }
+        for (int l = 0; l < MAXSLOT3; ++l) load_p(l);
+#pragma unroll
+        for (int l = 0; l < MAXDZ3; ++l) load_z(l);
     };
     f32x4 acc[4][5];                      // [cout tile][own N tile j]: N tile nt = wave + 8*j -> (tap nt >> 2, channel block nt & 3)
 #pragma unroll
@@ -446,6 +540,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_wgrad_kernel(C3WP p) {
         const int g = tile / p.tiles_per_group, tg = tile - g * p.tiles_per_group;
         const int tr = tg % p.tiles_per_img;
         const int npx = min(p.R, p.H - tr * p.R) * p.W;
+        C64_TS(0);
         {
             const float lo = act_lo(p.act), hi = act_hi(p.act);
             f32x8 sc, sh;
@@ -455,18 +550,20 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_wgrad_kernel(C3WP p) {
                 sc = load_f32x8(p.in_scale + (size_t)g * p.in_gstride + ech * 8);
                 sh = load_f32x8(p.in_shift + (size_t)g * p.in_gstride + ech * 8);
             }
+            const bool relu_bn = p.in_scale && p.act == ACT_RELU;
 #pragma unroll
             for (int l = 0; l < MAXSLOT3; ++l) {
                 const int e = tid + l * NT3;
                 if (e < nslots) {
                     bf16x8 v = rp[l];
-                    if (!((rok >> l) & 1u)) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (relu_bn) v = bn_relu8(v, sc, sh);                       // (uniform)
                     else if (p.in_scale) {
                         f32x8 f = bf8_to_f32(v);
 #pragma unroll
                         for (int i = 0; i < 8; ++i) f[i] = clamp_act(fmaf(f[i], sc[i], sh[i]), lo, hi);
                         v = f32_to_bf8(f);
                     }
+                    if (!((rok >> l) & 1u)) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
                     *reinterpret_cast<bf16x8*>(s_patch + (e >> 3) * PPIX + ech * 16) = v;
                 }
             }
@@ -480,8 +577,13 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_wgrad_kernel(C3WP p) {
                 *reinterpret_cast<s16x4*>(dst + 8) = u.s.b;
             }
         }
+        C64_TS(1);
         __syncthreads();
+        C64_TS(2);
+        // (issuing these 18 loads per thread a few per K step INSIDE the MFMA loop was measured and lost: 0.85 -> 1.00 ms, the loads
+        // that start late are not back when the next tile is staged -- tools/c64_ab.py)
         if (it + 1 < p.tpb && tile + 1 < p.total_tiles) load_tile(tile + 1);
+        C64_TS(3);
         const int nks = (npx + 31) >> 5;
         for (int ks = 0; ks < nks; ++ks) {
             const int q0 = ks * 32 + trow;
@@ -508,7 +610,10 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_wgrad_kernel(C3WP p) {
                 }
             }
         }
+        C64_TS(4);
         __syncthreads();
+        C64_TS(5);
+        C64_TS_FLUSH;
     }
     float* out = p.ws + (size_t)blockIdx.x * C64 * KT3;
 #pragma unroll
@@ -591,11 +696,11 @@ int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const 
     }
     const dim3 grid(ceil_div(p.total_tiles, p.tpb));
     if (pitch == 160) {
-        if (p.bn_z) hipLaunchKernelGGL((conv3x3_c64_kernel<true, 160>), grid, dim3(NT3), lds, stream, p);
-        else hipLaunchKernelGGL((conv3x3_c64_kernel<false, 160>), grid, dim3(NT3), lds, stream, p);
+        if (p.bn_z) hipLaunchKernelGGL((conv3x3_c64_kernel<true, 160>), grid, dim3(NT3), C64_LDS(lds), stream, p);
+        else hipLaunchKernelGGL((conv3x3_c64_kernel<false, 160>), grid, dim3(NT3), C64_LDS(lds), stream, p);
     } else {
-        if (p.bn_z) hipLaunchKernelGGL((conv3x3_c64_kernel<true, 144>), grid, dim3(NT3), lds, stream, p);
-        else hipLaunchKernelGGL((conv3x3_c64_kernel<false, 144>), grid, dim3(NT3), lds, stream, p);
+        if (p.bn_z) hipLaunchKernelGGL((conv3x3_c64_kernel<true, 144>), grid, dim3(NT3), C64_LDS(lds), stream, p);
+        else hipLaunchKernelGGL((conv3x3_c64_kernel<false, 144>), grid, dim3(NT3), C64_LDS(lds), stream, p);
     }
     return adamml_check_launch("conv3x3_c64");
 }
@@ -646,6 +751,17 @@ int adamml_conv3x3_c64_wgrad_launch(const adamml_conv_desc_t* d, const void* dz,
         if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv3x3_c64 wgrad: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_c64_wgrad_kernel, dim3(nblk), dim3(NT3), lds, stream, p);
+    hipLaunchKernelGGL(conv3x3_c64_wgrad_kernel, dim3(nblk), dim3(NT3), C64_LDS(lds), stream, p);
     return adamml_check_launch("conv3x3_c64 wgrad");
 }
+
+#ifdef C64_PHASE_TIMING
+extern "C" int c64_probe_launch(const adamml_conv_desc_t* d, const void* x, const void* w, const float* sc, const float* sh, void* y, double* stats,
+                                const void* bn_z, const float* bn_vec, int bn_act, hipStream_t s) {
+    return adamml_conv3x3_c64_launch(d, x, w, sc, sh, y, stats, bn_z, bn_vec, bn_act, s);
+}
+extern "C" int c64_probe_wgrad_blocks(const adamml_conv_desc_t* d, int* tpb) { return adamml_conv3x3_c64_wgrad_blocks(d, tpb); }
+extern "C" int c64_probe_wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* sc, const float* sh, float* ws, hipStream_t s) {
+    return adamml_conv3x3_c64_wgrad_launch(d, dz, x, sc, sh, ws, s);
+}
+#endif
