@@ -49,8 +49,10 @@ def _q(x):
 
 def conv(x, w, stride=1, padding=0, groups=1):
     """nn.Conv2d(bias=False).  Emulation: dense convs read bf16 activations and bf16 weights; depthwise convs
-    read the fp32-evaluated activation and fp32 weights; every conv output is stored in bf16."""
-    if groups == 1:
+    read the fp32-evaluated activation and fp32 weights -- and so does the one-channel spectrogram stem of the MobileNetV2s
+    (round 3: the HIP stem reads the caller's fp32 tensor and the fp32 weights, adamml_conv_stem1_fwd); every conv output
+    is stored in bf16."""
+    if groups == 1 and x.shape[1] > 1:
         y = F.conv2d(_q(x), _q(w), stride=stride, padding=padding)
     else:
         y = F.conv2d(x, w, stride=stride, padding=padding, groups=groups)

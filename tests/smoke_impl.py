@@ -47,9 +47,9 @@ def run_smoke():
     d_emu = np.abs(b - g).max() / np.abs(g).max()
     print("smoke: loss %.4f | logits |HIP-emulation| %.4f |HIP-reference| %.4f (|emulation-reference| %.4f) | decisions match"
           % (float(loss.detach()), e_emu, e_ref, d_emu))
-    # (the emulation rounds the spectrogram to bf16, the HIP stems read it as fp32 since round 3: the distance to the emulation is no longer
-    # the tighter of the two -- 0.158 / 0.135 measured for 0.113 between emulation and reference on this ill-conditioned 96-pixel case)
-    assert e_emu <= max(3e-2, 2.0 * d_emu) and e_ref <= max(3e-2, 2.0 * d_emu)
+    # (measured 0.075 / 0.140 for 0.163 between emulation and reference on this ill-conditioned 96-pixel case, the emulation reading the
+    # spectrogram in fp32 as the HIP stems do)
+    assert e_emu <= max(3e-2, 1.5 * d_emu) and e_ref <= max(3e-2, 2.0 * d_emu)
     del model
     # ---- (2) full-size, well-conditioned: the configs[1] workload at B = 4 against the reference golden
     c2 = CASES["adamml_c2"]

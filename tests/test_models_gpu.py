@@ -9,6 +9,9 @@ What can be stated (measured in this repo, see DESIGN.md "Parity"):
     (oracle.QUANT emulation, fp32 arithmetic) moves logits by ~1.5 % and gradients by 20-45 % relative L2, for any
     pipeline.  So the whole-network statement is relative to that emulation:
         logits:    |HIP - fp32| <= max(3e-2, 3 x |emulation - fp32|)  and  |HIP - emulation| <= max(3e-2, 1.5 x |emulation - fp32|)
+                   (the emulation has to store what the HIP path stores: while it still rounded the spectrogram and the MobileNetV2
+                   stem weights to bf16 -- the HIP stems read both in fp32 since round 3 -- the ill-conditioned 96-pixel RGB+Audio
+                   case measured 1.40 x and 1.58 x in two runs of one build; with the stem emulated as built: 0.46 x)
         gradients: relL2(HIP, fp32) <= max(0.35, 2.2 x relL2(emulation, fp32)), cosine(HIP, fp32) >= 0.6
                    (tensors whose EMULATION already sits > 0.5 relL2 from fp32 carry no information and are skipped)
         running statistics: relL2(HIP, emulation) <= 6e-2
