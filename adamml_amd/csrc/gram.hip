@@ -170,19 +170,21 @@ __global__ __launch_bounds__(NTHREADS) void gram_colsum_kernel(GramP p) {
     }
 }
 
-// G[g][i], s[g][i] = sum over the splits, in split order
+// G[g][i], s[g][i] = sum over the splits, in split order.  The ~200 partials of a group are summed in fp64 and rounded once: the
+// train-mode variance of conv_bn_add is diag(W G W^T) / n - mean^2 (adamml_gram_stats, fp64 from here on), and with all-positive
+// post-ReLU inputs that difference cancels -- the split sum should not add its own fp32 rounding to the partials' (ADVICE round 2).
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* ws, float* G, float* s, int n_g, int n_s, int nsplit) {
     const int i = blockIdx.x * 256 + threadIdx.x, grp = blockIdx.y;
     const int n = n_g + n_s;
     if (i >= n) return;
     const float* src = ws + (size_t)grp * nsplit * n + i;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int k = 0;
     for (; k + 4 <= nsplit; k += 4) {
         a0 += src[(size_t)k * n]; a1 += src[(size_t)(k + 1) * n]; a2 += src[(size_t)(k + 2) * n]; a3 += src[(size_t)(k + 3) * n];
     }
     for (; k < nsplit; ++k) a0 += src[(size_t)k * n];
-    const float v = (a0 + a1) + (a2 + a3);
+    const float v = (float)((a0 + a1) + (a2 + a3));
     if (i < n_g) G[(size_t)grp * n_g + i] = v;
     else s[(size_t)grp * n_s + (i - n_g)] = v;
 }
