@@ -17,6 +17,8 @@ import torch.multiprocessing as mp
 import torch.nn as nn
 import torch.nn.functional as F
 
+from tests.mp_plain import manager, plain, tensors  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 S, B = 2, 4
 LR, P_LR, WD = 0.05, 0.01, 1e-4
@@ -95,7 +97,7 @@ def _worker(rank, world, port, ret):
         gathered = [None] * world
         dist.all_gather_object(gathered, {k: float(v.double().sum()) for k, v in sd.items() if v.dtype.is_floating_point})
         if rank == 0:
-            ret["sd"], ret["sums"], ret["loss"] = sd, gathered, float(loss)
+            ret["sd"], ret["sums"], ret["loss"] = plain(sd), gathered, float(loss)
             ret["sync"] = [n.rt.sync.enabled for n in model.module.backbones()]
             ret["expose"] = [n.expose_param_grads for n in model.module.backbones()]
     finally:
@@ -104,7 +106,8 @@ def _worker(rank, world, port, ret):
 
 def test_reference_wrapping_and_iteration_work_unchanged():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    ret = mp.Manager().dict()
+    mgr = manager()                                         # (tests/mp_plain.py: spawned server, numpy payloads)
+    ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert all(ret["sync"]) and all(ret["expose"])         # SyncBatchNorm containers adopted, gradients delivered through autograd
     # (1) both ranks hold the same parameters after the step: DistributedDataParallel averaged the gradients it was handed
@@ -123,7 +126,7 @@ def test_reference_wrapping_and_iteration_work_unchanged():
     FlatSGD(one._flat_main, lr=LR, momentum=0.9, weight_decay=WD).step()
     torch.cuda.synchronize()
     sd1 = {k: v.detach().cpu() for k, v in one.state_dict().items()}
-    two = ret["sd"]
+    two = tensors(ret["sd"])
     rel = lambda x, y: ((x.double() - y.double()).norm() / (y.double().norm() + 1e-30)).item()
     changed = [k for k in sd0 if k.startswith("main_net.") and k.endswith("weight") and not torch.equal(two[k], sd0[k])]
     assert len(changed) > 100                               # the main nets were updated ...

@@ -12,6 +12,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 import torch.nn.functional as F
 
+from tests.mp_plain import manager, plain, tensors  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 S, B = 2, 4
 # BatchNorm gamma / beta gradients right under the classifier heads (above the noisy part of the backward pass): torch's
@@ -71,7 +73,7 @@ def _worker(rank, world, port, ret):
         interleave.stats["collectives"] = interleave.stats["coalesced_vectors"] = 0
         r = _step(model, ddp, rank, world)
         if rank == 0:
-            ret["r"] = r
+            ret["r"] = plain(r)
             ret["exchange"] = dict(interleave.stats)
     finally:
         dist.destroy_process_group()
@@ -79,10 +81,10 @@ def _worker(rank, world, port, ret):
 
 def test_two_rank_syncbn_step_equals_single_process_full_batch():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mgr = mp.Manager()
+    mgr = manager()                                         # (tests/mp_plain.py: spawned server, numpy payloads)
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
-    two = ret["r"]
+    two = tensors(ret["r"])
     # SyncBatchNorm exchanges of one step (S = 2 segments batched as groups): the 4 backbones have 53 / 52 / 52 / 52 BatchNorm
     # layers in forward and the two trainable ones 53 / 52 in backward = 314 statistic vectors; issued in lock-step rounds they
     # travel in one collective per BatchNorm depth: <= 53 forward + 53 backward

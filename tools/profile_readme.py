@@ -96,6 +96,22 @@ if all(os.path.exists(P + n + ".json") for n, _ in b9):
         d = line(n)
         out.append("| `%s_%s.json`: %s | %.0f | %.2f | %.2f | %.1f |" % (R, n, what, d["value"], d["ms_per_step"], d["host_issue_ms"], d["peak_mem_gib"]))
     out.append("")
+strong = [("bench_b72_forced_collectives", 1, 72), ("bench_b36_forced_collectives", 2, 36), ("bench_b18_forced_collectives", 4, 18),
+          ("bench_b9_forced_collectives_launch_plan", 8, 9)]
+if all(os.path.exists(P + n + ".json") for n, _, _ in strong):
+    out.append("The per-GPU shares of the reference's GLOBAL batch of 72 (`train_adamml.py:122`: `-b` is split over the ranks), each run on this one GPU with the "
+               "configs[2] choreography forced on a one-rank RCCL communicator (launch plans where the share is <= 16 videos).  What the table contains: everything "
+               "a rank does per step -- kernels, host issue, 106 SyncBN rounds, bucketed all-reduce launches; what it cannot contain: the time the messages spend on xGMI "
+               "(every collective is an identity here) and waiting for slower ranks:\n")
+    out.append("| GPUs of the recipe | videos per GPU | ms / step on one GPU | videos/s per GPU | projected global clips/s (x GPUs, transfers excluded) | per-GPU efficiency vs B = 72 |")
+    out.append("|---|---|---|---|---|---|")
+    base = None
+    for n, g, b in strong:
+        d = line(n)
+        vps = b / d["ms_per_step"] * 1e3
+        base = base or vps
+        out.append("| %d | %d | %.2f | %.0f | %.0f | %.2f |" % (g, b, d["ms_per_step"], vps, vps * 5 * g, vps / base))
+    out.append("")
 out.append("Per-layer tables of the same build (B = 72 shapes): `%s_per_layer_bench_conv.txt` (every ResNet-50 conv: forward / data gradient / weight gradient, GB/s and TFLOP/s;"
            " `tools/bench_conv.py`), `%s_per_layer_bench_fused.txt` (RES / DUAL forms), `%s_per_layer_bench_dw.txt` (depthwise), `%s_bench_elementwise.txt` (BatchNorm / residual passes"
            " against a plain copy), `%s_launch_table_resnet.txt` / `%s_launch_table_sound.txt` (every launch of one backbone step with its excess over a 5.3 TB/s / 800 TFLOP/s floor;"
