@@ -82,7 +82,9 @@ def test_twenty_steps_follow_the_reference_loss_curve(deterministic):
           "last update: logits %.4f of scale, ResNet fc weight UPDATE (w20 - w0) rel L2 %.4f" % (rel.max(), int(rel.argmax()), rel.mean(),
                                                                                                worst_logit, e_final, e_fc))
     assert losses[-1] < 0.2 * losses[0]                   # it trains: 3.49 -> 0.37 in the reference
-    assert rel_emu.max() <= 0.02, (int(rel_emu.argmax()), rel_emu.max())          # the curve bf16 storage allows, every step (1.3 x the measured 1.5 %)
+    # the curve bf16 storage allows, every step.  Measured 1.5 % .. 2.2 % at steps 17-19 across builds and modes (the last steps amplify a
+    # last-bit difference of any kernel: a 2 % bound failed once at 2.17 % after the fp64 Gram split-sum), hence 3 %
+    assert rel_emu.max() <= 0.03, (int(rel_emu.argmax()), rel_emu.max())
     assert rel.max() <= 0.21 and rel.mean() <= 0.065, (int(rel.argmax()), rel.max(), rel.mean())      # 1.3 x measured vs the fp32 reference
     assert e_final <= 0.056, e_final                      # 1.3 x measured
     assert e_fc <= 0.033, e_fc
