@@ -85,6 +85,9 @@ def test_twenty_steps_follow_the_reference_loss_curve(deterministic):
     # the curve bf16 storage allows, every step.  Measured 1.5 % .. 2.2 % at steps 17-19 across builds and modes (the last steps amplify a
     # last-bit difference of any kernel: a 2 % bound failed once at 2.17 % after the fp64 Gram split-sum), hence 3 %
     assert rel_emu.max() <= 0.03, (int(rel_emu.argmax()), rel_emu.max())
-    assert rel.max() <= 0.21 and rel.mean() <= 0.065, (int(rel.argmax()), rel.max(), rel.mean())      # 1.3 x measured vs the fp32 reference
-    assert e_final <= 0.056, e_final                      # 1.3 x measured
-    assert e_fc <= 0.033, e_fc
+    # vs the fp32 reference: measured over three builds / both modes 0.158 .. 0.199 at step 19, 0.050 .. 0.062 on average, final logits
+    # 0.043 .. 0.053, fc update 0.025 .. 0.031 (the bf16-storage lag of about one step in twenty; the emulation's own lag is 0.17 / 0.056).
+    # Bounds = 1.3 x the LARGEST of those: 1.3 x one build's value failed on the next build's last-bit differences
+    assert rel.max() <= 0.26 and rel.mean() <= 0.08, (int(rel.argmax()), rel.max(), rel.mean())
+    assert e_final <= 0.07, e_final
+    assert e_fc <= 0.041, e_fc
