@@ -163,8 +163,8 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
                 jobs.append(((lambda net=net, xin=xin: net.run_raw(xin, S)), st))
                 calls.append((net, xin, st))
             if not self.rng_policy:
-                # one job per policy backbone (each on its own stream): the lock-step rounds then carry the statistics of ALL
-                # backbones of a BatchNorm depth in one collective, 53 rounds per direction instead of 53 + 2 x 52
+                # one job per policy backbone (each on its own stream): a round then carries the statistics of ALL MobileNetV2s of a
+                # BatchNorm depth in one collective (the ResNet's travel in their own, alternating with it: interleave.GROUPS)
                 pstreams = [pside] + [self._side_stream(dev, 1 + k) for k in range(1, len(self.policy_net.joint_net.nets))]
                 for ps in pstreams[1:]:
                     ps.wait_stream(main)

@@ -11,9 +11,10 @@ parks.  When every unfinished job is parked, the scheduler gives each parked vec
 buffer (the statistics are collapsed straight into their slice: no concatenation), issues ONE all-reduce for the round on a
 communication stream that waits for the jobs' streams, hands each job its slice and resumes them.  The sequence of collectives
 is a pure function of the program (identical on every rank, which is all RCCL needs), there is one communicator, and the
-count per step drops from the SUM of the backbones' BatchNorm layers to their MAXIMUM per direction: 53 + 53 for ResNet-50 +
-MobileNetV2s instead of 314 -- each carrying all backbones' vectors of that depth (a few tens of KB: still one latency-bound
-message on xGMI).
+count per step drops from the SUM of the backbones' BatchNorm layers (314) to their MAXIMUM per direction and exchange group:
+53 + 53 with one group, 2 x (53 + 52) with the default two (GROUPS below: the ResNet-50 and the MobileNetV2s alternate, so that
+one group's kernels run while the other's exchange is in flight) -- each carrying all vectors of its group at that depth (a few
+tens of KB: still one latency-bound message on xGMI).
 
 Round 3: coroutines instead of threads.  The first form parked every job in its own Python thread behind semaphores; at the
 per-GPU share of the reference recipe (B = 9 of a global 72, train_adamml.py:122) the 848 thread hand-overs, the per-round
@@ -33,6 +34,14 @@ import torch.distributed as dist
 from . import hip
 
 ENABLED = os.environ.get("ADAMML_INTERLEAVE", "1") != "0"      # A/B aid; only ever used when SyncBatchNorm is on
+# Exchange groups.  1: every job parks in the same round and ONE collective carries all their vectors (fewest collectives; but while that
+# collective's latency chain runs -- collapse kernel, event hops into and out of the process group's stream, the RCCL kernel: ~110 us --
+# no stream has anything to run: B = 72 with the configs[2] choreography forced on one rank 127.0 ms against 115.2 without).  2 (default):
+# the first job (the ResNet-50 of the main net) and the other jobs (the MobileNetV2s) exchange in ALTERNATING collectives A0 B0 A1 B1 ...:
+# while one group's exchange is in flight the other group's kernels run.  Twice the collectives -- still one communicator, still a sequence
+# that is a pure function of the program, identical on every rank -- and measured on one rank at B = 72 / 36 / 18 / 9 (launch plans):
+# 127.0 / 71.5 / 43.8 / 29.3 -> 122.2 / 66.3 / 39.2 / 26.0 ms per step (tools/gpu_r3s.sh).
+GROUPS = 1 if os.environ.get("ADAMML_SYNC_GROUPS", "2") == "1" else 2
 stats = {"collectives": 0, "coalesced_vectors": 0}            # counters (tests, design notes)
 _current = [None]                                             # the job whose coroutine is running (None: plain code)
 
@@ -230,11 +239,12 @@ def _coalesced_all_reduce(parked, device, phase, ridx):
         j.pending = None
 
 
-def run_interleaved(jobs, device, phase="fwd"):
+def run_interleaved(jobs, device, phase="fwd", groups=None):
     """jobs: list of (callable, stream or None).  Runs them to completion in rounds: every unfinished job gets one turn per round,
-    in fixed order, and runs until it parks at an exchange / yield_point() or finishes; the exchanges parked in a round are
-    all-reduced as ONE collective.  Returns the list of results; the first exception is re-raised (the other jobs' coroutines are
-    dropped: nothing stays parked).  `phase` names the persistent round buffers ("fwd" / "bwd")."""
+    in fixed order, and runs until it parks at an exchange / yield_point() or finishes; the exchanges parked by the jobs of one
+    EXCHANGE GROUP in a round are all-reduced as ONE collective (GROUPS above: all jobs, or {first job} / {the others} alternating).
+    Returns the list of results; the first exception is re-raised (the other jobs' coroutines are dropped: nothing stays parked).
+    `phase` names the persistent round buffers ("fwd" / "bwd"); `groups`: 1 or 2, default GROUPS."""
     if _current[0] is not None:
         raise RuntimeError("run_interleaved: nested call from inside a job")
     sched = greenlet.getcurrent()
@@ -243,33 +253,38 @@ def run_interleaved(jobs, device, phase="fwd"):
     dev = torch.device(device) if on_gpu else None
     home = torch.cuda.current_stream(dev) if on_gpu else None
     js = [_Job(fn, (stream if stream is not None else home), ge, sched) for fn, stream in jobs]
+    two = len(js) > 1 and (groups or GROUPS) == 2
+    groups = [js[:1], js[1:]] if two else [js]
     active_jobs = list(js)
     ridx = 0
     try:
         while active_jobs:
-            for j in list(active_jobs):
-                _current[0] = j
-                if on_gpu:
-                    torch.cuda.set_stream(j.stream)
-                torch.set_grad_enabled(j.grad)
-                hip.recorder = j.recorder                  # (a job may be recording a launch plan: per coroutine, like the stream)
-                try:
-                    j.g.switch()
-                finally:
-                    j.recorder, hip.recorder = hip.recorder, None
-                    j.grad = torch.is_grad_enabled()
-                    _current[0] = None
+            for gi, members in enumerate(groups):
+                for j in members:
+                    if j not in active_jobs:
+                        continue
+                    _current[0] = j
                     if on_gpu:
-                        torch.cuda.set_stream(home)
-                    torch.set_grad_enabled(ge)
-                if j.done:
-                    active_jobs.remove(j)
-                    if j.error is not None:
-                        raise j.error
-            parked = [j for j in active_jobs if j.pending is not None]
-            if parked:
-                _coalesced_all_reduce(parked, dev, phase, ridx)
-                ridx += 1
+                        torch.cuda.set_stream(j.stream)
+                    torch.set_grad_enabled(j.grad)
+                    hip.recorder = j.recorder                  # (a job may be recording a launch plan: per coroutine, like the stream)
+                    try:
+                        j.g.switch()
+                    finally:
+                        j.recorder, hip.recorder = hip.recorder, None
+                        j.grad = torch.is_grad_enabled()
+                        _current[0] = None
+                        if on_gpu:
+                            torch.cuda.set_stream(home)
+                        torch.set_grad_enabled(ge)
+                    if j.done:
+                        active_jobs.remove(j)
+                        if j.error is not None:
+                            raise j.error
+                parked = [j for j in members if j in active_jobs and j.pending is not None]
+                if parked:
+                    _coalesced_all_reduce(parked, dev, "%s%d" % (phase, gi) if two else phase, ridx)
+            ridx += 1
     finally:
         _current[0] = None
     return [j.result for j in js]

@@ -197,16 +197,25 @@ def _coalesced(rank, world):
                 got.append(interleave.exchange(t).clone())
             return got
         return f
-    res = interleave.run_interleaved([(job("a", 3, 4), None), (job("b", 1, 2), None), (job("c", 2, 6), None)], None)
+    res = interleave.run_interleaved([(job("a", 3, 4), None), (job("b", 1, 2), None), (job("c", 2, 6), None)], None, groups=1)
     lone = interleave.exchange(torch.tensor([float(rank)], dtype=torch.float64))         # outside run_interleaved: a plain all-reduce
-    return res, log, dict(interleave.stats), lone
+    st = dict(interleave.stats)
+    # the same jobs with ALTERNATING exchange groups ({first job} / {the others}: the default, interleave.GROUPS)
+    interleave.stats["collectives"] = interleave.stats["coalesced_vectors"] = 0
+    del log[:]
+    res2 = interleave.run_interleaved([(job("a", 3, 4), None), (job("b", 1, 2), None), (job("c", 2, 6), None)], None, groups=2)
+    return res, list(log), st, lone, res2, dict(interleave.stats)
 
 
 def test_statistic_exchanges_of_a_round_are_one_collective():
     """SyncBatchNorm exchange (train_adamml.py:126-127): the vectors the backbones have pending at the same depth travel in ONE
     all-reduce; every job still receives exactly the sum over the ranks of ITS vector; the issue order is fixed."""
-    (r0, log0, st0, lone0), (r1, log1, st1, lone1) = _run(_coalesced)
+    (r0, log0, st0, lone0, r0b, st0b), (r1, log1, st1, lone1, r1b, st1b) = _run(_coalesced)
     assert log0 == log1 == [("a", 0), ("b", 0), ("c", 0), ("a", 1), ("c", 1), ("a", 2)]
+    # alternating groups: the same values for every job, on both ranks; the first job's 3 exchanges travel alone, the others' in 2 rounds
+    for a, b, c in zip(r0, r0b, r1b):
+        assert all(torch.equal(x, y) and torch.equal(x, z) for x, y, z in zip(a, b, c))
+    assert st0b["collectives"] == 3 + 2 and st0b["coalesced_vectors"] == 6 and st0b == st1b
     for name, n, width, got in (("a", 3, 4, r0[0]), ("b", 1, 2, r0[1]), ("c", 2, 6, r0[2])):
         for i in range(n):
             want = sum(float((rk + 1) * (i + 1)) + ord(name) for rk in range(2))

@@ -4,7 +4,7 @@ all-reduce) on a ONE-rank RCCL communicator (torch.distributed backend "nccl" ==
 With a single rank every collective is an identity, so the forced-distributed step must reproduce the plain step BIT FOR BIT
 (deterministic mode) -- but it runs everything the N > 1 path runs against the real, stream-asynchronous backend: the backbones
 issued in lock-step rounds on their own HIP streams with ONE coalesced statistics all-reduce per BatchNorm depth on a
-communication stream (interleave.py: 53 + 53 rounds), the backward tapes deferred to the end-of-backward callback, the
+communication stream (interleave.py: 53 + 53 rounds, one collective per round and exchange group), the backward tapes deferred to the end-of-backward callback, the
 bucketed ASYNCHRONOUS gradient all-reduce started from inside backward (distributed.py), and the waits between RCCL's internal
 stream and ours.  gloo (tests/test_syncbn_gpu.py) blocks the host in every collective and hides ordering bugs; RCCL does not.
 A missing stream wait shows up here as a bit difference (or garbage) in a gradient or a running statistic."""
