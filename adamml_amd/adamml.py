@@ -172,6 +172,7 @@ class AdaMML(nn.Module, MeanStdMixin, StockDDPAware):
                     xin = _frames(p_x[k])
                     jobs.append(((lambda net=net, xin=xin: net.run_raw(xin, S)), pstreams[k]))
                     calls.append((net, xin, pstreams[k]))
+            interleave.clips_hint[0] = B * S
             raw = interleave.run_interleaved(jobs, dev, phase="fwd")
             # the launch sequences are issued; attach each to autograd (adamml::backbone_call with the precomputed result) on its stream
             res = []

@@ -41,7 +41,13 @@ ENABLED = os.environ.get("ADAMML_INTERLEAVE", "1") != "0"      # A/B aid; only e
 # while one group's exchange is in flight the other group's kernels run.  Twice the collectives -- still one communicator, still a sequence
 # that is a pure function of the program, identical on every rank -- and measured on one rank at B = 72 / 36 / 18 / 9 (launch plans):
 # 127.0 / 71.5 / 43.8 / 29.3 -> 122.2 / 66.3 / 39.2 / 26.0 ms per step (tools/gpu_r3s.sh).
-GROUPS = 1 if os.environ.get("ADAMML_SYNC_GROUPS", "2") == "1" else 2
+# Every collective costs ~65 us of host time; an EAGER step at the per-GPU share of the reference recipe (9 videos) is bound by the host
+# (37.3 ms with two groups against 30.4 with one), so "auto" alternates only when the step is not: launch plans on (26.2 against 29.3 ms),
+# or at least SMALL_CLIPS clips per rank (the forward call leaves its clip count in `clips_hint` for the backward call).
+GROUPS = os.environ.get("ADAMML_SYNC_GROUPS", "auto")            # "1" | "2" | "auto"
+SMALL_CLIPS = 80
+clips_hint = [0]
+_resolved = [None]
 stats = {"collectives": 0, "coalesced_vectors": 0}            # counters (tests, design notes)
 _current = [None]                                             # the job whose coroutine is running (None: plain code)
 
@@ -244,7 +250,7 @@ def run_interleaved(jobs, device, phase="fwd", groups=None):
     in fixed order, and runs until it parks at an exchange / yield_point() or finishes; the exchanges parked by the jobs of one
     EXCHANGE GROUP in a round are all-reduced as ONE collective (GROUPS above: all jobs, or {first job} / {the others} alternating).
     Returns the list of results; the first exception is re-raised (the other jobs' coroutines are dropped: nothing stays parked).
-    `phase` names the persistent round buffers ("fwd" / "bwd"); `groups`: 1 or 2, default GROUPS."""
+    `phase` names the persistent round buffers ("fwd" / "bwd"); `groups`: 1 or 2, default by GROUPS."""
     if _current[0] is not None:
         raise RuntimeError("run_interleaved: nested call from inside a job")
     sched = greenlet.getcurrent()
@@ -253,7 +259,15 @@ def run_interleaved(jobs, device, phase="fwd", groups=None):
     dev = torch.device(device) if on_gpu else None
     home = torch.cuda.current_stream(dev) if on_gpu else None
     js = [_Job(fn, (stream if stream is not None else home), ge, sched) for fn, stream in jobs]
-    two = len(js) > 1 and (groups or GROUPS) == 2
+    if groups is None:
+        if _resolved[0] is None:
+            # decided ONCE per process, at the first SyncBatchNorm step: every rank must take the same decision for the whole run (the
+            # sequence of collectives depends on it), and the inputs -- launch plans on / off, the per-rank batch of the first step --
+            # are configuration, equal on all ranks of a job (DistributedSampler hands every rank equally sized batches)
+            from . import plan
+            _resolved[0] = 1 if GROUPS == "1" else 2 if (GROUPS == "2" or plan.ENABLED or clips_hint[0] >= SMALL_CLIPS) else 1
+        groups = _resolved[0]
+    two = len(js) > 1 and groups == 2
     groups = [js[:1], js[1:]] if two else [js]
     active_jobs = list(js)
     ridx = 0

@@ -19,6 +19,7 @@ timeout 600 python bench.py $b9 --launch-plan 2>/dev/null | grep '"metric"' > $o
 timeout 600 python bench.py $b9 --force-collectives 2>/dev/null | grep '"metric"' > $out/bench_b9_forced_collectives.json
 timeout 600 python bench.py $b9 --force-collectives --launch-plan 2>/dev/null | grep '"metric"' > $out/bench_b9_forced_collectives_launch_plan.json
 timeout 600 python bench.py $o --force-collectives 2>/dev/null | grep '"metric"' > $out/bench_b72_forced_collectives.json
+ADAMML_SYNC_GROUPS=1 timeout 600 python bench.py $o --force-collectives 2>/dev/null | grep '"metric"' > $out/bench_b72_forced_collectives_one_group.json
 timeout 600 python bench.py $o --batch 36 --force-collectives 2>/dev/null | grep '"metric"' > $out/bench_b36_forced_collectives.json
 timeout 600 python bench.py $o --batch 18 --steps 12 --warmup 4 --force-collectives 2>/dev/null | grep '"metric"' > $out/bench_b18_forced_collectives.json
 timeout 600 python bench.py $o --steps 6 --stage policy 2>/dev/null | grep '"metric"' > $out/bench_policy_stage.json

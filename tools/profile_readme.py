@@ -87,7 +87,8 @@ b9 = [("bench_b9", "B = 9 (the per-GPU share of the reference recipe: global bat
       ("bench_b9_launch_plan", "B = 9, launch plans (`--launch-plan`)"),
       ("bench_b9_forced_collectives", "B = 9 with the configs[2] choreography forced on a one-rank RCCL communicator (`--force-collectives`: SyncBN rounds + bucketed all-reduce)"),
       ("bench_b9_forced_collectives_launch_plan", "the same with launch plans"),
-      ("bench_b72_forced_collectives", "B = 72 with the forced choreography")]
+      ("bench_b72_forced_collectives", "B = 72 with the forced choreography (alternating exchange groups: the default)"),
+      ("bench_b72_forced_collectives_one_group", "B = 72, forced, `ADAMML_SYNC_GROUPS=1` (one coalesced collective per BatchNorm depth: the form before)")]
 if all(os.path.exists(P + n + ".json") for n, _ in b9):
     out.append("configs[2] as far as one GPU allows (host issue time = wall time `step()` takes to return, nothing in it synchronises):\n")
     out.append("| line | clips/s | ms / step | host issue ms | peak GiB |")
