@@ -48,6 +48,7 @@ GROUPS = os.environ.get("ADAMML_SYNC_GROUPS", "auto")            # "1" | "2" | "
 SMALL_CLIPS = 80
 clips_hint = [0]
 _resolved = [None]
+DIRECT = os.environ.get("ADAMML_SYNC_DIRECT", "1") != "0"      # single-job groups exchange on the job's own stream (A/B aid)
 stats = {"collectives": 0, "coalesced_vectors": 0}            # counters (tests, design notes)
 _current = [None]                                             # the job whose coroutine is running (None: plain code)
 
@@ -212,9 +213,29 @@ def _coalesced_all_reduce(parked, device, phase, ridx):
         rd.flat = torch.empty(max(total, 1024), dtype=dtype, device=device)
     while len(rd.ready) < len(parked):
         rd.ready.append(torch.cuda.Event())
-    comm = _comm_stream(device)
     flat = rd.flat[:total]
     prev = torch.cuda.current_stream(device)
+    if len(parked) == 1 and DIRECT:
+        # a group of ONE job (the ResNet-50 under alternating groups -- the long pole of the step): the collective is issued on the job's
+        # own stream.  No communication stream, no events of ours: the round's latency chain loses two of its four cross-stream hops
+        # (job -> comm -> process group's stream -> comm -> job becomes job -> process group's stream -> job)
+        j = parked[0]
+        kind, t, _, C, G = j.pending
+        try:
+            torch.cuda.set_stream(j.stream)
+            if kind == "stats":
+                hip.call("adamml_stats_collapse", hip.ptr(t), hip.ptr(flat), C, G)
+            else:
+                flat.copy_(t.reshape(-1))
+            dist.all_reduce(flat, group=group)
+        finally:
+            torch.cuda.set_stream(prev)
+        stats["collectives"] += 1
+        stats["coalesced_vectors"] += 1
+        j.reduced = flat if kind == "stats" else flat.view(t.shape)
+        j.pending = None
+        return
+    comm = _comm_stream(device)
     try:
         # every job's vector is collapsed / copied into its slice ON THE JOB'S OWN STREAM (the collapse kernels of the round then run
         # concurrently, not one after the other in front of the collective); the communication stream waits for all of them
