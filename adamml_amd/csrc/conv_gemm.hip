@@ -1661,6 +1661,63 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
     }
 }
 
+// The same reduction, four consecutive indices per thread (n % 4 == 0): 16-byte loads, 256 contiguous bytes per split row of a workgroup
+// instead of 64 -- the one-index form moved 1 TB/s and was, at 104 launches x 17 us, the largest of the step's small kernels
+// (1.8 ms per step; 2.2 of 34 ms of kernel time at the per-GPU share of the reference recipe).  Same fixed summation order per index.
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* ws, float* dw, size_t n, int nsplit, int taps, int cin, int store) {
+    ws += (size_t)blockIdx.y * nsplit * n;
+    dw += (size_t)blockIdx.y * n;
+    __shared__ f32x4 red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const size_t i = ((size_t)blockIdx.x * 16 + tx) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+        f32x4 a1 = a, a2 = a, a3 = a;
+        int s = ty;
+        for (; s + 48 < nsplit; s += 64) {
+            a += *reinterpret_cast<const f32x4*>(ws + (size_t)s * n + i);
+            a1 += *reinterpret_cast<const f32x4*>(ws + (size_t)(s + 16) * n + i);
+            a2 += *reinterpret_cast<const f32x4*>(ws + (size_t)(s + 32) * n + i);
+            a3 += *reinterpret_cast<const f32x4*>(ws + (size_t)(s + 48) * n + i);
+        }
+        for (; s < nsplit; s += 16) a += *reinterpret_cast<const f32x4*>(ws + (size_t)s * n + i);
+        a = (a + a1) + (a2 + a3);
+    }
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && i < n) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][tx];
+        if (taps > 1) {
+            const size_t per_co = (size_t)taps * cin;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t ii = i + q;
+                const size_t co = ii / per_co;
+                const int rem = (int)(ii - co * per_co), tap = rem / cin, ci = rem - tap * cin;
+                const size_t o = (co * cin + ci) * taps + tap;
+                if (store) dw[o] = t[q]; else dw[o] += t[q];
+            }
+        } else if ((reinterpret_cast<uintptr_t>(dw + i) & 15) == 0) {
+            f32x4* o = reinterpret_cast<f32x4*>(dw + i);
+            if (store) *o = t; else *o += t;
+        } else {                                  // (gradient views of the flat buffer are only 4-byte aligned behind an odd-sized parameter)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { if (store) dw[i + q] = t[q]; else dw[i + q] += t[q]; }
+        }
+    }
+}
+
+// picks the 16-byte form whenever the index count allows it
+void launch_wgrad_reduce(const float* ws, float* dw, size_t n, int nsplit, int taps, int cin, int store, int groups, hipStream_t stream) {
+    static const bool wide = !(getenv("ADAMML_REDUCE4") && getenv("ADAMML_REDUCE4")[0] == '0');       // A/B aid
+    if (wide && n % 4 == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0)
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((n / 4 + 15) / 16), groups), dim3(256), 0, stream, ws, dw, n, nsplit, taps, cin, store);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16), groups), dim3(256), 0, stream, ws, dw, n, nsplit, taps, cin, store);
+}
+
 int ilog2_exact(int v) {
     int s = 0;
     while ((1 << s) < v) ++s;
@@ -1837,8 +1894,7 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
             int rc = adamml_check_launch("conv_bwd_data_res_prod");
             if (rc) return rc;
             // P[g][ctile * 128 + r][c] = sum over the workgroups of (g, ctile), in workgroup order
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(128 * 64 / 16), groups * p.n_ctiles), dim3(256), 0, stream, (const float*)pf->ws, pf->out,
-                               (size_t)128 * 64, p.pf_nsplit, 1, 64, 1);
+            launch_wgrad_reduce((const float*)pf->ws, pf->out, (size_t)128 * 64, p.pf_nsplit, 1, 64, 1, groups * p.n_ctiles, stream);
             return adamml_check_launch("conv_bwd_data_res_prod (reduce)");
         }
         if (res_glds && res_eid && !in_scale && p.res_mask && p.accumulate && !p.bn_z && !p.bn_z2) {
@@ -2315,7 +2371,7 @@ static int wgrad_plan(const adamml_conv_desc_t* d, int cin_true, WgradPlan* pl) 
 }
 
 int adamml_launch_split_reduce(const float* ws, float* dw, size_t n, int nsplit, hipStream_t stream, int taps, int cin) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, ws, dw, n, nsplit, taps, cin, 0);
+    launch_wgrad_reduce(ws, dw, n, nsplit, taps, cin, 0, 1, stream);
     return adamml_check_launch("split_reduce");
 }
 
@@ -2445,8 +2501,7 @@ static int wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void*
     rc = adamml_check_launch("conv_bwd_weight");
     if (rc || !ws) return rc;
     if (ex && ex->per_group) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((dw_numel + 15) / 16), groups), dim3(256), 0, stream, ws, dw, dw_numel, pl.nsplit,
-                           1, cin_true, 1);
+        launch_wgrad_reduce(ws, dw, dw_numel, pl.nsplit, 1, cin_true, 1, groups, stream);
         return adamml_check_launch("split_reduce");
     }
     return adamml_launch_split_reduce(ws, dw, dw_numel, groups * pl.nsplit, stream, d->KH * d->KW, cin_true);
