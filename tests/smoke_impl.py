@@ -72,6 +72,6 @@ def run_smoke():
     e2 = np.abs(logits.detach().cpu().numpy() - g2).max() / np.abs(g2).max()
     ep = np.abs(model.last_policy_logits.detach().cpu().numpy() - gold2["train_main.policy_logits"]).max() / np.abs(gold2["train_main.policy_logits"]).max()
     print("smoke: full size (B=4, S=5, 224^2 / 256^2) logits |HIP-reference| %.4f, policy logits %.4f of scale | decisions match" % (e2, ep))
-    # logits measured 3.5e-2 .. 4.0e-2; the policy logits (two 52-layer random-weight MobileNetV2 stacks in front of them) 5.4e-2 .. 7.2e-2
+    # logits measured 3.1e-2 .. 4.2e-2; the policy logits (two 52-layer random-weight MobileNetV2 stacks in front of them) 5.4e-2 .. 7.2e-2
     # from run to run in default mode: 1.3 x the largest value seen
-    assert e2 <= 5.2e-2 and ep <= 9.5e-2
+    assert e2 <= 5.5e-2 and ep <= 9.5e-2

@@ -21,7 +21,7 @@ Measured on MI355X (this file prints the numbers): C1 logits 1.0e-2, statistics 
 max 0.13 (1.4e-2 in layer 4, growing towards the stem with ~100 bf16 gradient roundings); C2 logits 4.5e-2 and policy logits
 5.5e-2 (the random-weight MobileNetV2 stacks amplify any perturbation ~1.09x per layer: the oracle's own bf16-storage
 emulation sits at 5.0e-2 / 5.7e-2; inference on calibrated statistics 4.2e-2 / 7.1e-2; round 3, with the fp32 spectrogram read
-unrounded by the MobileNetV2 stems: logits 3.9e-2, policy logits 5.8e-2, policy logits 5.4e-2 .. 7.2e-2 from run to run in default mode; asserted at 1.3 x the largest: 5.2e-2 / 9.5e-2), statistics <= 1.8e-2 (p90 5e-3),
+unrounded by the MobileNetV2 stems: logits 3.9e-2, policy logits 5.8e-2, policy logits 5.4e-2 .. 7.2e-2 from run to run in default mode; logits 3.1e-2 .. 4.2e-2; asserted at 1.3 x the largest: 5.5e-2 / 9.5e-2), statistics <= 1.8e-2 (p90 5e-3),
 head gradients vs the reference 5e-3 (ResNet fc) .. 5.5e-2 (sound classifier) in the main stage, replay logits 3e-4, replay
 gradients median 2e-2 / p90 8e-2 / max 0.21, <= 3e-2 next to the heads."""
 import numpy as np
@@ -216,7 +216,7 @@ def test_c2_adamml_fullsize(mode):
     # logits 3.9e-2 / 3.8e-2, running statistics max 1.8e-2 (policy rgb features.17) / p90 4.8e-3
     print("  [%s] policy logits vs fp32 reference: %.4f of scale (bound 9.5e-2)" % (mode, ep))
     assert ep <= 9.5e-2, ep
-    check_forward_vs_golden(gold, mode, logits, state, logit_tol=5.2e-2, stat_tol_all=2.4e-2, stat_tol_p90=6.5e-3, groups=c["S"])
+    check_forward_vs_golden(gold, mode, logits, state, logit_tol=5.5e-2, stat_tol_all=2.4e-2, stat_tol_p90=6.5e-3, groups=c["S"])
     # main stage: the heads sit on ResNet / MobileNetV2 features (5.5e-2 worst, the sound classifier); policy stage: the head
     # gradients are driven by d(loss)/d(decisions), a difference of class logits of the gated main nets (0.23 worst, fcs.1)
     inside = check_grads_vs_golden(gold, mode, grads, head_tol=0.1 if mode == "train_main" else 0.4)
