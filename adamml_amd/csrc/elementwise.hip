@@ -84,18 +84,21 @@ __global__ void stats_collapse_kernel(const double* stats, double* out, int C, i
 }
 
 // one 32-lane group per channel: lane k reads slot k, the group folds with xor-shuffles (slot-parallel loads).
-// Slot sums of up to 32 groups at once: the loads of all groups are in flight together (four groups per batch), every lane of the
-// 32-lane channel group ends up holding the sums of group g0 + k in (m1, m2): the per-group arithmetic that follows (fp64 divisions,
-// square root) then runs one group per lane instead of one after the other on the lead lane.
+// Slot sums of up to 32 groups at once: the loads of all groups are in flight together (eight groups per batch: the S = 5 segments of the
+// benchmark are ONE batch -- with four per batch the second, one-group batch was a second dependent round trip in each of the step's 314
+// finalize launches), every lane of the 32-lane channel group ends up holding the sums of group g0 + k in (m1, m2): the per-group
+// arithmetic that follows (fp64 divisions, square root) then runs one group per lane instead of one after the other on the lead lane.
 __device__ __forceinline__ void slot_sums_groups(const double* stats, int nslots, int C, int c, int k, int g0, int groups, double& m1, double& m2) {
     m1 = 0.0; m2 = 0.0;
     const int ge = groups - g0 < 32 ? groups : g0 + 32;
-    for (int g = g0; g < ge; g += 4) {
-        double a1[4], a2[4];
+    constexpr int GB = 8;
+    for (int g = g0; g < ge; g += GB) {
+        double a1[GB], a2[GB];
+        const int nb = ge - g < GB ? ge - g : GB;           // (uniform)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < GB; ++j) {
             a1[j] = 0.0; a2[j] = 0.0;
-            if (g + j < ge && c < C && k < nslots) {
+            if (j < nb && c < C && k < nslots) {
                 const double* st = stats + (size_t)(g + j) * nslots * 2 * C;
                 if (det_mode() && nslots == ADAMML_STAT_SLOTS) {
                     a1[j] = det_bin_value(st + c, 2 * (size_t)C, k);
@@ -109,14 +112,16 @@ __device__ __forceinline__ void slot_sums_groups(const double* stats, int nslots
 #pragma unroll
         for (int off = 16; off >= 1; off >>= 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a1[j] += __shfl_xor(a1[j], off, 64);
-                a2[j] += __shfl_xor(a2[j], off, 64);
+            for (int j = 0; j < GB; ++j) {
+                if (j < nb) {
+                    a1[j] += __shfl_xor(a1[j], off, 64);
+                    a2[j] += __shfl_xor(a2[j], off, 64);
+                }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (k == g + j - g0) { m1 = a1[j]; m2 = a2[j]; }
+        for (int j = 0; j < GB; ++j)
+            if (j < nb && k == g + j - g0) { m1 = a1[j]; m2 = a2[j]; }
     }
 }
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # 16-byte split reduce: correctness + A/B against the previous build of the library (adamml_amd/libadamml_hip_base.so)
 out=gpurun_out/r3z; mkdir -p $out
-timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_parity_fullsize_gpu.py -x -q -k "wgrad or bwd or weight or deterministic or conv_fwd_bwd or dw or alg or fullsize or c2 or c1" > $out/pytest.log 2>&1; echo "pytest rc=$?"; grep "passed\|failed" $out/pytest.log | tail -1
+timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_rccl_gpu.py tests/test_syncbn_gpu.py tests/test_parity_fullsize_gpu.py -x -q -k "bn or finalize or rccl or syncbn or deterministic or block or sound or policy" > $out/pytest.log 2>&1; echo "pytest rc=$?"; grep "passed\|failed" $out/pytest.log | tail -1
 for rep in 1 2 3; do
   for lib in base new; do
     if [ $lib = base ]; then export ADAMML_HIP_LIB=$PWD/adamml_amd/libadamml_hip_base.so; else unset ADAMML_HIP_LIB; fi
