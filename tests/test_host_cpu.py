@@ -413,3 +413,46 @@ def test_launch_plan_thunks_are_in_sync_with_the_c_abi(built):
     assert ctypes.sizeof(plan.PlanOp) == 4 * 4 + 2 * 4 + 8 * plan.MAX_ARGS
     hdr = open(os.path.join(ROOT, "include", "adamml_hip.h")).read()
     assert ("#define ADAMML_PLAN_MAX_ARGS %d" % plan.MAX_ARGS) in hdr
+
+
+def test_launch_plan_recorder_encodes_calls_slots_waits_and_segments():
+    """adamml_amd/plan.py Recorder (no GPU needed: it only looks at addresses): a recorded call becomes one adamml_plan_op_t with the
+    entry point's index, the stream's slot, descriptor COPIES, pointer values, doubles as bit patterns, and slot references for the
+    call's input (slot 0) and the incoming gradient (slot 1); waits number their events; boundaries split segments per phase."""
+    import struct
+    from adamml_amd import hip, plan
+    x = torch.zeros(8)
+    rec = plan.Recorder(x)
+    d = hip.ConvDesc(2, 8, 8, 16, 8, 8, 32, 1, 1, 1, 0, 1, 0, 0, 1, 0)
+    rec.call("adamml_conv_bwd_data", (ctypes.byref(d), x.data_ptr(), 0x1000, None, 1), 0xAAA0)
+    op = rec.cur[-1]
+    assert (op.kind, op.fn, op.nargs, op.stream) == (plan.KIND_CALL, plan.fn_id("adamml_conv_bwd_data"), 5, 0)
+    assert op.slot_mask == 0b00010 and op.a[1] == 0                     # argument 1 = the call's input: slot 0, not its address
+    assert op.a[2] == 0x1000 and op.a[3] == 0 and op.a[4] == 1
+    copy = ctypes.cast(op.a[0], ctypes.POINTER(hip.ConvDesc)).contents   # a private copy of the descriptor, alive as long as the recorder
+    d.Cout = 7
+    assert copy.Cout == 32 and copy.N == 2
+    rec.call("adamml_bn_finalize", (0x2000, 32, 5, 123.5, 0x10, 0x20, None, None, 0.1, 1e-5, 0x30, 64), 0xBBB0)
+    op = rec.cur[-1]
+    assert op.stream == 1 and rec.streams == [0xAAA0, 0xBBB0]           # second stream handle -> slot 1
+    assert struct.unpack("<d", struct.pack("<Q", op.a[3]))[0] == 123.5 and abs(struct.unpack("<d", struct.pack("<Q", op.a[8]))[0] - 0.1) < 1e-7
+    rec.wait(0xBBB0, 0xAAA0)
+    rec.wait(0xAAA0, 0xBBB0)
+    w0, w1 = rec.cur[-2], rec.cur[-1]
+    assert (w0.kind, w0.stream, w0.a[0], w0.a[1]) == (plan.KIND_WAIT, 1, 0, 0) and (w1.stream, w1.a[0], w1.a[1]) == (0, 1, 1) and rec.n_events == 2
+    z = torch.zeros(6, dtype=torch.float64)
+    rec.zero(z, 0xAAA0)
+    assert (rec.cur[-1].kind, rec.cur[-1].a[0], rec.cur[-1].a[1]) == (plan.KIND_ZERO, z.data_ptr(), 48)
+    hit = []
+    rec.boundary(lambda: hit.append(1))
+    rec.call("adamml_conv_bwd_data", (ctypes.byref(d), 0x1, 0x2, 0x3, 0), 0xAAA0)
+    rec.end_forward()
+    assert [s.n for s in rec.fwd] == [5, 1] and rec.fwd[0].boundary is not None and rec.fwd[1].boundary is None
+    g = torch.zeros(4)
+    rec.begin_backward(g)
+    rec.call("adamml_conv_bwd_data", (ctypes.byref(d), g.data_ptr(), x.data_ptr(), 0x3, 0), 0xAAA0)
+    rec.end_backward()
+    op = rec.bwd[0].ops[0]
+    assert op.slot_mask == 0b00110 and (op.a[1], op.a[2]) == (1, 0)      # gradient = slot 1, input = slot 0
+    rec.call("adamml_conv_bwd_data", (ctypes.byref(d), 1, 2), 0xAAA0)    # wrong argument count: the recording is marked failed, not wrong
+    assert rec.failed is not None
