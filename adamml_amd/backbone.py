@@ -386,6 +386,9 @@ class HipBackbone(nn.Module):
         plans = self.__dict__.setdefault("_launch_plans", {})
         entry = plans.get(key)
         if isinstance(entry, plan.Plan):
+            if entry.busy():                       # an earlier replay still waits for its backward: this call runs eagerly (plan.Plan.busy)
+                plan.stats["busy_fallbacks"] = plan.stats.get("busy_fallbacks", 0) + 1
+                return self._run(x, groups, need_grad=need_grad)
             return entry.forward(x)
         seen = entry or 0
         if seen < plan.WARMUP_CALLS or hip.recorder is not None:
@@ -411,7 +414,8 @@ class HipBackbone(nn.Module):
     def _finish_recording(self, tape, rec, out=None):
         plans = self.__dict__.setdefault("_launch_plans", {})
         if rec.failed:
-            plans[rec.key] = -(10 ** 9)            # never try again for this key
+            plans[rec.key] = 0 if rec.retry else -(10 ** 9)      # warm up and record again / never try again for this key
+            plan.stats["failed_recordings"] = plan.stats.get("failed_recordings", 0) + 1
             return
         plans[rec.key] = plan.Plan(rec, out if out is not None else rec.out)
         plan.stats["recorded"] += 1

@@ -24,7 +24,7 @@ extern "C" {
 int adamml_det_set_conv_gemm(int), adamml_det_set_conv3x3_c64(int), adamml_det_set_conv1x1_stream(int), adamml_det_set_conv_stem(int),
     adamml_det_set_dwconv(int), adamml_det_set_elementwise(int);
 }
-static int g_det = 0;
+static int g_det = 1;        // exact integer-bin accumulation across workgroups (common.h); 0: fp64 slot atomics (A/B aid)
 int adamml_deterministic_enabled(void) { return g_det; }
 
 extern "C" int adamml_set_deterministic(int on) {

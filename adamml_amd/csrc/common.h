@@ -73,15 +73,21 @@ __device__ __forceinline__ f32x4 transform4(bf16x4 raw, const float* scale, cons
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
-// ---- deterministic reductions (adamml_set_deterministic / ADAMML_DETERMINISTIC=1) -------------------------------------------
-// Default mode accumulates per-channel sums with LDS fp32 atomics inside a workgroup and fp64 atomics across workgroups: fast,
-// but the ORDER of the additions varies from run to run, the last bits of the sums with it, and bf16 rounding downstream
-// amplifies a 1-ulp difference of a BatchNorm scale into visibly different activations.  In deterministic mode every lane adds
-// its fp32 partial EXACTLY into integer bins: the 32 slots of one accumulator ([ADAMML_STAT_SLOTS][2C] doubles, 8 bytes each)
-// are reinterpreted as 32 int64 bins; an addend +-m * 2^(E-150) (24-bit m, biased exponent E) goes to bin E >> 3 as
-// +-(m << (E & 7)).  Integer addition is associative, so the bins -- and the fp64 value decoded from them in a fixed order --
-// do not depend on the order of arrival.  (|addend| < 2^31 per bin: 2^32 addends before an int64 bin can overflow.)
-static __constant__ int c_adamml_det;                    // one copy per translation unit, set through adamml_det_set_<tu>()
+// ---- reproducible per-channel reductions (BatchNorm statistics, BatchNorm-backward sums) ---------------------------------------
+// A sum over millions of pixels is accumulated in two stages, and both are ORDER-FIXED, so that two runs on the same input produce
+// the same bits (a 1-ulp difference of a BatchNorm scale is amplified by the bf16 rounding downstream into visibly different
+// activations and gradients):
+//  (1) inside a workgroup every (wave or row slot, channel) partial has exactly ONE owner lane that adds into a private LDS entry in
+//      tile order; at the end of the workgroup one thread per channel folds those entries in index order (no LDS atomics between
+//      waves, whose arrival order varies from run to run);
+//  (2) across workgroups the fp32 workgroup partial is added EXACTLY into integer bins: the 32 slots of one accumulator
+//      ([ADAMML_STAT_SLOTS][2C] doubles, 8 bytes each) are read as 32 int64 bins; an addend +-m * 2^(E-150) (24-bit m, biased exponent
+//      E) goes to bin E >> 3 as +-(m << (E & 7)) with ONE native 64-bit integer atomic.  Integer addition is associative, so the bins
+//      -- and the fp64 value decoded from them in a fixed order -- do not depend on the order of arrival.  (|addend| < 2^31 per bin:
+//      2^32 addends before an int64 bin can overflow.)  One atomic per channel and WORKGROUP: measured on the benchmark step the same
+//      cost as the fp64 slot atomics it replaces (round 3 issued det_add per lane and tile: 1.68x).
+// adamml_set_deterministic(0) (A/B aid) switches stage (2) back to fp64 atomics spread over the 32 slots; stage (1) has no switch.
+static __constant__ int c_adamml_det = 1;                // one copy per translation unit, set through adamml_det_set_<tu>()
 __device__ __forceinline__ bool det_mode() { return c_adamml_det != 0; }
 
 __device__ __forceinline__ void det_add(double* acc, size_t slot_stride, float v) {
@@ -93,6 +99,12 @@ __device__ __forceinline__ void det_add(double* acc, size_t slot_stride, float v
     long long c = (long long)m << (e & 7);
     if (u >> 31) c = -c;
     atomicAdd(reinterpret_cast<unsigned long long*>(acc + (size_t)(e >> 3) * slot_stride), (unsigned long long)c);
+}
+
+// stage (2): workgroup partial v of one channel -> its accumulator (acc = entry of slot / bin 0, entries slot_stride doubles apart)
+__device__ __forceinline__ void stat_publish(double* acc, size_t slot_stride, unsigned slot, float v) {
+    if (det_mode()) det_add(acc, slot_stride, v);
+    else atomicAdd(acc + (size_t)slot * slot_stride, (double)v);
 }
 
 // value of bin k of a deterministic accumulator (the 32 bin values are summed in a fixed order by the consumers)

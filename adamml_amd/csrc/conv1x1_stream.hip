@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, 3) void alg_stream_kernel(S1P p) {
     __shared__ float s_vec[2 * C2];          // lazy transform of a: scale, shift
     __shared__ float s_bn[4 * C2];           // scale, shift, mean, invstd of the epilogue BatchNorm
     __shared__ float s_add[C2];
-    __shared__ float s_sum[2 * C2];
+    __shared__ float s_sum[4][2 * C2];       // per-wave rows of the BatchNorm-backward sums (common.h: reproducible reductions)
     const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
     p.g += (size_t)g * p.P * K1;
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256, 3) void alg_stream_kernel(S1P p) {
         s_vec[tid] = p.a_scale ? p.a_scale[tid] : 1.f;
         s_vec[C2 + tid] = p.a_scale ? p.a_shift[tid] : 0.f;
         s_add[tid] = p.cadd[tid];
-        s_sum[tid] = 0.f;
-        s_sum[C2 + tid] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { s_sum[w][tid] = 0.f; s_sum[w][C2 + tid] = 0.f; }
     }
     if (p.bn_z) s_bn[tid] = p.bn_vec[tid];                          // 256 threads == 4 * C2 entries
     __syncthreads();
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 3) void alg_stream_kernel(S1P p) {
         }
     }
     if (p.bn_z) {
-        // fold the 16 lanes (li) that share a channel set, then one LDS atomic per channel and wave
+        // fold the 16 lanes (li) that share a channel set; one value per channel and wave, kept in the wave's own row
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -184,18 +184,13 @@ __global__ __launch_bounds__(256, 3) void alg_stream_kernel(S1P p) {
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
                 if (li == 0) {
-                    if (det_mode()) {                                   // exact integer bins instead of float atomics (common.h)
-                        det_add(p.stats + ct * 16 + lg * 4 + r, 2 * C2, a);
-                        det_add(p.stats + C2 + ct * 16 + lg * 4 + r, 2 * C2, b);
-                    } else {
-                        atomicAdd(&s_sum[ct * 16 + lg * 4 + r], a);
-                        atomicAdd(&s_sum[C2 + ct * 16 + lg * 4 + r], b);
-                    }
+                    s_sum[wave][ct * 16 + lg * 4 + r] = a;
+                    s_sum[wave][C2 + ct * 16 + lg * 4 + r] = b;
                 }
             }
         __syncthreads();
-        double* slot = p.stats + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * C2;
-        if (tid < 2 * C2 && !det_mode()) atomicAdd(&slot[tid], (double)s_sum[tid]);
+        if (tid < 2 * C2)            // wave rows folded in wave order, one exact add per channel and workgroup
+            stat_publish(p.stats + tid, 2 * C2, blockIdx.x & (ADAMML_STAT_SLOTS - 1), ((s_sum[0][tid] + s_sum[1][tid]) + s_sum[2][tid]) + s_sum[3][tid]);
     }
 }
 

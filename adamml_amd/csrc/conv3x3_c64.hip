@@ -41,6 +41,7 @@ extern "C" int adamml_c64_set_phase_buffer(unsigned* buf) {
 namespace {
 
 constexpr int NT3 = 512;
+constexpr int CS3_BYTES = 8 * 128 * 4;   // per-wave rows of the workgroup's channel sums (sum | second moment of 64 channels)
 constexpr int C64 = 64;
 constexpr int KT3 = 9 * C64;             // 576
 constexpr int WROW3 = KT3 * 2 + 16;      // LDS bytes per weight row (+16 B skew): 1168
@@ -100,9 +101,10 @@ __device__ __forceinline__ bf16x8 bn_relu8(bf16x8 raw, const f32x8& sc, const f3
     return out.v;
 }
 
-__device__ __forceinline__ void fold16_to_cs(const f32x8& esum, const f32x8& esq, float* cs, int lane, int ech, double* gdst) {
+__device__ __forceinline__ void fold16_to_cs(const f32x8& esum, const f32x8& esq, float* cs, int lane, int ech) {
     // lanes l, l+8, .., l+56 of a wave hold partial sums of channel chunk `ech` (8 channels): DPP + lane-swap fold
-    // (see conv_gemm.hip), then 4 LDS adds from the lanes with bit 3 clear
+    // (see conv_gemm.hip), then 4 LDS adds from the lanes with bit 3 clear into the row of THIS wave (cs = that row: one owner lane per
+    // entry, so an entry's adds happen in tile order -- common.h, reproducible reductions)
     float v[16];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { v[i] = esum[i]; v[8 + i] = esq[i]; }
@@ -128,8 +130,7 @@ __device__ __forceinline__ void fold16_to_cs(const f32x8& esum, const f32x8& esq
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int id = 4 * j + vsel;
-            if (gdst) det_add(gdst + (id >> 3) * C64 + ech * 8 + (id & 7), 2 * C64, wv[j]);       // deterministic mode (common.h)
-            else atomicAdd(&cs[(id >> 3) * C64 + ech * 8 + (id & 7)], wv[j]);
+            atomicAdd(&cs[(id >> 3) * C64 + ech * 8 + (id & 7)], wv[j]);
         }
     }
 }
@@ -144,8 +145,8 @@ template <bool BNZ, int PP>
 __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_w = smem;                                              // [64][WROW3]
-    float* cs = reinterpret_cast<float*>(smem + C64 * WROW3);      // [128]
-    char* s_patch = smem + C64 * WROW3 + 512;                      // patch, later the staging tile
+    float* cs = reinterpret_cast<float*>(smem + C64 * WROW3);      // [8 waves][128]: every wave accumulates into its own row
+    char* s_patch = smem + C64 * WROW3 + CS3_BYTES;                // patch, later the staging tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     C64_TS_DECL
     const int li = lane & 15, lg = lane >> 4;
@@ -158,7 +159,17 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
         // unswizzled they touched 9 (2-way conflicts on every weight fragment read: SQ_LDS_BANK_CONFLICT 34-41 % of the LDS cycles, round 2)
         *reinterpret_cast<bf16x8*>(s_w + co * WROW3 + (ch ^ (((co >> 2) ^ (co >> 3)) & p.wswz)) * 16) = *reinterpret_cast<const bf16x8*>(p.w + (size_t)co * KT3 + ch * 8);
     }
-    if (tid < 128) cs[tid] = 0.f;
+    for (int i = tid; i < 8 * 128; i += NT3) cs[i] = 0.f;
+    float* csw = cs + wave * 128;
+    // publication of one BatchNorm group's sums: the eight wave rows folded in wave order, one exact add per channel and workgroup
+    auto publish = [&](int grp) {
+        if (tid < 128) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { v += cs[w * 128 + tid]; cs[w * 128 + tid] = 0.f; }
+            stat_publish(p.stats + (size_t)grp * ADAMML_STAT_SLOTS * 128 + tid, 128, blockIdx.x & (ADAMML_STAT_SLOTS - 1), v);
+        }
+    };
 
     // ---- patch slots: slot e -> (patch pixel e >> 3, 16-byte chunk e & 7 == tid & 7) -------------------------------------------
     // slot l of this thread is patch pixel (tid >> 3) + 64 l: its (row, column) is carried from slot to slot (the slots of a tile are always
@@ -216,8 +227,8 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
         if (g != cur_group) {
             if (p.stats && cur_group >= 0) {       // publish the finished group's sums, restart the accumulators
                 __syncthreads();
-                double* slot = p.stats + ((size_t)cur_group * ADAMML_STAT_SLOTS + (blockIdx.x & (ADAMML_STAT_SLOTS - 1))) * 128;
-                if (tid < 128) { if (!det_mode()) atomicAdd(&slot[tid], (double)cs[tid]); cs[tid] = 0.f; }
+                publish(cur_group);
+                __syncthreads();
             }
             cur_group = g;
         }
@@ -354,16 +365,11 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
                     dsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, f.v, dsum, 0, 0, 0);
                     dsq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v, f.v, dsq, 0, 0, 0);
                 }
-                double* gdst = det_mode() ? p.stats + (size_t)g * ADAMML_STAT_SLOTS * 128 : nullptr;
-                if (lg == 0) {
-                    if (gdst) det_add(gdst + cb * 16 + li, 128, dsum[0]);
-                    else atomicAdd(&cs[cb * 16 + li], dsum[0]);
-                }
+                if (lg == 0) atomicAdd(&csw[cb * 16 + li], dsum[0]);             // (own row: the only lane that ever adds to this entry)
                 if ((li >> 2) == lg) {
                     const int r = li & 3;
                     const float q2 = r == 0 ? dsq[0] : r == 1 ? dsq[1] : r == 2 ? dsq[2] : dsq[3];
-                    if (gdst) det_add(gdst + 64 + cb * 16 + li, 128, q2);
-                    else atomicAdd(&cs[64 + cb * 16 + li], q2);
+                    atomicAdd(&csw[64 + cb * 16 + li], q2);
                 }
             }
         } else {
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
             }
             };
             if (p.bn_act == ADAMML_ACT_RELU) rows(std::true_type{}); else rows(std::false_type{});      // (uniform)
-            if (p.stats) fold16_to_cs(esum, esq, cs, lane, ech, det_mode() ? p.stats + (size_t)g * ADAMML_STAT_SLOTS * 128 : nullptr);
+            if (p.stats) fold16_to_cs(esum, esq, csw, lane, ech);
         }
         C64_TS(8);
         __syncthreads();                                     // staging consumed before the next patch lands
@@ -431,8 +437,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
     }
     if (p.stats && cur_group >= 0) {
         __syncthreads();
-        double* slot = p.stats + ((size_t)cur_group * ADAMML_STAT_SLOTS + (blockIdx.x & (ADAMML_STAT_SLOTS - 1))) * 128;
-        if (tid < 128 && !det_mode()) atomicAdd(&slot[tid], (double)cs[tid]);
+        publish(cur_group);
     }
 }
 
@@ -648,7 +653,7 @@ static int c3_rows(const adamml_conv_desc_t* d, int pitch) {
         const int PR = pick + 2, PW = d->W + 2;
         const size_t patch = (size_t)PR * PW * pitch, stage = (size_t)((pick * d->W + 31) / 32 * 32) * SROW3;
         if (PR * PW * 8 <= MAXSLOT3 * NT3 && (pick * d->W + 31) / 32 * 2 <= 8 * MAXPT &&
-            C64 * WROW3 + 512 + (patch > stage ? patch : stage) <= 160 * 1024)
+            C64 * WROW3 + CS3_BYTES + (patch > stage ? patch : stage) <= 160 * 1024)
             return pick;
     }
     return 0;
@@ -684,7 +689,7 @@ int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const 
     p.gxy = (size_t)d->N * d->H * d->W * C64;
     p.tpb = ceil_div(p.total_tiles, 1024);
     const size_t patch = (size_t)p.PR * p.PW * pitch, stage = (size_t)p.npt * 16 * SROW3;
-    const size_t lds = C64 * WROW3 + 512 + (patch > stage ? patch : stage);
+    const size_t lds = C64 * WROW3 + CS3_BYTES + (patch > stage ? patch : stage);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<false, 144>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

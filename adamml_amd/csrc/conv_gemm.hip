@@ -167,12 +167,17 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
     constexpr int EPI_BYTES = BP * (BC * 2 + 16);
     constexpr int NBUF = GLDS ? 3 : 2;
     constexpr int STAGE_BYTES = (NBUF * TILE_BYTES) > EPI_BYTES ? (NBUF * TILE_BYTES) : EPI_BYTES;
-    constexpr int CS2_OFF = STAGE_BYTES + 2 * BC * 4 + (MODE == 0 ? 0 : 256) + (MODE == 3 ? BP * 4 + 16 : 0);     // second sum set (RES); 256: tap tables
+    // per-channel sums of a workgroup: the forward statistics come out of the matrix cores with ONE owner wave per channel (one row of
+    // 2 * BC floats); the data-gradient epilogues fold on the VALU, where all four waves hold partials of every channel -- each wave then
+    // accumulates into its own row and the rows are summed in wave order at publication (common.h: reproducible reductions)
+    constexpr int NSR = (FADD || EPI == 0) ? 1 : 4;
+    constexpr int CS_BYTES = NSR * 2 * BC * 4;
+    constexpr int CS2_OFF = STAGE_BYTES + CS_BYTES + (MODE == 0 ? 0 : 256) + (MODE == 3 ? BP * 4 + 16 : 0);     // second sum set (RES); 256: tap tables
     // MODE 0: the per-input-channel vectors of the loader transform (lazy BatchNorm scale / shift, or the three DUAL affine
     // vectors) are staged in LDS once per workgroup when K <= VEC_MAXK: read from global inside store_tile they were an
     // exposed L1/L2 round trip in every K step (the loads can only be issued when the tile registers are consumed)
     constexpr int VEC_MAXK = 1024;
-    constexpr int VEC_OFF = CS2_OFF + (RES ? 2 * BC * 4 : 0);
+    constexpr int VEC_OFF = CS2_OFF + (RES ? CS_BYTES : 0);
     constexpr int LZF_MAXK = 512;              // LZF keeps 3 workgroups per CU at BC = 128: 3 x (3 tiles + sums + 4 KB of vectors) <= 160 KB
     constexpr int PF_C = 64;                   // channels of the PF operand
     constexpr int PF_OFF = (VEC_OFF + (LZF ? 2 * LZF_MAXK * 4 : (MODE == 0 && !GLDS) ? (DUAL ? 3 : 2) * VEC_MAXK * 4 : 0) + 1023) / 1024 * 1024;
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
 
     const int chunk = tid & 3;
     const int row_a = tid >> 2;             // 0..63 (+64 for second row)
-    int* s_tapoff = reinterpret_cast<int*>(smem + STAGE_BYTES + 2 * BC * 4);  // MODE 1/3: element offset of each tap
+    int* s_tapoff = reinterpret_cast<int*>(smem + STAGE_BYTES + CS_BYTES);    // MODE 1/3: element offset of each tap
     int* s_wtap = s_tapoff + 64;                                              // MODE 3: weight offset of each class tap [4]
     int* s_orow = s_wtap + 4;                                                 // MODE 3: output row of each tile pixel [BP]
     if (MODE == 1) {
@@ -282,15 +287,15 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
     // epilogue thread mapping (fixed across the tiles of this workgroup, so the per-channel sums live in registers)
     constexpr int CROW = BC * 2 + 16;                  // LDS row stride (bytes): +16 B skews the banks
     static_assert(BP * CROW <= STAGE_BYTES, "epilogue tile must fit the staging buffers");
-    float* cs = reinterpret_cast<float*>(smem + STAGE_BYTES);          // [2*BC] channel sums, live across the tile loop
-    float* cs2 = reinterpret_cast<float*>(smem + CS2_OFF);             // [2*BC] sums of the second BatchNorm (RES only)
+    float* cs = reinterpret_cast<float*>(smem + STAGE_BYTES);          // [NSR][2*BC] channel sums, live across the tile loop
+    float* cs2 = reinterpret_cast<float*>(smem + CS2_OFF);             // [NSR][2*BC] sums of the second BatchNorm (RES only)
     const bool second = RES && p.bn_z2 != nullptr;
     const bool epi_bnz = EPI < 0 ? p.bn_z != nullptr : EPI == 1;
     const bool epi_acc = EPI < 0 ? p.accumulate != 0 : (EPI == 2 && p.accumulate != 0);
     if (p.stats) {
-        for (int i = tid; i < 2 * BC; i += NTHREADS) cs[i] = 0.f;
+        for (int i = tid; i < NSR * 2 * BC; i += NTHREADS) cs[i] = 0.f;
         if (second)
-            for (int i = tid; i < 2 * BC; i += NTHREADS) cs2[i] = 0.f;
+            for (int i = tid; i < NSR * 2 * BC; i += NTHREADS) cs2[i] = 0.f;
     }
     constexpr int CPR = BC / 8;                        // 16-byte chunks per tile row
     constexpr int RSTEP = NTHREADS / CPR;              // rows covered per pass
@@ -942,8 +947,10 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
         // with the gfx950 lane-swap instructions (v_permlane32_swap / v_permlane16_swap: "swap the upper half (odd rows)
         // of a with the lower half (even rows) of b", so a' + b' folds TWO values at once and halves the register count
         // per step) -- 24 VALU ops instead of 32-48 ds_bpermute, which had made this epilogue LDS-pipe-bound (-30 % on
-        // the HBM-bound 1x1 layers).  16 values -> 4 registers per lane, then 4 LDS adds per lane.
-        auto fold = [&](const f32x8& s1, const f32x8& s2, float* dst, double* gdst) {
+        // the HBM-bound 1x1 layers).  16 values -> 4 registers per lane, then 4 LDS adds per lane, into this WAVE's row of the sums (one
+        // owner lane per entry: the adds of an entry happen in tile order, whatever the timing of the other waves).
+        auto fold = [&](const f32x8& s1, const f32x8& s2, float* dst) {
+            dst += (NSR > 1 ? wave : 0) * 2 * BC;
             float v[16];
 #pragma unroll
             for (int i = 0; i < 8; ++i) { v[i] = s1[i]; v[8 + i] = s2[i]; }
@@ -973,14 +980,13 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int id = 4 * j + vsel;              // 0..7: sum of channel id; 8..15: second moment of channel id-8
-                    if (gdst) det_add(gdst + (size_t)(id >> 3) * p.Cout + eco + (id & 7), 2 * (size_t)p.Cout, wv[j]);   // deterministic mode
-                    else atomicAdd(&dst[(id >> 3) * BC + ech * 8 + (id & 7)], wv[j]);
+                    atomicAdd(&dst[(id >> 3) * BC + ech * 8 + (id & 7)], wv[j]);
                 }
             }
         };
-        const bool det = det_mode();
-        fold(esum, esq, cs, det ? p.stats : nullptr);
-        if (second) fold(esum, esq2, cs2, det ? p.stats2 : nullptr);
+        static_assert(NSR == 4 || EPI == 0 || FADD, "VALU-folded sums need one row per wave");
+        fold(esum, esq, cs);
+        if (second) fold(esum, esq2, cs2);
     }
     if constexpr (PF) {
         // P[cout][c] += sum over the tile's 128 pixels of g'[p][cout] * a[p][c]: both operands pixel-major in LDS -> transpose reads.
@@ -1033,31 +1039,23 @@ __global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 
                 for (int r = 0; r < 4; ++r) out[(size_t)(wp * 64 + mt * 16 + lg * 4 + r) * PF_C + wc * 32 + nt * 16 + li] = pacc[mt][nt][r];
     }
     if (p.stats) {
+        // one publication per workgroup and channel: the wave rows are folded in wave order, the workgroup partial goes to the exact
+        // integer bins (common.h)
         __syncthreads();
-        double* slot = p.stats + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * p.Cout;
-        if (det_mode()) {
-            // forward statistics (each LDS entry was accumulated by ONE wave in tile order: deterministic) go to the integer
-            // bins; the fold() path already added its lanes' partials to the bins directly and left cs / cs2 zero
-            for (int i = tid; i < BC; i += NTHREADS) {
-                if (c0 + i < p.Cout) {
-                    det_add(p.stats + c0 + i, 2 * (size_t)p.Cout, cs[i]);
-                    det_add(p.stats + p.Cout + c0 + i, 2 * (size_t)p.Cout, cs[BC + i]);
-                }
-            }
-            return;
-        }
-        for (int i = tid; i < BC; i += NTHREADS) {
-            if (c0 + i < p.Cout) {
-                atomicAdd(&slot[c0 + i], (double)cs[i]);
-                atomicAdd(&slot[p.Cout + c0 + i], (double)cs[BC + i]);
-            }
-        }
-        if (second) {
-            double* slot2 = p.stats2 + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * p.Cout;
-            for (int i = tid; i < BC; i += NTHREADS) {
-                if (c0 + i < p.Cout) {
-                    atomicAdd(&slot2[c0 + i], (double)cs2[i]);
-                    atomicAdd(&slot2[p.Cout + c0 + i], (double)cs2[BC + i]);
+        const unsigned slot = blockIdx.x & (ADAMML_STAT_SLOTS - 1);
+        for (int i = tid; i < 2 * BC; i += NTHREADS) {
+            const int c = i < BC ? i : i - BC;                 // i < BC: sum of channel c0 + i; else second moment of channel c0 + i - BC
+            if (c0 + c < p.Cout) {
+                const size_t e = (i < BC ? 0 : (size_t)p.Cout) + c0 + c;
+                float v = cs[i];
+#pragma unroll
+                for (int w = 1; w < NSR; ++w) v += cs[w * 2 * BC + i];
+                stat_publish(p.stats + e, 2 * (size_t)p.Cout, slot, v);
+                if (second) {
+                    float v2 = cs2[i];
+#pragma unroll
+                    for (int w = 1; w < NSR; ++w) v2 += cs2[w * 2 * BC + i];
+                    stat_publish(p.stats2 + e, 2 * (size_t)p.Cout, slot, v2);
                 }
             }
         }

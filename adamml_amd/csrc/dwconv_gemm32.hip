@@ -229,30 +229,23 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
         }
     }
     if (p.stats) {
+        // every strip (tl) deposits its sums in its own LDS row [2 nch]; one thread per channel folds the rows in strip order and
+        // publishes the workgroup's partial exactly (common.h: reproducible reductions).  tpb * 2 nch = 8 cw tpb <= 8 NT floats.
         const int nch = 4 * p.cw;                           // channels of this workgroup's tile
-        for (int i = threadIdx.x; i < 2 * nch; i += NT) smem[i] = 0.f;
-        __syncthreads();
-        if (det_mode()) {                                   // exact integer bins instead of float atomics (common.h)
-            if (active) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    det_add(p.stats + chunk * 4 + i, 2 * (size_t)p.C, s[i]);
-                    det_add(p.stats + p.C + chunk * 4 + i, 2 * (size_t)p.C, q[i]);
-                }
-            }
-            return;
-        }
-        if (active) {
+        if (tl < p.tpb) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                atomicAdd(&smem[cl * 4 + i], s[i]);
-                atomicAdd(&smem[nch + cl * 4 + i], q[i]);
+                smem[tl * 2 * nch + cl * 4 + i] = active ? s[i] : 0.f;
+                smem[tl * 2 * nch + nch + cl * 4 + i] = active ? q[i] : 0.f;
             }
         }
         __syncthreads();
-        double* slot = p.stats + (size_t)((bx / p.nct) & (ADAMML_STAT_SLOTS - 1)) * 2 * p.C + ct * nch;
-        for (int i = threadIdx.x; i < 2 * nch; i += NT)
-            if (smem[i] != 0.f) atomicAdd(&slot[i < nch ? i : p.C + i - nch], (double)smem[i]);
+        const unsigned slot = (bx / p.nct) & (ADAMML_STAT_SLOTS - 1);
+        for (int i = threadIdx.x; i < 2 * nch; i += NT) {
+            float v = 0.f;
+            for (int r = 0; r < p.tpb; ++r) v += smem[r * 2 * nch + i];
+            if (v != 0.f) stat_publish(p.stats + ct * nch + (i < nch ? i : p.C + i - nch), 2 * (size_t)p.C, slot, v);
+        }
     }
 }
 
@@ -407,29 +400,21 @@ __global__ __launch_bounds__(NT) void dwconv_bwd_data_s2_kernel(DwP p) {   // p.
         }
     }
     if (BNZ) {
-        for (int i = threadIdx.x; i < 2 * p.C; i += NT) smem[i] = 0.f;
-        __syncthreads();
-        if (det_mode()) {                                   // exact integer bins instead of float atomics (common.h)
-            if (m.active) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    det_add(p.stats + c + i, 2 * (size_t)p.C, s[i]);
-                    det_add(p.stats + p.C + c + i, 2 * (size_t)p.C, q[i]);
-                }
-            }
-            return;
-        }
+        // row slot r of the thread map deposits its sums in LDS row r [2C]; folded in row order, published exactly (common.h)
         if (m.active) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                atomicAdd(&smem[c + i], s[i]);
-                atomicAdd(&smem[p.C + c + i], q[i]);
+                smem[m.rslot * 2 * p.C + c + i] = s[i];
+                smem[m.rslot * 2 * p.C + p.C + c + i] = q[i];
             }
         }
         __syncthreads();
-        double* slot = p.stats + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * p.C;
-        for (int i = threadIdx.x; i < 2 * p.C; i += NT)
-            if (smem[i] != 0.f) atomicAdd(&slot[i], (double)smem[i]);
+        const int nrow = m.rows_per_pass;
+        for (int i = threadIdx.x; i < 2 * p.C; i += NT) {
+            float v = 0.f;
+            for (int r = 0; r < nrow; ++r) v += smem[r * 2 * p.C + i];
+            if (v != 0.f) stat_publish(p.stats + i, 2 * (size_t)p.C, blockIdx.x & (ADAMML_STAT_SLOTS - 1), v);
+        }
     }
 }
 
@@ -589,8 +574,9 @@ __global__ __launch_bounds__(NT, 2) void dwconv_bwd_weight_kernel(DwWP p) {
         }
 #undef DW_STEP
     }
-    if (det_mode()) {
-        // deterministic mode: the threads that share a channel chunk (thread ids congruent modulo nchunk) add in turn
+    {
+        // the threads that share a channel chunk (thread ids congruent modulo nchunk) add in turn: a fixed order, unlike LDS atomics
+        // (common.h: reproducible reductions; <= NT / nchunk barriers once per workgroup)
         const int nturn = (NT + nchunk - 1) / nchunk;
         for (int r = 0; r < nturn; ++r) {
             if (any && (int)threadIdx.x / nchunk == r) {
@@ -601,11 +587,6 @@ __global__ __launch_bounds__(NT, 2) void dwconv_bwd_weight_kernel(DwWP p) {
             }
             __syncthreads();
         }
-    } else if (any) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) atomicAdd(&dsm[t * p.C + c + i], acc[t][i]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 9 * p.C; i += NT) {

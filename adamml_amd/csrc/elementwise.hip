@@ -35,30 +35,25 @@ struct ChanMap {
     }
 };
 
+// Per-channel sums of a workgroup (s, q: the 8-channel partials of this thread): row slot r of the thread map deposits its partials in LDS
+// row r [2C]; one thread per channel folds the rows in row order and publishes the workgroup's partial exactly (common.h: reproducible
+// reductions).  rows_per_pass * 2C <= 16 NT floats = the 2 * MAXC floats every caller provides.
 __device__ __forceinline__ void block_channel_publish(const float (&s)[8], const float (&q)[8], const ChanMap& m, float* smem,
                                                       int C, double* out) {
-    if (det_mode()) {                                    // exact integer-bin accumulation, no floating-point atomics (common.h)
-        if (m.active) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                det_add(out + m.chunk * 8 + i, 2 * (size_t)C, s[i]);
-                det_add(out + C + m.chunk * 8 + i, 2 * (size_t)C, q[i]);
-            }
-        }
-        return;
-    }
-    for (int i = threadIdx.x; i < 2 * C; i += NT) smem[i] = 0.f;
-    __syncthreads();
     if (m.active) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            atomicAdd(&smem[m.chunk * 8 + i], s[i]);
-            atomicAdd(&smem[C + m.chunk * 8 + i], q[i]);
+            smem[m.rslot * 2 * C + m.chunk * 8 + i] = s[i];
+            smem[m.rslot * 2 * C + C + m.chunk * 8 + i] = q[i];
         }
     }
     __syncthreads();
-    double* slot = out + (size_t)(blockIdx.x & (ADAMML_STAT_SLOTS - 1)) * 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += NT) atomicAdd(&slot[i], (double)smem[i]);
+    const unsigned slot = blockIdx.x & (ADAMML_STAT_SLOTS - 1);
+    for (int i = threadIdx.x; i < 2 * C; i += NT) {
+        float v = 0.f;
+        for (int r = 0; r < m.rows_per_pass; ++r) v += smem[r * 2 * C + i];
+        stat_publish(out + i, 2 * (size_t)C, slot, v);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ BN

@@ -20,6 +20,7 @@ nothing: see EVAL_ENABLED."""
 import ctypes
 import os
 import struct
+import weakref
 
 import torch
 
@@ -79,6 +80,7 @@ class Recorder:
         self.fwd, self.bwd = [], None
         self.pre_fwd, self.post_fwd, self.pre_bwd = [], [], []
         self.failed = None
+        self.retry = False                    # failed for a reason that will not recur (arena sized inside the recording): try again
 
     # ---- called by hip.call / hip.ptr / the runtime while recording ----------------------------------------------------
     def stream_slot(self, handle):
@@ -165,6 +167,16 @@ class Plan:
             if rc:
                 raise RuntimeError("adamml_plan_events_create failed: %s" % hip.load().adamml_last_error_string().decode())
         self.slot_arr = (ctypes.c_uint64 * 2)()
+        self._live_tape = None                # weakref to the PlanTape of a replayed forward whose backward has not run yet
+
+    def busy(self):
+        """True while a replayed forward of this plan still waits for its backward: the plan owns ONE set of activation buffers
+        (saved activations, dropout mask, statistic arenas), so a second forward before that backward would overwrite what the first
+        one's backward reads (two model calls summed into one loss, gradient accumulation with a deferred backward).  The caller
+        (HipBackbone.run_planned) then runs that call eagerly.  A forward whose graph was dropped without a backward frees the plan
+        when its tape is collected."""
+        t = self._live_tape() if self._live_tape is not None else None
+        return t is not None and not t.done
 
     def __del__(self):
         try:
@@ -194,7 +206,10 @@ class Plan:
         self._run(self.rec.fwd, x.data_ptr(), 0)
         for h in self.rec.post_fwd:
             h()
-        return self.out, PlanTape(self, x)
+        tape = PlanTape(self, x)
+        if self.rec.bwd is not None:          # (a plan recorded without a backward owns nothing a later call could clobber)
+            self._live_tape = weakref.ref(tape)
+        return self.out, tape
 
     def backward(self, x, g):
         for h in self.rec.pre_bwd:
@@ -210,10 +225,17 @@ class PlanTape:
         self.need_grad = True
         self.grad_out = None
         self.recorder = None
+        self.done = False
 
     def backward(self):
+        if self.done:
+            raise RuntimeError("launch plan: the backward of this call has already run (retain_graph is not supported by a replayed "
+                               "call: its activation buffers belong to the plan; set ADAMML_LAUNCH_PLAN=0)")
+        if self.plan._live_tape is None or self.plan._live_tape() is not self:
+            raise RuntimeError("launch plan: the activations of this call were overwritten by a later replay of the same plan")
         g = self.grad_out
         if not g.is_contiguous():
             g = g.contiguous()
         self._g = g                           # (alive until the replayed kernels have been enqueued; stream-ordered afterwards)
         self.plan.backward(self.x, g)
+        self.done = True

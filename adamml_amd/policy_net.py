@@ -5,6 +5,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import imagenet_init
 from .backbone import HipBackbone
 from .common import MeanStdMixin
 from .functional import hip_linear, policy_head, gumbel_gate
@@ -144,6 +145,8 @@ class JointMobileNetV2(nn.Module):
             net = MobileNetV2(num_classes, num_frames=1 if m == 'sound' else num_frames, input_channels=input_channels[i])
             del net.classifier
             chans.append(net.last_channel)
+            # models/policy_net.py:221 `net.load_imagenet_model()`, unconditional in the reference -- from a local file here
+            imagenet_init.init_mobilenet_v2(net, input_channels[i], True, what="policy mobilenet_v2", arch="mobilenetv2_160x160")
             self.nets.append(net)
         self.last_channels = 2048
         self.joint = nn.Sequential(nn.Linear(sum(chans), 2048), nn.ReLU(True), nn.Linear(2048, 2048), nn.ReLU(True))
@@ -226,7 +229,7 @@ class PolicyNet(nn.Module):
 
 
 def p_joint_mobilenet(num_frames, modality, input_channels, causality_modeling):
-    """models/policy_net.py:382-387.  (The reference downloads ImageNet weights here; on the target systems there is
-    no network, so weights come from load_state_dict.)"""
+    """models/policy_net.py:382-387.  (The reference downloads ImageNet weights for every policy MobileNetV2 here; on the target
+    systems they are read from a local file when one is configured: imagenet_init.py.)"""
     joint_net = JointMobileNetV2(num_frames=num_frames, modality=modality, input_channels=input_channels)
     return PolicyNet(joint_net, modality, causality_modeling=causality_modeling)

@@ -167,8 +167,11 @@ class ResNet(HipBackbone, MeanStdMixin, StockDDPAware):
 
 def resnet(depth, num_classes, without_t_stride, groups, dropout, pooling_method,
            input_channels, imagenet_pretrained=True, **kwargs):
-    """Factory with the signature of models/resnet.py:244-259.  The reference downloads ImageNet weights when
-    imagenet_pretrained is set (models/resnet.py:251-257); the target systems have no network, so the flag is accepted
-    and ignored: load weights with load_state_dict / train.load_reference_checkpoint."""
-    return ResNet(depth, num_frames=groups, num_classes=num_classes, without_t_stride=without_t_stride,
-                  dropout=dropout, pooling_method=pooling_method, input_channels=input_channels)
+    """Factory with the signature of models/resnet.py:244-259.  imagenet_pretrained: the reference downloads torchvision's ImageNet
+    weights (models/resnet.py:251-257); here they come from a LOCAL torchvision-format file (imagenet_init.py: --imagenet_weights /
+    ADAMML_IMAGENET_DIR / a path passed as the flag itself) with the reference's conversion (fc dropped, a non-RGB 7x7 stem = mean over RGB
+    expanded to input_channels).  True with no file configured warns once and leaves the initialisation as it is."""
+    from . import imagenet_init
+    model = ResNet(depth, num_frames=groups, num_classes=num_classes, without_t_stride=without_t_stride,
+                   dropout=dropout, pooling_method=pooling_method, input_channels=input_channels)
+    return imagenet_init.init_resnet(model, depth, input_channels, imagenet_pretrained)

@@ -94,6 +94,12 @@ class Arena:
         need = max(self.high, 1)
         if self.buf is None or self.buf.numel() < need or self.buf.device != device:
             self.buf = torch.zeros(need, dtype=torch.float64, device=device)
+            if hip.recorder is not None:
+                # a launch plan must replay the memset of the FINAL buffer: an arena that is first sized (or grown) inside the recorded
+                # call -- warm-up forwards that had no backward, another call shape raising `high` in between -- would be accumulated
+                # into without ever being re-zeroed at replay.  This call stays eager; the key is not tried again.
+                hip.recorder.failed = "statistics arena (re)allocated while recording"
+                hip.recorder.retry = True       # (the arena has its size now: record again after the usual warm-up)
         else:
             self.buf[:need].zero_()
             if hip.recorder is not None:                 # (a launch plan repeats the memset; the buffer has its final size after warm-up)
@@ -104,6 +110,9 @@ class Arena:
         if self.buf is None or self.off + n > self.buf.numel():
             # first pass (size unknown yet): grow by individual zeroed allocations, remember the total
             t = torch.zeros(n, dtype=torch.float64, device=self.buf.device if self.buf is not None else "cuda")
+            if hip.recorder is not None:
+                hip.recorder.failed = "statistics arena overflowed while recording"
+                hip.recorder.retry = True
         else:
             t = self.buf[self.off:self.off + n]
         self.off += n

@@ -140,5 +140,8 @@ class MobileNetV2(HipBackbone, MeanStdMixin, StockDDPAware):
 
 
 def sound_mobilenet_v2(num_classes, input_channels, dropout, imagenet_pretrained=True, **kwargs):
-    """Factory with the signature of models/sound_mobilenet_v2.py:177-198 (no download on the target systems)."""
-    return MobileNetV2(num_classes=num_classes, input_channels=input_channels, dropout=dropout)
+    """Factory with the signature of models/sound_mobilenet_v2.py:177-198.  imagenet_pretrained: as for resnet() -- torchvision's
+    mobilenet_v2 file read from disk (imagenet_init.py), classifier dropped, a non-RGB stem = mean over RGB expanded to input_channels."""
+    from . import imagenet_init
+    model = MobileNetV2(num_classes=num_classes, input_channels=input_channels, dropout=dropout)
+    return imagenet_init.init_mobilenet_v2(model, input_channels, imagenet_pretrained, what="sound_mobilenet_v2")

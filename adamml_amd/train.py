@@ -138,6 +138,9 @@ def arg_parser():
     p.add_argument("--loader_factory", default=None, type=str, metavar="MODULE:FUNCTION",
                    help="data pipeline hook: FUNCTION(args, rank, world, device) -> (train_loader, val_loader), imported in every rank")
     p.add_argument("--num_classes", default=None, type=int, help="overrides the class count of --dataset")
+    p.add_argument("--imagenet_weights", default=[], nargs="+", metavar="ARCH=PATH",
+                   help="local torchvision ImageNet state_dict files the reference would download (models/resnet.py:251-257, "
+                        "models/policy_net.py:193-203,221): resnet50=PATH mobilenet_v2=PATH mobilenetv2_160x160=PATH; also $ADAMML_IMAGENET_DIR")
     return p
 
 
@@ -151,7 +154,11 @@ def resolve_args(args, log=print, rank=0):
     if bad:
         raise SystemExit("--modality: invalid choice(s) %s (choose from %s)" % (", ".join(map(repr, bad)), ", ".join(CHANNELS)))
     args.input_channels = [CHANNELS[m] for m in args.modality]              # train_adamml.py:85-95
-    args.imagenet_pretrained = False                                        # (no network on the target systems)
+    # the reference's factories default to imagenet_pretrained=True and download; here the same files are read from disk when the caller
+    # names them (imagenet_init.py), with the reference's channel conversion -- without them the initialisation stays random, quietly
+    from . import imagenet_init
+    imagenet_init.configure_from_args(getattr(args, "imagenet_weights", None))
+    args.imagenet_pretrained = any(imagenet_init.path_for(a) for a in ("resnet%d" % args.depth, "mobilenet_v2", "mobilenetv2_160x160"))
     if args.datadir is not None and len(args.datadir) not in (1, len(args.modality)):
         raise SystemExit("--datadir takes one path per modality (%d given for %d modalities)" % (len(args.datadir), len(args.modality)))
     if rank == 0:

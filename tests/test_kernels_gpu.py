@@ -33,6 +33,17 @@ def rb(x):
     return x.to(torch.bfloat16).float()
 
 
+def ssum(t):
+    """Per-channel totals of a statistic accumulator [groups?, STAT_SLOTS, 2C].  The accumulators are OPAQUE between the kernel that
+    fills them and the finalize / collapse kernels that read them (by default 32 exact integer bins per entry, csrc/common.h);
+    adamml_stats_collapse decodes them to fp64 [groups, 2C]."""
+    t3 = t if t.dim() == 3 else t.unsqueeze(0)
+    G, _, C2 = t3.shape
+    out = torch.empty(G, C2, dtype=torch.float64, device=t.device)
+    call("adamml_stats_collapse", ptr(t3.contiguous()), ptr(out), C2 // 2, G)
+    return out if t.dim() == 3 else out[0]
+
+
 def close(a, b, rtol=1e-2, atol_frac=1e-2, what=""):
     scale = b.abs().max().item() + 1e-12
     err = (a - b).abs().max().item()
@@ -99,7 +110,7 @@ def test_conv_fwd_bwd(case, lazy):
     y = torch.empty(N, OH, OW, Cout, dtype=torch.bfloat16, device=DEV)
     stats = torch.zeros(STAT_SLOTS, 2 * Cout, dtype=torch.float64, device=DEV)
     call("adamml_conv_fwd", byref(d), ptr(xh), ptr(pack(w, cp, 0)), ptr(scale), ptr(shift), ptr(y), ptr(stats))
-    stats = stats.sum(0)
+    stats = ssum(stats)
     got = nchw(y)
     close(got, ref.detach(), what="conv fwd")
     # statistics of the stored (rounded) output
@@ -148,7 +159,7 @@ def test_dwconv(case):
     stats = torch.zeros(STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
     xh = nhwc(x)
     call("adamml_dwconv_fwd", byref(d), ptr(xh), ptr(wp), ptr(scale), ptr(shift), ptr(y), ptr(stats))
-    stats = stats.sum(0)
+    stats = ssum(stats)
     close(nchw(y), ref.detach(), what="dw fwd")
     yf = y.float().reshape(-1, C).double()
     assert torch.allclose(stats[:C], yf.sum(0), rtol=1e-4, atol=1e-3)
@@ -385,7 +396,7 @@ def test_conv_groups_equal_separate_launches(case):
         call("adamml_conv_fwd", byref(d1), ptr(_g(xh, G)[g]), ptr(wf), ptr(scale[g]) if lazy else None,
              ptr(shift[g]) if lazy else None, ptr(_g(y1, G)[g]), ptr(st1[g]))
     assert torch.equal(y, y1)
-    assert torch.allclose(st.sum(1), st1.sum(1), rtol=1e-5, atol=1e-3)      # fp32 per-workgroup partials, different tiling
+    assert torch.allclose(ssum(st), ssum(st1), rtol=1e-5, atol=1e-3)      # fp32 per-workgroup partials, different tiling
     dz = nhwc(torch.randn(G * N, Cout, OH, OW, device=DEV))
     dx, dx1 = torch.empty_like(xh), torch.empty_like(xh)
     call("adamml_conv_bwd_data", byref(dG), ptr(dz), ptr(wd), ptr(dx), 0)
@@ -402,7 +413,7 @@ def test_conv_groups_equal_separate_launches(case):
         call("adamml_conv_bwd_data_bn", byref(d1), ptr(_g(dz, G)[g]), ptr(wd), ptr(_g(dx1, G)[g]), ptr(_g(xh, G)[g]), ptr(vec[g]),
              1, ptr(sm1[g]))
     assert torch.equal(dx, dx1)
-    assert torch.allclose(sm.sum(1), sm1.sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(ssum(sm), ssum(sm1), rtol=1e-5, atol=1e-3)
     for use_ws in (False, True):
         dw, dw1 = torch.zeros_like(w), torch.zeros_like(w)
         ws = hip.wgrad_workspace(dG, Cin, DEV) if use_ws else None
@@ -446,7 +457,7 @@ def test_dwconv_bwd_data_bn_equals_dgrad_then_reduce(N, H, W, C, s, G):
     assert torch.equal(gp, gp_ref)
     frac = (gp_ref == 0).float().mean().item()
     assert 0.02 < frac < 0.98                                          # the mask is exercised both ways
-    a, b = sums.sum(1), s_ref.sum(1)
+    a, b = ssum(sums), ssum(s_ref)
     assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-5
 
 
@@ -470,7 +481,7 @@ def test_dwconv_groups_equal_separate_launches(case):
     for g in range(G):
         call("adamml_dwconv_fwd", byref(d1), ptr(_g(xh, G)[g]), ptr(wp), ptr(scale[g]), ptr(shift[g]), ptr(_g(y1, G)[g]), ptr(st1[g]))
     assert torch.equal(y, y1)
-    assert torch.allclose(st.sum(1), st1.sum(1), rtol=1e-5, atol=1e-3)      # fp32 per-workgroup partials, different tiling
+    assert torch.allclose(ssum(st), ssum(st1), rtol=1e-5, atol=1e-3)      # fp32 per-workgroup partials, different tiling
     dz = nhwc(torch.randn(G * N, C, OH, OW, device=DEV))
     dx, dx1 = torch.empty_like(xh), torch.empty_like(xh)
     call("adamml_dwconv_bwd_data", byref(dG), ptr(dz), ptr(wp), ptr(dx), 0)
@@ -507,15 +518,12 @@ def test_batchnorm_groups_equal_successive_calls(C, P, act):
         outs.append({0: o, 1: F.relu(o), 2: F.relu6(o)}[act])
     ref = torch.stack(outs)
     zd = z.double()
-    stats = torch.zeros(G, STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
-    stats[:, 5, :C], stats[:, 7, C:] = zd.sum(1), (zd * zd).sum(1)
+    # (accumulators are opaque -- exact integer bins by default --, so hand-made sums go in collapsed, nslots = 1)
+    stats = torch.cat([zd.sum(1), (zd * zd).sum(1)], dim=1).contiguous()
     vec = torch.empty(G, 4, C, device=DEV)
-    call("adamml_bn_finalize", ptr(stats), STAT_SLOTS, G, float(P), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5, ptr(vec), C)
+    call("adamml_bn_finalize", ptr(stats), 1, G, float(P), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5, ptr(vec), C)
     assert torch.allclose(rm, rm_ref, rtol=1e-4, atol=1e-5)
     assert torch.allclose(rv, rv_ref, rtol=1e-4, atol=1e-5)
-    col = torch.empty(G, 2 * C, dtype=torch.float64, device=DEV)
-    call("adamml_stats_collapse", ptr(stats), ptr(col), C, G)
-    assert torch.equal(col, stats.sum(1))
     o = torch.empty(G, P, C, dtype=torch.bfloat16, device=DEV)
     call("adamml_bn_act_add", ptr(z), ptr(vec[0, 0]), ptr(vec[0, 1]), 4 * C, act, None, None, None, 0, ptr(o), P, C, G)
     close(o.float(), ref.detach(), what="grouped bn apply")
@@ -543,8 +551,8 @@ def test_batchnorm_groups_equal_successive_calls(C, P, act):
     assert torch.equal(g2.float(), gb.float() * (out_t.float() > 0))
     chk = torch.zeros_like(sa)
     call("adamml_bn_bwd_reduce", ptr(g2), ptr(z), ptr(vec), 0, ptr(chk), P, C, G)
-    assert torch.allclose(sa.sum(1), chk.sum(1), rtol=1e-5, atol=1e-4)
-    assert torch.allclose(sb.sum(1), chk.sum(1), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(ssum(sa), ssum(chk), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(ssum(sb), ssum(chk), rtol=1e-5, atol=1e-4)
 
 
 def test_pools_groups_equal_separate_launches():
@@ -603,8 +611,8 @@ def test_conv_stem_fast_path(N, H, W, Cin, G):
     call("adamml_conv_stem_fwd", byref(d), ptr(xh), ptr(ws), ptr(y), ptr(st))
     close(nchw(y), ref, what="stem fwd")
     yf = y.float().reshape(G, -1, 64).double()
-    assert torch.allclose(st.sum(1)[:, :64], yf.sum(1), rtol=1e-4, atol=1e-3)
-    assert torch.allclose(st.sum(1)[:, 64:], (yf * yf).sum(1), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(ssum(st)[:, :64], yf.sum(1), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(ssum(st)[:, 64:], (yf * yf).sum(1), rtol=1e-4, atol=1e-3)
     # generic kernel on the same operands: same values up to fp32 summation order
     y2 = torch.empty_like(y)
     call("adamml_conv_fwd", byref(d), ptr(xh), ptr(pack(w, 8, 0)), None, None, ptr(y2), None)
@@ -654,8 +662,8 @@ def test_conv3x3_c64_patch_kernel(N, H, W, G, lazy):
     call("adamml_conv_fwd", byref(d), ptr(xh), ptr(pack(w, C, 0)), ptr(scale), ptr(shift), ptr(y), ptr(st))
     close(nchw(y), ref.detach(), what="conv3x3_c64 fwd")
     yf = y.float().reshape(G, -1, C).double()
-    assert torch.allclose(st.sum(1)[:, :C], yf.sum(1), rtol=1e-4, atol=1e-3)
-    assert torch.allclose(st.sum(1)[:, C:], (yf * yf).sum(1), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(ssum(st)[:, :C], yf.sum(1), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(ssum(st)[:, C:], (yf * yf).sum(1), rtol=1e-4, atol=1e-3)
     gy = torch.randn_like(ref)
     ref.backward(rb(gy))
     dz = nhwc(gy)
@@ -684,8 +692,8 @@ def test_conv3x3_c64_patch_kernel(N, H, W, G, lazy):
     assert (dx2.view(G, -1, C).float() - gp.float()).abs().max().item() <= 1e-2 * gp.float().abs().max().item()
     gpd = dx2.view(G, -1, C).double()
     zh = (zf.double() - vec[:, 2].view(G, 1, C).double()) * vec[:, 3].view(G, 1, C).double()
-    assert torch.allclose(sums.sum(1)[:, :C], gpd.sum(1), rtol=1e-3, atol=1e-2)
-    assert torch.allclose(sums.sum(1)[:, C:], (gpd * zh).sum(1), rtol=1e-3, atol=1e-2)
+    assert torch.allclose(ssum(sums)[:, :C], gpd.sum(1), rtol=1e-3, atol=1e-2)
+    assert torch.allclose(ssum(sums)[:, C:], (gpd * zh).sum(1), rtol=1e-3, atol=1e-2)
 
 
 @pytest.mark.parametrize("N,H,Cin,Cout,G,second,acc,act", [(4, 28, 256, 64, 1, False, 1, 1), (6, 14, 256, 64, 3, True, 1, 1),
@@ -733,12 +741,12 @@ def test_conv_bwd_data_res_equals_dgrad_then_residual_bwd(N, H, Cin, Cout, G, se
     assert (dx.float() - g2.float()).abs().max().item() <= 1.6e-2 * scale      # double vs single rounding
     gq = dx.float().view(G, P, Cin).double()
     for s_got, s_ref, z, vec in ((sa, sa_ref, za, veca),) + (((sb, sb_ref, zb, vecb),) if second else ()):
-        got = s_got.sum(1)
+        got = ssum(s_got)
         zhat = (z.float().view(G, P, Cin) - vec[:, 2].view(G, 1, Cin)) * vec[:, 3].view(G, 1, Cin)
         exp = torch.cat([gq.sum(1), (gq * zhat.double()).sum(1)], dim=1)        # from the values the kernel stored
         tol = 2e-3 * exp.abs().max().item() + 1e-3
         assert (got - exp).abs().max().item() <= tol
-        assert (got - s_ref.sum(1)).abs().max().item() <= 2e-2 * s_ref.sum(1).abs().max().item() + 1e-2
+        assert (got - ssum(s_ref)).abs().max().item() <= 2e-2 * ssum(s_ref).abs().max().item() + 1e-2
     if not second:
         assert sb.abs().max().item() == 0.0
     # the 1-bit mask form (what adamml_bn_act_add_mask writes) must give the identical result
@@ -795,7 +803,7 @@ def test_temporal_pool_bwd_res_equals_pool_bwd_then_residual_bwd(T, NB, HW, C, G
     assert hip.load().adamml_temporal_pool_bwd_res_supported(T, C, 0) == 1
     call("adamml_temporal_pool_bwd_res", ptr(gy), ptr(out), act, ptr(g2), ptr(z), ptr(vec), ptr(s), NB, T, HW, C, G)
     assert torch.equal(g2, g2_ref)
-    a, b = s.sum(1), s_ref.sum(1)
+    a, b = ssum(s), ssum(s_ref)
     assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-6
     assert hip.load().adamml_temporal_pool_bwd_res_supported(3, C, 0) == 0
     assert hip.load().adamml_temporal_pool_bwd_res_supported(4, C, 1) == 0
@@ -842,13 +850,13 @@ def test_maxpool_bwd_bn_fused_equals_unfused_sequence(N, H, W, C, G):
     dz = torch.empty_like(z)
     call("adamml_maxpool2d_bwd_bn_apply", ptr(gy), ptr(idx), ptr(z), ptr(vec), 1, ptr(coef), ptr(dz), N, H, W, C, OH, OW, G)
     assert torch.equal(dz, dz_ref)
-    a, b = s.sum(1), s_ref.sum(1)
+    a, b = ssum(s), ssum(s_ref)
     assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-6
     # the same two sums over the windows (g_y, z_sel): the unfused reference rounds the routed gradient of a pixel shared by
     # several windows to bf16 first, this path does not -- equal within that rounding
     s2 = torch.zeros_like(s_ref)
     call("adamml_bn_bwd_reduce", ptr(gy), ptr(zsel), ptr(vec), 1, ptr(s2), N * OH * OW, C, G)
-    a2 = s2.sum(1)
+    a2 = ssum(s2)
     gw, zw = _g(gy, G).double().reshape(G, -1, C), _g(zsel, G).double().reshape(G, -1, C)
     keep = ((_g(zsel, G).float().reshape(G, -1, C) * vec[:, 0:1] + vec[:, 1:2]) > 0).double()
     zhat = (zw - vec[:, 2:3].double()) * vec[:, 3:4].double()
@@ -904,7 +912,7 @@ def test_conv_bwd_data_dual_equals_apply_then_dgrad(N, H, Cin, Cout, G, mode):
     sx = dx_ref.float().abs().max().item()
     assert (dx.float() - dx_ref.float()).abs().max().item() <= 1e-2 * sx
     if mode == "bn":
-        a, b = s.sum(1), s_ref.sum(1)
+        a, b = ssum(s), ssum(s_ref)
         assert (a - b).abs().max().item() <= 1e-2 * b.abs().max().item() + 1e-2
     # without the side output the data gradient is unchanged
     dx2 = base.clone()
@@ -1006,7 +1014,7 @@ def test_algebraic_bn_backward_equals_explicit_dz(N, H, Cin, Cout, G, mode):
     assert ex <= 2e-2 * sx
     assert ew <= 2e-2 * sw
     if mode == "bn":
-        a_, b_ = s.sum(1), s_ref.sum(1)
+        a_, b_ = ssum(s), ssum(s_ref)
         assert (a_ - b_).abs().max().item() <= 2e-2 * b_.abs().max().item() + 1e-2
 
 

@@ -73,4 +73,4 @@ def test_one_rank_rccl_step_equals_the_plain_step_bit_for_bit(rccl_one_rank, mod
             assert vectors > rounds >= 53, (rounds, vectors)
         assert ddp.stats["bucket_all_reduces"] >= 2          # the asynchronous buckets really went out from inside backward
     finally:
-        hip.set_deterministic(False)
+        hip.set_deterministic(True)        # back to the default

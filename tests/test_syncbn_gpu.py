@@ -1,8 +1,13 @@
-"""SURVEY.md section 8(e) parity check on the real backbones: a 2-rank data-parallel step with SyncBatchNorm (two gloo
-ranks sharing one MI355X, videos r::2 per rank) must reproduce the single-process step on the concatenated batch --
-BatchNorm batch statistics (through the running statistics they update), loss and the averaged gradient.  The first
-BatchNorm layers must agree to fp32 reduction-order accuracy; deep-layer quantities to the bf16 / atomic-order noise of
-two runs of the same network (a few 1e-3, see tests/test_models_gpu.py)."""
+"""SURVEY.md section 8(e) parity check on the real backbones: an N-rank data-parallel step with SyncBatchNorm (videos r::N per rank)
+must reproduce the single-process step on the concatenated batch -- BatchNorm batch statistics (through the running statistics they
+update), loss and the averaged gradient -- "within fp32 reduction-order tolerance".  Every per-channel sum is order-fixed and exact
+across workgroups (csrc/common.h: reproducible reductions), so both sides are reproducible numbers and the bounds below are
+1.3 x ONE measured value, not a noise band: what remains between the two sides is the fp32 rounding of per-workgroup partial sums over
+differently composed tiles (1e-7 relative on a first-layer statistic), amplified by the bf16 storage of ~100 layers on the way down.
+
+  * two gloo ranks sharing one MI355X (runs on every GPU box);
+  * min(8, device_count) RCCL ranks, one GPU each, over xGMI -- skipped (not failed) on a one-GPU box, so the first multi-GPU node the
+    suite meets exercises SyncBatchNorm + the bucketed gradient all-reduce with real peers (train_adamml.py:122-129)."""
 import os
 import socket
 
@@ -15,7 +20,7 @@ import torch.nn.functional as F
 from tests.mp_plain import manager, plain, tensors  # noqa: E402
 
 pytestmark = pytest.mark.gpu
-S, B = 2, 4
+S, B = 2, 4            # B = videos of the GLOBAL batch of the two-rank test (the RCCL test uses 2 per rank)
 # BatchNorm gamma / beta gradients right under the classifier heads (above the noisy part of the backward pass): torch's
 # SyncBatchNorm keeps them LOCAL and DDP averages them, so the averaged value equals the single-process gradient
 BN_GRAD_KEYS = ("main_net.nets.0.layer4.2.bn3.weight", "main_net.nets.0.layer4.2.bn3.bias",
@@ -31,11 +36,12 @@ def _build():
     return m.to("cuda")
 
 
-def _step(model, ddp, rank, world):
+def _step(model, ddp, rank, world, nvid=B):
     from adamml_amd import synth
-    xs = [t[rank::world].to("cuda") for t in synth.synth_inputs(["rgb", "sound"], B, S, 8, 64, seed=5)]
-    tgt = synth.synth_labels(B, 31, seed=5)[rank::world].to("cuda")
-    expo = synth.synth_gumbel_exponential(S, 2, B, seed=11).view(S, 2, B, 2)[:, :, rank::world].reshape(S, -1, 2).to("cuda")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    xs = [t[rank::world].to(dev) for t in synth.synth_inputs(["rgb", "sound"], nvid, S, 8, 64, seed=5)]
+    tgt = synth.synth_labels(nvid, 31, seed=5)[rank::world].to(dev)
+    expo = synth.synth_gumbel_exponential(S, 2, nvid, seed=11).view(S, 2, nvid, 2)[:, :, rank::world].reshape(S, -1, 2).to(dev)
     model.freeze_policy_net()
     model.train()
     model.zero_grad()
@@ -50,69 +56,108 @@ def _step(model, ddp, rank, world):
         loss = lt / world
     torch.cuda.synchronize()
     sd = model.state_dict()
-    keys = ["main_net.nets.0.bn1.running_mean", "main_net.nets.0.bn1.running_var", "main_net.nets.0.layer1.0.bn1.running_mean",
-            "main_net.nets.1.features.0.1.running_mean", "policy_net.joint_net.nets.0.features.0.1.running_mean",
-            "main_net.nets.0.layer4.2.bn3.running_mean"]
     return {"loss": float(loss.detach()), "sel": sel.detach().cpu(), "grad": model._flat_main.flat_grad.detach().cpu().clone(),
             "fc_grad": model.main_net.nets[0].fc.weight.grad.detach().cpu().clone(),
             "sound_fc_grad": model.main_net.nets[1].classifier[1].weight.grad.detach().cpu().clone(),
             "bn_grads": {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if k in BN_GRAD_KEYS},
-            "stats": {k: sd[k].detach().cpu().clone() for k in keys}}
+            "stats": {k: v.detach().cpu().clone() for k, v in sd.items() if k.endswith(("running_mean", "running_var"))}}
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, backend, nvid):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank if backend == "nccl" else 0)          # RCCL: one GPU per rank; gloo: the ranks share GPU 0
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         from adamml_amd.distributed import HipDDP
-        from adamml_amd import interleave
+        from adamml_amd import hip, interleave
+        assert hip.deterministic()
+        one = torch.ones(1, device="cuda")
+        dist.all_reduce(one)                                         # the communicator really spans `world` ranks
         model = _build()
         ddp = HipDDP(model, sync_bn=True)
         interleave.stats["collectives"] = interleave.stats["coalesced_vectors"] = 0
-        r = _step(model, ddp, rank, world)
+        r = _step(model, ddp, rank, world, nvid)
         if rank == 0:
             ret["r"] = plain(r)
             ret["exchange"] = dict(interleave.stats)
+            ret["communicator_ranks"] = int(one.item())
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_syncbn_step_equals_single_process_full_batch():
+def _rel(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+# Bounds = 1.3 x the value measured on MI355X (two gloo ranks, B = 4, S = 2, 64 px; reproducible: see the module docstring).
+FIRST_LAYER_STATS = ("main_net.nets.0.bn1.", "main_net.nets.1.features.0.1.", "policy_net.joint_net.nets.0.features.0.1.",
+                     "policy_net.joint_net.nets.1.features.0.1.")
+TOL = {"first_layer_stats": 1e-5, "stats_max": 2.0e-2, "stats_p90": 5e-3, "loss": 1e-3, "fc_grad": 3e-2, "sound_fc_grad": 3e-2,
+       "bn_grad": 0.15, "grad_rel_l2": 0.75}
+
+
+def _compare(two, one, world, tol=TOL):
+    assert torch.equal(two["sel"], one["sel"][0::world])                 # rank 0 holds videos 0, N, 2N.. and takes the same decisions
+    errs = {k: _rel(two["stats"][k], v) for k, v in one["stats"].items()}
+    first = max(e for k, e in errs.items() if k.startswith(FIRST_LAYER_STATS))
+    ranked = sorted(errs.values())
+    p90, worst = ranked[int(0.9 * (len(ranked) - 1))], ranked[-1]
+    wk = max(errs, key=errs.get)
+    print("  %d running statistics, rel L2: first layers (no bf16 stage above them) max %.2e | p90 %.2e | max %.2e (%s)"
+          % (len(errs), first, p90, worst, wk))
+    g_all = _rel(two["grad"], one["grad"])
+    cos = F.cosine_similarity(two["grad"].double(), one["grad"].double(), dim=0).item()
+    e_fc, e_sfc = _rel(two["fc_grad"], one["fc_grad"]), _rel(two["sound_fc_grad"], one["sound_fc_grad"])
+    print("  loss %.6f vs %.6f | head gradients rel L2: resnet fc %.2e, sound classifier %.2e | all main-net gradients: rel L2 %.3f, cosine %.3f"
+          % (two["loss"], one["loss"], e_fc, e_sfc, g_all, cos))
+    assert first <= tol["first_layer_stats"], first
+    assert worst <= tol["stats_max"] and p90 <= tol["stats_p90"], (worst, p90, wk)
+    assert abs(two["loss"] - one["loss"]) <= tol["loss"] * abs(one["loss"])
+    # the classifier heads sit above the chaotic part of the backward pass: their averaged gradients must agree closely
+    assert e_fc <= tol["fc_grad"] and e_sfc <= tol["sound_fc_grad"], (e_fc, e_sfc)
+    for k in BN_GRAD_KEYS:
+        e = _rel(two["bn_grads"][k], one["bn_grads"][k])
+        print("  %-60s averaged gradient rel L2 %.2e" % (k, e))
+        assert e <= tol["bn_grad"], (k, e)     # (a world-times-too-large SyncBN gamma / beta gradient would read 1.0)
+    # every main-net gradient, as ONE vector: the deep layers of a randomly initialised train-mode-BatchNorm network amplify the 1e-7
+    # difference of the first statistics through ReLU / max-pool decision flips (tools/conditioning_study.py: sqrt law)
+    assert g_all <= tol["grad_rel_l2"], g_all
+
+
+def _spawn(world, backend, nvid):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mgr = manager()                                         # (tests/mp_plain.py: spawned server, numpy payloads)
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
-    two = tensors(ret["r"])
+    mp.spawn(_worker, args=(world, port, ret, backend, nvid), nprocs=world, join=True)
+    return tensors(ret["r"]), ret["exchange"], ret["communicator_ranks"]
+
+
+def test_two_rank_syncbn_step_equals_single_process_full_batch():
+    two, ex, ranks = _spawn(2, "gloo", B)
+    assert ranks == 2
     # SyncBatchNorm exchanges of one step (S = 2 segments batched as groups): the 4 backbones have 53 / 52 / 52 / 52 BatchNorm
     # layers in forward and the two trainable ones 53 / 52 in backward = 314 statistic vectors; issued in rounds they travel in one
     # collective per BatchNorm depth and exchange group (the ResNet alone, the MobileNetV2s together, alternating: interleave.GROUPS):
     # <= (53 + 52) forward + (53 + 52) backward; <= 53 + 53 with ADAMML_SYNC_GROUPS=1
-    ex = ret["exchange"]
     print("  SyncBatchNorm exchange: %d statistic vectors in %d collectives" % (ex["coalesced_vectors"], ex["collectives"]))
     from adamml_amd import interleave
     assert ex["coalesced_vectors"] == 53 + 3 * 52 + 53 + 52 and ex["collectives"] <= (2 * (53 + 52) if interleave.GROUPS == "2" else 53 + 53)      # (8 clips: "auto" keeps one group)
     one = _step(_build(), None, 0, 1)
-    assert torch.equal(two["sel"], one["sel"][0::2])                     # rank 0 holds videos 0, 2 and takes the same decisions
-    rel = lambda a, b: ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
-    for k, v in one["stats"].items():
-        e = rel(two["stats"][k], v)
-        tol = 2e-5 if k.endswith(("nets.0.bn1.running_mean", "nets.0.bn1.running_var", "features.0.1.running_mean")) else 2e-2
-        print("  %-60s rel L2 %.2e" % (k, e))
-        assert e <= tol, (k, e)
-    cos = F.cosine_similarity(two["grad"].double(), one["grad"].double(), dim=0).item()
-    print("  loss %.5f vs %.5f | head gradients rel L2: resnet fc %.2e, sound classifier %.2e | all main-net gradients: rel L2 %.2f, cosine %.3f"
-          % (two["loss"], one["loss"], rel(two["fc_grad"], one["fc_grad"]), rel(two["sound_fc_grad"], one["sound_fc_grad"]),
-             rel(two["grad"], one["grad"]), cos))
-    assert abs(two["loss"] - one["loss"]) <= 2e-3 * abs(one["loss"])
-    # the classifier heads sit above the chaotic part of the backward pass: their averaged gradients must agree closely
-    assert rel(two["fc_grad"], one["fc_grad"]) <= 3e-2
-    assert rel(two["sound_fc_grad"], one["sound_fc_grad"]) <= 3e-2
-    for k in BN_GRAD_KEYS:
-        e = rel(two["bn_grads"][k], one["bn_grads"][k])
-        print("  %-60s averaged gradient rel L2 %.2e" % (k, e))
-        assert e <= 0.15, (k, e)               # (a world-times-too-large SyncBN gamma / beta gradient would read 1.0; measured 2e-2 .. 7e-2)
-    # deep in a randomly initialised train-mode-BatchNorm ResNet two runs of the SAME pipeline already differ by 0.2-0.5 in
-    # relative L2 (atomic order, bf16 storage; tests/test_models_gpu.py GRAD_FLOOR): direction only
-    assert cos >= 0.6
+    _compare(two, one, 2)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: RCCL ranks over xGMI, one GPU each")
+def test_n_rank_rccl_step_equals_full_batch():
+    """configs[2] with real peers: min(8, device_count) RCCL ranks, 2 videos each, SyncBatchNorm + bucketed asynchronous gradient
+    all-reduce, against the one-process step on the concatenated batch (same bounds as the two-rank test)."""
+    world = min(8, torch.cuda.device_count())
+    nvid = 2 * world
+    got, ex, ranks = _spawn(world, "nccl", nvid)
+    assert ranks == world, "the RCCL communicator spans %d ranks, expected %d" % (ranks, world)
+    print("  %d RCCL ranks: %d statistic vectors in %d collectives" % (world, ex["coalesced_vectors"], ex["collectives"]))
+    assert ex["coalesced_vectors"] == 53 + 3 * 52 + 53 + 52
+    torch.cuda.set_device(0)
+    one = _step(_build(), None, 0, 1, nvid)
+    _compare(got, one, world)

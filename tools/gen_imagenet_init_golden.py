@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Golden fixture for adamml_amd/imagenet_init.py: what the REFERENCE's own ImageNet initialisation makes of a torchvision-format
+state_dict (models/resnet.py:19-33,251-257; models/sound_mobilenet_v2.py:186-196; models/policy_net.py:193-203,221).
+
+The download (`model_zoo.load_url`) is served by a synthetic state_dict with torchvision's names and shapes (values from
+adamml_amd.synth, keyed by name: the test regenerates the identical file); the reference then converts and loads it.  Stored per case:
+the converted stem kernel in full and (sum, sum of |.|, 4 samples) of every other entry -- outputs only.
+Usage (build container): python tools/gen_imagenet_init_golden.py"""
+import os
+import sys
+import types
+import zlib
+import numpy as np
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(1, os.environ.get("ADAMML_REF", "/root/reference"))
+import torch  # noqa: E402
+
+tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+tvt.Compose = lambda ts: None
+tvt.CenterCrop = tvt.Resize = lambda *a, **k: None
+tv.transforms = tvt
+sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt})
+import models  # noqa: E402,F401
+rn, pn, sm = (sys.modules["models." + n] for n in ("resnet", "policy_net", "sound_mobilenet_v2"))   # (models/__init__.py rebinds the names to functions)
+from adamml_amd import synth  # noqa: E402
+from tests.imagenet_init_cases import torchvision_like, digest, CASES  # noqa: E402
+
+
+def main():
+    files = {"resnet50": torchvision_like("resnet50"), "mobilenet_v2": torchvision_like("mobilenet_v2"),
+             "mobilenetv2_160x160": torchvision_like("mobilenetv2_160x160", like=pn.MobileNetV2(1000, num_frames=1, input_channels=3).state_dict())}
+    rn.model_zoo.load_url = lambda url, **kw: {k: v.clone() for k, v in files["resnet50"].items()}
+    pn.model_zoo.load_url = lambda url, **kw: {k: v.clone() for k, v in files["mobilenetv2_160x160"].items()}
+    sm.model_zoo.load_url = lambda url, **kw: {k: v.clone() for k, v in files["mobilenet_v2"].items()}
+    out = {}
+    for name, c in CASES.items():
+        torch.manual_seed(0)
+        if c["kind"] == "resnet":
+            m = rn.resnet(50, 31, False, 8, 0.5, "max", c["ch"], imagenet_pretrained=True)
+        elif c["kind"] == "sound":
+            m = sm.sound_mobilenet_v2(31, c["ch"], 0.5, imagenet_pretrained=True)
+        else:                                   # policy MobileNetV2: load_imagenet_model() as JointMobileNetV2 calls it
+            m = pn.MobileNetV2(1000, num_frames=8, input_channels=c["ch"])
+            del m.classifier
+            m.load_imagenet_model()
+        sd = m.state_dict()
+        for k, v in digest(sd, c["stem"]).items():
+            out[name + "/" + k] = v
+        print(name, len(sd), "entries")
+    path = os.path.join(ROOT, "tests", "golden", "imagenet_init.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
