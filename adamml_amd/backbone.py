@@ -13,12 +13,18 @@ class FlatBuffers:
     second flat buffer: one memset zeroes all gradients, one RCCL all-reduce synchronises them, and the fused
     optimizer kernels update the whole sub-network in one launch."""
 
+    RECHECK_EVERY = 32
+
     def __init__(self, module):
         self.module = module
         self.flat = None
         self.flat_grad = None
         self.params = []
         self.detached = False       # True: .grad belongs to autograd / torch.optim (enable_autograd_param_grads)
+
+    def invalidate(self):
+        """The next ensure() walks the module's parameters again (a parameter object may have been replaced)."""
+        self._calls = -1
 
     def set_detached(self, on):
         """on: stop managing .grad (drop the flat views so that AccumulateGrad creates ordinary gradient tensors)."""
@@ -35,12 +41,17 @@ class FlatBuffers:
         # module.parameters() -- ~1400 modules for AdaMML -- costs ~1 ms per sub-network per step, which matters at the per-GPU batch
         # of the reference recipe where the step is host-bound; a parameter REPLACED by the caller is caught by the data_ptr probes of
         # the first and the last one and by the optimizers / load_state_dict going through .data, which keeps the objects.)
-        if self.flat is not None and self.flat.device == device and self.params and \
+        # A parameter OBJECT swapped by the caller in the middle of the list (a new `fc` for another class count) is not seen by those two
+        # probes: every RECHECK_EVERY-th call takes the full walk anyway (round-3 advisor finding), and so does the first call after invalidate().
+        self._calls = getattr(self, "_calls", 0) + 1
+        if self.flat is not None and self.flat.device == device and self.params and self._calls % self.RECHECK_EVERY and \
                 self.params[0].data_ptr() == self.views[0].data_ptr() and self.params[-1].data_ptr() == self.views[-1].data_ptr():
             return
         params = [p for p in self.module.parameters()]
+        for m in self.module.modules():             # (the backbones cache their parameter lists too)
+            m.__dict__.pop("_plist", None)
         if self.flat is not None and self.flat.device == device and len(params) == len(self.params) and \
-                all(p.data_ptr() == v.data_ptr() for p, v in zip(params[:2], self.views[:2])):
+                all(p.data_ptr() == v.data_ptr() for p, v in zip(params, self.views)):
             self.params = params
             return
         total = sum(p.numel() for p in params)
@@ -77,6 +88,20 @@ class FlatBuffers:
             off += n
 
 
+def queue_end_of_backward(fn):
+    """Run fn() once the current autograd backward pass has executed all its nodes.  torch exposes this only as
+    `Variable._execution_engine.queue_callback` -- the hook torch's own DistributedDataParallel reducer and FSDP finalise their
+    backward with, unchanged since torch 1.0, but not part of the documented API: it is reached through this ONE function, which fails
+    with a clear message when a torch build moves it (tests/test_host_cpu.py::test_autograd_end_of_backward_callback pins the behaviour
+    this package relies on)."""
+    eng = getattr(torch.autograd.Variable, "_execution_engine", None)
+    q = getattr(eng, "queue_callback", None)
+    if q is None:
+        raise RuntimeError("torch %s has no autograd end-of-backward callback (Variable._execution_engine.queue_callback): adamml_amd "
+                           "defers the SyncBatchNorm backward rounds and the side-stream join to it" % torch.__version__)
+    q(fn)
+
+
 def run_backward(net, tape, g, params):
     """Backward of one backbone invocation (autograd formula of adamml::backbone_call, ops.py): the recorded tape in reverse.
     params empty  -> the weight-gradient kernels accumulate into the pre-attached flat .grad views; returns [].
@@ -88,7 +113,7 @@ def run_backward(net, tape, g, params):
         # handed every backbone its output gradient -- nothing upstream waits for a backbone's input gradient
         _deferred.append((tape, g.contiguous(), net, torch.cuda.current_stream()))
         if len(_deferred) == 1:
-            torch.autograd.Variable._execution_engine.queue_callback(_run_deferred)
+            queue_end_of_backward(_run_deferred)
         return []
     if not params:
         run_tape(tape, g, net)
@@ -153,7 +178,7 @@ def _queue_default_stream_join(net, device, side):
         if _in_deferred_run[0]:
             _join()                     # already past the engine's callbacks: join right away
         else:
-            torch.autograd.Variable._execution_engine.queue_callback(_join)
+            queue_end_of_backward(_join)
 
 
 _deferred = []

@@ -114,7 +114,7 @@ def _resolve(arch, flag, what):
     p = path_for(arch)
     if p is None and (arch, what) not in _WARNED:
         _WARNED.add((arch, what))
-        warnings.warn("%s: the reference initialises this network from torchvision's ImageNet %s weights (downloaded); no local file is "
+        warnings.warn("%s: the reference initialises this network from downloaded ImageNet weights (%s); no local file is "
                       "configured (--imagenet_weights %s=PATH / ADAMML_IMAGENET_DIR / imagenet_init.configure), so the weights keep "
                       "their random initialisation" % (what, arch, arch))
     return p

@@ -27,9 +27,13 @@ dispatcher's key guards are thread-local too): the jobs therefore call the backb
 """
 import os
 
-import greenlet
 import torch
 import torch.distributed as dist
+
+try:
+    import greenlet                                # requirements.txt: the only dependency besides torch / numpy
+except ImportError:                                # pragma: no cover
+    greenlet = None
 
 from . import hip
 
@@ -40,7 +44,7 @@ ENABLED = os.environ.get("ADAMML_INTERLEAVE", "1") != "0"      # A/B aid; only e
 # the first job (the ResNet-50 of the main net) and the other jobs (the MobileNetV2s) exchange in ALTERNATING collectives A0 B0 A1 B1 ...:
 # while one group's exchange is in flight the other group's kernels run.  Twice the collectives -- still one communicator, still a sequence
 # that is a pure function of the program, identical on every rank -- and measured on one rank at B = 72 / 36 / 18 / 9 (launch plans):
-# 127.0 / 71.5 / 43.8 / 29.3 -> 122.2 / 66.3 / 39.2 / 26.0 ms per step (tools/gpu_r3s.sh).
+# 127.0 / 71.5 / 43.8 / 29.3 -> 122.2 / 66.3 / 39.2 / 26.0 ms per step.
 # Every collective costs ~65 us of host time; an EAGER step at the per-GPU share of the reference recipe (9 videos) is bound by the host
 # (37.3 ms with two groups against 30.4 with one), so "auto" alternates only when the step is not: launch plans on (26.2 against 29.3 ms),
 # or at least SMALL_CLIPS clips per rank (the forward call leaves its clip count in `clips_hint` for the backward call).
@@ -274,6 +278,10 @@ def run_interleaved(jobs, device, phase="fwd", groups=None):
     `phase` names the persistent round buffers ("fwd" / "bwd"); `groups`: 1 or 2, default by GROUPS."""
     if _current[0] is not None:
         raise RuntimeError("run_interleaved: nested call from inside a job")
+    if greenlet is None:
+        raise RuntimeError("SyncBatchNorm over several backbones issues them as coroutines and needs the `greenlet` package "
+                           "(requirements.txt; pip install greenlet), or ADAMML_INTERLEAVE=0 for sequential issue (one exchange per "
+                           "BatchNorm instead of one per BatchNorm depth)")
     sched = greenlet.getcurrent()
     ge = torch.is_grad_enabled()
     on_gpu = device is not None and torch.device(device).type == "cuda"

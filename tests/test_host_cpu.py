@@ -456,3 +456,92 @@ def test_launch_plan_recorder_encodes_calls_slots_waits_and_segments():
     assert op.slot_mask == 0b00110 and (op.a[1], op.a[2]) == (1, 0)      # gradient = slot 1, input = slot 0
     rec.call("adamml_conv_bwd_data", (ctypes.byref(d), 1, 2), 0xAAA0)    # wrong argument count: the recording is marked failed, not wrong
     assert rec.failed is not None
+
+
+def test_imagenet_initialisation_from_local_files_matches_the_reference(tmp_path):
+    """models/resnet.py:19-33,251-257, models/sound_mobilenet_v2.py:186-196, models/policy_net.py:193-203,221: the reference starts from
+    downloaded ImageNet weights, converting a non-RGB stem to the mean over RGB expanded to the input channels and dropping the
+    classifier.  adamml_amd.imagenet_init does the same from LOCAL files.  Golden = the reference's own functions run on synthetic files
+    with the published names and shapes (tools/gen_imagenet_init_golden.py -> tests/golden/imagenet_init.npz); the test writes the
+    identical files (name-keyed generator) and compares every state_dict entry of the initialised models."""
+    import warnings
+    import numpy as np
+    from adamml_amd import imagenet_init, policy_net
+    from adamml_amd.resnet import resnet
+    from adamml_amd.sound_mobilenet_v2 import sound_mobilenet_v2
+    from tests.imagenet_init_cases import CASES as ICASES, torchvision_like, digest
+    gold = np.load(os.path.join(ge.ROOT, "tests", "golden", "imagenet_init.npz"))
+    dli = policy_net.MobileNetV2(1000, num_frames=1, input_channels=3).state_dict()       # (the d-li14 file is named like the policy net itself)
+    files = {"resnet50": torchvision_like("resnet50"), "mobilenet_v2": torchvision_like("mobilenet_v2"),
+             "mobilenetv2_160x160": torchvision_like("mobilenetv2_160x160", like=dli)}
+    for arch, sd in files.items():
+        torch.save(sd, str(tmp_path / (arch + "-0000.pth")))
+    # three ways to name the files: configure(), $ADAMML_IMAGENET_DIR, the launcher's --imagenet_weights
+    imagenet_init.configure(resnet50=str(tmp_path / "resnet50-0000.pth"))
+    os.environ["ADAMML_IMAGENET_DIR"] = str(tmp_path)
+    try:
+        assert imagenet_init.path_for("mobilenet_v2").endswith("mobilenet_v2-0000.pth")
+        assert imagenet_init.path_for("mobilenetv2_160x160").endswith("mobilenetv2_160x160-0000.pth")
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                       # everything is configured: no "keeps its random initialisation" warning
+            for name, c in ICASES.items():
+                if c["kind"] == "resnet":
+                    m = resnet(50, 31, False, 8, 0.5, "max", c["ch"], imagenet_pretrained=True)
+                elif c["kind"] == "sound":
+                    m = sound_mobilenet_v2(31, c["ch"], 0.5, imagenet_pretrained=True)
+                else:
+                    m = policy_net.JointMobileNetV2(8, ["x"], input_channels=[c["ch"]]).nets[0]      # models/policy_net.py:215-222
+                got = digest(m.state_dict(), c["stem"])
+                keys = [k[len(name) + 1:] for k in gold.files if k.startswith(name + "/")]
+                assert sorted(keys) == sorted(got), (name, set(keys) ^ set(got))
+                for k in keys:
+                    g = gold[name + "/" + k]
+                    if k.endswith("num_batches_tracked") or not (k.startswith("fc.") or k.startswith("classifier")):
+                        assert np.allclose(got[k], g, rtol=1e-6, atol=1e-7), (name, k)
+                    # (fc / classifier are NOT loaded: both sides keep their own random initialisation there -- only the size is compared)
+                    assert got[k].shape == g.shape and (k == c["stem"] or got[k][-1] == g[-1]), (name, k)
+                stem = m.state_dict()[c["stem"]]
+                assert stem.shape[1] == c["ch"]
+                if c["ch"] != 3:                                 # mean over RGB, repeated: all input channels equal
+                    assert torch.equal(stem, stem[:, :1].expand_as(stem))
+    finally:
+        del os.environ["ADAMML_IMAGENET_DIR"]
+        imagenet_init.configure(resnet50=None)
+    # the launcher flag (opts.py has no equivalent: the reference downloads) and the quiet default
+    from adamml_amd import train
+    a = train.arg_parser().parse_args(["--backbone_net", "adamml", "--modality", "rgb", "sound", "--dataset", "kinetics-sounds",
+                                       "--imagenet_weights", "resnet50=" + str(tmp_path / "resnet50-0000.pth")])
+    try:
+        a = train.resolve_args(a, log=lambda *x: None)
+        assert a.imagenet_pretrained is True and imagenet_init.path_for("resnet50").endswith("resnet50-0000.pth")
+    finally:
+        imagenet_init.configure(resnet50=None)
+    with pytest.warns(UserWarning, match="no local file"):
+        imagenet_init._WARNED.clear()
+        resnet(50, 31, False, 8, 0.5, "max", 3, imagenet_pretrained=True)
+
+
+def test_autograd_end_of_backward_callback():
+    """backbone.queue_end_of_backward wraps the one semi-private torch hook the package uses (the engine's queue_callback, as torch's
+    own DistributedDataParallel / FSDP do): a callback queued from inside a backward node runs exactly once, after EVERY node of that
+    backward pass has run, and a later backward pass does not run it again."""
+    from adamml_amd.backbone import queue_end_of_backward
+    log = []
+
+    class Node(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, tag):
+            ctx.tag = tag
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            log.append("node" + ctx.tag)
+            if ctx.tag == "B":                       # the LAST node of the forward is the first to run in backward
+                queue_end_of_backward(lambda: log.append("end"))
+            return g * 2, None
+    x = torch.ones(3, requires_grad=True)
+    Node.apply(Node.apply(x, "A"), "B").sum().backward()
+    assert log == ["nodeB", "nodeA", "end"], log
+    Node.apply(x, "A").sum().backward()
+    assert log == ["nodeB", "nodeA", "end", "nodeA"], log

@@ -32,9 +32,12 @@ from tests.imagenet_init_cases import torchvision_like, digest, CASES  # noqa: E
 def main():
     files = {"resnet50": torchvision_like("resnet50"), "mobilenet_v2": torchvision_like("mobilenet_v2"),
              "mobilenetv2_160x160": torchvision_like("mobilenetv2_160x160", like=pn.MobileNetV2(1000, num_frames=1, input_channels=3).state_dict())}
-    rn.model_zoo.load_url = lambda url, **kw: {k: v.clone() for k, v in files["resnet50"].items()}
-    pn.model_zoo.load_url = lambda url, **kw: {k: v.clone() for k, v in files["mobilenetv2_160x160"].items()}
-    sm.model_zoo.load_url = lambda url, **kw: {k: v.clone() for k, v in files["mobilenet_v2"].items()}
+    # (the three modules share ONE torch.utils.model_zoo object: dispatch on the URL each of them asks for)
+    def load_url(url, **kw):
+        arch = "resnet50" if "resnet50" in url else "mobilenetv2_160x160" if "mobilenetv2_160x160" in url else "mobilenet_v2"
+        assert arch != "mobilenet_v2" or "mobilenet_v2" in url, url
+        return {k: v.clone() for k, v in files[arch].items()}
+    rn.model_zoo.load_url = load_url
     out = {}
     for name, c in CASES.items():
         torch.manual_seed(0)
