@@ -28,6 +28,13 @@ CASES = {
     "resnet50_c1": dict(kind="resnet", modality=["rgb"], groups=8, B=4, size=224, modes=["eval_cal", "train"], full=True),
     "adamml_c2": dict(kind="adamml", modality=["rgb", "sound"], groups=8, B=4, S=5, size=224, sound_size=256,
                       modes=["eval_cal", "train_main", "train_policy"], full=True, margin=0.08),
+    # BASELINE.json configs[3] / configs[4] at full size (B = 2 videos, 5 segments, 224^2): the 3- and 4-modality workloads with the
+    # policy / main modality-order quirk (models/adamml.py:143-146,85-86: decisions index (rgb, [sound,] rgbdiff), main nets take
+    # (rgb, [sound,] flow)), the 10-channel ResNet stem (models/resnet.py:138) and the 15-channel policy stem (models/policy_net.py:195-200)
+    "adamml_c4": dict(kind="adamml", modality=["rgb", "flow", "rgbdiff"], groups=8, B=2, S=5, size=224, sound_size=256,
+                      modes=["eval_cal", "train_main"], full=True, margin=0.08),
+    "adamml_c5": dict(kind="adamml", modality=["rgb", "sound", "flow", "rgbdiff"], groups=8, B=2, S=5, size=224, sound_size=256,
+                      modes=["eval_cal", "train_main", "train_policy"], full=True, margin=0.08),
 }
 
 

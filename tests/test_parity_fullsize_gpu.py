@@ -170,11 +170,10 @@ def check_replay(c, mode, logits, plog, grads, state, captured, top_prefixes, to
           "heads: max %.3f" % (mode, len(v), v[len(v) // 2], v[int(0.9 * len(v))], v[-1], worst, len(top), max(top.values())))
     assert max(top.values()) <= top_tol, max(top, key=top.get)
     assert v[int(0.9 * len(v))] <= p90_tol
-    # max_tol holds for all but the two worst tensors; the worst itself only has to stay correlated (< 1).  In default mode the single
-    # deepest tensor of a MobileNetV2 stack (the stem's BatchNorm weight, 50 layers below the loss) measured 0.12 .. 0.20 in six runs
-    # of one build and 0.59 in a seventh: the atomic statistics' last bits differ from run to run and the stack amplifies them
-    assert v[-3] <= max_tol, (worst, v[-3:])
-    assert v[-1] < 1.0, (worst, v[-1])
+    # every per-channel sum is order-fixed and exact across workgroups (csrc/common.h), so these are reproducible numbers: max_tol holds
+    # for EVERY tensor (round 3 exempted the two worst ones: with fp64 atomic statistics the deepest MobileNetV2 tensor read 0.12 .. 0.59
+    # from run to run)
+    assert v[-1] <= max_tol, (worst, v[-3:])
 
 
 def test_c1_resnet50_fullsize():
@@ -225,6 +224,61 @@ def test_c2_adamml_fullsize(mode):
            "main_net.nets.1.classifier.", "main_net.lf_weights") if mode == "train_main" else \
           ("policy_net.fcs.", "policy_net.lstm.", "policy_net.joint_net.joint.")
     check_replay(c, mode, logits, plog, grads, state, captured, top_prefixes=top, top_tol=5e-2, p90_tol=0.12, max_tol=0.4)
+
+
+# BASELINE.json configs[3] / configs[4] at full size (B = 2 videos, S = 5, 224^2 / 256^2).  What these add to C2: the policy / main
+# modality-order quirk (models/adamml.py:143-146,85-86 -- decisions index (rgb, [sound,] rgbdiff) while the main nets take
+# (rgb, [sound,] flow)), the 10-channel ResNet stem (models/resnet.py:138) and the 15-channel policy stem (models/policy_net.py:195-200),
+# two ResNet-50 main nets side by side.  Bounds = 1.3 x the values measured on MI355X (reproducible: order-fixed sums), in BOUNDS below.
+BOUNDS = {
+    ("adamml_c4", "train_main"): dict(plog=9.5e-2, logits=5.5e-2, stat_all=2.4e-2, stat_p90=6.5e-3, head=0.1),
+    ("adamml_c5", "train_main"): dict(plog=9.5e-2, logits=5.5e-2, stat_all=2.4e-2, stat_p90=6.5e-3, head=0.1),
+    ("adamml_c5", "train_policy"): dict(plog=9.5e-2, logits=5.5e-2, stat_all=2.4e-2, stat_p90=6.5e-3, head=0.4),
+    ("adamml_c4", "eval_cal"): dict(plog=8.7e-2, logits=5.8e-2),
+    ("adamml_c5", "eval_cal"): dict(plog=8.7e-2, logits=5.8e-2),
+}
+
+
+@pytest.mark.parametrize("name,mode", [("adamml_c4", "train_main"), ("adamml_c5", "train_main"), ("adamml_c5", "train_policy")])
+def test_c4_c5_adamml_fullsize(name, mode):
+    c = CASES[name]
+    gold = load_golden(name)
+    b = BOUNDS[(name, mode)]
+    model = build(c)
+    sd = synth.synth_state_dict(manifest(c), seed=1234)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    print("%s (%s, B=%d, S=%d, 224^2), golden min decision margin %.3f" % (name, "+".join(c["modality"]), c["B"], c["S"],
+                                                                          float(gold["min_decision_margin"])))
+    logits, sel, plog, grads, state, _ = hip_train_step(model, c, mode, sd)
+    # decisions [B, S, M'] over the POLICY modalities (rgbdiff stands in for flow): the same hard decisions as the reference
+    assert sel.shape == gold[mode + ".decisions"].shape, (sel.shape, gold[mode + ".decisions"].shape)
+    assert np.array_equal(np.round(sel.numpy()), np.round(gold[mode + ".decisions"])), "decisions differ from the reference"
+    ep = rel_max(plog.numpy(), gold[mode + ".policy_logits"])
+    print("  [%s] policy logits vs fp32 reference: %.4f of scale (bound %.1e)" % (mode, ep, b["plog"]))
+    assert ep <= b["plog"], ep
+    check_forward_vs_golden(gold, mode, logits, state, logit_tol=b["logits"], stat_tol_all=b["stat_all"], stat_tol_p90=b["stat_p90"],
+                            groups=c["S"])
+    inside = check_grads_vs_golden(gold, mode, grads, head_tol=b["head"])
+    assert inside >= 0.9
+
+
+@pytest.mark.parametrize("name", ["adamml_c4", "adamml_c5"])
+def test_c4_c5_adamml_fullsize_inference(name):
+    c = CASES[name]
+    gold = load_golden(name)
+    b = BOUNDS[(name, "eval_cal")]
+    model = build(c)
+    sd = synth.synth_state_dict(manifest(c), seed=1234)
+    xs, _ = case_inputs(c)
+    model.load_state_dict(calibrated_state(c, sd, xs))
+    model.to(DEV).eval()
+    with torch.no_grad():
+        logits, sel = model([t.to(DEV) for t in xs], gumbel_exponential=case_gumbel(c).to(DEV))
+    assert np.array_equal(np.round(sel.cpu().numpy()), np.round(gold["eval_cal.decisions"])), "decisions differ from the reference"
+    ep = rel_max(model.last_policy_logits.cpu().numpy(), gold["eval_cal.policy_logits"])
+    e = rel_max(logits.cpu().numpy(), gold["eval_cal.logits"])
+    print("%s [eval_cal, decision-driven skipping on] policy logits %.4f, logits %.4f of scale vs fp32 reference" % (name, ep, e))
+    assert ep <= b["plog"] and e <= b["logits"], (ep, e)
 
 
 def test_c2_adamml_fullsize_inference():
