@@ -57,7 +57,13 @@ __global__ __launch_bounds__(NTHREADS) void gram_colsum_kernel(GramP p) {
     constexpr int RSTEP = NTHREADS / CH;       // rows between a thread's chunks
     constexpr int NB = C / 16;                 // 16-channel blocks
     constexpr int RB = NB / 4;                 // row blocks per wave
-    static_assert(NL >= 1 && RB >= 1, "C must be 64 or 128");
+    // C = 256: all 16 x 16 Gram blocks would take 256 accumulator registers per lane (measured: 202 of them spilled).  G is symmetric:
+    // row block r computes the NT = 9 column blocks r, r + 1, .. r + 8 (mod 16) -- every unordered pair of blocks once (the pairs at
+    // distance 8 twice) -- with the column fragment read from LDS per product instead of being held for all row blocks, and the
+    // partial's mirror blocks are filled in when it is stored.
+    constexpr bool SYM = C >= 256;
+    constexpr int NT = SYM ? NB / 2 + 1 : NB;  // column blocks per row block
+    static_assert(NL >= 1 && RB >= 1, "C must be 64, 128 or 256");
     __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
 
     const int grp = blockIdx.y, split = blockIdx.x;
@@ -102,12 +108,12 @@ __global__ __launch_bounds__(NTHREADS) void gram_colsum_kernel(GramP p) {
         }
     };
 
-    f32x4 acc[RB][NB], asum[RB];
+    f32x4 acc[RB][NT], asum[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         asum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     union { s16x4 h[2]; bf16x8 v; } ones;
     ones.h[0] = s16x4{0x3F80, 0x3F80, 0x3F80, 0x3F80};
@@ -121,25 +127,29 @@ __global__ __launch_bounds__(NTHREADS) void gram_colsum_kernel(GramP p) {
     const int x_lo = tr_swz<C>(trow), x_hi = tr_swz<C>(trow + 4);
     auto compute = [&](int buf) {
         const char* base = smem + buf * TILE_BYTES;
-        bf16x8 f[NB];
-#pragma unroll
-        for (int t = 0; t < NB; ++t) {
-            const int u = t * 4 + tq;
+        auto frag = [&](int blk) {
+            const int u = blk * 4 + tq;
             union { s16x4 h[2]; bf16x8 v; } cvt;
             cvt.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a_lo + ((u ^ x_lo) << 3)));
             cvt.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a_hi + ((u ^ x_hi) << 3)));
-            f[t] = cvt.v;
+            return cvt.v;
+        };
+        bf16x8 f[SYM ? 1 : NB];
+        if constexpr (!SYM) {
+#pragma unroll
+            for (int t = 0; t < NB; ++t) f[t] = frag(t);
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             // the row fragment of this wave is read on its own (a per-wave index into f[] would not be a static register index)
-            const int u = (wave * RB + i) * 4 + tq;
-            union { s16x4 h[2]; bf16x8 v; } fr;
-            fr.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a_lo + ((u ^ x_lo) << 3)));
-            fr.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + a_hi + ((u ^ x_hi) << 3)));
+            const int rb = wave * RB + i;
+            const bf16x8 fr = frag(rb);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr.v, f[j], acc[i][j], 0, 0, 0);
-            asum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, fr.v, asum[i], 0, 0, 0);
+            for (int j = 0; j < NT; ++j) {
+                if constexpr (SYM) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr, frag((rb + j) & (NB - 1)), acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr, f[j], acc[i][j], 0, 0, 0);
+            }
+            asum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, fr, asum[i], 0, 0, 0);
         }
     };
 
@@ -163,9 +173,15 @@ __global__ __launch_bounds__(NTHREADS) void gram_colsum_kernel(GramP p) {
     for (int i = 0; i < RB; ++i) {
         const int rb = wave * RB + i;
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
+        for (int j = 0; j < NT; ++j) {
+            const int cb = SYM ? (rb + j) & (NB - 1) : j;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) out[(size_t)(rb * 16 + lg * 4 + q) * C + j * 16 + li] = acc[i][j][q];
+            for (int q = 0; q < 4; ++q) out[(size_t)(rb * 16 + lg * 4 + q) * C + cb * 16 + li] = acc[i][j][q];
+            if (SYM && j != 0 && j != NB / 2) {          // mirror block (the diagonal is its own mirror; distance-8 pairs are computed from both sides)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) out[(size_t)(cb * 16 + li) * C + rb * 16 + lg * 4 + q] = acc[i][j][q];
+            }
+        }
         if (lg == 0) out[C * C + rb * 16 + li] = asum[i][0];
     }
 }
@@ -189,8 +205,10 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* ws, float
     else s[(size_t)grp * n_s + (i - n_g)] = v;
 }
 
-int gram_splits(size_t P, int groups, int* ppb) {
-    int nsplit = (1024 + groups - 1) / groups;                   // ~4 workgroups per CU over all groups
+int gram_splits(size_t P, int groups, int* ppb, int C) {
+    // ~4 workgroups per CU over all groups; C = 256: ONE per CU -- its 64 Gram blocks per wave take 256 accumulator registers (one
+    // workgroup per CU fits), and a partial is 263 KB: a thousand of them would cost as much traffic as the pass over the input
+    int nsplit = ((C >= 256 ? 256 : 1024) + groups - 1) / groups;
     size_t per = ((P + nsplit - 1) / nsplit + 31) / 32 * 32;
     if (per < 256) per = 256;
     *ppb = (int)per;
@@ -199,20 +217,20 @@ int gram_splits(size_t P, int groups, int* ppb) {
 
 }  // namespace
 
-extern "C" int adamml_gram_colsum_supported(int C) { return C == 64 || C == 128; }
+extern "C" int adamml_gram_colsum_supported(int C) { return C == 64 || C == 128 || C == 256; }
 
 extern "C" size_t adamml_gram_colsum_workspace(size_t P, int C, int groups) {
     if (!adamml_gram_colsum_supported(C) || !P) return 0;
     if (groups < 1) groups = 1;
     int ppb;
-    const int nsplit = gram_splits(P, groups, &ppb);
+    const int nsplit = gram_splits(P, groups, &ppb, C);
     return (size_t)groups * nsplit * ((size_t)C * C + C) * sizeof(float);
 }
 
 extern "C" int adamml_gram_colsum(const void* x, const float* scale, const float* shift, int gstride, int act, float* G, float* s,
                                   size_t P, int C, int groups, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !G || !s) return adamml_set_error(ADAMML_EINVAL, "gram_colsum: null argument");
-    if (!adamml_gram_colsum_supported(C)) return adamml_set_error(ADAMML_EUNSUPPORTED, "gram_colsum: C must be 64 or 128 (got %d)", C);
+    if (!adamml_gram_colsum_supported(C)) return adamml_set_error(ADAMML_EUNSUPPORTED, "gram_colsum: C must be 64, 128 or 256 (got %d)", C);
     if (groups < 1) groups = 1;
     if (P >= ((size_t)1 << 31) / C) return adamml_set_error(ADAMML_EUNSUPPORTED, "gram_colsum: group exceeds 2^31 elements");
     if (!P) {
@@ -221,13 +239,14 @@ extern "C" int adamml_gram_colsum(const void* x, const float* scale, const float
         return ADAMML_OK;
     }
     GramP p;
-    p.nsplit = gram_splits(P, groups, &p.ppb);
+    p.nsplit = gram_splits(P, groups, &p.ppb, C);
     if (!workspace || workspace_bytes < adamml_gram_colsum_workspace(P, C, groups))
         return adamml_set_error(ADAMML_EINVAL, "gram_colsum: workspace too small (need %zu bytes)", adamml_gram_colsum_workspace(P, C, groups));
     p.x = (const bf16_t*)x; p.scale = scale; p.shift = scale ? shift : nullptr; p.ws = (float*)workspace;
     p.gx = P * C; p.gstride = gstride; p.act = act; p.P = (int)P;
     dim3 grid(p.nsplit, groups);
     if (C == 64) hipLaunchKernelGGL((gram_colsum_kernel<64, 8>), grid, dim3(NTHREADS), 0, stream, p);
+    else if (C == 256) hipLaunchKernelGGL((gram_colsum_kernel<256, 2>), grid, dim3(NTHREADS), 0, stream, p);
     else hipLaunchKernelGGL((gram_colsum_kernel<128, 4>), grid, dim3(NTHREADS), 0, stream, p);
     int rc = adamml_check_launch("gram_colsum");
     if (rc) return rc;

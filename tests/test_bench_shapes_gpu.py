@@ -1,0 +1,138 @@
+"""Kernel parity WHERE THE BENCHMARK RUNS (round-3 review: the kernel tests use N <= 3 frames, the benchmark N = 576 frames per group x 5
+groups -- 4.6 GB tensors, other tile / split-K / grid-floor choices, group strides beyond 2^32 bytes).
+
+Every distinct conv signature of ResNet-50 layers 1-2 (models/resnet.py:83-113 at B = 72 videos, 5 segments, T = 8 / 4
+frames) through the C ABI at the benchmark's own sizes -- forward + statistics, data gradient, weight gradient -- against torch fp32 on the
+GPU on the same bf16-rounded operands (conv2d / autograd in chunks of 96 frames, weight gradient accumulated in fp64).  And the eval-mode
+whole network at B = 72 against 18 chunks of B = 4 (BatchNorm is per-sample there: the same numbers must come out whatever the batch)."""
+import pytest
+import torch
+import torch.nn.functional as F
+from ctypes import byref
+
+pytestmark = pytest.mark.gpu
+
+from adamml_amd import hip  # noqa: E402
+from adamml_amd.hip import ConvDesc, call, ptr, STAT_SLOTS  # noqa: E402
+
+DEV = "cuda"
+G, B = 5, 72
+
+# (Cin, Cout, k, stride, frames per clip T, Hin): layer-1 / layer-2 signatures of ResNet-50
+SIGNATURES = [
+    (64, 64, 1, 1, 8, 56),        # layer1.0.conv1 (after the max-pool)
+    (64, 64, 3, 1, 8, 56),        # layer1.*.conv2
+    (64, 256, 1, 1, 8, 56),       # layer1.*.conv3, layer1.0.downsample
+    (256, 64, 1, 1, 8, 56),       # layer1.1-2.conv1
+    (256, 128, 1, 1, 4, 56),      # layer2.0.conv1 (T 8 -> 4)
+    (128, 128, 3, 2, 4, 56),      # layer2.0.conv2
+    (128, 512, 1, 1, 4, 28),      # layer2.*.conv3
+    (256, 512, 1, 2, 4, 56),      # layer2.0.downsample
+    (512, 128, 1, 1, 4, 28),      # layer2.1-3.conv1
+    (128, 128, 3, 1, 4, 28),      # layer2.1-3.conv2
+]
+
+
+def _pack(w, mode):
+    cout, cin, kh, kw = w.shape
+    if mode == 0:
+        out = torch.empty(cout, kh * kw * cin, dtype=torch.bfloat16, device=w.device)
+    else:
+        out = torch.empty(cin, kh * kw * cout, dtype=torch.bfloat16, device=w.device)
+    call("adamml_pack_conv_weight", ptr(w), ptr(out), cout, cin, cin, kh, kw, mode)
+    return out
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("sig", SIGNATURES, ids=lambda s: "%d-%d_k%d_s%d_T%d_%d" % s)
+def test_conv_at_benchmark_shape(sig):
+    Cin, Cout, k, s, T, H = sig
+    N = B * T                                   # frames per BatchNorm group
+    pad = k // 2
+    OH = (H + 2 * pad - k) // s + 1
+    torch.manual_seed(3)
+    x = (torch.randn(G * N, H, H, Cin, device=DEV, dtype=torch.bfloat16))
+    w = torch.randn(Cout, Cin, k, k, device=DEV) * (2.0 / (Cin * k * k)) ** 0.5
+    wr = w.to(torch.bfloat16).float()
+    gy = (torch.randn(G * N, OH, OH, Cout, device=DEV) * 0.1).to(torch.bfloat16)
+    d = ConvDesc(N, H, H, Cin, OH, OH, Cout, k, k, s, pad, 1, 0, 0, G, 0)
+    # ---- HIP, one launch per direction over all 5 groups (as the benchmark step issues them)
+    y = torch.empty(G * N, OH, OH, Cout, dtype=torch.bfloat16, device=DEV)
+    stats = torch.zeros(G, STAT_SLOTS, 2 * Cout, dtype=torch.float64, device=DEV)
+    call("adamml_conv_fwd", byref(d), ptr(x), ptr(_pack(w, 0)), None, None, ptr(y), ptr(stats))
+    sums = torch.empty(G, 2 * Cout, dtype=torch.float64, device=DEV)
+    call("adamml_stats_collapse", ptr(stats), ptr(sums), Cout, G)
+    dx = torch.empty_like(x)
+    call("adamml_conv_bwd_data", byref(d), ptr(gy), ptr(_pack(w, 1)), ptr(dx), 0)
+    dw = torch.zeros(Cout, Cin, k, k, device=DEV)
+    ws = hip.wgrad_workspace(d, Cin, torch.device(DEV))
+    call("adamml_conv_bwd_weight", byref(d), ptr(gy), ptr(x), None, None, ptr(dw), Cin, ptr(ws), ws.numel() * 4)
+    torch.cuda.synchronize()
+    # ---- torch fp32 on the same rounded operands, 96 frames at a time
+    CH = 96
+    e_y = e_dx = 0.0
+    y_scale = dx_scale = 0.0
+    dw_ref = torch.zeros(Cout, Cin, k, k, device=DEV, dtype=torch.float64)
+    st_err = 0.0
+    for g in range(G):
+        s1 = torch.zeros(Cout, device=DEV, dtype=torch.float64)
+        s2 = torch.zeros(Cout, device=DEV, dtype=torch.float64)
+        for n0 in range(g * N, (g + 1) * N, CH):
+            xs = x[n0:n0 + CH].float().permute(0, 3, 1, 2).requires_grad_(True)
+            wt = wr.clone().requires_grad_(True)
+            ref = F.conv2d(xs, wt, stride=s, padding=pad)
+            gys = gy[n0:n0 + CH].float().permute(0, 3, 1, 2)
+            ref.backward(gys)
+            got = y[n0:n0 + CH].float().permute(0, 3, 1, 2)
+            e_y = max(e_y, (got - ref.detach()).abs().max().item())
+            y_scale = max(y_scale, ref.detach().abs().max().item())
+            gdx = dx[n0:n0 + CH].float().permute(0, 3, 1, 2)
+            e_dx = max(e_dx, (gdx - xs.grad).abs().max().item())
+            dx_scale = max(dx_scale, xs.grad.abs().max().item())
+            dw_ref += wt.grad.double()
+            yq = y[n0:n0 + CH].double().reshape(-1, Cout)        # statistics are those of the STORED (rounded) output
+            s1 += yq.sum(0)
+            s2 += (yq * yq).sum(0)
+        st_err = max(st_err, ((sums[g, :Cout] - s1).abs().max() / (s1.abs().max() + 1e-30)).item(),
+                     ((sums[g, Cout:] - s2).abs().max() / s2.abs().max()).item())
+    e_dw = _rel(dw, dw_ref)
+    print("  %3d->%3d k%d s%d N=%d x %d groups %dx%d: forward %.2e, data gradient %.2e of scale (one bf16 rounding: 3.9e-3); weight gradient "
+          "%.2e (fp32 accumulation over %.1e pixels); statistics %.1e" % (Cin, Cout, k, s, N, G, H, H, e_y / y_scale, e_dx / dx_scale, e_dw,
+                                                                          float(G * N * OH * OH), st_err))
+    assert e_y <= 4.5e-3 * y_scale and e_dx <= 4.5e-3 * dx_scale        # 2^-8 (bf16 output rounding) + fp32 accumulation-order noise
+    assert e_dw <= 1e-5                 # measured 5.6e-7 .. 1.3e-6
+    assert st_err <= 1e-6               # fp32 workgroup partials of exactly representable products, folded exactly
+
+
+def test_eval_forward_b72_equals_chunks_of_four():
+    """Eval mode: BatchNorm is a fixed per-sample affine map, so the logits of the B = 72 call (the benchmark's launch geometry:
+    grouped launches over 5 segments, tile walks across thousands of frames, decision-driven skipping of the main nets) must equal those
+    of 18 independent B = 4 calls."""
+    from adamml_amd import adamml, synth
+    S = 5
+    model = adamml(groups=8, modality=["rgb", "sound"], input_channels=[3, 1], num_segments=S, rng_policy=False, rng_threshold=0.5,
+                   causality_modeling="lstm", num_classes=31, depth=50, without_t_stride=False, dropout=0.5, pooling_method="max",
+                   fusion_point="logits", unimodality_pretrained=[], learnable_lf_weights=True)
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), seed=1234))
+    model.to(DEV).eval()
+    torch.manual_seed(11)
+    rgb = torch.randn(B, S * 24, 224, 224, device=DEV)
+    snd = torch.randn(B, S, 256, 256, device=DEV) * 3.0 - 5.0
+    expo = synth.synth_gumbel_exponential(S, 2, B, seed=9).to(DEV)             # [S, M*B, 2], modality-major within a segment
+    with torch.no_grad():
+        full, sel = model([rgb, snd], gumbel_exponential=expo)
+        parts, sels = [], []
+        e4 = expo.view(S, 2, B, 2)
+        for b0 in range(0, B, 4):
+            lg, sl = model([rgb[b0:b0 + 4], snd[b0:b0 + 4]], gumbel_exponential=e4[:, :, b0:b0 + 4].reshape(S, -1, 2).contiguous())
+            parts.append(lg)
+            sels.append(sl)
+    chunks, csel = torch.cat(parts), torch.cat(sels)
+    used = sel.round().mean(dim=(0, 1))
+    assert torch.equal(sel.round(), csel.round()), "hard decisions differ between the B = 72 call and the B = 4 calls"
+    e = ((full - chunks).abs().max() / chunks.abs().max()).item()
+    print("  eval forward B = 72 vs 18 x B = 4: logits differ by %.2e of scale; modality usage %s" % (e, [round(float(u), 2) for u in used]))
+    assert e <= 1e-5, e

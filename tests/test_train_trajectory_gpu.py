@@ -82,12 +82,13 @@ def test_twenty_steps_follow_the_reference_loss_curve(deterministic):
           "last update: logits %.4f of scale, ResNet fc weight UPDATE (w20 - w0) rel L2 %.4f" % (rel.max(), int(rel.argmax()), rel.mean(),
                                                                                                worst_logit, e_final, e_fc))
     assert losses[-1] < 0.2 * losses[0]                   # it trains: 3.49 -> 0.37 in the reference
-    # the curve bf16 storage allows, every step.  Measured 1.5 % .. 2.2 % at steps 17-19 across builds and modes (the last steps amplify a
-    # last-bit difference of any kernel: a 2 % bound failed once at 2.17 % after the fp64 Gram split-sum), hence 3 %
-    assert rel_emu.max() <= 0.03, (int(rel_emu.argmax()), rel_emu.max())
-    # vs the fp32 reference: measured over three builds / both modes 0.158 .. 0.199 at step 19, 0.050 .. 0.062 on average, final logits
-    # 0.043 .. 0.053, fc update 0.025 .. 0.031 (the bf16-storage lag of about one step in twenty; the emulation's own lag is 0.17 / 0.056).
-    # Bounds = 1.3 x the LARGEST of those: 1.3 x one build's value failed on the next build's last-bit differences
-    assert rel.max() <= 0.26 and rel.mean() <= 0.08, (int(rel.argmax()), rel.max(), rel.mean())
-    assert e_final <= 0.07, e_final
-    assert e_fc <= 0.041, e_fc
+    # Every per-channel sum is order-fixed (csrc/common.h), so the trajectory is a reproducible sequence of numbers (both modes print the
+    # same curve to the last digit shown) and the bounds are 1.3 x ONE measured value (round 3 had to take 1.3 x the largest of several
+    # builds: with fp64 atomic statistics the last steps amplified run-to-run last-bit differences).
+    # the curve bf16 storage allows, every step: measured max 1.56 % (step 14), mean 0.56 %
+    assert rel_emu.max() <= 0.0203, (int(rel_emu.argmax()), rel_emu.max())
+    # vs the fp32 reference: measured 0.1814 at step 19, 0.0609 on average, final logits 0.0522, fc update 0.0310 (the bf16-storage lag of
+    # about one step in twenty; the emulation's own lag is 0.17 / 0.056)
+    assert rel.max() <= 0.236 and rel.mean() <= 0.0792, (int(rel.argmax()), rel.max(), rel.mean())
+    assert e_final <= 0.068, e_final
+    assert e_fc <= 0.0403, e_fc
