@@ -1,14 +1,20 @@
 #!/bin/bash
-# Whole evidence refresh of round 3 in ONE gpurun call (the full pytest -m gpu runs in its own call, tools/gpu_r3i.sh): PMC traffic passes
-# first (so that the default bench line carries the traffic of THIS build), the default bench line, single-stream rocprofv3 kernel stats,
-# the per-GPU share of the reference recipe (B = 9: plain / launch plan / forced one-rank RCCL choreography), B = 72 with the forced
-# choreography, the non-headline lines, per-layer tables.  Usage: bash tools/gpu_round3.sh [tag]
-tag=${1:-r03}
+# Whole evidence refresh of a round in ONE gpurun call (the full `pytest -m gpu` runs in its own call): PMC traffic passes first (so that
+# the default bench line carries the traffic of THIS build), the default bench line, its A/B against fp64-atomic statistics, single-stream
+# rocprofv3 kernel stats, the per-GPU share of the reference recipe (B = 9: plain / launch plan / forced one-rank RCCL choreography),
+# B = 72 with the forced choreography, the non-headline lines, per-layer and per-launch tables.
+# Usage (through gpurun): bash tools/gpu_round.sh [tag] [round, e.g. r04]; then, in the build container: bash tools/install_profiles.sh <tag> <round>
+tag=${1:-r04}; round=${2:-r04}
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
-bash tools/gpu_pmc.sh ${tag}pmc
-cp gpurun_out/${tag}pmc/r03_pmc_hbm_traffic.json profiles/r03_pmc_hbm_traffic.json
+bash tools/gpu_pmc.sh ${tag}pmc $round
+cp gpurun_out/${tag}pmc/${round}_pmc_hbm_traffic.json profiles/${round}_pmc_hbm_traffic.json
 timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err; tail -c 300 $out/bench_default.json
+# reproducible (order-fixed, exact) statistics are the default; the same step with fp64 slot atomics across workgroups, back to back, twice
+for i in 1 2; do
+  ADAMML_DETERMINISTIC=0 timeout 600 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | grep '"metric"' > $out/bench_atomic_stats_$i.json
+  timeout 600 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | grep '"metric"' > $out/bench_deterministic_$i.json
+done
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o ss -- python bench.py --single-stream --no-cpu-baseline > $out/bench_ss.json 2> $out/prof.err
 find $out/prof -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
 rm -rf $out/prof
@@ -34,5 +40,7 @@ timeout 600 python tools/bench_dw.py 2>&1 | grep -v amdgpu > $out/bench_dw.txt
 timeout 600 python tools/bench_elementwise.py 2>&1 | grep -v amdgpu > $out/bench_elementwise.txt
 timeout 600 python tools/launch_table.py resnet 72 60 2>&1 | grep -v amdgpu > $out/launch_table_resnet.txt
 timeout 600 python tools/launch_table.py sound 72 40 2>&1 | grep -v amdgpu > $out/launch_table_sound.txt
+timeout 600 python tools/launch_table.py policy_rgb 72 400 2>&1 | grep -v "amdgpu\|Warning\|warnings.warn" > $out/launch_table_policy_rgb.txt
+timeout 600 python tools/launch_table.py policy_sound 72 400 2>&1 | grep -v "amdgpu\|Warning\|warnings.warn" > $out/launch_table_policy_sound.txt
 timeout 600 python tools/bench_nets.py 2>&1 | grep -v amdgpu > $out/bench_nets.txt
 tail -3 $out/bench_conv.txt | cut -c1-200; cat $out/bench_nets.txt

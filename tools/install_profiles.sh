@@ -1,21 +1,23 @@
 #!/bin/bash
-# Copies the evidence of one tools/gpu_round3.sh call (gpurun_out/<tag>, <tag>pmc) and of the full pytest call (gpurun_out/r3i) into
-# profiles/ under the round's names and regenerates profiles/README.md.  Usage (build container): bash tools/install_profiles.sh <tag> [r03]
-tag=${1:-r03}; r=${2:-r03}; g=gpurun_out
+# Copies the evidence of one tools/gpu_round.sh call (gpurun_out/<tag>, <tag>pmc) and of the full pytest call (gpurun_out/<tag>t/pytest.log)
+# into profiles/ under the round's names and regenerates profiles/README.md.  Usage (build container): bash tools/install_profiles.sh <tag> [r04]
+tag=${1:-r04}; r=${2:-r04}; g=gpurun_out
 grep '"metric"' $g/$tag/bench_default.json | tail -1 > profiles/${r}_bench_default.json
 grep '"metric"' $g/$tag/bench_ss.json | tail -1 > profiles/${r}_bench_single_stream_under_rocprof.json
 cp $g/$tag/kernel_stats.csv profiles/${r}_bench_single_stream_kernel_stats.csv
-[ -f $g/r3i/pytest.log ] && cp $g/r3i/pytest.log profiles/${r}_gpu_tests.txt
-cp $g/${tag}pmc/r03_pmc_hbm_traffic.json profiles/${r}_pmc_hbm_traffic.json
+[ -f $g/${tag}t/pytest.log ] && cp $g/${tag}t/pytest.log profiles/${r}_gpu_tests.txt
+cp $g/${tag}pmc/${r}_pmc_hbm_traffic.json profiles/${r}_pmc_hbm_traffic.json
 for n in b9 b9_launch_plan b9_forced_collectives b9_forced_collectives_launch_plan b72_forced_collectives b72_forced_collectives_one_group b36_forced_collectives b18_forced_collectives policy_stage inference_skipping \
          c4_rgb_flow_rgbdiff_b72 c5_four_modalities_b48; do cp $g/$tag/bench_$n.json profiles/${r}_bench_$n.json; done
-[ -f $g/$tag/bench_deterministic.json ] && cp $g/$tag/bench_deterministic.json profiles/${r}_bench_deterministic.json
+cat $g/$tag/bench_atomic_stats_1.json $g/$tag/bench_deterministic_1.json $g/$tag/bench_atomic_stats_2.json $g/$tag/bench_deterministic_2.json > profiles/${r}_bench_deterministic.json   # A/B pairs, "deterministic" false / true
 cp $g/$tag/bench_conv.txt profiles/${r}_per_layer_bench_conv.txt
 cp $g/$tag/bench_dw.txt profiles/${r}_per_layer_bench_dw.txt
 cp $g/$tag/bench_fused.txt profiles/${r}_per_layer_bench_fused.txt
 cp $g/$tag/bench_elementwise.txt profiles/${r}_bench_elementwise.txt
 cp $g/$tag/launch_table_resnet.txt profiles/${r}_launch_table_resnet.txt
 cp $g/$tag/launch_table_sound.txt profiles/${r}_launch_table_sound.txt
+cp $g/$tag/launch_table_policy_rgb.txt profiles/${r}_launch_table_policy_rgb.txt
+cp $g/$tag/launch_table_policy_sound.txt profiles/${r}_launch_table_policy_sound.txt
 cp $g/$tag/bench_nets.txt profiles/${r}_bench_nets.txt
 python tools/profile_readme.py $r
 python - <<PY
