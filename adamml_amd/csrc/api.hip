@@ -22,7 +22,7 @@ int adamml_check_launch(const char* what) {
 
 extern "C" {
 int adamml_det_set_conv_gemm(int), adamml_det_set_conv3x3_c64(int), adamml_det_set_conv1x1_stream(int), adamml_det_set_conv_stem(int),
-    adamml_det_set_dwconv(int), adamml_det_set_elementwise(int), adamml_det_set_mbconv(int);
+    adamml_det_set_dwconv(int), adamml_det_set_elementwise(int);
 }
 static int g_det = 1;        // exact integer-bin accumulation across workgroups (common.h); 0: fp64 slot atomics (A/B aid)
 int adamml_deterministic_enabled(void) { return g_det; }
@@ -30,7 +30,7 @@ int adamml_deterministic_enabled(void) { return g_det; }
 extern "C" int adamml_set_deterministic(int on) {
     on = on ? 1 : 0;
     int rc = adamml_det_set_conv_gemm(on) | adamml_det_set_conv3x3_c64(on) | adamml_det_set_conv1x1_stream(on) |
-             adamml_det_set_conv_stem(on) | adamml_det_set_dwconv(on) | adamml_det_set_elementwise(on) | adamml_det_set_mbconv(on);
+             adamml_det_set_conv_stem(on) | adamml_det_set_dwconv(on) | adamml_det_set_elementwise(on);
     if (rc) return adamml_set_error(ADAMML_ELAUNCH, "set_deterministic: hipMemcpyToSymbol failed (%d)", rc);
     g_det = on;
     return ADAMML_OK;

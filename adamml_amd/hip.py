@@ -59,8 +59,6 @@ SIGNATURES = {
     "adamml_conv_stem_fwd": [_DESC, _P, _P, _P, _P, _P],
     "adamml_conv_stem_bwd_weight": [_DESC, _P, _P, _P, _I, _P, _Z, _P],
     "adamml_dwconv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
-    "adamml_mbconv_expand_stats": [_DESC, _P, _I, _P, _P, _I, _P, _P, _P],
-    "adamml_mbconv_expand_dw": [_DESC, _P, _I, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P],
     "adamml_conv_stem1_fwd": [_DESC, _P, _Z, _Z, _P, _P, _P, _P],
     "adamml_conv_stem1_bwd_weight": [_DESC, _P, _P, _Z, _Z, _P, _P, _Z, _P],
     "adamml_dwconv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
@@ -146,8 +144,6 @@ def load():
     lib.adamml_conv_bwd_data_res_supported.restype = c_int
     lib.adamml_temporal_pool_bwd_res_supported.argtypes = [_I, _I, _I]
     lib.adamml_temporal_pool_bwd_res_supported.restype = c_int
-    lib.adamml_mbconv_supported.argtypes = [_DESC, _I]
-    lib.adamml_mbconv_supported.restype = c_int
     lib.adamml_dwconv_bwd_data_bn_supported.argtypes = [_DESC]
     lib.adamml_dwconv_bwd_data_bn_supported.restype = c_int
     lib.adamml_conv_stem_supported.argtypes = [_DESC]

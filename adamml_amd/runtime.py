@@ -494,64 +494,6 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
     return out
 
 
-FUSE_MBCONV = os.environ.get("ADAMML_FUSE_MBCONV", "1")      # "1": every block | "s2": stride-2 blocks only | "0": off (A/B aid)
-
-
-def mbconv_supported(rt, x, cs_pw, cs_dw):
-    """Can the 1x1 expansion + BatchNorm + ReLU6 + depthwise 3x3 of an inverted-residual block run as ONE kernel that never writes the
-    expanded tensor (csrc/mbconv.hip)?  Forward-only calls: the backward pass of a trainable net needs the expanded tensor (BatchNorm
-    backward, ReLU6 mask, depthwise weight gradient) -- the frozen policy nets of the main-net stage and inference qualify.  Not while
-    a test captures the conv outputs (NetRT.capture: the expansion's output would be missing from the capture)."""
-    if FUSE_MBCONV == "0" or rt.tape.need_grad or rt.capture is not None or x.act != ACT_NONE:
-        return False
-    if cs_pw.depthwise or cs_pw.kh != 1 or cs_pw.stride != 1 or cs_pw.cin != cs_pw.cin_true or x.shape[3] != cs_pw.cin or not cs_dw.depthwise:
-        return False
-    if FUSE_MBCONV == "s2" and cs_dw.stride != 2:
-        return False
-    n, h, w, _ = x.shape
-    d = cs_dw.desc((n, h, w, cs_dw.cout), ACT_RELU6, rt.groups, 0)
-    return bool(hip.load().adamml_mbconv_supported(byref(d), cs_pw.cin))
-
-
-def mbconv_expand_dw(rt, x, pw, dw):
-    """act(bn1(conv1x1(x))) -> depthwise 3x3 -> lazy (raw depthwise output, bn2, ReLU6): models/policy_net.py:72-80 /
-    models/sound_mobilenet_v2.py:52-58 without the expanded tensor in HBM.  pw / dw: (ConvState, BatchNorm2d) of the expansion and the
-    depthwise conv.  Train mode: a statistics-only pass over the expansion first (its BatchNorm needs the batch statistics before the
-    fused kernel can normalise), then the fused kernel, whose epilogue accumulates the depthwise output's statistics -- two reads of the
-    narrow input and one write of the depthwise output instead of a write + a read of the 6x wider tensor."""
-    (cs1, bn1), (cs2, bn2) = pw, dw
-    G = rt.groups
-    n, h, w, cin = x.shape
-    Cexp = cs2.cout
-    d = cs2.desc((n, h, w, Cexp), ACT_RELU6, G, 0)
-    dev = x.data.device
-    count1, count2 = d.N * h * w, d.N * d.OH * d.OW
-    if rt.training:
-        st1 = rt.fwd_arena.take(G * 2 * Cexp * STAT_SLOTS)
-        hip.next_meta = (2.0 * count1 * G * Cexp * cin, 2.0 * G * count1 * cin)
-        call("adamml_mbconv_expand_stats", byref(d), ptr(x.data), cin, ptr(x.scale), ptr(x.shift), x.gs, ptr(cs1.w_fwd), ptr(st1))
-        vec1 = _bn_vectors(rt, bn1, st1, count1, Cexp, dev)
-        rt.touched_bns.append(bn1)
-        s1, h1, gs1 = vec1[0, 0], vec1[0, 1], 4 * Cexp
-        st2 = rt.fwd_arena.take(G * 2 * Cexp * STAT_SLOTS)
-    else:
-        ev = _bn_eval_vectors(rt, bn1, Cexp, dev)
-        s1, h1, gs1, st2 = ev[0], ev[1], 0, None
-    y = torch.empty(G * d.N, d.OH, d.OW, Cexp, dtype=torch.bfloat16, device=dev)
-    hip.next_meta = (2.0 * count1 * G * Cexp * cin + 18.0 * count2 * G * Cexp, 2.0 * G * count1 * cin + 2.0 * G * count2 * Cexp)
-    call("adamml_mbconv_expand_dw", byref(d), ptr(x.data), cin, ptr(x.scale), ptr(x.shift), x.gs, ptr(cs1.w_fwd), ptr(s1), ptr(h1), gs1,
-         ptr(cs2.w_fwd), ptr(y), ptr(st2))
-    if rt.training:
-        vec2 = _bn_vectors(rt, bn2, st2, count2, Cexp, dev)
-        rt.touched_bns.append(bn2)
-        out = Lazy(y, vec2[0, 0], vec2[0, 1], ACT_RELU6, requires_grad=False, gs=4 * Cexp)
-        out.vec = vec2
-    else:
-        ev2 = _bn_eval_vectors(rt, bn2, Cexp, dev)
-        out = Lazy(y, ev2[0], ev2[1], ACT_RELU6, requires_grad=False)
-    return out
-
-
 STEM1_F32 = os.environ.get("ADAMML_STEM1_F32", "1") != "0"     # fp32 spectrogram straight into the MobileNetV2 stems (A/B aid)
 
 

@@ -200,25 +200,6 @@ size_t adamml_conv_stem_bwd_weight_workspace(const adamml_conv_desc_t* d);
 int adamml_conv_stem_bwd_weight(const adamml_conv_desc_t* d, const void* dz, const void* x, float* dw, int cin_true,
                                 void* workspace, size_t workspace_bytes, hipStream_t stream);
 
-/* Forward of a MobileNetV2 inverted-residual block's 1x1 expansion -> BatchNorm -> ReLU6 -> depthwise 3x3 (models/policy_net.py:72-80,
- * models/sound_mobilenet_v2.py:52-58) WITHOUT the 6x-expanded tensor in HBM (csrc/mbconv.hip): a workgroup expands the narrow input
- * patch of an 8 x 8 output tile on the matrix cores chunk by chunk and runs the depthwise conv from LDS.  Same rounding points as
- * adamml_conv_fwd + adamml_dwconv_fwd.  d describes the DEPTHWISE conv (N, H, W = the block input's frames, Cin == Cout == expanded
- * channels, 3x3, pad 1, stride 1 | 2, act = activation of the expansion's BatchNorm, groups); x [groups*N, H, W, cin] bf16 is the narrow
- * block input with value x_scale * x + x_shift when x_scale != null (per group, x_gstride floats apart); w_expand_packed [Cexp][cin]
- * bf16 (adamml_pack_conv_weight mode 0).  Forward only (a backward pass needs the expanded tensor).
- *   adamml_mbconv_expand_stats: train-mode pre-pass -- stats [groups][SLOTS][2 Cexp] += sum / sum of squares of the (bf16-rounded)
- *                               expansion output, nothing written (the BatchNorm statistics adamml_conv_fwd would have produced);
- *   adamml_mbconv_expand_dw:    bn1_scale / bn1_shift [Cexp] per group (bn1_gstride apart: train-mode vectors of adamml_bn_finalize, or
- *                               the eval-mode affine with stride 0) -> y [groups*N, OH, OW, Cexp] raw depthwise output and, when stats
- *                               != null, its statistics. */
-int adamml_mbconv_supported(const adamml_conv_desc_t* d, int cin);
-int adamml_mbconv_expand_stats(const adamml_conv_desc_t* d, const void* x, int cin, const float* x_scale, const float* x_shift,
-                               int x_gstride, const void* w_expand_packed, double* stats, hipStream_t stream);
-int adamml_mbconv_expand_dw(const adamml_conv_desc_t* d, const void* x, int cin, const float* x_scale, const float* x_shift,
-                            int x_gstride, const void* w_expand_packed, const float* bn1_scale, const float* bn1_shift,
-                            int bn1_gstride, const float* w_dw_tapmajor, void* y, double* stats, hipStream_t stream);
-
 /* depthwise 3x3 conv (groups == channels; sound_mobilenet_v2.py:58, policy_net.py:66,80) */
 int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, const float* w_tapmajor, const float* in_scale,
                       const float* in_shift, void* y, double* stats, hipStream_t stream);

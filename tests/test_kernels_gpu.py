@@ -1255,94 +1255,3 @@ def test_conv_stem1_reads_the_fp32_spectrogram_directly(B, G, H, W, C):
     ws = torch.empty(need // 4 + 1, device=DEV)
     call("adamml_conv_stem1_bwd_weight", byref(d), ptr(dz), ptr(x), G * H * W, H * W, ptr(dw), ptr(ws), ws.numel() * 4)
     assert (dw - wr.grad).abs().max().item() <= 2e-4 * wr.grad.abs().max().item()
-
-
-@pytest.mark.parametrize("case", [(2, 40, 40, 16, 96, 2, 2, True), (1, 21, 19, 24, 144, 1, 1, True), (3, 10, 10, 64, 384, 1, 2, False),
-                                  (2, 5, 5, 160, 960, 1, 1, True), (2, 17, 23, 96, 576, 2, 3, True), (1, 80, 80, 16, 96, 2, 1, True),
-                                  (2, 8, 8, 32, 192, 2, 1, False), (1, 33, 9, 32, 192, 1, 2, True)])
-def test_mbconv_expand_dw_equals_the_unfused_pair(case):
-    """csrc/mbconv.hip: 1x1 expansion + BatchNorm + ReLU6 + depthwise 3x3 in one kernel (the expanded tensor never written) against
-    adamml_conv_fwd -> adamml_bn_finalize -> adamml_dwconv_fwd on the same operands: same rounding points, so the raw depthwise output
-    must be the SAME bf16 numbers; the statistics of the expansion (statistics-only pass) and of the depthwise output agree to fp32
-    partial-sum rounding.  Ragged tiles, 1 - 5 K steps, channel counts that are not a multiple of the 32-channel chunk, groups."""
-    N, H, W, Cin, Cexp, S, G, lazy = case
-    torch.manual_seed(Cexp + H)
-    x = (torch.randn(G * N, H, W, Cin, device=DEV) * 1.3).to(torch.bfloat16)
-    xv = torch.rand(G, 4, Cin, device=DEV) + 0.5
-    xv[:, 1] -= 0.7
-    xs, xh, xgs = (ptr(xv[0, 0]), ptr(xv[0, 1]), 4 * Cin) if lazy else (None, None, 0)
-    w1 = torch.randn(Cexp, Cin, 1, 1, device=DEV) * (2.0 / Cin) ** 0.5
-    wdw = torch.randn(Cexp, 1, 3, 3, device=DEV) * 0.4
-    w1p, wdp = pack(w1, Cin, 0), pack(wdw, 1, 2)
-    gamma, beta = torch.rand(Cexp, device=DEV) + 0.5, torch.randn(Cexp, device=DEV) * 0.3
-    OH, OW = (H - 1) // S + 1, (W - 1) // S + 1
-    # ---- unfused pair
-    d1 = ConvDesc(N, H, W, Cin, H, W, Cexp, 1, 1, 1, 0, 1, 0, 0, G, xgs)
-    e1 = torch.empty(G * N, H, W, Cexp, dtype=torch.bfloat16, device=DEV)
-    st1 = torch.zeros(G, STAT_SLOTS, 2 * Cexp, dtype=torch.float64, device=DEV)
-    call("adamml_conv_fwd", byref(d1), ptr(x), ptr(w1p), xs, xh, ptr(e1), ptr(st1))
-    vec1 = torch.empty(G, 4, Cexp, device=DEV)
-    rm, rv = torch.zeros(Cexp, device=DEV), torch.ones(Cexp, device=DEV)
-    call("adamml_bn_finalize", ptr(st1), STAT_SLOTS, G, float(N * H * W), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5, ptr(vec1), Cexp)
-    d2 = ConvDesc(N, H, W, Cexp, OH, OW, Cexp, 3, 3, S, 1, 1, 2, 0, G, 4 * Cexp)
-    e2 = torch.empty(G * N, OH, OW, Cexp, dtype=torch.bfloat16, device=DEV)
-    st2 = torch.zeros(G, STAT_SLOTS, 2 * Cexp, dtype=torch.float64, device=DEV)
-    call("adamml_dwconv_fwd", byref(d2), ptr(e1), ptr(wdp), ptr(vec1[0, 0]), ptr(vec1[0, 1]), ptr(e2), ptr(st2))
-    # ---- fused
-    assert hip.load().adamml_mbconv_supported(byref(d2), Cin)
-    st1f = torch.zeros_like(st1)
-    call("adamml_mbconv_expand_stats", byref(d2), ptr(x), Cin, xs, xh, xgs, ptr(w1p), ptr(st1f))
-    a, b = ssum(st1f), ssum(st1)
-    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * b.abs().max().item()), (a - b).abs().max().item()
-    y = torch.full_like(e2, 7.0)
-    st2f = torch.zeros_like(st2)
-    call("adamml_mbconv_expand_dw", byref(d2), ptr(x), Cin, xs, xh, xgs, ptr(w1p), ptr(vec1[0, 0]), ptr(vec1[0, 1]), 4 * Cexp, ptr(wdp),
-         ptr(y), ptr(st2f))
-    diff = (y.float() - e2.float()).abs()
-    nbad = int((diff > 0).sum())
-    print("  mbconv %s: %d of %d outputs differ from the unfused pair (max %.3g of scale %.3g)" % (case, nbad, y.numel(), diff.max().item(),
-                                                                                             e2.float().abs().max().item()))
-    assert nbad == 0
-    a, b = ssum(st2f), ssum(st2)
-    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * b.abs().max().item()), (a - b).abs().max().item()
-    # eval-mode form: one shared affine (stride 0), no statistics
-    y2 = torch.empty_like(e2)
-    call("adamml_mbconv_expand_dw", byref(d2), ptr(x), Cin, xs, xh, xgs, ptr(w1p), ptr(vec1[0, 0]), ptr(vec1[0, 1]), 0, ptr(wdp), ptr(y2), None)
-    assert torch.equal(y2[:N], y[:N])                    # group 0 uses the same vectors in both calls
-
-
-@pytest.mark.parametrize("channels,hw,frames", [(3, 160, 4), (1, 256, 1)])
-def test_policy_mobilenet_with_fused_blocks_equals_unfused(channels, hw, frames):
-    """The frozen policy MobileNetV2 of the main-net stage (train-mode BatchNorm, no gradient: models/policy_net.py:142-149 under
-    utils/utils.py:335 model.train()) with its expansion + depthwise pairs fused (runtime.mbconv_expand_dw) against the same net with
-    the unfused launches: pooled features and every running statistic.  The two forms store the same numbers per layer; what differs is
-    the fp32 order of the statistic partial sums (other tiles), i.e. last-bit differences of BatchNorm vectors that the bf16 storage of
-    ~50 layers amplifies."""
-    from adamml_amd import policy_net, runtime, synth
-    G, B = 2, 3
-    net = policy_net.MobileNetV2(1000, num_frames=frames, input_channels=channels)
-    del net.classifier
-    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=77))
-    net.to(DEV).train()
-    for p_ in net.parameters():
-        p_.requires_grad_(False)
-    torch.manual_seed(5)
-    x = torch.randn(G * B * frames, hw, hw, 8, device=DEV).to(torch.bfloat16)
-    x[..., channels:] = 0
-    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
-    outs, states = {}, {}
-    old = runtime.FUSE_MBCONV
-    try:
-        for mode in ("0", "1"):
-            runtime.FUSE_MBCONV = mode
-            net.load_state_dict(sd0)
-            net.mark_weights_dirty()
-            with torch.no_grad():
-                outs[mode] = net.feature_extraction(x, G).float().clone()
-            states[mode] = {k: v.detach().float().clone() for k, v in net.state_dict().items() if k.endswith(("running_mean", "running_var"))}
-    finally:
-        runtime.FUSE_MBCONV = old
-    e = ((outs["1"] - outs["0"]).abs().max() / outs["0"].abs().max()).item()
-    es = max(((states["1"][k] - v).norm() / (v.norm() + 1e-30)).item() for k, v in states["0"].items())
-    print("  policy MobileNetV2 (%d ch, %d^2): fused vs unfused blocks: features %.2e of scale, running statistics max rel L2 %.2e" % (channels, hw, e, es))
-    assert e <= 3e-2 and es <= 1e-2, (e, es)
