@@ -47,9 +47,9 @@ def run_smoke():
     d_emu = np.abs(b - g).max() / np.abs(g).max()
     print("smoke: loss %.4f | logits |HIP-emulation| %.4f |HIP-reference| %.4f (|emulation-reference| %.4f) | decisions match"
           % (float(loss.detach()), e_emu, e_ref, d_emu))
-    # (measured 0.075 / 0.140 for 0.163 between emulation and reference on this ill-conditioned 96-pixel case, the emulation reading the
-    # spectrogram in fp32 as the HIP stems do)
-    assert e_emu <= max(3e-2, 1.5 * d_emu) and e_ref <= max(3e-2, 2.0 * d_emu)
+    # fixed numbers, 1.3 x measured (0.0555 / 0.1357; reproducible: order-fixed sums, csrc/common.h) -- this 96-pixel case is ill-conditioned
+    # by construction (the bf16-storage emulation itself sits 0.163 from the fp32 reference); the tight statement is the full-size one below
+    assert e_emu <= 0.072 and e_ref <= 0.176, (e_emu, e_ref)
     del model
     # ---- (2) full-size, well-conditioned: the configs[1] workload at B = 4 against the reference golden
     c2 = CASES["adamml_c2"]
@@ -72,6 +72,5 @@ def run_smoke():
     e2 = np.abs(logits.detach().cpu().numpy() - g2).max() / np.abs(g2).max()
     ep = np.abs(model.last_policy_logits.detach().cpu().numpy() - gold2["train_main.policy_logits"]).max() / np.abs(gold2["train_main.policy_logits"]).max()
     print("smoke: full size (B=4, S=5, 224^2 / 256^2) logits |HIP-reference| %.4f, policy logits %.4f of scale | decisions match" % (e2, ep))
-    # logits measured 3.1e-2 .. 4.2e-2; the policy logits (two 52-layer random-weight MobileNetV2 stacks in front of them) 5.4e-2 .. 7.2e-2
-    # from run to run in default mode: 1.3 x the largest value seen
-    assert e2 <= 5.5e-2 and ep <= 9.5e-2
+    # 1.3 x measured (logits 3.09e-2; policy logits, two 52-layer random-weight MobileNetV2 stacks in front of them, 5.60e-2): reproducible
+    assert e2 <= 4.0e-2 and ep <= 7.3e-2, (e2, ep)
