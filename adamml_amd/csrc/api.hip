@@ -20,22 +20,13 @@ int adamml_check_launch(const char* what) {
     return ADAMML_OK;
 }
 
-extern "C" {
-int adamml_det_set_conv_gemm(int), adamml_det_set_conv3x3_c64(int), adamml_det_set_conv1x1_stream(int), adamml_det_set_conv_stem(int),
-    adamml_det_set_dwconv(int), adamml_det_set_elementwise(int);
-}
-static int g_det = 1;        // exact integer-bin accumulation across workgroups (common.h); 0: fp64 slot atomics (A/B aid)
-int adamml_deterministic_enabled(void) { return g_det; }
-
+// Reproducible reductions are the only mode (csrc/common.h); the two entry points remain so that callers written against the switch of
+// earlier versions keep linking: asking for the non-reproducible form is an error, not a silent no-op.
 extern "C" int adamml_set_deterministic(int on) {
-    on = on ? 1 : 0;
-    int rc = adamml_det_set_conv_gemm(on) | adamml_det_set_conv3x3_c64(on) | adamml_det_set_conv1x1_stream(on) |
-             adamml_det_set_conv_stem(on) | adamml_det_set_dwconv(on) | adamml_det_set_elementwise(on);
-    if (rc) return adamml_set_error(ADAMML_ELAUNCH, "set_deterministic: hipMemcpyToSymbol failed (%d)", rc);
-    g_det = on;
+    if (!on) return adamml_set_error(ADAMML_EUNSUPPORTED, "set_deterministic(0): the per-channel sums are always order-fixed and exact (no other mode exists)");
     return ADAMML_OK;
 }
-extern "C" int adamml_get_deterministic(void) { return g_det; }
+extern "C" int adamml_get_deterministic(void) { return 1; }
 
 extern "C" int adamml_version(void) { return 101; }
 extern "C" const char* adamml_last_error_string(void) { return g_err; }

@@ -86,9 +86,8 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 //      -- and the fp64 value decoded from them in a fixed order -- do not depend on the order of arrival.  (|addend| < 2^31 per bin:
 //      2^32 addends before an int64 bin can overflow.)  One atomic per channel and WORKGROUP: measured on the benchmark step the same
 //      cost as the fp64 slot atomics it replaces (round 3 issued det_add per lane and tile: 1.68x).
-// adamml_set_deterministic(0) (A/B aid) switches stage (2) back to fp64 atomics spread over the 32 slots; stage (1) has no switch.
-static __constant__ int c_adamml_det = 1;                // one copy per translation unit, set through adamml_det_set_<tu>()
-__device__ __forceinline__ bool det_mode() { return c_adamml_det != 0; }
+// There is no other mode and no switch: the library keeps no mutable state (round 3 had a process-global flag selecting fp64 atomics
+// spread over the 32 slots instead; the A/B of the two forms is profiles/r04_bench_deterministic.json: 114.6 ms either way).
 
 __device__ __forceinline__ void det_add(double* acc, size_t slot_stride, float v) {
     const unsigned u = __float_as_uint(v);
@@ -102,9 +101,10 @@ __device__ __forceinline__ void det_add(double* acc, size_t slot_stride, float v
 }
 
 // stage (2): workgroup partial v of one channel -> its accumulator (acc = entry of slot / bin 0, entries slot_stride doubles apart)
+// (`slot`: the publishing workgroup's slot of the pre-round-4 layout; unused -- every workgroup adds into the same 32 bins)
 __device__ __forceinline__ void stat_publish(double* acc, size_t slot_stride, unsigned slot, float v) {
-    if (det_mode()) det_add(acc, slot_stride, v);
-    else atomicAdd(acc + (size_t)slot * slot_stride, (double)v);
+    (void)slot;
+    det_add(acc, slot_stride, v);
 }
 
 // value of bin k of a deterministic accumulator (the 32 bin values are summed in a fixed order by the consumers)
@@ -128,13 +128,6 @@ __device__ __forceinline__ void det_encode(double* acc, size_t slot_stride, doub
         r -= (double)f;
     }
 }
-
-// host side: every translation unit with kernels exports a setter for its copy of c_adamml_det (api.hip calls them all)
-#define ADAMML_DET_SETTER(tu)                                                                               \
-    extern "C" int adamml_det_set_##tu(int v) {                                                             \
-        return (int)hipMemcpyToSymbol(HIP_SYMBOL(c_adamml_det), &v, sizeof(int), 0, hipMemcpyHostToDevice); \
-    }
-int adamml_deterministic_enabled(void);                  // host mirror of the flag (api.hip)
 
 // Workgroups are dealt round-robin to the 8 XCDs (linear id % 8), each with a private L2.  This bijection gives XCD k
 // the k-th CONTIGUOUS eighth of the logical work list, in dispatch order, so neighbouring tiles (shared halo rows,

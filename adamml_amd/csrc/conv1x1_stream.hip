@@ -9,7 +9,6 @@
 #include "common.h"
 #include "../../include/adamml_hip.h"
 
-ADAMML_DET_SETTER(conv1x1_stream)
 
 namespace {
 

@@ -15,7 +15,6 @@
 #include "common.h"
 #include "../../include/adamml_hip.h"
 
-ADAMML_DET_SETTER(conv3x3_c64)
 
 // Phase timing (tools/c64_phase_probe.py builds this file alone with -DC64_PHASE_TIMING; never part of the shipped library): every wave of
 // one workgroup stamps the shader clock at the phase boundaries of its first tiles.

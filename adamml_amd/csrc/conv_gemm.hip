@@ -14,7 +14,6 @@
 #include <stdlib.h>
 #include <stdio.h>
 
-ADAMML_DET_SETTER(conv_gemm)
 
 namespace {
 
@@ -2201,15 +2200,13 @@ __global__ void alg_sumfix_kernel(const float* w, const float* P, const float* v
     const int g = e / Cout, co = e - g * Cout;
     double* sg = sums + (size_t)g * ADAMML_STAT_SLOTS * 2 * Cout;
     double s1 = 0.0;
-    if (det_mode()) s1 = det_decode(sg + co, 2 * (size_t)Cout);
-    else for (int k = 0; k < ADAMML_STAT_SLOTS; ++k) s1 += sg[(size_t)k * 2 * Cout + co];
+    s1 = det_decode(sg + co, 2 * (size_t)Cout);
     const float* Pg = P + ((size_t)g * Cout + co) * Cin;
     double dot = 0.0;
     for (int cj = 0; cj < Cin; ++cj) dot += (double)w[(size_t)co * Cin + cj] * (double)Pg[cj];
     const float* v = vec + (size_t)g * 4 * Cout;
     const double r = (double)v[3 * Cout + co] * (dot - (double)v[2 * Cout + co] * s1);
-    if (det_mode()) det_encode(sg + Cout + co, 2 * (size_t)Cout, r);
-    else sg[Cout + co] = r;
+    det_encode(sg + Cout + co, 2 * (size_t)Cout, r);
 }
 
 extern "C" int adamml_alg_sumfix(const float* w, const float* P, const float* vec, double* sums, int Cout, int Cin, int groups,

@@ -13,7 +13,6 @@
 #include "common.h"
 #include "../../include/adamml_hip.h"
 
-ADAMML_DET_SETTER(conv_stem)
 
 namespace {
 
@@ -203,12 +202,8 @@ __global__ __launch_bounds__(NT, 2) void conv_stem_kernel(StemP p) {
     }
     if (p.stats) {
         __syncthreads();
-        double* slot = p.stats + ((size_t)g * ADAMML_STAT_SLOTS + (blockIdx.x & (ADAMML_STAT_SLOTS - 1))) * 128;
-        if (tid < 128) {
-            // (every cs entry was accumulated by one wave in tile order; deterministic mode adds it to exact integer bins)
-            if (det_mode()) det_add(p.stats + (size_t)g * ADAMML_STAT_SLOTS * 128 + tid, 128, cs[tid]);
-            else atomicAdd(&slot[tid], (double)cs[tid]);
-        }
+        // (every cs entry was accumulated by one wave in tile order; one exact integer-bin add per channel and workgroup: common.h)
+        if (tid < 128) det_add(p.stats + (size_t)g * ADAMML_STAT_SLOTS * 128 + tid, 128, cs[tid]);
     }
 }
 

@@ -4,7 +4,6 @@
 #include "common.h"
 #include "../../include/adamml_hip.h"
 
-ADAMML_DET_SETTER(dwconv)
 
 namespace {
 

@@ -5,7 +5,6 @@
 #include "common.h"
 #include "../../include/adamml_hip.h"
 
-ADAMML_DET_SETTER(elementwise)
 
 namespace {
 
@@ -70,7 +69,7 @@ __global__ void stats_collapse_kernel(const double* stats, double* out, int C, i
     double v[ADAMML_STAT_SLOTS];
     const double* st = stats + (size_t)g * ADAMML_STAT_SLOTS * 2 * C + j;
 #pragma unroll
-    for (int k = 0; k < ADAMML_STAT_SLOTS; ++k) v[k] = det_mode() ? det_bin_value(st, 2 * (size_t)C, k) : st[(size_t)k * 2 * C];
+    for (int k = 0; k < ADAMML_STAT_SLOTS; ++k) v[k] = det_bin_value(st, 2 * (size_t)C, k);
 #pragma unroll
     for (int off = ADAMML_STAT_SLOTS / 2; off >= 1; off >>= 1)
 #pragma unroll
@@ -95,7 +94,7 @@ __device__ __forceinline__ void slot_sums_groups(const double* stats, int nslots
             a1[j] = 0.0; a2[j] = 0.0;
             if (j < nb && c < C && k < nslots) {
                 const double* st = stats + (size_t)(g + j) * nslots * 2 * C;
-                if (det_mode() && nslots == ADAMML_STAT_SLOTS) {
+                if (nslots == ADAMML_STAT_SLOTS) {              // integer bins; nslots == 1: plain doubles (collapsed / all-reduced sums)
                     a1[j] = det_bin_value(st + c, 2 * (size_t)C, k);
                     a2[j] = det_bin_value(st + C + c, 2 * (size_t)C, k);
                 } else {
@@ -396,16 +395,11 @@ __global__ __launch_bounds__(NT) void lazy_colsum_kernel(const bf16_t* x, const 
         // (rounded to bf16 like the operand the conv kernels stage: s is then the exact column sum of what the MFMAs multiply)
         for (size_t p = pb + m.rslot; p < pe; p += m.rows_per_pass)
             acc += bf8_to_f32(f32_to_bf8(transform8(*reinterpret_cast<const bf16x8*>(x + p * C + c), scale, shift, c, act)));
-        if (!det_mode()) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) atomicAdd(&smem[c + i], acc[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) accd[i] = acc[i];
-        }
+        for (int i = 0; i < 8; ++i) accd[i] = acc[i];
     }
-    if (det_mode()) {
-        // deterministic mode (one workgroup per group, see the launcher): the row slots add in turn, in a fixed order
+    {
+        // one workgroup per group (see the launcher); the row slots add in turn, in a fixed order
         for (int r = 0; r < m.rows_per_pass; ++r) {
             if (m.active && m.rslot == r) {
 #pragma unroll
@@ -1523,7 +1517,8 @@ extern "C" int adamml_lazy_colsum(const void* x, const float* scale, const float
     if (!P) return ADAMML_OK;
     size_t ppb, nblk;
     reduce_grid(P, C, groups, &ppb, &nblk);
-    if (adamml_deterministic_enabled()) { ppb = P; nblk = 1; }     // one workgroup per group: its fp32 adds run in a fixed order
+    ppb = P; nblk = 1;             // one workgroup per group: its fp32 adds run in a fixed order (fallback path only: adamml_gram_colsum
+                                   // serves the channel counts of the model)
     hipLaunchKernelGGL(lazy_colsum_kernel, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)x, scale, shift, gstride, act, s, P, C, ppb);
     return adamml_check_launch("lazy_colsum");
 }

@@ -162,18 +162,13 @@ def load():
     lib.adamml_set_deterministic.restype = c_int
     lib.adamml_get_deterministic.restype = c_int
     _lib = lib
-    if os.environ.get("ADAMML_DETERMINISTIC", "1") in ("0",) and torch.cuda.is_available():
-        set_deterministic(False)          # A/B aid: fp64 slot atomics across workgroups instead of the exact integer bins
     return lib
 
 
 def set_deterministic(on=True):
-    """Exact, order-independent accumulation of every per-channel statistic (include/adamml_hip.h: adamml_set_deterministic):
-    two runs of the same step are bit-identical.  This is the DEFAULT (csrc/common.h: reproducible reductions); `False` /
-    ADAMML_DETERMINISTIC=0 switch the cross-workgroup stage back to fp64 atomics (A/B aid).  Call between steps."""
+    """Every per-channel statistic is order-fixed and exact (csrc/common.h: reproducible reductions): two runs of the same step are
+    bit-identical, always.  Kept for callers of earlier versions: True is a no-op, False raises (no other mode exists)."""
     lib = _lib if _lib is not None else load()
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
     rc = lib.adamml_set_deterministic(1 if on else 0)
     if rc != 0:
         raise RuntimeError("adamml_set_deterministic failed (%d): %s" % (rc, lib.adamml_last_error_string().decode()))

@@ -49,10 +49,12 @@ typedef struct {
 
 int adamml_version(void);
 const char* adamml_last_error_string(void);
-/* Deterministic reductions (process-wide, set while no kernel of this library is in flight): every per-channel statistic /
- * BatchNorm-backward sum is accumulated exactly (integer bins, order-independent) instead of with floating-point atomics, so
- * two runs of the same step are bit-identical.  Slower; meant for parity tests and debugging.  The statistic buffers keep
- * their size and meaning for the caller ([groups][ADAMML_STAT_SLOTS][2C] doubles, zeroed by the caller, opaque in between). */
+/* Reproducible reductions: every per-channel statistic / BatchNorm-backward sum is order-fixed inside a workgroup and accumulated
+ * exactly across workgroups (integer bins: csrc/common.h), so two runs of the same step are bit-identical.  This is the ONLY mode
+ * and the library keeps no mutable state; the two entry points remain for callers written against the switch of earlier versions:
+ * adamml_set_deterministic(1) succeeds, (0) returns ADAMML_EUNSUPPORTED; adamml_get_deterministic() == 1.  The statistic buffers
+ * ([groups][ADAMML_STAT_SLOTS][2C] doubles, zeroed by the caller) are OPAQUE between the kernel that fills them and
+ * adamml_bn_finalize / adamml_bn_bwd_finalize / adamml_stats_collapse, which decode them. */
 int adamml_set_deterministic(int on);
 int adamml_get_deterministic(void);
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Whole evidence refresh of a round in ONE gpurun call (the full `pytest -m gpu` runs in its own call): PMC traffic passes first (so that
-# the default bench line carries the traffic of THIS build), the default bench line, its A/B against fp64-atomic statistics, single-stream
+# the default bench line carries the traffic of THIS build), the default bench line, single-stream
 # rocprofv3 kernel stats, the per-GPU share of the reference recipe (B = 9: plain / launch plan / forced one-rank RCCL choreography),
 # B = 72 with the forced choreography, the non-headline lines, per-layer and per-launch tables.
 # Usage (through gpurun): bash tools/gpu_round.sh [tag] [round, e.g. r04]; then, in the build container: bash tools/install_profiles.sh <tag> <round>
@@ -10,11 +10,6 @@ export TMPDIR=/tmp
 bash tools/gpu_pmc.sh ${tag}pmc $round
 cp gpurun_out/${tag}pmc/${round}_pmc_hbm_traffic.json profiles/${round}_pmc_hbm_traffic.json
 timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err; tail -c 300 $out/bench_default.json
-# reproducible (order-fixed, exact) statistics are the default; the same step with fp64 slot atomics across workgroups, back to back, twice
-for i in 1 2; do
-  ADAMML_DETERMINISTIC=0 timeout 600 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | grep '"metric"' > $out/bench_atomic_stats_$i.json
-  timeout 600 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | grep '"metric"' > $out/bench_deterministic_$i.json
-done
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o ss -- python bench.py --single-stream --no-cpu-baseline > $out/bench_ss.json 2> $out/prof.err
 find $out/prof -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
 rm -rf $out/prof

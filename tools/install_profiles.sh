@@ -9,7 +9,6 @@ cp $g/$tag/kernel_stats.csv profiles/${r}_bench_single_stream_kernel_stats.csv
 cp $g/${tag}pmc/${r}_pmc_hbm_traffic.json profiles/${r}_pmc_hbm_traffic.json
 for n in b9 b9_launch_plan b9_forced_collectives b9_forced_collectives_launch_plan b72_forced_collectives b72_forced_collectives_one_group b36_forced_collectives b18_forced_collectives policy_stage inference_skipping \
          c4_rgb_flow_rgbdiff_b72 c5_four_modalities_b48; do cp $g/$tag/bench_$n.json profiles/${r}_bench_$n.json; done
-cat $g/$tag/bench_atomic_stats_1.json $g/$tag/bench_deterministic_1.json $g/$tag/bench_atomic_stats_2.json $g/$tag/bench_deterministic_2.json > profiles/${r}_bench_deterministic.json   # A/B pairs, "deterministic" false / true
 cp $g/$tag/bench_conv.txt profiles/${r}_per_layer_bench_conv.txt
 cp $g/$tag/bench_dw.txt profiles/${r}_per_layer_bench_dw.txt
 cp $g/$tag/bench_fused.txt profiles/${r}_per_layer_bench_fused.txt
