@@ -399,7 +399,9 @@ class HipBackbone(nn.Module):
             # worth it for serving-sized calls only
             return None
         ws = rt.wgrad_stream.cuda_stream if rt.wgrad_stream is not None else 0
-        return (tuple(x.shape), x.dtype, groups, need_grad, self.training, hip.deterministic(), rt.sync.enabled, ws, hip._stream(),
+        if not x.is_contiguous():
+            return None            # (a launch sequence that first copies its input would bake the copy's address into the plan: round-3 advisor finding)
+        return (tuple(x.shape), x.dtype, groups, need_grad, self.training, rt.sync.enabled, ws, hip._stream(),
                 tuple(p.requires_grad for p in self._params()), self.flat_owner.flat.data_ptr() if (self.flat_owner is not None and
                 self.flat_owner.flat is not None) else self._params()[0].data_ptr(), self.grad_hook is not None)
 

@@ -514,7 +514,10 @@ def conv_stem1_bn(rt, x1, cs, bn, act):
     B, G, H, W = x1.shape
     if G != rt.groups:
         raise RuntimeError("conv_stem1_bn: input has %d groups (dim 1), the call %d" % (G, rt.groups))
-    x1 = x1.contiguous()
+    if not x1.is_contiguous():
+        if hip.recorder is not None:
+            hip.recorder.failed = "non-contiguous input (its copy's address would be baked into the plan)"
+        x1 = x1.contiguous()
     C = cs.cout
     d = ConvDesc(B, H, W, 8, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C, 3, 3, 2, 1, 1, 0, 0, G, 0)
     dev = x1.device
