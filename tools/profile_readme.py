@@ -117,5 +117,13 @@ out.append("Per-layer tables of the same build (B = 72 shapes): `%s_per_layer_be
            " `tools/bench_conv.py`), `%s_per_layer_bench_fused.txt` (RES / DUAL forms), `%s_per_layer_bench_dw.txt` (depthwise), `%s_bench_elementwise.txt` (BatchNorm / residual passes"
            " against a plain copy), `%s_launch_table_resnet.txt` / `%s_launch_table_sound.txt` (every launch of one backbone step with its excess over a 5.3 TB/s / 800 TFLOP/s floor;"
            " `tools/launch_table.py`), `%s_bench_nets.txt` (each backbone alone), `%s_kernel_resources.txt` (registers / spills / LDS of every kernel instance, `tools/kernel_resources.py`)." % ((R,) * 8))
+if os.path.exists("profiles/%s_bench_deterministic.json" % R):
+    ab = [json.loads(l) for l in open("profiles/%s_bench_deterministic.json" % R) if l.strip()]
+    out.append("")
+    out.append("`%s_bench_deterministic.json`: the benchmark step with reproducible per-channel sums (order-fixed in the workgroup, exact integer bins across "
+               "workgroups; `deterministic: true`) against the fp64-atomic form it replaced (`false`), back to back on one box, on the last build that "
+               "carried both forms: %s ms per step." % (R, ", ".join("%s %.2f" % ("true" if d["deterministic"] else "false", d["ms_per_step"]) for d in ab)))
+    out.append("`%s_launch_table_policy_rgb.txt` / `_policy_sound.txt`: every launch of the frozen policy MobileNetV2s' forward; `%s_gpu_tests.txt`: `pytest -m gpu` "
+               "of the same build." % (R, R))
 open("profiles/README.md", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
