@@ -138,30 +138,57 @@ def _spawn(world, backend, nvid):
     return tensors(ret["r"]), ret["exchange"], ret["communicator_ranks"]
 
 
-def test_two_rank_syncbn_step_equals_single_process_full_batch():
-    two, ex, ranks = _spawn(2, "gloo", B)
-    assert ranks == 2
+def _loose(tol, k):
+    return {n: v * k for n, v in tol.items()}
+
+
+# Bounds per world size (2 videos per rank beyond world 2): 1.3 x the values measured with gloo ranks sharing one MI355X -- the arithmetic
+# of an N-rank step does not depend on the transport (the statistic exchange sums fp64 vectors, the gradient all-reduce fp32 buckets), so
+# these are also the RCCL test's bounds; a world size that was never measured gets 3 x the two-rank bounds.
+TOL_BY_WORLD = {
+    2: TOL,
+    # 4 ranks, 8 videos: statistics 1.85e-7 / max 5.27e-3 / p90 1.41e-3, loss 9.0e-4, heads 1.14e-2 / 2.11e-2, bn3 gamma 9.1e-2, all gradients 0.652
+    4: {"first_layer_stats": 1e-6, "stats_max": 6.9e-3, "stats_p90": 1.9e-3, "loss": 1.2e-3, "fc_grad": 1.5e-2, "sound_fc_grad": 2.8e-2,
+        "bn_grad": 0.12, "grad_rel_l2": 0.85},
+    # 8 ranks, 16 videos (ADAMML_TEST_GLOO_WORLDS=8): 1.45e-7 / 3.71e-3 / 9.8e-4, loss 4.6e-4, heads 1.17e-2 / 2.41e-2, bn3 gamma 8.5e-2, 0.647
+    8: {"first_layer_stats": 1e-6, "stats_max": 4.9e-3, "stats_p90": 1.3e-3, "loss": 6.1e-4, "fc_grad": 1.6e-2, "sound_fc_grad": 3.2e-2,
+        "bn_grad": 0.112, "grad_rel_l2": 0.85},
+}
+
+
+def _n_rank(world, backend, nvid):
+    got, ex, ranks = _spawn(world, backend, nvid)
+    assert ranks == world, "the communicator spans %d ranks, expected %d" % (ranks, world)
     # SyncBatchNorm exchanges of one step (S = 2 segments batched as groups): the 4 backbones have 53 / 52 / 52 / 52 BatchNorm
     # layers in forward and the two trainable ones 53 / 52 in backward = 314 statistic vectors; issued in rounds they travel in one
     # collective per BatchNorm depth and exchange group (the ResNet alone, the MobileNetV2s together, alternating: interleave.GROUPS):
     # <= (53 + 52) forward + (53 + 52) backward; <= 53 + 53 with ADAMML_SYNC_GROUPS=1
-    print("  SyncBatchNorm exchange: %d statistic vectors in %d collectives" % (ex["coalesced_vectors"], ex["collectives"]))
-    from adamml_amd import interleave
-    assert ex["coalesced_vectors"] == 53 + 3 * 52 + 53 + 52 and ex["collectives"] <= (2 * (53 + 52) if interleave.GROUPS == "2" else 53 + 53)      # (8 clips: "auto" keeps one group)
-    one = _step(_build(), None, 0, 1)
-    _compare(two, one, 2)
+    print("  %d %s ranks: SyncBatchNorm exchange: %d statistic vectors in %d collectives" % (world, backend, ex["coalesced_vectors"], ex["collectives"]))
+    assert ex["coalesced_vectors"] == 53 + 3 * 52 + 53 + 52 and ex["collectives"] <= 2 * (53 + 52)
+    torch.cuda.set_device(0)
+    one = _step(_build(), None, 0, 1, nvid)
+    tol = TOL_BY_WORLD.get(world) or _loose(TOL, 3.0)
+    if backend == "nccl":
+        # never run with real peers: RCCL may sum the exchanged vectors in another order than gloo (last-bit differences that the bf16
+        # layers amplify like any other): 1.25 x on top of the gloo-calibrated bounds until a multi-GPU box has printed its own numbers
+        tol = _loose(tol, 1.25)
+    _compare(got, one, world, tol)
+
+
+def test_two_rank_syncbn_step_equals_single_process_full_batch():
+    _n_rank(2, "gloo", B)
+
+
+@pytest.mark.parametrize("world", [int(w) for w in os.environ.get("ADAMML_TEST_GLOO_WORLDS", "4").split(",")])
+def test_n_rank_gloo_syncbn_step_equals_full_batch(world):
+    """The N-rank form of the test above (2 videos per rank; ranks share the one GPU): the harness and the bounds the RCCL test below
+    will use on a multi-GPU box, exercised wherever the suite runs.  ADAMML_TEST_GLOO_WORLDS=8 runs the 8-rank form (calibration)."""
+    _n_rank(world, "gloo", 2 * world)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: RCCL ranks over xGMI, one GPU each")
 def test_n_rank_rccl_step_equals_full_batch():
     """configs[2] with real peers: min(8, device_count) RCCL ranks, 2 videos each, SyncBatchNorm + bucketed asynchronous gradient
-    all-reduce, against the one-process step on the concatenated batch (same bounds as the two-rank test)."""
+    all-reduce, against the one-process step on the concatenated batch (bounds: TOL_BY_WORLD)."""
     world = min(8, torch.cuda.device_count())
-    nvid = 2 * world
-    got, ex, ranks = _spawn(world, "nccl", nvid)
-    assert ranks == world, "the RCCL communicator spans %d ranks, expected %d" % (ranks, world)
-    print("  %d RCCL ranks: %d statistic vectors in %d collectives" % (world, ex["coalesced_vectors"], ex["collectives"]))
-    assert ex["coalesced_vectors"] == 53 + 3 * 52 + 53 + 52
-    torch.cuda.set_device(0)
-    one = _step(_build(), None, 0, 1, nvid)
-    _compare(got, one, world)
+    _n_rank(world, "nccl", 2 * world)
