@@ -131,14 +131,20 @@ def test_reference_wrapping_and_iteration_work_unchanged():
     changed = [k for k in sd0 if k.startswith("main_net.") and k.endswith("weight") and not torch.equal(two[k], sd0[k])]
     assert len(changed) > 100                               # the main nets were updated ...
     assert all(torch.equal(two[k], sd0[k]) for k in sd0 if k.startswith("policy_net.") and k.endswith(("weight", "bias")))   # ... the frozen policy was not
-    for k in ("main_net.nets.0.fc.weight", "main_net.nets.0.fc.bias", "main_net.nets.1.classifier.1.weight", "main_net.lf_weights"):
+    # bounds = 1.3 x measured (reproducible: order-fixed sums on both sides): head updates 8.3e-3 / 3.3e-4 / 1.8e-2 / 8.3e-3; all main-net
+    # weight updates as one vector: rel L2 printed below, cosine 0.793 -- the distance at the bottom of a randomly initialised network is
+    # the bf16 amplification of the 1e-7 difference between the two partitions' partial sums, not a gradient error
+    head_tol = {"main_net.nets.0.fc.weight": 1.1e-2, "main_net.nets.0.fc.bias": 4.4e-4, "main_net.nets.1.classifier.1.weight": 2.4e-2,
+                "main_net.lf_weights": 1.1e-2}
+    for k, tol in head_tol.items():
         e = rel(two[k] - sd0[k], sd1[k] - sd0[k])
         print("  update of %-44s DDP(2 ranks, torch.optim.SGD) vs single process (flat SGD): rel L2 %.2e" % (k, e))
-        assert e <= 5e-2, (k, e)
+        assert e <= tol, (k, e)
     upd2 = torch.cat([(two[k] - sd0[k]).flatten() for k in changed]).double()
     upd1 = torch.cat([(sd1[k] - sd0[k]).flatten() for k in changed]).double()
     cos = F.cosine_similarity(upd2, upd1, dim=0).item()
-    print("  all main-net weight updates: cosine %.3f; loss %.5f" % (cos, ret["loss"]))
-    assert cos >= 0.6
+    e_all = ((upd2 - upd1).norm() / upd1.norm()).item()
+    print("  all main-net weight updates: rel L2 %.3f, cosine %.3f; loss %.5f" % (e_all, cos, ret["loss"]))
+    assert cos >= 0.75 and e_all <= 0.83, (cos, e_all)            # measured 0.793 / 0.639
     for k in ("main_net.nets.0.bn1.running_mean", "main_net.nets.1.features.0.1.running_var"):
         assert rel(two[k], sd1[k]) <= 1e-4, k              # SyncBatchNorm statistics == full-batch statistics
