@@ -104,10 +104,22 @@ def check_against_emulation(model, emu, ref, mode, logits):
     assert ws[0] <= 1.0, ws
 
 
-def check_against_golden(model, gold, emu, mode, logits, k=3.0):
+# Fixed-number gates of the reduced cases: 1.3 x the logit error measured on MI355X against the reference golden (reproducible: every
+# per-channel sum is order-fixed).  These cases are ill-conditioned BY CONSTRUCTION (B = 1-2 at 64-96 px: 4-18 samples per BatchNorm
+# channel in the deep layers) -- the bf16-storage emulation of the oracle itself sits as far from fp32 (second column of the printout) --
+# so the numbers are large; they pin the plumbing of each variant, the tight statements are the full-size ones (test_parity_fullsize_gpu.py).
+LOGIT_BOUND = {("resnet50_train", "train"): 0.0236, ("resnet50_avg", "train"): 0.0120, ("resnet50_flow", "train"): 0.0370,
+               ("sound_mbv2", "train"): 0.156, ("adamml_rgb_sound", "train_main"): 0.177, ("adamml_rgb_sound", "train_policy"): 0.177,
+               ("adamml_rgb_sound_nolstm", "train_policy"): 0.567, ("adamml_rgb_flow_rgbdiff", "train_main"): 0.0471,
+               ("adamml_4mod", "train_policy"): 0.0331}
+
+
+def check_against_golden(model, gold, emu, mode, logits, k=3.0, name=None):
     e_hip, e_emu = rel_err(logits, gold[mode + ".logits"]), rel_err(emu[mode + ".logits"], gold[mode + ".logits"])
     print("  [%s] vs fp32 golden: HIP logits %.4f, emulation %.4f" % (mode, e_hip, e_emu))
     assert e_hip <= max(3e-2, k * e_emu)
+    if (name, mode) in LOGIT_BOUND:
+        assert e_hip <= LOGIT_BOUND[(name, mode)], (name, mode, e_hip)
     if mode + ".grad_names" not in gold:
         return
     names = list(gold[mode + ".grad_names"])
@@ -183,7 +195,7 @@ def test_resnet50(name):
     F.cross_entropy(y, target).backward()
     print(name)
     check_against_emulation(model, emu, ref, "train", y.detach().cpu().numpy())
-    check_against_golden(model, gold, emu, "train", y.detach().cpu().numpy())
+    check_against_golden(model, gold, emu, "train", y.detach().cpu().numpy(), name=name)
     if name != "resnet50_train":
         return          # the reduced B=1 / 64x64 cases leave 4 samples per layer4 channel: calibration is meaningless
     # eval mode with calibrated running statistics: BatchNorm is a fixed affine map -> plain bf16 tolerance vs fp32
@@ -216,7 +228,7 @@ def test_sound_mobilenet_v2():
     F.cross_entropy(y, target).backward()
     print(name)
     check_against_emulation(model, emu, ref, "train", y.detach().cpu().numpy())
-    check_against_golden(model, gold, emu, "train", y.detach().cpu().numpy())
+    check_against_golden(model, gold, emu, "train", y.detach().cpu().numpy(), name="sound_mbv2")
     cal = calibrated_state(sd, lambda s: O.sound_mbv2_forward(s, "", x_cpu, 0.0, True))
     model.load_state_dict(cal)
     model.eval()
@@ -279,7 +291,7 @@ def test_adamml(name):
             loss = loss + O.policy_loss("blockdrop", sel, cw, torch.tensor(10.0, device=DEV), logits, target)
         loss.backward()
         check_against_emulation(model, emu, ref, mode, logits.detach().cpu().numpy())
-        check_against_golden(model, gold, emu, mode, logits.detach().cpu().numpy())
+        check_against_golden(model, gold, emu, mode, logits.detach().cpu().numpy(), name=name)
 
 
 def test_eval_skipping_equals_masking():
