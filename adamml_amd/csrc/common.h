@@ -92,7 +92,12 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __device__ __forceinline__ void det_add(double* acc, size_t slot_stride, float v) {
     const unsigned u = __float_as_uint(v);
     unsigned e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
-    if (e == 0xffu) return;                              // inf / nan never reach a statistic of a healthy run
+    if (e == 0xffu) {                                    // inf / nan: poison the accumulator, as a floating-point sum would be --
+        // bin 31 (exponents >= 2^121: no finite statistic lives there) decodes to NaN as soon as it is non-zero (det_bin_value), so
+        // a diverged run shows up in the BatchNorm vectors and the loss instead of being normalised with the finite remainder
+        atomicAdd(reinterpret_cast<unsigned long long*>(acc + (size_t)31 * slot_stride), 1ull);
+        return;
+    }
     if (e) m |= 0x800000u; else e = 1;                   // denormals: no implicit bit, exponent of the smallest normal
     if (!m) return;
     long long c = (long long)m << (e & 7);
@@ -110,6 +115,7 @@ __device__ __forceinline__ void stat_publish(double* acc, size_t slot_stride, un
 // value of bin k of a deterministic accumulator (the 32 bin values are summed in a fixed order by the consumers)
 __device__ __forceinline__ double det_bin_value(const double* acc, size_t slot_stride, int k) {
     const long long b = *reinterpret_cast<const long long*>(acc + (size_t)k * slot_stride);
+    if (k == 31 && b != 0) return __builtin_nan("");     // poisoned by an inf / nan addend (det_add)
     return scalbn((double)b, 8 * k - 150);
 }
 

@@ -1255,3 +1255,26 @@ def test_conv_stem1_reads_the_fp32_spectrogram_directly(B, G, H, W, C):
     ws = torch.empty(need // 4 + 1, device=DEV)
     call("adamml_conv_stem1_bwd_weight", byref(d), ptr(dz), ptr(x), G * H * W, H * W, ptr(dw), ptr(ws), ws.numel() * 4)
     assert (dw - wr.grad).abs().max().item() <= 2e-4 * wr.grad.abs().max().item()
+
+
+def test_nan_in_an_activation_poisons_the_statistics():
+    """The per-channel sums are accumulated in exact integer bins (csrc/common.h); a NaN / Inf addend has no integer image, so it
+    poisons the accumulator (bin 31 decodes to NaN): a diverged run shows up in the BatchNorm vectors as it would with floating-point
+    sums, instead of being normalised with the statistics of the finite remainder."""
+    torch.manual_seed(0)
+    N, H, Cin, Cout = 2, 12, 64, 64
+    for bad in (float("nan"), float("inf")):
+        x = torch.randn(N, H, H, Cin, device=DEV).to(torch.bfloat16)
+        x[1, 3, 4, 7] = bad
+        w = torch.randn(Cout, Cin, 1, 1, device=DEV) * 0.2
+        d = ConvDesc(N, H, H, Cin, H, H, Cout, 1, 1, 1, 0, 1, 0, 0)
+        y = torch.empty(N, H, H, Cout, dtype=torch.bfloat16, device=DEV)
+        stats = torch.zeros(STAT_SLOTS, 2 * Cout, dtype=torch.float64, device=DEV)
+        call("adamml_conv_fwd", byref(d), ptr(x), ptr(pack(w, Cin, 0)), None, None, ptr(y), ptr(stats))
+        s = ssum(stats)
+        assert not torch.isfinite(s).any(), "every output channel saw the bad pixel"
+        vec = torch.empty(4, Cout, device=DEV)
+        rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+        g, b = torch.ones(Cout, device=DEV), torch.zeros(Cout, device=DEV)
+        call("adamml_bn_finalize", ptr(stats), STAT_SLOTS, 1, float(N * H * H), ptr(g), ptr(b), ptr(rm), ptr(rv), 0.1, 1e-5, ptr(vec), Cout)
+        assert torch.isnan(vec[0]).all() and torch.isnan(rm).all()
