@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256, 3) void alg_stream_kernel(S1P p) {
     if (p.bn_z) s_bn[tid] = p.bn_vec[tid];                          // 256 threads == 4 * C2 entries
     __syncthreads();
 
-    const float alo = p.a_scale ? act_lo(p.a_act) : -INFINITY, ahi = p.a_scale ? act_hi(p.a_act) : INFINITY;
+    // (wave-uniform clamp bounds pinned to scalar registers: as vector registers one of them was spilled to scratch and re-read per tile)
+    auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    const float alo = uniform(p.a_scale ? act_lo(p.a_act) : -INFINITY), ahi = uniform(p.a_scale ? act_hi(p.a_act) : INFINITY);
     float ssum[4][4], ssq[4][4];                                    // [cout tile][r]: channel ct*16 + lg*4 + r
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256, 3) void alg_stream_kernel(S1P p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- epilogue: lane (li, lg) holds channels ct*16 + lg*4 .. +3 of pixel pg*16 + li
-        const float blo = act_lo(p.bn_act), bhi = act_hi(p.bn_act);
+        const float blo = uniform(act_lo(p.bn_act)), bhi = uniform(act_hi(p.bn_act));
 #pragma unroll
         for (int pg = 0; pg < NPG; ++pg) {
             const long px = p0 + pg * 16 + li;

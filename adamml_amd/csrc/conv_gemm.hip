@@ -155,9 +155,22 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
 // every edit of a data-gradient epilogue move the register allocation of the forward instances (spills inside their K loops); apart,
 // the forward instances carry no dead epilogue state and the data-gradient ones can request a batch of rows ahead of their stores.
 // PF: see ConvP::pf_a (BC = 128, 64 channels of a; RES + GLDS + EID only).
+// Workgroups per CU the register allocation is sized for.  The fused instances (RES / DUAL / CAT / EID) take 256 registers; the plain
+// ones rely on occupancy (PD 1: 3-4 workgroups per CU) or on their register ring (PD 3).  The instances under "fewer" did not fit
+// that budget (2-13 registers in scratch, tools/kernel_resources.py) and get one workgroup less: the data-gradient epilogues that are
+// staged through registers at 64-wide tiles, the strided (MODE 2) loaders and the FADD epilogue without EID.
+constexpr int conv_gemm_wg_per_cu(int BC, int MODE, int PD, bool RES, bool DUAL, bool CAT, bool FADD, bool GLDS, int EID, int EPI) {
+    if (RES || DUAL || CAT || EID) return 2;
+    const int n = PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3);
+    const bool fewer = (MODE == 2 && !(BC == 128 && PD == 3)) || FADD ||
+                       (BC == 64 && PD == 1 && ((EPI == 1 && !(MODE == 0 && GLDS)) || (EPI == 2 && MODE == 1))) ||
+                       (BC == 128 && MODE == 1 && EPI == 2 && !GLDS);
+    return fewer ? n - 1 : n;
+}
+
 template <int BC, int MODE, int PD, bool RES = false, bool DUAL = false, bool CAT = false, bool FADD = false, bool GLDS = false, int EID = 0,
           bool LZF = false, int EPI = -1, bool PF = false, int TP = 0>
-__global__ __launch_bounds__(NTHREADS, (RES || DUAL || CAT || EID) ? 2 : (PD == 1 ? (BC == 128 ? 3 : 4) : (BC == 128 ? 2 : 3))) void conv_gemm_kernel(ConvP p) {
+__global__ __launch_bounds__(NTHREADS, conv_gemm_wg_per_cu(BC, MODE, PD, RES, DUAL, CAT, FADD, GLDS, EID, EPI)) void conv_gemm_kernel(ConvP p) {
     static_assert(TP == 0 || (FADD && EID && MODE == 0 && BC == 128 && (TP == 2 || TP == 4 || TP == 8)), "TP: FADD + EID, 128-wide cout tiles");
     constexpr int PPF = TP ? BP / TP : BP;  // TP: pixels of one frame in a tile
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
@@ -1458,7 +1471,7 @@ struct W3P {
     int in_gstride;
 };
 
-template <int S>
+template <int S, int MAXSLOT>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_wgrad_kernel(W3P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lb = (int)xcd_contiguous(blockIdx.x, gridDim.x);   // (group, split, tile) list, tile fastest (see conv_wgrad_kernel)
@@ -1480,8 +1493,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_wgrad_kernel(W3P p) {
     // dz tile: 32 rows x 8 chunks = 256 chunks -> one per thread
     const int a_j = tid >> 3, a_ch = tid & 7;
     const int a_r = a_j / p.cw, a_c = a_j - a_r * p.cw;
-    // patch: PR*PC pixels x 8 chunks, up to 6 slots per thread
-    constexpr int MAXSLOT = 6;
+    // patch: PR*PC pixels x 8 chunks, up to MAXSLOT slots per thread
     const int n_chunks = p.PR * p.PC * 8;
     int s_pr[MAXSLOT], s_pc[MAXSLOT];
 #pragma unroll
@@ -1876,7 +1888,6 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     }
     if (res) {
         if (mode != 0) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res: only 1x1 / stride-1 convs");
-        static const bool res_glds = !(getenv("ADAMML_RES_GLDS") && getenv("ADAMML_RES_GLDS")[0] == '0');
         static const bool res_eid = !(getenv("ADAMML_RES_EID") && getenv("ADAMML_RES_EID")[0] == '0');
         if (pf) {
             if (BC != 128 || d->Cout % 128 || pf->C != 64 || in_scale || !p.res_mask || !p.accumulate || p.bn_z || p.bn_z2 || !stats)
@@ -1894,17 +1905,15 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
             launch_wgrad_reduce((const float*)pf->ws, pf->out, (size_t)128 * 64, p.pf_nsplit, 1, 64, 1, groups * p.n_ctiles, stream);
             return adamml_check_launch("conv_bwd_data_res_prod (reduce)");
         }
-        if (res_glds && res_eid && !in_scale && p.res_mask && p.accumulate && !p.bn_z && !p.bn_z2) {
+        if (in_scale) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res: the gradient operand is never lazy");
+        if (res_eid && p.res_mask && p.accumulate && !p.bn_z && !p.bn_z2) {
             // the algebraic backward's form (identity gradient + 1-bit mask, sum(g') only): identity-side loads at the start of each tile
             if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, true, false, false, false, true, 1>), grid, block, 0, stream, p);
             else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, true, false, false, false, true, 1>), grid, block, 0, stream, p);
-        } else
-        if (res_glds && !in_scale) {
+        } else {
             if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, true, false, false, false, true>), grid, block, 0, stream, p);
             else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, true, false, false, false, true>), grid, block, 0, stream, p);
-        } else
-        if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 1, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, true>), grid, block, 0, stream, p);
+        }
         return adamml_check_launch("conv_bwd_data_res");
     }
     if (cat) {
@@ -1916,7 +1925,7 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     if (dual) {
         if (mode != 0 || res) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_dual: only 1x1 / stride-1 convs");
         if (BC == 64) hipLaunchKernelGGL((conv_gemm_kernel<64, 0, 3, false, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 3, false, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 2, false, true>), grid, block, 0, stream, p);       // (a third ring slot of g, z and weights does not fit 256 registers at 128-wide tiles)
         return adamml_check_launch("conv_bwd_data_dual");
     }
     static const bool glds_on = !(getenv("ADAMML_CONV_GLDS") && getenv("ADAMML_CONV_GLDS")[0] == '0');
@@ -2317,6 +2326,8 @@ extern "C" int adamml_conv_bwd_data(const adamml_conv_desc_t* d, const void* dz,
     return adamml_conv_fwd(&g, dz, w_dgrad_packed, nullptr, nullptr, dx, nullptr, stream);
 }
 
+constexpr int W3_SLOTS = 4;      // 16-byte patch chunks a thread of conv3x3_wgrad_kernel stages per unit (3 x 34 pixels x 8 chunks = 816 <= 4 x 256)
+
 // split plan shared by the workspace query and the launcher
 struct WgradPlan { bool use3x3; int nsplit, per_block, n_cotiles, n_tiles, BM, BN, NK, cin_shift; int cw, rows, PR, PC, upi, upr, total_units, buf_bytes; };
 
@@ -2325,7 +2336,8 @@ static int wgrad_plan(const adamml_conv_desc_t* d, int cin_true, WgradPlan* pl) 
     pl->use3x3 = false;
     // the LDS-patch kernel only pays on wide feature maps (measured on MI355X: 56x56 1.87 ms vs 1.97 ms generic; at
     // 28x28 and below the generic implicit-GEMM gather is 5-40 % faster)
-    if (d->OW > 32 && d->KH == 3 && d->KW == 3 && d->pad == 1 && (d->stride == 1 || d->stride == 2) && d->Cin % 64 == 0 && d->Cout % 64 == 0 &&
+    // (stride 1 only: a 32-column strip of a stride-2 conv needs a 3 x 65 patch, more than the staging slots of a workgroup hold)
+    if (d->OW > 32 && d->KH == 3 && d->KW == 3 && d->pad == 1 && d->stride == 1 && d->Cin % 64 == 0 && d->Cout % 64 == 0 &&
         cin_true == d->Cin) {
         if (d->OW > 32) { pl->cw = 32; pl->rows = 1; pl->upr = ceil_div(d->OW, 32); }
         else { pl->cw = d->OW; pl->rows = 32 / d->OW; pl->upr = 1; }
@@ -2334,7 +2346,7 @@ static int wgrad_plan(const adamml_conv_desc_t* d, int cin_true, WgradPlan* pl) 
         pl->upi = ceil_div(d->OH, pl->rows) * pl->upr;
         pl->total_units = d->N * pl->upi;
         pl->buf_bytes = 32 * 128 + pl->PR * pl->PC * 128;
-        if (pl->PR * pl->PC * 8 <= 6 * NTHREADS && 2 * pl->buf_bytes <= 64 * 1024 && pl->total_units > 0) {
+        if (pl->PR * pl->PC * 8 <= W3_SLOTS * NTHREADS && 2 * pl->buf_bytes <= 64 * 1024 && pl->total_units > 0) {
             pl->use3x3 = true;
             pl->n_cotiles = d->Cout / 64;
             pl->n_tiles = pl->n_cotiles * (d->Cin / 64);
@@ -2438,8 +2450,7 @@ static int wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void*
         q.act = d->act; q.cin_true = cin_true;
         q.cw = pl.cw; q.rows = pl.rows; q.PR = pl.PR; q.PC = pl.PC; q.units_per_img = pl.upi; q.units_per_row = pl.upr;
         q.total_units = pl.total_units; q.units_per_block = pl.per_block; q.n_cotiles = pl.n_cotiles; q.n_tiles = pl.n_tiles;
-        if (d->stride == 1) hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, block, 2 * pl.buf_bytes, stream, q);
-        else hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, block, 2 * pl.buf_bytes, stream, q);
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<1, W3_SLOTS>), grid, block, 2 * pl.buf_bytes, stream, q);
     } else {
         WgradP p;
         p.dz = (const bf16_t*)dz; p.x = (const bf16_t*)x; p.in_scale = in_scale; p.in_shift = in_shift; p.dw = dw;

@@ -231,11 +231,16 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
         // every strip (tl) deposits its sums in its own LDS row [2 nch]; one thread per channel folds the rows in strip order and
         // publishes the workgroup's partial exactly (common.h: reproducible reductions).  tpb * 2 nch = 8 cw tpb <= 8 NT floats.
         const int nch = 4 * p.cw;                           // channels of this workgroup's tile
-        if (tl < p.tpb) {
+        // (the strip / chunk indices are recomputed from an opaque copy of the thread id: kept live across the walk they were the two
+        // registers the BNZ instance spilled to scratch)
+        int tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));
+        const int cl2 = tid2 % p.cw, tl2 = tid2 / p.cw;
+        if (tl2 < p.tpb) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                smem[tl * 2 * nch + cl * 4 + i] = active ? s[i] : 0.f;
-                smem[tl * 2 * nch + nch + cl * 4 + i] = active ? q[i] : 0.f;
+                smem[tl2 * 2 * nch + cl2 * 4 + i] = active ? s[i] : 0.f;
+                smem[tl2 * 2 * nch + nch + cl2 * 4 + i] = active ? q[i] : 0.f;
             }
         }
         __syncthreads();

@@ -121,7 +121,7 @@ __device__ __forceinline__ void slot_sums_groups(const double* stats, int nslots
 
 // The running statistics see the groups IN ORDER (the reference updates them once per segment call): lane g of a channel's
 // 32-lane group finalises group g, the lead lane then folds the groups' (mean, unbiased variance) in order.
-__global__ void bn_finalize_kernel(const double* stats, int nslots, int groups, double count, const float* gamma, const float* beta,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* stats, int nslots, int groups, double count, const float* gamma, const float* beta,
                                    float* rm, float* rv, float momentum, float eps, float* vec, int C) {
     const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), k = threadIdx.x & 31;
     float rmean = 0.f, rvar = 0.f;

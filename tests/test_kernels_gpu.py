@@ -81,6 +81,8 @@ CONV_CASES = [
     (1, 7, 7, 512, 2048, 1, 1, 0),
     (3, 7, 7, 512, 512, 3, 1, 1),
     (1, 5, 5, 320, 1280, 1, 1, 0),
+    (2, 40, 40, 64, 128, 3, 1, 1),          # wide 3x3 that is not 64 -> 64: the LDS-patch weight gradient (conv3x3_wgrad_kernel)
+    (1, 66, 66, 128, 128, 3, 2, 1),         # wide stride-2 3x3: generic implicit-GEMM weight gradient
 ]
 
 
