@@ -446,10 +446,18 @@ __global__ __launch_bounds__(NTHREADS, conv_gemm_wg_per_cu(BC, MODE, PD, RES, DU
 
     // register prefetch ring of depth PD: global loads run PD K-steps ahead of the MFMAs.  One K step of compute is
     // ~0.15 us but an HBM round trip is 1-2 us, so a one-step look-ahead left the kernel latency-bound.
+    // UNC (the deep rings): every ring load is issued UNCONDITIONALLY from a clamped (always valid) address and zeroed on its way into
+    // LDS.  Behind `if (ok)` each load sat in its own exec-masked block; the compiler's wait-count bookkeeping must then assume that none
+    // of the younger loads was issued and waits for a slot with vmcnt(0) -- at the top of every PD K steps the whole ring drained and the
+    // most recent request was exposed as a full HBM round trip (the ring was one step deep in effect).  Unconditional loads make the
+    // counts exact: the wait for a slot leaves the (PD - 1) younger slots in flight.
+    // Only the CAT / DUAL instances: the plain deep-ring instances (layer 3-4 shapes, small grids) measured 5-7 % SLOWER with it.
+    constexpr bool UNC = PD > 1 && (CAT || DUAL);
     bf16x8 ra[PD][2], rw[PD][WROWS];
     bf16x8 ra2[DUAL ? PD : 1][2];
     int rci[PD];
     bool rav[PD][2];
+    bool rkok[UNC ? PD : 1];
 #pragma unroll
     for (int i = 0; i < PD; ++i) rci[i] = 0;
 
@@ -465,6 +473,13 @@ __global__ __launch_bounds__(NTHREADS, conv_gemm_wg_per_cu(BC, MODE, PD, RES, DU
             for (int r = 0; r < 2; ++r) {
                 const bool ok = a_ok[r] && kok;
                 rav[SL][r] = ok;
+                if constexpr (UNC) {
+                    const bf16_t* src = p.x + (size_t)(unsigned)(a_base[r] + k);
+                    if (CAT && from_b) src = p.xb + (size_t)(unsigned)(a_base[r] / p.K1) * p.C2 + (k - p.K1);
+                    ra[SL][r] = *reinterpret_cast<const bf16x8*>(ok ? src : p.x);
+                    if (DUAL) ra2[DUAL ? SL : 0][r] = *reinterpret_cast<const bf16x8*>(ok ? p.x2 + (size_t)(unsigned)(a_base[r] + k) : p.x2);
+                    continue;
+                }
                 bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (CAT && from_b) {
                     if (ok) v = *reinterpret_cast<const bf16x8*>(p.xb + (size_t)(unsigned)(a_base[r] / p.K1) * p.C2 + (k - p.K1));
@@ -486,6 +501,10 @@ __global__ __launch_bounds__(NTHREADS, conv_gemm_wg_per_cu(BC, MODE, PD, RES, DU
             for (int r = 0; r < 2; ++r) {
                 const bool ok = kok && ((a_mask[r] >> tap) & 1ull);
                 rav[SL][r] = ok;
+                if constexpr (UNC) {
+                    ra[SL][r] = *reinterpret_cast<const bf16x8*>(ok ? p.x + (size_t)(unsigned)(a_base[r] + toff) : p.x);
+                    continue;
+                }
                 bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + (size_t)(unsigned)(a_base[r] + toff));
                 ra[SL][r] = v;
@@ -504,6 +523,10 @@ __global__ __launch_bounds__(NTHREADS, conv_gemm_wg_per_cu(BC, MODE, PD, RES, DU
                 iw >>= p.up_shift;
                 ok = ok && ih < p.H && iw < p.W;
                 rav[SL][r] = ok;
+                if constexpr (UNC) {
+                    ra[SL][r] = *reinterpret_cast<const bf16x8*>(ok ? p.x + ((size_t)(a_n[r] * p.H + ih) * p.W + iw) * p.Cin + ci : p.x);
+                    continue;
+                }
                 bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (ok) v = *reinterpret_cast<const bf16x8*>(p.x + ((size_t)(a_n[r] * p.H + ih) * p.W + iw) * p.Cin + ci);
                 ra[SL][r] = v;
@@ -511,10 +534,15 @@ __global__ __launch_bounds__(NTHREADS, conv_gemm_wg_per_cu(BC, MODE, PD, RES, DU
         }
 #pragma unroll
         for (int r = 0; r < WROWS; ++r) {
+            if constexpr (UNC) {
+                rw[SL][r] = *reinterpret_cast<const bf16x8*>(wrow[r] + (kok ? kw_off : 0));       // (wrow is row 0 for rows past Cout)
+                continue;
+            }
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (w_ok[r] && kok) v = *reinterpret_cast<const bf16x8*>(wrow[r] + kw_off);
             rw[SL][r] = v;
         }
+        if constexpr (UNC) rkok[SL] = kok;
     };
     auto store_tile = [&](auto slot_c, int buf) {
         constexpr int SL = decltype(slot_c)::value;
@@ -544,11 +572,15 @@ __global__ __launch_bounds__(NTHREADS, conv_gemm_wg_per_cu(BC, MODE, PD, RES, DU
                     v = f32_to_bf8(f);
                 } else v = f32_to_bf8(transform8(v, p.in_scale, p.in_shift, rci[SL], p.act));
             }
+            if (UNC && !rav[SL][r]) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             *reinterpret_cast<bf16x8*>(base + lds_off(row_a + r * 64, chunk)) = v;
         }
 #pragma unroll
-        for (int r = 0; r < WROWS; ++r)
-            *reinterpret_cast<bf16x8*>(base + BP * 64 + lds_off(row_a + r * 64, chunk)) = rw[SL][r];
+        for (int r = 0; r < WROWS; ++r) {
+            bf16x8 v = rw[SL][r];
+            if (UNC && !(w_ok[r] && rkok[UNC ? SL : 0])) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<bf16x8*>(base + BP * 64 + lds_off(row_a + r * 64, chunk)) = v;
+        }
     };
 
     f32x4 acc[WCT][4];
@@ -646,12 +678,29 @@ __global__ __launch_bounds__(NTHREADS, conv_gemm_wg_per_cu(BC, MODE, PD, RES, DU
             buf = buf == 2 ? 0 : buf + 1;
         }
     } else {
+    int kt0 = 0;
+    if (UNC && nk >= 2 * PD) {                           // (uniform)
+        // steady state of a deep ring, with NO run-time condition around a load: prologue and every step issue, so the compiler's
+        // wait counts are exact (a load issued under a condition -- even a uniform one -- forces every wait that follows the join to
+        // assume it was not issued, i.e. vmcnt(0..3) for a slot instead of vmcnt((PD - 1) x loads per slot))
+        static_for<PD>([&](auto sc) { issue_loads(sc, (int)decltype(sc)::value); });
+        for (; kt0 + 2 * PD <= nk; kt0 += PD) {
+            static_for<PD>([&](auto sc) {
+                const int kt = kt0 + (int)decltype(sc)::value;
+                store_tile(sc, kt & 1);
+                issue_loads(sc, kt + PD);
+                __syncthreads();
+                compute(kt & 1);
+            });
+        }
+    } else {
     // prologue: fill the ring
     static_for<PD>([&](auto sc) {
         if ((int)decltype(sc)::value < nk) issue_loads(sc, (int)decltype(sc)::value);
     });
+    }
     issue_eid();
-    for (int kt0 = 0; kt0 < nk; kt0 += PD) {
+    for (; kt0 < nk; kt0 += PD) {
         static_for<PD>([&](auto sc) {
             const int kt = kt0 + (int)decltype(sc)::value;
             if (kt < nk) {                               // uniform

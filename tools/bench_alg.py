@@ -1,10 +1,11 @@
-"""Layer-1 algebraic data gradient (Cout 256 -> Cin 64, B=72 x 5 segments): streaming kernel vs the CAT instance of conv_gemm_kernel
-(run with ADAMML_ALG_STREAM=0 / 1)."""
+"""Algebraic data gradient at the benchmark shapes (B=72 x 5 segments): layer 1 (Cout 256 -> Cin 64: streaming kernel vs the CAT instance of
+conv_gemm_kernel, run with ADAMML_ALG_STREAM=0 / 1) or, `python tools/bench_alg.py 2`, layer 2 (Cout 512 -> Cin 128: CAT instance)."""
 import os, sys, torch
 from ctypes import byref
 sys.path.insert(0, ".")
 from adamml_amd.hip import call, ptr, STAT_SLOTS, ConvDesc
-DEV, G, N, H, Cin, Cout = "cuda", 5, 576, 56, 64, 256
+DEV, G = "cuda", 5
+N, H, Cin, Cout = (288, 28, 128, 512) if len(sys.argv) > 1 and sys.argv[1] == "2" else (576, 56, 64, 256)
 bf = lambda *s: torch.randn(*s, device=DEV).to(torch.bfloat16)
 g, a, dx = bf(G * N, H, H, Cout), bf(G * N, H, H, Cin), bf(G * N, H, H, Cin)
 vin = torch.rand(G, 4, Cin, device=DEV) + 0.5

@@ -15,5 +15,9 @@ for which in prev new; do
   ADAMML_HIP_LIB=$PWD/$lib timeout 300 python tools/bench_dual_mb.py > $out/dual_$which.txt 2>&1
   ADAMML_HIP_LIB=$PWD/$lib timeout 300 python tools/explore_stream.py 72 1 alg 10 > $out/stream_$which.txt 2>&1
   ADAMML_HIP_LIB=$PWD/$lib timeout 300 python tools/bench_nets.py > $out/nets_$which.txt 2>&1
+  ADAMML_HIP_LIB=$PWD/$lib ADAMML_ALG_STREAM=0 timeout 300 python tools/bench_alg.py > $out/alg1_$which.txt 2>&1
+  ADAMML_HIP_LIB=$PWD/$lib timeout 300 python tools/bench_alg.py 2 > $out/alg2_$which.txt 2>&1
+  ADAMML_HIP_LIB=$PWD/$lib timeout 600 python tools/bench_conv.py 2>&1 | grep -v amdgpu > $out/conv_$which.txt
 done
-tail -n 30 $out/dual_prev.txt $out/dual_new.txt $out/stream_prev.txt $out/stream_new.txt $out/nets_prev.txt $out/nets_new.txt
+tail -n 30 $out/dual_prev.txt $out/dual_new.txt $out/stream_prev.txt $out/stream_new.txt $out/nets_prev.txt $out/nets_new.txt $out/alg1_prev.txt $out/alg1_new.txt $out/alg2_prev.txt $out/alg2_new.txt
+paste -d'\n' $out/conv_prev.txt $out/conv_new.txt | cut -c1-200 | tail -34
