@@ -14,7 +14,7 @@ namespace {
 
 constexpr int K1 = 256, C2 = 64, KT = K1 + C2, KP = KT + 8;      // KP: padded LDS row (bank spread for the 16-lane row reads)
 constexpr int NKS = KT / 32;                                      // 10 K steps: 8 from g', 2 from a
-constexpr int PD = 5;                                             // K steps of global loads in flight per wave
+constexpr int PD = 4;                                             // K steps of global loads in flight per wave, issued in PAIRS (below)
 constexpr int NPG = 2;                                            // 16-pixel groups per wave tile (64 px spilled 119 VGPRs)
 constexpr int TPX = NPG * 16;
 
@@ -113,7 +113,11 @@ __global__ __launch_bounds__(256, 3) void alg_stream_kernel(S1P p) {
             bf16x8 fb[NPG];
 #pragma unroll
             for (int pg = 0; pg < NPG; ++pg) fb[pg] = ring[k % PD][pg];
-            if (k + PD < NKS) issue(k % PD, k + PD);
+            // the ring is refilled two K steps at a time: steps 2s and 2s + 1 are the two 64-byte halves of one 128-byte line of every pixel
+            // (g' rows are four lines, a rows one), and requested back to back they cost the vector L1 one miss where requests a K step
+            // apart cost two (profiles/r04_pmc_alg_stream.txt: 1.7 L2 requests per line, the L1 stalled 57 % of the time): 1.58 -> 1.55 ms
+            // with a ring of 4 against the one-step refill of a ring of 5 (a paired ring of 6 does not fit 168 registers)
+            if ((k & 1) && k - 1 + PD < NKS) { issue((k - 1) % PD, k - 1 + PD); issue(k % PD, k + PD); }
             if (k >= K1 / 32 && p.a_scale) {                        // lazy transform of the conv input: act(scale a + shift)
                 const int c0 = (k - K1 / 32) * 32 + lg * 8;
                 const f32x8 sc = load_f32x8(s_vec + c0), sh = load_f32x8(s_vec + C2 + c0);
