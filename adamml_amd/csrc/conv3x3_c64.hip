@@ -54,6 +54,17 @@ constexpr int PPIX = C64 * 2 + 16;       // patch pixel pitch: 144 B
 #define C64_STAGGER 94                   // s_sleep units (64 cycles) per phase step; 0 = off (A/B aid)
 #endif
 #define C64_STAGGER_PH 4
+// Round 5 (A/B aids, tools/c64_ab.py): C64_ROWMAP -- patch slot l of a thread is patch ROW l / ncb, column block l % ncb (64 pixel columns
+// per block), so a request's row address is wave-uniform (scalar registers) and its column offset a per-thread constant: the slot-to-slot
+// (row, column) carry chain (12 VALU instructions per request) is gone.  C64_DIRECT_EPI -- the forward epilogue stores straight from the
+// accumulators (pairs of cout tiles exchanged with v_permlane16_swap so that a lane holds 8 consecutive channels: 16-byte stores, 64
+// contiguous bytes per pixel and instruction) and keeps the statistics in registers: no staging tile, two barriers per tile fewer.
+#ifndef C64_ROWMAP
+#define C64_ROWMAP 0
+#endif
+#ifndef C64_DIRECT_EPI
+#define C64_DIRECT_EPI 1
+#endif
 #define C64_STAGGER_START do { if (C64_STAGGER && p.tpb >= 8 && blockIdx.x < 256) { const int ph = (blockIdx.x >> 3) & (C64_STAGGER_PH - 1); for (int i = 0; i < ph; ++i) __builtin_amdgcn_s_sleep(C64_STAGGER); } } while (0)
 constexpr int SROW3 = C64 * 2 + 8;       // staging row: 136 B (144 measured the same)
 constexpr int MAXPT = 4;                 // pixel tiles (16 px) per wave
@@ -75,6 +86,7 @@ struct C3P {
     int in_gstride;
     int wswz;                // 1: weight rows stored with the chunk swizzle (A/B aid ADAMML_C64_WSWZ)
     int nbg, spb;            // conv3x3_c64_pp_kernel: workgroups per BatchNorm group, strips per workgroup
+    int ncb;                 // C64_ROWMAP: 64-pixel column blocks of a patch row
     size_t gxy;              // elements per group of x and y (same shape)
 };
 
@@ -134,6 +146,19 @@ __device__ __forceinline__ void fold16_to_cs(const f32x8& esum, const f32x8& esq
         }
     }
 }
+
+// A wave-uniform GLOBAL pointer moved into scalar registers (64-bit products are computed on the VALU and stay in vector registers
+// otherwise: every access through them then needs a per-lane 64-bit add instead of the scalar-base + 32-bit-offset addressing mode).
+// The result keeps the global address space: through a plain integer round trip the compiler no longer knows it and emits FLAT
+// accesses, which also count on lgkmcnt -- the phase barrier's `s_waitcnt lgkmcnt(0)` then waits for every patch request in flight.
+typedef __attribute__((address_space(1))) char gchar;
+__device__ __forceinline__ gchar* uniform_gptr(const void* q) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (gchar*)(((unsigned long long)hi << 32) | lo);
+}
+typedef __attribute__((address_space(1))) bf16x8 g_bf16x8;
+typedef __attribute__((address_space(1))) bf16x4 g_bf16x4;
 
 // BNZ: the data-gradient form (activation mask + BatchNorm-backward sums in the epilogue, p.bn_z != null) is its own instantiation, so
 // that its epilogue -- which keeps a batch of z rows in flight -- does not weigh on the register allocation of the forward kernel.
@@ -195,6 +220,18 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
     auto load_slot = [&](int l) {
         // UNCONDITIONAL loads from clamped (always valid) addresses, zeroed at the LDS write: a branch per slot makes
         // the compiler wait for each load before the next one is issued (one HBM round trip per slot)
+#if C64_ROWMAP
+        {
+            const int r = l / p.ncb, cb = l - r * p.ncb;                         // (uniform)
+            const int ih = nih0 + r, iw = cb * 64 + (tid >> 3) - 1;
+            const bool ok = (unsigned)ih < (unsigned)p.H && r < p.PR && (unsigned)iw < (unsigned)p.W;
+            rok |= (ok ? 1u : 0u) << l;
+            const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
+            const char* rowp = nimg + (size_t)((unsigned)(ihc * p.W) * (unsigned)(C64 * 2));      // (uniform)
+            rp[l] = *reinterpret_cast<const bf16x8*>(rowp + ((unsigned)iwc * (C64 * 2) + ech * 16));
+            return;
+        }
+#endif
         const int ih = nih0 + cpr, iw = cpc - 1;
         const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && tid + l * NT3 < nslots;
         rok |= (ok ? 1u : 0u) << l;
@@ -244,10 +281,20 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
                 sh = load_f32x8(p.in_shift + (size_t)g * p.in_gstride + ech * 8);
             }
             const bool relu_bn = p.in_scale && p.act == ACT_RELU;
+            int tido = tid;                                   // (opaque per tile: the slots' LDS addresses are tile-invariant and would be hoisted as a 10-register table)
+            asm volatile("" : "+v"(tido));
 #pragma unroll
             for (int l = 0; l < MAXSLOT3; ++l) {
-                const int e = tid + l * NT3;
-                if (e < nslots) {
+#if C64_ROWMAP
+                const int sr = l / p.ncb, scol = (l - sr * p.ncb) * 64 + (tid >> 3);
+                const bool in_patch = sr < p.PR && scol < p.PW;
+                const int spix = sr * p.PW + scol;
+#else
+                const int e = tido + l * NT3;
+                const bool in_patch = e < nslots;
+                const int spix = e >> 3;
+#endif
+                if (in_patch) {
                     bf16x8 v = rp[l];
                     if (relu_bn) v = bn_relu8(v, sc, sh);                       // (uniform)
                     else if (p.in_scale) {
@@ -257,7 +304,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
                         v = f32_to_bf8(f);
                     }
                     if (!((rok >> l) & 1u)) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                    *reinterpret_cast<bf16x8*>(s_patch + (e >> 3) * PP + ech * 16) = v;
+                    *reinterpret_cast<bf16x8*>(s_patch + spix * PP + (tido & 7) * 16) = v;
                 }
             }
         }
@@ -318,6 +365,94 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
         else mfma_loop(std::integral_constant<int, 3>{});
         if constexpr (BNZ) asm volatile("" ::"v"(ztouch));   // (keeps the touch load's destination allocated until it has landed)
         C64_TS(4);
+#if C64_DIRECT_EPI
+        if constexpr (!BNZ) {
+            // ---- forward epilogue straight from the accumulators.  A lane of the D fragment holds channels ct*16 + lg*4 .. +3 of pixel li;
+            // after v_permlane16_swap of the packed words of cout tiles (2c, 2c+1) a lane holds 8 consecutive channels -- row 0: tile 2c
+            // channels 0-7, row 1: tile 2c+1 channels 0-7, row 2: tile 2c 8-15, row 3: tile 2c+1 8-15 -- i.e. a 16-byte store per lane and
+            // 64 contiguous bytes per pixel and instruction (8-byte stores are issue-bound: twice the instructions for the same bytes).
+            gchar* yb = uniform_gptr(p.y + (size_t)g * p.gxy + ((size_t)n * p.H + oh0) * p.W * C64);
+            // (the lane's offsets are tile-invariant: recomputed per tile from opaque copies of the lane coordinates -- hoisted out of the
+            // tile loop they become long-lived registers, spill, and every reload waits for ALL loads and stores in flight, vmcnt(0))
+            int lio = li, lgo = lg;
+            asm volatile("" : "+v"(lio), "+v"(lgo));
+            const int chb = ((lgo & 1) * 16 + (lgo >> 1) * 8) * 2;          // byte offset of this lane's 8 channels within a tile pair
+            auto direct = [&](auto npt_c, auto full_c) {
+                constexpr int NPT = decltype(npt_c)::value;
+                constexpr bool FULL = decltype(full_c)::value;
+                float ssum[4][4], ssq[4][4];                 // this tile's sums of channel ct * 16 + lg * 4 + r over the lane's pixels
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) { ssum[a][b] = 0.f; ssq[a][b] = 0.f; }
+#pragma unroll
+                for (int j = 0; j < NPT; ++j) {
+                    const int q = (wave + 8 * j) * 16 + lio;
+                    const bool live = FULL || q < npx;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        union { bf16x4 v; unsigned w[2]; } a, b;
+                        a.v = f32_to_bf4(acc[2 * c][j]);
+                        b.v = f32_to_bf4(acc[2 * c + 1][j]);
+                        if (p.stats) {                                   // (uniform)
+                            f32x4 fa = bf4_to_f32(a.v), fb = bf4_to_f32(b.v);
+                            if (!live) { fa = f32x4{0.f, 0.f, 0.f, 0.f}; fb = fa; }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                ssum[2 * c][r] += fa[r]; ssq[2 * c][r] += fa[r] * fa[r];
+                                ssum[2 * c + 1][r] += fb[r]; ssq[2 * c + 1][r] += fb[r] * fb[r];
+                            }
+                        }
+                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a.w[0]), "+v"(b.w[0]));
+                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a.w[1]), "+v"(b.w[1]));
+                        union { unsigned w[4]; bf16x8 v; } o;
+                        o.w[0] = a.w[0]; o.w[1] = a.w[1]; o.w[2] = b.w[0]; o.w[3] = b.w[1];
+                        if (live) *(g_bf16x8*)(yb + ((unsigned)q * (C64 * 2) + chb) + c * 64) = o.v;
+                    }
+                }
+                if (p.stats) {
+                    // the 16 lanes of a row hold the same channels: rotate-and-add within the row (DPP), lane 0 of the row adds into this
+                    // wave's own row of cs (one owner lane per entry, tile order: reproducible)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float a = ssum[ct][r], b = ssq[ct][r];
+                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x128, 0xf, 0xf, false));
+                            b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x128, 0xf, 0xf, false));
+                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x124, 0xf, 0xf, false));
+                            b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x124, 0xf, 0xf, false));
+                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x122, 0xf, 0xf, false));
+                            b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x122, 0xf, 0xf, false));
+                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x121, 0xf, 0xf, false));
+                            b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x121, 0xf, 0xf, false));
+                            ssum[ct][r] = a; ssq[ct][r] = b;
+                        }
+                    if (lio == 0) {
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct) {
+                            f32x4* ps = reinterpret_cast<f32x4*>(csw + ct * 16 + lgo * 4);
+                            f32x4* pq = reinterpret_cast<f32x4*>(csw + 64 + ct * 16 + lgo * 4);
+                            f32x4 vs = *ps, vq = *pq;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { vs[r] += ssum[ct][r]; vq[r] += ssq[ct][r]; }
+                            *ps = vs; *pq = vq;
+                        }
+                    }
+                }
+            };
+            const bool full = (npx & 15) == 0;
+            if (__builtin_amdgcn_readfirstlane(last_live ? 1 : 0)) {
+                if (full) direct(std::integral_constant<int, 4>{}, std::true_type{}); else direct(std::integral_constant<int, 4>{}, std::false_type{});
+            } else if (full && (wave + 16) * 16 < npx) direct(std::integral_constant<int, 3>{}, std::true_type{});
+            else direct(std::integral_constant<int, 4>{}, std::false_type{});
+            C64_TS(5); C64_TS(6); C64_TS(7); C64_TS(8);
+            __syncthreads();                                 // patch consumed by every wave before the next one is staged
+            C64_TS(9);
+            C64_TS_FLUSH;
+            continue;
+        }
+#endif
         __syncthreads();                                     // patch consumed: its LDS becomes the staging tile
         C64_TS(5);
 
@@ -469,19 +604,6 @@ constexpr int LDS2 = C64 * WROW2 + 2 * PATCH2;       // 163 840 = all of a CU's 
 #ifndef C64_PP_DEFAULT
 #define C64_PP_DEFAULT 0                             // measured slower than the one-group kernel (profiles/r05_c64_two_phase_probe.txt): off
 #endif
-
-// A wave-uniform GLOBAL pointer moved into scalar registers (64-bit products are computed on the VALU and stay in vector registers
-// otherwise: every access through them then needs a per-lane 64-bit add instead of the scalar-base + 32-bit-offset addressing mode).
-// The result keeps the global address space: through a plain integer round trip the compiler no longer knows it and emits FLAT
-// accesses, which also count on lgkmcnt -- the phase barrier's `s_waitcnt lgkmcnt(0)` then waits for every patch request in flight.
-typedef __attribute__((address_space(1))) char gchar;
-__device__ __forceinline__ gchar* uniform_gptr(const void* q) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (gchar*)(((unsigned long long)hi << 32) | lo);
-}
-typedef __attribute__((address_space(1))) bf16x8 g_bf16x8;
-typedef __attribute__((address_space(1))) bf16x4 g_bf16x4;
 
 template <bool BNZ>
 __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_pp_kernel(C3P p) {
@@ -1002,7 +1124,7 @@ static int c3_rows(const adamml_conv_desc_t* d, int pitch) {
             if (d->H % r == 0) { pick = r; break; }
         const int PR = pick + 2, PW = d->W + 2;
         const size_t patch = (size_t)PR * PW * pitch, stage = (size_t)((pick * d->W + 31) / 32 * 32) * SROW3;
-        if (PR * PW * 8 <= MAXSLOT3 * NT3 && (pick * d->W + 31) / 32 * 2 <= 8 * MAXPT &&
+        if (PR * PW * 8 <= MAXSLOT3 * NT3 && (pick * d->W + 31) / 32 * 2 <= 8 * MAXPT && (!C64_ROWMAP || PR * ((PW + 63) / 64) <= MAXSLOT3) &&
             C64 * WROW3 + CS3_BYTES + (patch > stage ? patch : stage) <= 160 * 1024)
             return pick;
     }
@@ -1074,6 +1196,7 @@ int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const 
     static const int wswz = getenv("ADAMML_C64_WSWZ") ? atoi(getenv("ADAMML_C64_WSWZ")) & 1 : 1;
     p.wswz = wswz;
     p.R = R; p.PR = R + 2; p.PW = d->W + 2;
+    p.ncb = (p.PW + 63) / 64;
     p.npt = (R * d->W + 31) / 32 * 2;            // staged rows cover whole 32-pixel statistic steps
     const int groups = d->groups < 1 ? 1 : d->groups;
     p.tiles_per_img = ceil_div(d->H, R);
