@@ -54,17 +54,6 @@ constexpr int PPIX = C64 * 2 + 16;       // patch pixel pitch: 144 B
 #define C64_STAGGER 94                   // s_sleep units (64 cycles) per phase step; 0 = off (A/B aid)
 #endif
 #define C64_STAGGER_PH 4
-// Round 5 (A/B aids, tools/c64_ab.py): C64_ROWMAP -- patch slot l of a thread is patch ROW l / ncb, column block l % ncb (64 pixel columns
-// per block), so a request's row address is wave-uniform (scalar registers) and its column offset a per-thread constant: the slot-to-slot
-// (row, column) carry chain (12 VALU instructions per request) is gone.  C64_DIRECT_EPI -- the forward epilogue stores straight from the
-// accumulators (pairs of cout tiles exchanged with v_permlane16_swap so that a lane holds 8 consecutive channels: 16-byte stores, 64
-// contiguous bytes per pixel and instruction) and keeps the statistics in registers: no staging tile, two barriers per tile fewer.
-#ifndef C64_ROWMAP
-#define C64_ROWMAP 0
-#endif
-#ifndef C64_DIRECT_EPI
-#define C64_DIRECT_EPI 1
-#endif
 #define C64_STAGGER_START do { if (C64_STAGGER && p.tpb >= 8 && blockIdx.x < 256) { const int ph = (blockIdx.x >> 3) & (C64_STAGGER_PH - 1); for (int i = 0; i < ph; ++i) __builtin_amdgcn_s_sleep(C64_STAGGER); } } while (0)
 constexpr int SROW3 = C64 * 2 + 8;       // staging row: 136 B (144 measured the same)
 constexpr int MAXPT = 4;                 // pixel tiles (16 px) per wave
@@ -85,8 +74,6 @@ struct C3P {
     int PW, PR, npt;         // patch width / rows (pixels); pixel tiles per tile
     int in_gstride;
     int wswz;                // 1: weight rows stored with the chunk swizzle (A/B aid ADAMML_C64_WSWZ)
-    int nbg, spb;            // conv3x3_c64_pp_kernel: workgroups per BatchNorm group, strips per workgroup
-    int ncb;                 // C64_ROWMAP: 64-pixel column blocks of a patch row
     size_t gxy;              // elements per group of x and y (same shape)
 };
 
@@ -146,19 +133,6 @@ __device__ __forceinline__ void fold16_to_cs(const f32x8& esum, const f32x8& esq
         }
     }
 }
-
-// A wave-uniform GLOBAL pointer moved into scalar registers (64-bit products are computed on the VALU and stay in vector registers
-// otherwise: every access through them then needs a per-lane 64-bit add instead of the scalar-base + 32-bit-offset addressing mode).
-// The result keeps the global address space: through a plain integer round trip the compiler no longer knows it and emits FLAT
-// accesses, which also count on lgkmcnt -- the phase barrier's `s_waitcnt lgkmcnt(0)` then waits for every patch request in flight.
-typedef __attribute__((address_space(1))) char gchar;
-__device__ __forceinline__ gchar* uniform_gptr(const void* q) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (gchar*)(((unsigned long long)hi << 32) | lo);
-}
-typedef __attribute__((address_space(1))) bf16x8 g_bf16x8;
-typedef __attribute__((address_space(1))) bf16x4 g_bf16x4;
 
 // BNZ: the data-gradient form (activation mask + BatchNorm-backward sums in the epilogue, p.bn_z != null) is its own instantiation, so
 // that its epilogue -- which keeps a batch of z rows in flight -- does not weigh on the register allocation of the forward kernel.
@@ -220,18 +194,6 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
     auto load_slot = [&](int l) {
         // UNCONDITIONAL loads from clamped (always valid) addresses, zeroed at the LDS write: a branch per slot makes
         // the compiler wait for each load before the next one is issued (one HBM round trip per slot)
-#if C64_ROWMAP
-        {
-            const int r = l / p.ncb, cb = l - r * p.ncb;                         // (uniform)
-            const int ih = nih0 + r, iw = cb * 64 + (tid >> 3) - 1;
-            const bool ok = (unsigned)ih < (unsigned)p.H && r < p.PR && (unsigned)iw < (unsigned)p.W;
-            rok |= (ok ? 1u : 0u) << l;
-            const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
-            const char* rowp = nimg + (size_t)((unsigned)(ihc * p.W) * (unsigned)(C64 * 2));      // (uniform)
-            rp[l] = *reinterpret_cast<const bf16x8*>(rowp + ((unsigned)iwc * (C64 * 2) + ech * 16));
-            return;
-        }
-#endif
         const int ih = nih0 + cpr, iw = cpc - 1;
         const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && tid + l * NT3 < nslots;
         rok |= (ok ? 1u : 0u) << l;
@@ -281,20 +243,10 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
                 sh = load_f32x8(p.in_shift + (size_t)g * p.in_gstride + ech * 8);
             }
             const bool relu_bn = p.in_scale && p.act == ACT_RELU;
-            int tido = tid;                                   // (opaque per tile: the slots' LDS addresses are tile-invariant and would be hoisted as a 10-register table)
-            asm volatile("" : "+v"(tido));
 #pragma unroll
             for (int l = 0; l < MAXSLOT3; ++l) {
-#if C64_ROWMAP
-                const int sr = l / p.ncb, scol = (l - sr * p.ncb) * 64 + (tid >> 3);
-                const bool in_patch = sr < p.PR && scol < p.PW;
-                const int spix = sr * p.PW + scol;
-#else
-                const int e = tido + l * NT3;
-                const bool in_patch = e < nslots;
-                const int spix = e >> 3;
-#endif
-                if (in_patch) {
+                const int e = tid + l * NT3;
+                if (e < nslots) {
                     bf16x8 v = rp[l];
                     if (relu_bn) v = bn_relu8(v, sc, sh);                       // (uniform)
                     else if (p.in_scale) {
@@ -304,7 +256,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
                         v = f32_to_bf8(f);
                     }
                     if (!((rok >> l) & 1u)) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                    *reinterpret_cast<bf16x8*>(s_patch + spix * PP + (tido & 7) * 16) = v;
+                    *reinterpret_cast<bf16x8*>(s_patch + (e >> 3) * PP + ech * 16) = v;
                 }
             }
         }
@@ -365,94 +317,6 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
         else mfma_loop(std::integral_constant<int, 3>{});
         if constexpr (BNZ) asm volatile("" ::"v"(ztouch));   // (keeps the touch load's destination allocated until it has landed)
         C64_TS(4);
-#if C64_DIRECT_EPI
-        if constexpr (!BNZ) {
-            // ---- forward epilogue straight from the accumulators.  A lane of the D fragment holds channels ct*16 + lg*4 .. +3 of pixel li;
-            // after v_permlane16_swap of the packed words of cout tiles (2c, 2c+1) a lane holds 8 consecutive channels -- row 0: tile 2c
-            // channels 0-7, row 1: tile 2c+1 channels 0-7, row 2: tile 2c 8-15, row 3: tile 2c+1 8-15 -- i.e. a 16-byte store per lane and
-            // 64 contiguous bytes per pixel and instruction (8-byte stores are issue-bound: twice the instructions for the same bytes).
-            gchar* yb = uniform_gptr(p.y + (size_t)g * p.gxy + ((size_t)n * p.H + oh0) * p.W * C64);
-            // (the lane's offsets are tile-invariant: recomputed per tile from opaque copies of the lane coordinates -- hoisted out of the
-            // tile loop they become long-lived registers, spill, and every reload waits for ALL loads and stores in flight, vmcnt(0))
-            int lio = li, lgo = lg;
-            asm volatile("" : "+v"(lio), "+v"(lgo));
-            const int chb = ((lgo & 1) * 16 + (lgo >> 1) * 8) * 2;          // byte offset of this lane's 8 channels within a tile pair
-            auto direct = [&](auto npt_c, auto full_c) {
-                constexpr int NPT = decltype(npt_c)::value;
-                constexpr bool FULL = decltype(full_c)::value;
-                float ssum[4][4], ssq[4][4];                 // this tile's sums of channel ct * 16 + lg * 4 + r over the lane's pixels
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) { ssum[a][b] = 0.f; ssq[a][b] = 0.f; }
-#pragma unroll
-                for (int j = 0; j < NPT; ++j) {
-                    const int q = (wave + 8 * j) * 16 + lio;
-                    const bool live = FULL || q < npx;
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        union { bf16x4 v; unsigned w[2]; } a, b;
-                        a.v = f32_to_bf4(acc[2 * c][j]);
-                        b.v = f32_to_bf4(acc[2 * c + 1][j]);
-                        if (p.stats) {                                   // (uniform)
-                            f32x4 fa = bf4_to_f32(a.v), fb = bf4_to_f32(b.v);
-                            if (!live) { fa = f32x4{0.f, 0.f, 0.f, 0.f}; fb = fa; }
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                ssum[2 * c][r] += fa[r]; ssq[2 * c][r] += fa[r] * fa[r];
-                                ssum[2 * c + 1][r] += fb[r]; ssq[2 * c + 1][r] += fb[r] * fb[r];
-                            }
-                        }
-                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a.w[0]), "+v"(b.w[0]));
-                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a.w[1]), "+v"(b.w[1]));
-                        union { unsigned w[4]; bf16x8 v; } o;
-                        o.w[0] = a.w[0]; o.w[1] = a.w[1]; o.w[2] = b.w[0]; o.w[3] = b.w[1];
-                        if (live) *(g_bf16x8*)(yb + ((unsigned)q * (C64 * 2) + chb) + c * 64) = o.v;
-                    }
-                }
-                if (p.stats) {
-                    // the 16 lanes of a row hold the same channels: rotate-and-add within the row (DPP), lane 0 of the row adds into this
-                    // wave's own row of cs (one owner lane per entry, tile order: reproducible)
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float a = ssum[ct][r], b = ssq[ct][r];
-                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x128, 0xf, 0xf, false));
-                            b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x128, 0xf, 0xf, false));
-                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x124, 0xf, 0xf, false));
-                            b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x124, 0xf, 0xf, false));
-                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x122, 0xf, 0xf, false));
-                            b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x122, 0xf, 0xf, false));
-                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x121, 0xf, 0xf, false));
-                            b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x121, 0xf, 0xf, false));
-                            ssum[ct][r] = a; ssq[ct][r] = b;
-                        }
-                    if (lio == 0) {
-#pragma unroll
-                        for (int ct = 0; ct < 4; ++ct) {
-                            f32x4* ps = reinterpret_cast<f32x4*>(csw + ct * 16 + lgo * 4);
-                            f32x4* pq = reinterpret_cast<f32x4*>(csw + 64 + ct * 16 + lgo * 4);
-                            f32x4 vs = *ps, vq = *pq;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { vs[r] += ssum[ct][r]; vq[r] += ssq[ct][r]; }
-                            *ps = vs; *pq = vq;
-                        }
-                    }
-                }
-            };
-            const bool full = (npx & 15) == 0;
-            if (__builtin_amdgcn_readfirstlane(last_live ? 1 : 0)) {
-                if (full) direct(std::integral_constant<int, 4>{}, std::true_type{}); else direct(std::integral_constant<int, 4>{}, std::false_type{});
-            } else if (full && (wave + 16) * 16 < npx) direct(std::integral_constant<int, 3>{}, std::true_type{});
-            else direct(std::integral_constant<int, 4>{}, std::false_type{});
-            C64_TS(5); C64_TS(6); C64_TS(7); C64_TS(8);
-            __syncthreads();                                 // patch consumed by every wave before the next one is staged
-            C64_TS(9);
-            C64_TS_FLUSH;
-            continue;
-        }
-#endif
         __syncthreads();                                     // patch consumed: its LDS becomes the staging tile
         C64_TS(5);
 
@@ -573,343 +437,6 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_kernel(C3P p) {
     if (p.stats && cur_group >= 0) {
         __syncthreads();
         publish(cur_group);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 5: the same convolution as TWO WAVE GROUPS IN OPPOSITE PHASES (models/resnet.py:37-43,87-88 forward, its data gradient with
-// the flipped pack).  conv3x3_c64_kernel above is bound by the serial phases of its one workgroup per CU (tools/c64_phase_probe.py:
-// 22 500 cycles per 448-pixel tile for 8 064 cycles of MFMA issue -- while the CU computes HBM idles, while it stages or stores the
-// matrix cores idle).  Here waves 0-3 (one per SIMD) and waves 4-7 (their SIMD mates) each own a 4-row half strip with its OWN patch
-// buffer and alternate roles, one workgroup barrier per phase:
-//     compute role : 18 K steps of MFMA from LDS (weights + own patch), accumulators stay in registers;
-//     stage role   : the patch of its next strip (requested two phases earlier, BatchNorm + ReLU of the producer applied once) -> LDS,
-//                    then the EPILOGUE of the strip it computed in the previous phase STRAIGHT FROM THE ACCUMULATORS (a lane of the
-//                    D fragment owns 4 consecutive output channels of one pixel: 8-byte stores, four of them complete a 128-byte
-//                    line; statistics / BatchNorm-backward sums accumulate in registers) -- no staging tile, no extra barriers --,
-//                    then the requests for the strip after next.
-// So every SIMD always has one wave issuing MFMAs and one wave doing VALU / memory work.  LDS: weights 64 x 1152 B (unpadded; chunk c
-// of row r at c ^ ((r >> 1) & 7): conflict-free fragment reads) + 2 patches of (R + 2) x (W + 2) pixels x 128 B (chunk c of patch pixel
-// P at c ^ (P & 7): conflict-free for 16 consecutive pixels, 2-way where a pixel tile wraps to the next image row: 4.6 LDS cycles per
-// ds_read_b128 on average against 8.6 for the 144-byte pitch, tools/lds_pitch_search.py) (padded to 352 pixels) = exactly the 160 KB of a CU.
-// A workgroup works inside ONE BatchNorm group (grid = groups x blocks per group): one publication of its sums at the end.
-constexpr int WROW2 = KT3 * 2;                       // 1152
-constexpr int PATCH2 = 352 * 128;                    // bytes per patch buffer: (R + 2) * (W + 2) <= 352 pixels = 11 slots x 256 threads / 8 chunks
-constexpr int NTG2 = 256;                            // threads per phase group
-constexpr int MAXSLOT2 = 11;                         // 16-byte patch slots per thread (352 * 8 / 256)
-constexpr int LDS2 = C64 * WROW2 + 2 * PATCH2;       // 163 840 = all of a CU's LDS
-#ifndef C64_PP_PRIO
-#define C64_PP_PRIO 0
-#endif
-#ifndef C64_PP_DEFAULT
-#define C64_PP_DEFAULT 0                             // measured slower than the one-group kernel (profiles/r05_c64_two_phase_probe.txt): off
-#endif
-
-template <bool BNZ>
-__global__ __launch_bounds__(NT3, 1) void conv3x3_c64_pp_kernel(C3P p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_w = smem;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gi = wave >> 2, wq = wave & 3;                     // phase group; wave within the group
-    const int tg = tid & (NTG2 - 1);
-    const int li = lane & 15, lg = lane >> 4;
-    char* mybuf = smem + C64 * WROW2 + gi * PATCH2;
-    const int g = blockIdx.x / p.nbg, bi = blockIdx.x - g * p.nbg;
-    const int s0 = bi * p.spb;
-    const int n = min(p.spb, p.tiles_per_group - s0);           // strips of this workgroup (uniform)
-    if (n <= 0) return;
-
-    for (int e = tid; e < C64 * (KT3 / 8); e += NT3) {
-        const int co = e / (KT3 / 8), ch = e - co * (KT3 / 8);
-        *reinterpret_cast<bf16x8*>(s_w + co * WROW2 + (((ch & ~7) | ((ch & 7) ^ ((co >> 1) & 7))) << 4)) =
-            *reinterpret_cast<const bf16x8*>(p.w + (size_t)co * KT3 + ch * 8);
-    }
-
-    // ---- patch slots of this group: slot l of thread tg is patch pixel P = (tg >> 3) + 32 l, chunk tg & 7, stored at P * 128 + ((chunk ^ (P & 7)) << 4).
-    // All MAXSLOT2 slots of every thread are loaded (clamped addresses) and written (the buffer is padded to 352 pixels; slots beyond
-    // the patch carry zeros): no branch in the request or staging code, so the slots' dependency chains interleave.
-    const int nslots = p.PR * p.PW * 8;
-    const int ech = tg & 7;
-    const int pstep_r = 32 / p.PW, pstep_c = 32 - pstep_r * p.PW;
-    const int pr0 = (tg >> 3) / p.PW, pc0 = (tg >> 3) - pr0 * p.PW;
-    const int wpos = (tg >> 3) * 128 + ((ech ^ ((tg >> 3) & 7)) << 4);
-    int cpr = pr0, cpc = pc0;
-    bf16x8 rp[MAXSLOT2];
-    unsigned rok = 0;
-    const char* gbase = reinterpret_cast<const char*>(p.x + (size_t)g * p.gxy);
-    auto issue = [&](int s) {                                    // request the patch of strip s (index within the group)
-        const int im = s / p.tiles_per_img, tr = s - im * p.tiles_per_img;
-        const int nih0 = tr * p.R - 1;
-        const gchar* nimg = uniform_gptr(gbase + (size_t)im * p.H * p.W * (C64 * 2));
-        rok = 0;
-        cpr = pr0; cpc = pc0;
-        asm volatile("" : "+v"(cpr), "+v"(cpc));                 // (opaque: see conv3x3_c64_kernel)
-#pragma unroll
-        for (int l = 0; l < MAXSLOT2; ++l) {
-            const int ih = nih0 + cpr, iw = cpc - 1;
-            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && tg + l * NTG2 < nslots;
-            rok |= (ok ? 1u : 0u) << l;
-            const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
-            const unsigned off = (unsigned)(ihc * p.W + iwc) * (C64 * 2) + ech * 16;
-            rp[l] = *(const g_bf16x8*)(nimg + off);
-            cpc += pstep_c;
-            const bool wrap = cpc >= p.PW;
-            cpc -= wrap ? p.PW : 0;
-            cpr += pstep_r + (wrap ? 1 : 0);
-        }
-    };
-    auto stage = [&]() {                                         // requested patch -> own LDS buffer
-        if constexpr (!BNZ) {                                    // (the BatchNorm-fused data gradient reads a materialised dz: no transform)
-            if (p.in_scale) {                                    // (uniform; one branch around ALL slots)
-                const f32x8 sc = load_f32x8(p.in_scale + (size_t)g * p.in_gstride + ech * 8);
-                const f32x8 sh = load_f32x8(p.in_shift + (size_t)g * p.in_gstride + ech * 8);
-                if (p.act == ACT_RELU) {
-#pragma unroll
-                    for (int l = 0; l < MAXSLOT2; ++l) rp[l] = bn_relu8(rp[l], sc, sh);
-                } else {
-                    const float lo = act_lo(p.act), hi = act_hi(p.act);
-#pragma unroll
-                    for (int l = 0; l < MAXSLOT2; ++l) {
-                        f32x8 f = bf8_to_f32(rp[l]);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) f[i] = clamp_act(fmaf(f[i], sc[i], sh[i]), lo, hi);
-                        rp[l] = f32_to_bf8(f);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int l = 0; l < MAXSLOT2; ++l) {
-            bf16x8 v = rp[l];
-            if (!((rok >> l) & 1u)) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            *reinterpret_cast<bf16x8*>(mybuf + wpos + l * (32 * 128)) = v;
-        }
-    };
-
-    f32x4 acc[4][4];                                             // [cout tile][own pixel tile j = tile wq + 4 j of the strip]
-    float ssum[4][4], ssq[4][4];                                 // per-lane partial sums of channel ct * 16 + lg * 4 + r
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { ssum[a][b] = 0.f; ssq[a][b] = 0.f; acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const int wsw = (li >> 1) & 7;
-    // weight fragment of (cout tile ct, tap row kh, tap column kw, 32-channel half): row ct * 16 + li, chunks (kh * 3 + kw) * 8 + half * 4 + lg
-    const char* wbase0 = s_w + li * WROW2 + ((lg ^ wsw) << 4);
-    const char* wbase1 = s_w + li * WROW2 + (((4 | lg) ^ wsw) << 4);
-
-    auto strip_geo = [&](int s, int& npx, size_t& obase) {
-        const int im = s / p.tiles_per_img, tr = s - im * p.tiles_per_img;
-        const int oh0 = tr * p.R;
-        npx = min(p.R, p.H - oh0) * p.W;
-        obase = (size_t)g * p.gxy + ((size_t)im * p.H + oh0) * p.W * C64;
-    };
-    // live pixel tiles of this wave in a strip of npx pixels (tiles wq, wq + 4, ..)
-    auto live_tiles = [&](int npx) { return max(0, (((npx + 15) >> 4) - wq + 3) >> 2); };
-
-    auto compute = [&](int s) {
-        int npx; size_t obase;
-        strip_geo(s, npx, obase);
-        unsigned ztouch = 0;
-        if constexpr (BNZ) ztouch = *reinterpret_cast<const unsigned*>(p.bn_z + obase + (size_t)min(tg, npx - 1) * C64);
-        int P0[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            int q = (wq + 4 * j) * 16 + li;
-            if (q >= npx) q = 0;
-            const int r = q / p.W, c = q - r * p.W;
-            P0[j] = r * p.PW + c;
-        }
-        if (C64_PP_PRIO) __builtin_amdgcn_s_setprio(C64_PP_PRIO);
-        // 18 K steps (tap, 32-channel half), SOFTWARE-PIPELINED: the fragments of step k + 1 are requested before the MFMAs of step k (two
-        // fragment sets, scheduling barriers between the steps so that the requests are not hoisted further -- fully unrolled and left to
-        // the scheduler the kernel spilled ~200 registers).  With one MFMA wave per SIMD nothing else hides the LDS round trip: the
-        // unpipelined loop of the one-group kernel ran 34-38 cycles per MFMA here (tools/c64_pp_probe.py) against 17 back to back.
-        auto mfma_loop = [&](auto npt_c) {
-            constexpr int NPT = decltype(npt_c)::value;
-            bf16x8 fwA[4], faA[NPT], fwB[4], faB[NPT];
-            auto ld = [&](int kh, int kk, bf16x8 (&fw)[4], bf16x8 (&fa)[NPT]) {          // kk = (kw, half) compile-time, kh run-time
-                const int kw = kk >> 1, half = kk & 1;
-                const char* wk = (half ? wbase1 : wbase0) + kh * 384 + kw * 128;
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) fw[ct] = *reinterpret_cast<const bf16x8*>(wk + ct * 16 * WROW2);
-#pragma unroll
-                for (int j = 0; j < NPT; ++j) {
-                    const int P = P0[j] + kh * p.PW + kw;
-                    fa[j] = *reinterpret_cast<const bf16x8*>(mybuf + (((P << 7) + ((lg ^ (P & 7)) << 4)) ^ (half << 6)));
-                }
-            };
-            auto mma = [&](bf16x8 (&fw)[4], bf16x8 (&fa)[NPT]) {
-#pragma unroll
-                for (int j = 0; j < NPT; ++j)
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
-                        acc[ct][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ct], fa[j], acc[ct][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            ld(0, 0, fwA, faA);
-#pragma unroll 1
-            for (int kh = 0; kh < 3; ++kh) {
-                ld(kh, 1, fwB, faB); mma(fwA, faA);
-                ld(kh, 2, fwA, faA); mma(fwB, faB);
-                ld(kh, 3, fwB, faB); mma(fwA, faA);
-                ld(kh, 4, fwA, faA); mma(fwB, faB);
-                ld(kh, 5, fwB, faB); mma(fwA, faA);
-                ld(min(kh + 1, 2), 0, fwA, faA); mma(fwB, faB);          // (the last iteration re-reads a valid fragment set it does not use)
-            }
-        };
-        if (__builtin_amdgcn_readfirstlane(live_tiles(npx)) == 4) mfma_loop(std::integral_constant<int, 4>{});
-        else mfma_loop(std::integral_constant<int, 3>{});
-        if (C64_PP_PRIO) __builtin_amdgcn_s_setprio(0);
-        if constexpr (BNZ) asm volatile("" ::"v"(ztouch));      // (one dword per z line of the strip, requested ahead of the MFMA loop: the epilogue's loads hit L2)
-    };
-    // BNZ: z of the D fragments (a lane: 4 consecutive channels of one pixel), requested at the START of the stage role
-    auto load_z = [&](int s, bf16x4 (&zr)[4][4]) {
-        int npx; size_t obase;
-        strip_geo(s, npx, obase);
-        const gchar* zb = uniform_gptr(p.bn_z + obase);          // (uniform 64-bit base + 32-bit lane offsets)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned off = (unsigned)min((wq + 4 * j) * 16 + li, npx - 1) * (C64 * 2) + lg * 8;
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) zr[ct][j] = *(const g_bf16x4*)(zb + off + ct * 32);
-        }
-    };
-    // epilogue of strip s straight from the accumulators.  NPT live tiles; FULL: every pixel of them is live (no per-lane test, no
-    // exec-masked branch around each store)
-    auto epilogue = [&](int s, auto npt_c, auto full_c, bf16x4 (&zr)[4][4]) {
-        constexpr int NPT = decltype(npt_c)::value;
-        constexpr bool FULL = decltype(full_c)::value;
-        int npx; size_t obase;
-        strip_geo(s, npx, obase);
-        gchar* yb = uniform_gptr(p.y + obase);
-        const float* cv = p.bn_vec + (size_t)g * 256;            // BNZ: [4][64] scale, shift, mean, invstd of this BatchNorm group
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            f32x4 bsc, bsh, mu;                                  // (invstd multiplies the folded sum once, at publication)
-            if constexpr (BNZ) {
-                bsc = *reinterpret_cast<const f32x4*>(cv + ct * 16 + lg * 4);
-                bsh = *reinterpret_cast<const f32x4*>(cv + 64 + ct * 16 + lg * 4);
-                mu = *reinterpret_cast<const f32x4*>(cv + 128 + ct * 16 + lg * 4);
-            }
-#pragma unroll
-            for (int j = 0; j < NPT; ++j) {
-                const int q = (wq + 4 * j) * 16 + li;
-                const bool live = FULL || q < npx;
-                f32x4 f = acc[ct][j];
-                f32x4 zv = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (BNZ) {
-                    zv = bf4_to_f32(zr[ct][j]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) f[r] = fmaf(zv[r], bsc[r], bsh[r]) > 0.f ? f[r] : 0.f;
-                }
-                const bf16x4 o = f32_to_bf4(f);
-                if (live) *(g_bf16x4*)(yb + ((unsigned)q * (C64 * 2) + lg * 8) + ct * 32) = o;
-                f32x4 fr = bf4_to_f32(o);
-                if (!live) fr = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ssum[ct][r] += fr[r];
-                    if constexpr (BNZ) ssq[ct][r] += fr[r] * (zv[r] - mu[r]);
-                    else ssq[ct][r] += fr[r] * fr[r];
-                }
-            }
-        }
-    };
-    auto epilogue_any = [&](int s, bf16x4 (&zr)[4][4]) {
-        int npx; size_t obase;
-        strip_geo(s, npx, obase);
-        const int nl = __builtin_amdgcn_readfirstlane(live_tiles(npx));
-        if ((npx & 15) == 0 && nl == 4) epilogue(s, std::integral_constant<int, 4>{}, std::true_type{}, zr);
-        else if ((npx & 15) == 0 && nl == 3) epilogue(s, std::integral_constant<int, 3>{}, std::true_type{}, zr);
-        else epilogue(s, std::integral_constant<int, 4>{}, std::false_type{}, zr);
-    };
-
-    // ---- prologue: group 0 stages strip 0 (and requests strip 2), group 1 requests strip 1 -------------------------------------------
-    // (requests and staging are UNCONDITIONAL, of a clamped strip index: a request the compiler sees on every path ends the life of the
-    // previous patch registers at its staging -- behind `if (ph + 3 < n)` they stayed allocated through the epilogue, which then spilled;
-    // the price is two redundant patch requests at the end of a workgroup's ~40 strips)
-    if (gi == 0) {
-        issue(s0);
-        stage();
-        issue(s0 + min(2, n - 1));
-    } else issue(s0 + min(1, n - 1));
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-#ifdef C64_PHASE_TIMING
-    // tools/c64_pp_probe.py: cycles per role segment, summed over the phases of one workgroup (per wave)
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev;
-#define PP_T0 tprev = __builtin_readcyclecounter()
-#define PP_T(k) do { const unsigned long long tn_ = __builtin_readcyclecounter(); tacc[k] += tn_ - tprev; tprev = tn_; } while (0)
-#else
-#define PP_T0 do { } while (0)
-#define PP_T(k) do { } while (0)
-#endif
-    for (int ph = 0; ph <= n; ++ph) {
-        PP_T0;
-        if ((ph & 1) == gi) {
-            if (ph < n) compute(s0 + ph);
-            PP_T(0);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            PP_T(1);
-        } else {
-            bf16x4 zr[4][4];
-            if constexpr (BNZ) {
-                if (ph >= 1) load_z(s0 + ph - 1, zr);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            stage();                                             // strip ph + 1 (requested two phases ago)
-            __builtin_amdgcn_sched_barrier(0);
-            PP_T(2);
-            if (ph >= 1) epilogue_any(s0 + ph - 1, zr);
-            __builtin_amdgcn_sched_barrier(0);
-            PP_T(3);
-            issue(s0 + min(ph + 3, n - 1));
-            PP_T(4);
-            // LDS writes of the stage role drained; loads and stores in flight cross the barrier (a __syncthreads() would wait for them)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            PP_T(5);
-        }
-    }
-#ifdef C64_PHASE_TIMING
-    if (c64_dbg && blockIdx.x == 8 && lane == 0) {
-        for (int k = 0; k < 6; ++k) c64_dbg[wave * 8 + k] = (unsigned)tacc[k];
-        c64_dbg[wave * 8 + 6] = (unsigned)n;
-    }
-#endif
-
-    if (p.stats) {
-        // lanes li = 0..15 of a 16-lane row hold partial sums of the same 16 channels: fold the row (fixed order), then the waves in order
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    ssum[ct][r] += __shfl_xor(ssum[ct][r], m, 16);
-                    ssq[ct][r] += __shfl_xor(ssq[ct][r], m, 16);
-                }
-            }
-        float* fold = reinterpret_cast<float*>(smem + C64 * WROW2);      // (both patch buffers are dead)
-        if (li == 0) {
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    fold[wave * 128 + ct * 16 + lg * 4 + r] = ssum[ct][r];
-                    fold[wave * 128 + 64 + ct * 16 + lg * 4 + r] = ssq[ct][r];
-                }
-        }
-        __syncthreads();
-        if (tid < 128) {
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) v += fold[w * 128 + tid];
-            if constexpr (BNZ) { if (tid >= 64) v *= p.bn_vec[(size_t)g * 256 + 192 + tid - 64]; }       // sum g' (z - mean) -> sum g' zhat
-            stat_publish(p.stats + (size_t)g * ADAMML_STAT_SLOTS * 128 + tid, 128, blockIdx.x & (ADAMML_STAT_SLOTS - 1), v);
-        }
     }
 }
 
@@ -1124,23 +651,11 @@ static int c3_rows(const adamml_conv_desc_t* d, int pitch) {
             if (d->H % r == 0) { pick = r; break; }
         const int PR = pick + 2, PW = d->W + 2;
         const size_t patch = (size_t)PR * PW * pitch, stage = (size_t)((pick * d->W + 31) / 32 * 32) * SROW3;
-        if (PR * PW * 8 <= MAXSLOT3 * NT3 && (pick * d->W + 31) / 32 * 2 <= 8 * MAXPT && (!C64_ROWMAP || PR * ((PW + 63) / 64) <= MAXSLOT3) &&
+        if (PR * PW * 8 <= MAXSLOT3 * NT3 && (pick * d->W + 31) / 32 * 2 <= 8 * MAXPT &&
             C64 * WROW3 + CS3_BYTES + (patch > stage ? patch : stage) <= 160 * 1024)
             return pick;
     }
     return 0;
-}
-
-// rows per half strip of conv3x3_c64_pp_kernel: the largest R with (R + 2) (W + 2) <= 352 patch pixels and R W <= 256 output pixels
-// (preferring, among the top three, one that divides H); 0 when the shape does not fit
-static int c3_rows_pp(const adamml_conv_desc_t* d) {
-    int R = 256 / d->W;
-    while (R >= 1 && (R + 2) * (d->W + 2) * 128 > PATCH2) --R;
-    if (R > d->H) R = d->H;
-    if (R < 1) return 0;
-    for (int r = R; r >= R - 2 && r >= 1; --r)
-        if (d->H % r == 0) return r;
-    return R;
 }
 
 // d: the FORWARD-shaped descriptor of the conv that is executed (for a data gradient: H/W of dz == H/W of dx).
@@ -1158,45 +673,11 @@ int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const 
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.in_scale = in_scale; p.in_shift = in_shift; p.y = (bf16_t*)y;
     p.stats = stats; p.bn_z = (const bf16_t*)bn_z; p.bn_vec = bn_vec; p.bn_act = bn_act; p.act = d->act;
     p.N = d->N; p.H = d->H; p.W = d->W;
-    p.nbg = p.spb = 0;
-    static const int use_pp = getenv("ADAMML_C64_PP") ? atoi(getenv("ADAMML_C64_PP")) : C64_PP_DEFAULT;       // A/B aid: 0 = the one-group kernel of rounds 1-4
-    const int R2 = use_pp && !(bn_z && (in_scale || bn_act != ADAMML_ACT_RELU)) ? c3_rows_pp(d) : 0;
-    if (R2 > 0) {
-        // two wave groups in opposite phases (conv3x3_c64_pp_kernel): half strips of R2 rows, workgroups inside one BatchNorm group
-        const int groups = d->groups < 1 ? 1 : d->groups;
-        p.R = R2; p.PR = R2 + 2; p.PW = d->W + 2;
-        p.npt = ceil_div(R2 * d->W, 16);
-        p.wswz = 1;
-        p.tiles_per_img = ceil_div(d->H, R2);
-        p.tiles_per_group = d->N * p.tiles_per_img;
-        p.total_tiles = groups * p.tiles_per_group;
-        if (p.total_tiles <= 0) return ADAMML_OK;
-        p.tpb = 0;
-        p.in_gstride = d->in_gstride;
-        p.gxy = (size_t)d->N * d->H * d->W * C64;
-        int nbg = 1024 / groups;
-        if (nbg < 1) nbg = 1;
-        if (nbg > p.tiles_per_group) nbg = p.tiles_per_group;
-        p.spb = ceil_div(p.tiles_per_group, nbg);
-        p.nbg = ceil_div(p.tiles_per_group, p.spb);
-        static bool attr_pp = false;
-        if (!attr_pp) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_pp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_pp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv3x3_c64 (two-phase): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-            attr_pp = true;
-        }
-        const dim3 grid2(groups * p.nbg);
-        if (p.bn_z) hipLaunchKernelGGL((conv3x3_c64_pp_kernel<true>), grid2, dim3(NT3), C64_LDS(LDS2), stream, p);
-        else hipLaunchKernelGGL((conv3x3_c64_pp_kernel<false>), grid2, dim3(NT3), C64_LDS(LDS2), stream, p);
-        return adamml_check_launch("conv3x3_c64 (two-phase)");
-    }
     const int pitch = c3_pitch();
     const int R = c3_rows(d, pitch);
     static const int wswz = getenv("ADAMML_C64_WSWZ") ? atoi(getenv("ADAMML_C64_WSWZ")) & 1 : 1;
     p.wswz = wswz;
     p.R = R; p.PR = R + 2; p.PW = d->W + 2;
-    p.ncb = (p.PW + 63) / 64;
     p.npt = (R * d->W + 31) / 32 * 2;            // staged rows cover whole 32-pixel statistic steps
     const int groups = d->groups < 1 ? 1 : d->groups;
     p.tiles_per_img = ceil_div(d->H, R);
