@@ -1,6 +1,9 @@
 """Shared machinery of the HIP backbones: parameter containers with reference-identical state_dict names,
 flat fp32 parameter / gradient buffers, weight re-packing, and the autograd bridge that runs one backbone
 call as a single node (forward = fused HIP launches, backward = the recorded tape in reverse)."""
+import warnings
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -21,6 +24,11 @@ class FlatBuffers:
         self.flat_grad = None
         self.params = []
         self.detached = False       # True: .grad belongs to autograd / torch.optim (enable_autograd_param_grads)
+        # every backbone below `module` reports an assigned / deleted parameter or sub-module (HipBackbone.__setattr__): a swapped `fc`
+        # is re-homed by the NEXT ensure(), not by the every-32nd-call walk (round-4 advisor finding)
+        for m in module.modules():
+            if isinstance(m, HipBackbone):
+                m.__dict__.setdefault("_flat_watchers", []).append(weakref.ref(self))
 
     def invalidate(self):
         """The next ensure() walks the module's parameters again (a parameter object may have been replaced)."""
@@ -270,6 +278,33 @@ class HipBackbone(nn.Module):
         self._precomputed = None
         self._bn_probe = None
 
+    # -- a parameter or sub-module assigned / removed after construction (e.g. a new `fc` for another class count) ---------------
+    def _params_changed(self):
+        self.__dict__.pop("_plist", None)
+        self.__dict__["_packed_version"] = None
+        for ref in self.__dict__.get("_flat_watchers", ()):
+            fb = ref()
+            if fb is not None:
+                fb.invalidate()
+        fo = self.__dict__.get("flat_owner")
+        if fo is not None:
+            fo.invalidate()
+
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        if isinstance(value, (nn.Parameter, nn.Module)):
+            self._params_changed()
+
+    def __delattr__(self, name):
+        watched = name in self._parameters or name in self._modules
+        super().__delattr__(name)
+        if watched:
+            self._params_changed()
+
+    def register_parameter(self, name, param):
+        super().register_parameter(name, param)
+        self._params_changed()
+
     # -- weight packs ------------------------------------------------------------------------------
     def _register_conv(self, conv, depthwise=False):
         cs = ConvState(conv.weight, conv.stride[0], conv.padding[0], depthwise)
@@ -415,7 +450,13 @@ class HipBackbone(nn.Module):
         if isinstance(entry, plan.Plan):
             if entry.busy():                       # an earlier replay still waits for its backward: this call runs eagerly (plan.Plan.busy)
                 plan.stats["busy_fallbacks"] = plan.stats.get("busy_fallbacks", 0) + 1
+                entry.busy_streak = getattr(entry, "busy_streak", 0) + 1
+                if entry.busy_streak == 8:         # (a replayed forward whose graph is kept alive without a backward pins its plan forever)
+                    warnings.warn("adamml launch plan: %d consecutive calls of %s ran eagerly because an earlier replayed forward of the same "
+                                  "call still waits for its backward (outputs kept without detach()?); the plan is bypassed until that "
+                                  "graph is released" % (entry.busy_streak, type(self).__name__))
                 return self._run(x, groups, need_grad=need_grad)
+            entry.busy_streak = 0
             return entry.forward(x)
         seen = entry or 0
         if seen < plan.WARMUP_CALLS or hip.recorder is not None:

@@ -21,9 +21,15 @@ int adamml_check_launch(const char* what) {
 }
 
 // Reproducible reductions are the only mode (csrc/common.h); the two entry points remain so that callers written against the switch of
-// earlier versions keep linking: asking for the non-reproducible form is an error, not a silent no-op.
+// earlier versions keep linking AND keep working: (0) is accepted and ignored (round 4 returned an error, which a caller's
+// `finally: set_deterministic(False)` turned into an exception masking its real result -- round-4 advisor finding), with one warning
+// per process; adamml_get_deterministic() tells the truth.
 extern "C" int adamml_set_deterministic(int on) {
-    if (!on) return adamml_set_error(ADAMML_EUNSUPPORTED, "set_deterministic(0): the per-channel sums are always order-fixed and exact (no other mode exists)");
+    static bool warned = false;
+    if (!on && !warned) {
+        warned = true;
+        fprintf(stderr, "libadamml_hip: set_deterministic(0) ignored: the per-channel sums are always order-fixed and exact (no other mode exists)\n");
+    }
     return ADAMML_OK;
 }
 extern "C" int adamml_get_deterministic(void) { return 1; }

@@ -167,7 +167,9 @@ def load():
 
 def set_deterministic(on=True):
     """Every per-channel statistic is order-fixed and exact (csrc/common.h: reproducible reductions): two runs of the same step are
-    bit-identical, always.  Kept for callers of earlier versions: True is a no-op, False raises (no other mode exists)."""
+    bit-identical, always.  Kept for callers of earlier versions: True and False are both accepted and change nothing (False warns
+    once: a `try: set_deterministic(True) ... finally: set_deterministic(False)` caller keeps working); `deterministic()` stays True.
+    The ADAMML_DETERMINISTIC environment variable of rounds 2-3 is no longer read."""
     lib = _lib if _lib is not None else load()
     rc = lib.adamml_set_deterministic(1 if on else 0)
     if rc != 0:

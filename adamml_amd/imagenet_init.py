@@ -61,13 +61,17 @@ def path_for(arch):
     d = os.environ.get("ADAMML_IMAGENET_DIR")
     if d:
         hits = sorted(glob.glob(os.path.join(d, _FILE_STEMS[arch] + "*.pth")))
+        if len(hits) > 1:
+            warnings.warn("%s: %d files match %s*.pth in $ADAMML_IMAGENET_DIR; using %s (configure the path explicitly to choose another)"
+                          % (arch, len(hits), _FILE_STEMS[arch], hits[0]))
         if hits:
             return hits[0]
     return None
 
 
 def _read(path):
-    sd = torch.load(path, map_location="cpu")
+    # weights_only: the path comes from a command-line flag / an environment variable; a published checkpoint is tensors only
+    sd = torch.load(path, map_location="cpu", weights_only=True)
     if isinstance(sd, dict) and "state_dict" in sd and not any(torch.is_tensor(v) for v in sd.values()):
         sd = sd["state_dict"]
     return {k: v for k, v in sd.items() if torch.is_tensor(v)}

@@ -97,7 +97,8 @@ class Arena:
             if hip.recorder is not None:
                 # a launch plan must replay the memset of the FINAL buffer: an arena that is first sized (or grown) inside the recorded
                 # call -- warm-up forwards that had no backward, another call shape raising `high` in between -- would be accumulated
-                # into without ever being re-zeroed at replay.  This call stays eager; the key is not tried again.
+                # into without ever being re-zeroed at replay.  This call stays eager; with its size known now the arena no longer moves,
+                # so the key is recorded again after the usual warm-up (`retry`).
                 hip.recorder.failed = "statistics arena (re)allocated while recording"
                 hip.recorder.retry = True       # (the arena has its size now: record again after the usual warm-up)
         else:

@@ -38,7 +38,7 @@ cg = [v for k, v in agg.items() if k.startswith("conv_gemm_kernel")]
 cg_calls, cg_ms = sum(v[0] for v in cg), sum(v[1] for v in cg)
 out = []
 out.append("# Round %s profile summary (MI355X, B=72 x 5 segments, single-stream run so that kernel durations are not inflated by overlap)\n" % R[1:].lstrip("0"))
-out.append("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --single-stream --no-cpu-baseline` (`tools/gpu_refresh.sh`;")
+out.append("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --single-stream --no-cpu-baseline` (`tools/gpu_round.sh`;")
 out.append("%d steps: %d warm-up + %d timed + 2 of the roofline leg).  Full per-kernel table: `%s_bench_single_stream_kernel_stats.csv`;" % (steps, ss["warmup"], ss["steps"], R))
 out.append("the JSON line that run printed: `%s_bench_single_stream_under_rocprof.json` (%.1f ms/step); the default multi-stream bench line of the same box:" % (R, ss["ms_per_step"]))
 out.append("`%s_bench_default.json` (**%.0f clips/s, %.1f ms/step**, HIP-event median step %.1f ms, peak memory %.0f GiB); GPU test log of the same call: `%s_gpu_tests.txt`.\n"
