@@ -587,3 +587,22 @@ def test_swapped_parameter_object_is_rehomed_by_the_next_call():
     fb.ensure(cpu)
     assert lo <= res.layer1[0].bn1.weight.data_ptr() < hi or fb.flat.data_ptr() != lo
     assert float(res.layer1[0].bn1.weight.data[0]) == 3.0
+
+
+def test_parity_bounds_table_respects_the_stated_tolerances():
+    """tests/parity_bounds.json is re-based by tools/rebase_bounds.py from one GPU run; whatever a re-base does, no bound may drift
+    past the stated tolerance of its category (logits <= 4e-2, policy logits <= 8e-2, running statistics <= 3e-2, replay gradients
+    p90 <= 0.13, ...) and every bound is min(1.3 x measured, ceiling)."""
+    from tests import parity_bounds as pb
+    t = pb.table()
+    assert len(t) >= 40
+    assert pb.CEILINGS["logits"] <= 4e-2 and pb.CEILINGS["plog"] <= 8e-2 and pb.CEILINGS["stats"] <= 3e-2 and pb.CEILINGS["replay_p90"] <= 0.13
+    for k, e in t.items():
+        ceil = pb.CEILINGS[e["cat"]]
+        assert 0 < e["measured"] <= ceil, (k, e)
+        assert e["bound"] <= ceil * (1 + 1e-9), (k, e)
+        assert abs(e["bound"] - min(pb.FACTOR * e["measured"], ceil)) <= 2e-3 * e["bound"], (k, e)
+    for case in ("c1.train", "c2.train_main", "c2.train_policy", "c4.train_main", "c5.train_main", "c5.train_policy"):
+        assert case + ".logits" in t and case + ".stats" in t and case + ".head" in t
+    src = open(os.path.join(ROOT, "tests", "test_parity_fullsize_gpu.py")).read()
+    assert "_tol=" not in src and "max_tol" not in src          # no scattered literals left in the full-size file

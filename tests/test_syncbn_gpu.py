@@ -36,10 +36,21 @@ def _build():
     return m.to("cuda")
 
 
-def _step(model, ddp, rank, world, nvid=B):
+# gradient stages of the main nets, from the heads down (the 224^2 form asserts one rel-L2 figure per stage: the deeper the stage, the
+# more bf16 layers with ReLU / max-pool decisions have amplified the 1e-7 difference of the first statistics)
+STAGES = {
+    "heads": ("main_net.nets.0.layer4.", "main_net.nets.0.fc.", "main_net.nets.1.features.17.", "main_net.nets.1.features.18.",
+              "main_net.nets.1.classifier.", "main_net.lf_weights"),
+    "layer3": ("main_net.nets.0.layer3.",),
+    "layer12": ("main_net.nets.0.conv1.", "main_net.nets.0.bn1.", "main_net.nets.0.layer1.", "main_net.nets.0.layer2."),
+    "mbv2": tuple("main_net.nets.1.features.%d." % i for i in range(17)),
+}
+
+
+def _step(model, ddp, rank, world, nvid=B, px=64):
     from adamml_amd import synth
     dev = torch.device("cuda", torch.cuda.current_device())
-    xs = [t[rank::world].to(dev) for t in synth.synth_inputs(["rgb", "sound"], nvid, S, 8, 64, seed=5)]
+    xs = [t[rank::world].to(dev) for t in synth.synth_inputs(["rgb", "sound"], nvid, S, 8, px, seed=5)]
     tgt = synth.synth_labels(nvid, 31, seed=5)[rank::world].to(dev)
     expo = synth.synth_gumbel_exponential(S, 2, nvid, seed=11).view(S, 2, nvid, 2)[:, :, rank::world].reshape(S, -1, 2).to(dev)
     model.freeze_policy_net()
@@ -56,14 +67,18 @@ def _step(model, ddp, rank, world, nvid=B):
         loss = lt / world
     torch.cuda.synchronize()
     sd = model.state_dict()
+    named = dict(model.named_parameters())
+    stage = {st: torch.cat([named[k].grad.detach().flatten() for k in named if k.startswith(pre) and named[k].grad is not None]).cpu()
+             for st, pre in STAGES.items()}
     return {"loss": float(loss.detach()), "sel": sel.detach().cpu(), "grad": model._flat_main.flat_grad.detach().cpu().clone(),
+            "stage_grads": stage,
             "fc_grad": model.main_net.nets[0].fc.weight.grad.detach().cpu().clone(),
             "sound_fc_grad": model.main_net.nets[1].classifier[1].weight.grad.detach().cpu().clone(),
             "bn_grads": {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if k in BN_GRAD_KEYS},
             "stats": {k: v.detach().cpu().clone() for k, v in sd.items() if k.endswith(("running_mean", "running_var"))}}
 
 
-def _worker(rank, world, port, ret, backend, nvid):
+def _worker(rank, world, port, ret, backend, nvid, px=64):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -78,7 +93,7 @@ def _worker(rank, world, port, ret, backend, nvid):
         model = _build()
         ddp = HipDDP(model, sync_bn=True)
         interleave.stats["collectives"] = interleave.stats["coalesced_vectors"] = 0
-        r = _step(model, ddp, rank, world, nvid)
+        r = _step(model, ddp, rank, world, nvid, px)
         if rank == 0:
             ret["r"] = plain(r)
             ret["exchange"] = dict(interleave.stats)
@@ -130,11 +145,11 @@ def _compare(two, one, world, tol=TOL):
     assert g_all <= tol["grad_rel_l2"], g_all
 
 
-def _spawn(world, backend, nvid):
+def _spawn(world, backend, nvid, px=64):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mgr = manager()                                         # (tests/mp_plain.py: spawned server, numpy payloads)
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, ret, backend, nvid), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, backend, nvid, px), nprocs=world, join=True)
     return tensors(ret["r"]), ret["exchange"], ret["communicator_ranks"]
 
 
@@ -156,8 +171,35 @@ TOL_BY_WORLD = {
 }
 
 
-def _n_rank(world, backend, nvid):
-    got, ex, ranks = _spawn(world, backend, nvid)
+def _compare_224(two, one, world, key, assert_grads=True):
+    """The well-conditioned form (224^2: >= 196 samples per BatchNorm channel even in layer 4): per-stage gradient figures from the
+    heads down, each against its own table entry (tests/parity_bounds.json, `key`.*), instead of one number over 25.8 M elements."""
+    from tests.parity_bounds import check
+    assert torch.equal(two["sel"], one["sel"][0::world])
+    errs = {k: _rel(two["stats"][k], v) for k, v in one["stats"].items()}
+    ranked = sorted(errs.values())
+    check(key + ".first_stats", max(e for k, e in errs.items() if k.startswith(FIRST_LAYER_STATS)), "first-layer running statistics", cat="nrank_first_stats")
+    check(key + ".stats", ranked[-1], max(errs, key=errs.get), cat="nrank_stats")
+    check(key + ".stats_p90", ranked[int(0.9 * (len(ranked) - 1))], cat="nrank_stats")
+    check(key + ".loss", abs(two["loss"] - one["loss"]) / abs(one["loss"]), "%.6f vs %.6f" % (two["loss"], one["loss"]), cat="nrank_loss")
+    check(key + ".head", max(_rel(two["fc_grad"], one["fc_grad"]), _rel(two["sound_fc_grad"], one["sound_fc_grad"])),
+          "classifier-head gradients (resnet fc, sound classifier)", cat="nrank_head")
+    for k in BN_GRAD_KEYS:                               # (a world-times-too-large SyncBN gamma / beta gradient would read 1.0)
+        e = _rel(two["bn_grads"][k], one["bn_grads"][k])
+        print("  %-60s averaged gradient rel L2 %.2e" % (k, e))
+        assert e <= 0.2, (k, e)
+    for st in STAGES:
+        a, b = two["stage_grads"][st], one["stage_grads"][st]
+        e = _rel(a, b)
+        cos = F.cosine_similarity(a.double(), b.double(), dim=0).item()
+        if assert_grads:
+            check("%s.grad_%s" % (key, st), e, "%d elements, cosine %.3f" % (a.numel(), cos), cat="nrank_grad")
+        else:                                            # first contact with real peers: printed, not asserted
+            print("  [first contact] gradients of stage %-8s rel L2 %.3f cosine %.3f over %d elements" % (st, e, cos, a.numel()))
+
+
+def _n_rank(world, backend, nvid, px=64):
+    got, ex, ranks = _spawn(world, backend, nvid, px)
     assert ranks == world, "the communicator spans %d ranks, expected %d" % (ranks, world)
     # SyncBatchNorm exchanges of one step (S = 2 segments batched as groups): the 4 backbones have 53 / 52 / 52 / 52 BatchNorm
     # layers in forward and the two trainable ones 53 / 52 in backward = 314 statistic vectors; issued in rounds they travel in one
@@ -166,13 +208,13 @@ def _n_rank(world, backend, nvid):
     print("  %d %s ranks: SyncBatchNorm exchange: %d statistic vectors in %d collectives" % (world, backend, ex["coalesced_vectors"], ex["collectives"]))
     assert ex["coalesced_vectors"] == 53 + 3 * 52 + 53 + 52 and ex["collectives"] <= 2 * (53 + 52)
     torch.cuda.set_device(0)
-    one = _step(_build(), None, 0, 1, nvid)
-    tol = TOL_BY_WORLD.get(world) or _loose(TOL, 3.0)
-    if backend == "nccl":
-        # never run with real peers: RCCL may sum the exchanged vectors in another order than gloo (last-bit differences that the bf16
-        # layers amplify like any other): 1.25 x on top of the gloo-calibrated bounds until a multi-GPU box has printed its own numbers
-        tol = _loose(tol, 1.25)
-    _compare(got, one, world, tol)
+    one = _step(_build(), None, 0, 1, nvid, px)
+    if px == 224:
+        # statistics, loss and head gradients are asserted with the gloo-measured table entries (the exchange sums fp64 vectors and
+        # fp32 buckets: no transport-dependent factor); with real peers the per-stage gradient figures are PRINTED on first contact
+        _compare_224(got, one, world, "nrank%d_224" % (2 if backend == "nccl" else world), assert_grads=backend != "nccl")
+        return
+    _compare(got, one, world, TOL_BY_WORLD.get(world) or _loose(TOL, 3.0))
 
 
 def test_two_rank_syncbn_step_equals_single_process_full_batch():
@@ -186,9 +228,19 @@ def test_n_rank_gloo_syncbn_step_equals_full_batch(world):
     _n_rank(world, "gloo", 2 * world)
 
 
+def test_two_rank_syncbn_step_at_224_per_stage_gradients():
+    """The well-conditioned statement (round-4 review): B = 4 videos, S = 2 segments at 224^2 / 256^2 on two gloo ranks against the
+    single-process full batch -- statistics, loss, head gradients and one gradient figure PER STAGE (heads + layer 4, layer 3, stem +
+    layers 1-2, the Sound-MobileNetV2 trunk), each with its own entry in tests/parity_bounds.json.  The 64-pixel forms above stay as
+    plumbing tests (4-16 samples per BatchNorm channel in the deep layers: ill-conditioned by construction)."""
+    _n_rank(2, "gloo", B, px=224)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: RCCL ranks over xGMI, one GPU each")
 def test_n_rank_rccl_step_equals_full_batch():
-    """configs[2] with real peers: min(8, device_count) RCCL ranks, 2 videos each, SyncBatchNorm + bucketed asynchronous gradient
-    all-reduce, against the one-process step on the concatenated batch (bounds: TOL_BY_WORLD)."""
+    """configs[2] with real peers: min(8, device_count) RCCL ranks, 2 videos each at 224^2, SyncBatchNorm + bucketed asynchronous
+    gradient all-reduce, against the one-process step on the concatenated batch.  Asserted: `communicator_ranks`, the exchange counts,
+    running statistics, loss and head gradients (the two-rank 224^2 table entries, no transport factor); the per-stage gradient
+    figures are printed on first contact."""
     world = min(8, torch.cuda.device_count())
-    _n_rank(world, "nccl", 2 * world)
+    _n_rank(world, "nccl", 2 * world, px=224)
