@@ -666,6 +666,85 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmP p) {
     }
 }
 
+// The same product on the matrix cores when both operands are K-contiguous (nn.Linear forward: x [M,K] row-major, weight [N,K]) and
+// 16-byte aligned: exact fp32 (v_mfma_f32_16x16x4_f32 multiplies and accumulates in fp32), no LDS and no barrier.  A lane (row li,
+// K group lg) loads 4 consecutive K values of its row per 16-deep K chunk (one 16-byte load per operand tile) and feeds element s of
+// the vector to MFMA step s: over the four lane groups and four steps a chunk's 16 K values are each used once, in the same
+// position for A and B.  A wave owns 16 x 32 outputs, a workgroup (2 x 2 waves) 32 x 64: the 64 x 64 VALU tiles above gave the joint
+// FC / LSTM-gate products of the policy net (M = 360, N = 2048, K = 2048..2560) 192 workgroups of serial 16-deep K steps with two
+// barriers each -- under one wave per SIMD, latency-bound at 184 us per launch (rocprofv3, round 4).
+__global__ __launch_bounds__(NT) void gemm_f32_mfma_kernel(GemmP p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int m0 = blockIdx.y * 32 + (wave >> 1) * 16, n0 = blockIdx.x * 64 + (wave & 1) * 32;
+    if (m0 >= p.M || n0 >= p.N) return;                                    // (wave-uniform; no barrier in this kernel)
+    const float* ar = p.a + (int64_t)min(m0 + li, p.M - 1) * p.a_sm + 4 * lg;
+    const float* br0 = p.b + (int64_t)min(n0 + li, p.N - 1) * p.b_sn + 4 * lg;
+    const float* br1 = p.b + (int64_t)min(n0 + 16 + li, p.N - 1) * p.b_sn + 4 * lg;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int kfull = p.K & ~63;
+    int k0 = 0;
+    if (kfull) {
+        // 64-deep steps with the 12 loads of step i + 1 requested under the MFMAs of step i.  Measured (tools/bench_gemm.py, M = 360,
+        // N = 2048, K = 2560): 230 us (VALU tiles) -> 110 us, 34 TFLOP/s; the look-ahead itself changed nothing (113 us), so the bound is
+        // not the L2 round trip: a fragment load touches 16 ROWS 8-10 KB apart (one 64-byte piece each), i.e. a few L2 channels per
+        // instruction -- the LDS-staged form (rows read in long contiguous runs; rocBLAS needs 38 us here) is what would lift it.
+        f32x4 a[4], b0[4], b1[4], na[4], nb0[4], nb1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            a[c] = *reinterpret_cast<const f32x4*>(ar + 16 * c);
+            b0[c] = *reinterpret_cast<const f32x4*>(br0 + 16 * c);
+            b1[c] = *reinterpret_cast<const f32x4*>(br1 + 16 * c);
+        }
+        for (; k0 < kfull; k0 += 64) {
+            const int kn = k0 + 64 < kfull ? k0 + 64 : k0;             // (the last step re-requests its own chunk: unconditional loads)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                na[c] = *reinterpret_cast<const f32x4*>(ar + kn + 16 * c);
+                nb0[c] = *reinterpret_cast<const f32x4*>(br0 + kn + 16 * c);
+                nb1[c] = *reinterpret_cast<const f32x4*>(br1 + kn + 16 * c);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][s_], b0[c][s_], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][s_], b1[c][s_], acc1, 0, 0, 0);
+                }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { a[c] = na[c]; b0[c] = nb0[c]; b1[c] = nb1[c]; }
+        }
+    }
+    for (; k0 < p.K; k0 += 16) {                                           // K tail (K % 4 == 0: a lane's 4 values are all in or all out)
+        const bool in = k0 + 4 * lg < p.K;
+        const int kc = in ? k0 : 0;
+        f32x4 a = *reinterpret_cast<const f32x4*>(ar + kc), b0 = *reinterpret_cast<const f32x4*>(br0 + kc), b1 = *reinterpret_cast<const f32x4*>(br1 + kc);
+        if (!in) { a = f32x4{0.f, 0.f, 0.f, 0.f}; b0 = a; b1 = a; }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_], b0[s_], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_], b1[s_], acc1, 0, 0, 0);
+        }
+    }
+    // D fragment: lane (li, lg) holds rows 4 lg .. 4 lg + 3 of column li
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int nn = n0 + 16 * t + li;
+        if (nn >= p.N) continue;
+        const f32x4 acc = t ? acc1 : acc0;
+        const float bv = p.bias ? p.bias[nn] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mm = m0 + 4 * lg + r;
+            if (mm >= p.M) continue;
+            float v = apply_act(acc[r] + bv, p.act);
+            float* dst = p.c + (int64_t)mm * p.c_sm + (int64_t)nn * p.c_sn;
+            if (p.accumulate) v += *dst;
+            *dst = v;
+        }
+    }
+}
+
 static int dw_blocks(size_t P, int C, size_t* ppb_out) {
     const int rows = NT / (C / 8) > 0 ? NT / (C / 8) : 1;
     size_t ppb = (size_t)rows * 8;
@@ -927,6 +1006,12 @@ extern "C" int adamml_gemm_f32(const float* a, int64_t a_sm, int64_t a_sk, const
     if (!a || !b || !c) return adamml_set_error(ADAMML_EINVAL, "gemm_f32: null argument");
     if (M <= 0 || N <= 0) return ADAMML_OK;
     GemmP p{a, a_sm, a_sk, b, b_sn, b_sk, c, c_sm, c_sn, bias, act, accumulate, M, N, K};
+    static const int use_mfma = getenv("ADAMML_GEMM_MFMA") ? atoi(getenv("ADAMML_GEMM_MFMA")) : 1;          // A/B aid
+    if (use_mfma && a_sk == 1 && b_sk == 1 && K >= 16 && (K & 3) == 0 && (a_sm & 3) == 0 && (b_sn & 3) == 0 &&
+        ((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0) {
+        hipLaunchKernelGGL(gemm_f32_mfma_kernel, dim3(ceil_div(N, 64), ceil_div(M, 32)), dim3(NT), 0, stream, p);
+        return adamml_check_launch("gemm_f32 (mfma)");
+    }
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(NT), 0, stream, p);
     return adamml_check_launch("gemm_f32");
 }

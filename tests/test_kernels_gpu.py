@@ -341,6 +341,22 @@ def test_gemm_f32_variants():
     out = torch.ones(129, 300, device=DEV)
     gemm_f32(g, a, out=out, trans_a=True, trans_b=False, accumulate=True)
     assert torch.allclose(out, 1 + g.t() @ a, rtol=1e-4, atol=1e-3)
+    # K-contiguous operands take the fp32 matrix-core kernel (csrc/dwconv_gemm32.hip gemm_f32_mfma_kernel): ragged M / N tiles, a K tail
+    # (K % 16 != 0), K below one 64-deep step, bias + ReLU, accumulate, a row-strided view; against float64
+    for M, N, K in ((360, 2048, 2560), (70, 129, 300), (33, 65, 20), (16, 32, 64), (5, 7, 16)):
+        a, b = torch.randn(M, K, device=DEV), torch.randn(N, K, device=DEV)
+        bias = torch.randn(N, device=DEV)
+        ref = (a.double() @ b.double().t() + bias.double())
+        y = gemm_f32(a, b, bias=bias)
+        assert (y.double() - ref).abs().max().item() <= 1e-5 * K ** 0.5 * 4, (M, N, K)
+        y = gemm_f32(a, b, bias=bias, act=1)
+        assert (y.double() - ref.clamp_min(0)).abs().max().item() <= 1e-5 * K ** 0.5 * 4, (M, N, K)
+        out = torch.full((M, N), 2.0, device=DEV)
+        gemm_f32(a, b, out=out, accumulate=True)
+        assert (out.double() - 2 - (ref - bias.double())).abs().max().item() <= 1e-5 * K ** 0.5 * 4, (M, N, K)
+    big = torch.randn(40, 512, device=DEV)
+    a, b = big[:, :256], torch.randn(48, 256, device=DEV)                  # row stride 512, K = 256
+    assert torch.allclose(gemm_f32(a, b), a @ b.t(), rtol=1e-4, atol=1e-4)
 
 
 def test_fused_optimizers_match_torch():
