@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--launch-plan", action="store_true",
                     help="replay the static launch sequence of every backbone call from C (adamml_amd/plan.py): for small per-GPU batches, "
                          "where the Python issue of ~1300 launches per step bounds the step (non-headline)")
+    ap.add_argument("--u8-input", action="store_true",
+                    help="non-headline: the visual modalities arrive as decoded uint8 frames [B, H, W, S*F*C] (what utils/video_transforms.py "
+                         "Stack produces) and are normalised inside the input kernel: 1 byte per value through HBM instead of 4")
     ap.add_argument("--single-stream", action="store_true", help="profiling aid: no side streams, so per-kernel durations "
                     "in a rocprofv3 trace are not inflated by concurrently running kernels")
     return ap.parse_args()
@@ -100,6 +103,8 @@ def synth_batch(args, b, device, rank):
     for m in args.modalities:
         if m == "sound":
             xs.append(torch.randn(b, s, 256, 256, device=device) * 3.0 - 5.0)
+        elif args.u8_input:
+            xs.append(torch.randint(0, 256, (b, 224, 224, s * 8 * CHANNELS[m]), dtype=torch.uint8, device=device))
         else:
             xs.append(torch.randn(b, s * 8 * CHANNELS[m], 224, 224, device=device))
     tgt = torch.randint(0, 31, (b,), generator=g).to(device)
@@ -399,7 +404,7 @@ def run_rank(args):
         cpu = cpu_baseline(args)
 
     if rank == 0:
-        headline = args.stage == "main" and args.modalities == ["rgb", "sound"]
+        headline = args.stage == "main" and args.modalities == ["rgb", "sound"] and not args.u8_input
         res = {
             "metric": "clips/sec (train fwd+bwd) RGB+Audio AdaMML @224^2, 5 seg" if args.stage != "infer" else
                       "clips/sec (inference fwd, policy-gated) AdaMML @224^2, 5 seg", "value": round(value, 2), "unit": "clips/s",
@@ -409,7 +414,8 @@ def run_rank(args):
             # when it approaches ms_per_step the step is host-bound
             "host_issue_ms": round(statistics.median(issue_ms), 2), "deterministic": bool(hip.deterministic()),
             "launch_plan": bool(args.launch_plan),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic" if not args.u8_input else "synthetic (non-headline: uint8 decoded frames in, normalised by the input kernel)",
             "config": {"workload": ("AdaMML %s (non-headline), eval-mode forward with decision-driven skipping of the main nets, "
                                     "%d segments x 8 frames" % ("+".join(args.modalities), args.segments)) if args.stage == "infer" else
                        ("AdaMML RGB+Audio (ResNet-50 + Sound-MobileNetV2 + MobileNetV2/LSTM policy), %s-net "

@@ -323,6 +323,8 @@ def test_clip_to_nhwc_and_resize():
     # 4-channel pixels for the 7x7 stem kernels (ResNet.input_cpad): same values, 8 bytes per pixel
     y4 = clip_to_nhwc(x, S, Fr, C, cpad=4)
     assert y4.shape[-1] == 4 and torch.equal(y4[..., :C], y[..., :C]) and y4[..., C:].float().abs().max().item() == 0
+    y4s, y8s = clip_to_nhwc(x, S, Fr, C, frame_step=2, cpad=4), clip_to_nhwc(x, S, Fr, C, frame_step=2)       # (4-pixel-per-thread kernel vs the generic one)
+    assert y4s.shape[1] == B * 4 and torch.equal(y4s[..., :C], y8s[..., :C]) and y4s[..., C:].float().abs().max().item() == 0
     y24 = clip_to_nhwc(x, S, Fr, C, out_hw=(40, 40), frame_step=2, cpad=4)
     assert torch.equal(y24[..., :C], y2[..., :C]) and y24[..., C:].float().abs().max().item() == 0
     # sound: [B, S, 64, 64] -> [S, B, 64, 64, 8]
