@@ -1338,6 +1338,90 @@ __global__ void clip_u8_to_nhwc_kernel(const uint8_t* x, bf16_t* y, int B, int S
     }
 }
 
+// The RGB case of the kernel above (C = 3 source channels, 8 frames per segment: every visual input of the reference recipes that is not
+// RGB-diff) at streaming speed.  Round 5 priced the generic kernel with `bench.py --u8-input`: 11 ms per step more than the fp32 path -- it
+// issues one BYTE load per value (120 per pixel, each touching 64 lines of a wave's 7.5 KB) and two fp32 divisions per value.  Here a
+// thread reads its pixel's S * 24 bytes with 8-byte loads into registers (the frames' bytes are then at compile-time positions: S and
+// the frame step are template parameters), and the normalisation ((u8 / 255) - mean) / std is a 3 x 256-entry fp32 table in LDS filled
+// with exactly that expression -- bit-identical to the generic kernel by construction, no division per value.  Stores as there: 8 or 16
+// bytes per lane, consecutive lanes = consecutive pixels of one frame plane.
+template <int S, int STEP, bool RESIZE>
+__global__ __launch_bounds__(NT) void clip_u8_rgb_kernel(const uint8_t* x, bf16_t* y, int B, int H, int W, int OH, int OW, int c_pad, NormVec nv,
+                                                         int div255) {
+    constexpr int F = 8, FK = F / STEP, NW = 3 * S;           // S * F * 3 bytes = NW 8-byte words per source pixel
+    __shared__ float lut[3][256];
+    for (int i = threadIdx.x; i < 3 * 256; i += NT) {
+        const int c = i >> 8;
+        float t = (float)(i & 255);
+        if (div255) t = t / 255.f;
+        lut[c][i & 255] = (t - nv.mean[c % nv.n]) / nv.std[c % nv.n];
+    }
+    __syncthreads();
+    const size_t total = (size_t)B * OH * OW;
+    const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+    for (size_t e = (size_t)blockIdx.x * NT + threadIdx.x; e < total; e += (size_t)gridDim.x * NT) {
+        size_t r = e;
+        const int ow = (int)(r % OW); r /= OW;
+        const int oh = (int)(r % OH);
+        const int b = (int)(r / OH);
+        int h0 = oh, h1 = oh, w0 = ow, w1 = ow;
+        float lh1 = 0.f, lw1 = 0.f;
+        if (RESIZE) {
+            float fh = fmaxf(sh * (oh + 0.5f) - 0.5f, 0.f), fw = fmaxf(sw * (ow + 0.5f) - 0.5f, 0.f);
+            h0 = (int)fh; w0 = (int)fw;
+            h1 = h0 + (h0 < H - 1 ? 1 : 0); w1 = w0 + (w0 < W - 1 ? 1 : 0);
+            lh1 = fh - h0; lw1 = fw - w0;
+        }
+        const float lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+        constexpr int NSRC = RESIZE ? 4 : 1;
+        uint64_t wd[NSRC][NW];
+        const uint64_t* src[4] = {reinterpret_cast<const uint64_t*>(x + (((size_t)b * H + h0) * W + w0) * (NW * 8)),
+                                  reinterpret_cast<const uint64_t*>(x + (((size_t)b * H + h0) * W + w1) * (NW * 8)),
+                                  reinterpret_cast<const uint64_t*>(x + (((size_t)b * H + h1) * W + w0) * (NW * 8)),
+                                  reinterpret_cast<const uint64_t*>(x + (((size_t)b * H + h1) * W + w1) * (NW * 8))};
+#pragma unroll
+        for (int q = 0; q < NSRC; ++q)
+#pragma unroll
+            for (int i = 0; i < NW; ++i) wd[q][i] = src[q][i];
+        auto byte_of = [&](int q, int pos) { return (unsigned)(wd[q][pos >> 3] >> (8 * (pos & 7))) & 255u; };      // pos: compile-time after unrolling
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int fk = 0; fk < FK; ++fk) {
+                const int off = (s * F + fk * STEP) * 3;
+                float v[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (RESIZE)
+                        v[c] = lh0 * (lw0 * lut[c][byte_of(0, off + c)] + lw1 * lut[c][byte_of(1, off + c)]) +
+                               lh1 * (lw0 * lut[c][byte_of(2, off + c)] + lw1 * lut[c][byte_of(3, off + c)]);
+                    else
+                        v[c] = lut[c][byte_of(0, off + c)];
+                }
+                bf16_t* dst = y + (((((size_t)s * B + b) * FK + fk) * OH + oh) * OW + ow) * c_pad;
+                if (c_pad == 4) *reinterpret_cast<bf16x4*>(dst) = f32_to_bf4(f32x4{v[0], v[1], v[2], 0.f});
+                else {
+                    f32x8 o8 = {v[0], v[1], v[2], 0.f, 0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<bf16x8*>(dst) = f32_to_bf8(o8);
+                    for (int c8 = 8; c8 < c_pad; c8 += 8) *reinterpret_cast<bf16x8*>(dst + c8) = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            }
+    }
+}
+
+template <int S>
+static bool launch_u8_rgb(const uint8_t* x, bf16_t* y, int B, int H, int W, int OH, int OW, int frame_step, int c_pad, const NormVec& nv, int div255,
+                          size_t n, hipStream_t stream) {
+    const bool resize = OH != H || OW != W;
+    const dim3 grid(grid_for(n)), block(NT);
+    if (frame_step == 1 && !resize) hipLaunchKernelGGL((clip_u8_rgb_kernel<S, 1, false>), grid, block, 0, stream, x, y, B, H, W, OH, OW, c_pad, nv, div255);
+    else if (frame_step == 1) hipLaunchKernelGGL((clip_u8_rgb_kernel<S, 1, true>), grid, block, 0, stream, x, y, B, H, W, OH, OW, c_pad, nv, div255);
+    else if (frame_step == 2 && !resize) hipLaunchKernelGGL((clip_u8_rgb_kernel<S, 2, false>), grid, block, 0, stream, x, y, B, H, W, OH, OW, c_pad, nv, div255);
+    else if (frame_step == 2) hipLaunchKernelGGL((clip_u8_rgb_kernel<S, 2, true>), grid, block, 0, stream, x, y, B, H, W, OH, OW, c_pad, nv, div255);
+    else return false;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ weights
 __device__ __forceinline__ void pack_one(const float* w, void* out, int cout, int cin_true, int cin_pad, int taps, int mode, size_t e) {
     if (mode == 0) {            // [co][tap][ci]
@@ -1795,6 +1879,18 @@ extern "C" int adamml_clip_u8_to_nhwc(const uint8_t* x, void* y, int B, int S, i
     NormVec nv;
     nv.n = n_mean;
     for (int i = 0; i < 4; ++i) { nv.mean[i] = i < n_mean ? mean[i] : 0.f; nv.std[i] = i < n_mean ? std[i] : 1.f; }
+    static const int fast = getenv("ADAMML_U8_FAST") ? atoi(getenv("ADAMML_U8_FAST")) : 1;            // A/B aid: 0 = the generic kernel
+    if (fast && C == 3 && F == 8 && n_mean == 3 && S >= 1 && S <= 5 && ((uintptr_t)x & 7) == 0) {
+        bool ok = false;
+        switch (S) {
+            case 1: ok = launch_u8_rgb<1>(x, (bf16_t*)y, B, H, W, OH, OW, frame_step, c_pad, nv, div255, n, stream); break;
+            case 2: ok = launch_u8_rgb<2>(x, (bf16_t*)y, B, H, W, OH, OW, frame_step, c_pad, nv, div255, n, stream); break;
+            case 3: ok = launch_u8_rgb<3>(x, (bf16_t*)y, B, H, W, OH, OW, frame_step, c_pad, nv, div255, n, stream); break;
+            case 4: ok = launch_u8_rgb<4>(x, (bf16_t*)y, B, H, W, OH, OW, frame_step, c_pad, nv, div255, n, stream); break;
+            case 5: ok = launch_u8_rgb<5>(x, (bf16_t*)y, B, H, W, OH, OW, frame_step, c_pad, nv, div255, n, stream); break;
+        }
+        if (ok) return adamml_check_launch("clip_u8_to_nhwc (rgb)");
+    }
     hipLaunchKernelGGL(clip_u8_to_nhwc_kernel<false>, dim3(grid_for(n)), dim3(NT), 0, stream, x, (bf16_t*)y, B, S, F, C, H, W, OH, OW, frame_step,
                        Fk, c_pad, nv, div255);
     return adamml_check_launch("clip_u8_to_nhwc");
