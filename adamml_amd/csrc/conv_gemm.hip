@@ -1785,6 +1785,12 @@ int ilog2_exact(int v) {
 }  // namespace
 
 bool adamml_conv3x3_c64_supported(const adamml_conv_desc_t* d);
+bool adamml_conv1x1_narrow_fwd_supported(const adamml_conv_desc_t* d);
+bool adamml_conv1x1_narrow_wgrad_supported(const adamml_conv_desc_t* d, int cin_true);
+int adamml_conv1x1_narrow_wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale, const float* in_shift,
+                                       float* ws, int max_blocks_per_group, int* nblk_out, hipStream_t stream);
+int adamml_conv1x1_narrow_fwd_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
+                                     void* y, double* stats, hipStream_t stream);
 int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
                               const float* in_shift, void* y, double* stats, const void* bn_z, const float* bn_vec, int bn_act,
                               hipStream_t stream);
@@ -1816,6 +1822,9 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     if (d->Cin % 8 || d->Cout % 8) return adamml_set_error(ADAMML_EINVAL, "conv_fwd: channels must be multiples of 8 (Cin=%d Cout=%d)", d->Cin, d->Cout);
     if (!cls && !fadd && adamml_conv3x3_c64_supported(d))
         return adamml_conv3x3_c64_launch(d, x, w_packed, in_scale, in_shift, y, stats, bn_z, bn_vec, bn_act, stream);
+    // narrow 1x1 convs of the MobileNetV2s (plain forward / plain data gradient): the barrier-free streaming kernel (conv1x1_narrow.hip)
+    if (!cls && !fadd && !res && !dual && !cat && !pf && !bn_z && adamml_conv1x1_narrow_fwd_supported(d))
+        return adamml_conv1x1_narrow_fwd_launch(d, x, w_packed, in_scale, in_shift, y, stats, stream);
     ConvP p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.in_scale = in_scale; p.in_shift = in_shift;
     p.y = (bf16_t*)y; p.stats = stats;
@@ -2493,6 +2502,13 @@ static int wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void*
             if (rc) return rc;
             return adamml_launch_split_reduce((const float*)workspace, dw, dw_numel, nblk, stream, 9, cin_true);
         }
+    }
+    if (!ex && workspace && adamml_conv1x1_narrow_wgrad_supported(d, cin_true) && workspace_bytes >= (size_t)groups * pl.nsplit * dw_numel * sizeof(float)) {
+        // narrow 1x1 convs of the MobileNetV2s: barrier-free streaming kernel, one partial per workgroup (conv1x1_narrow.hip)
+        int nblk = 0;
+        rc = adamml_conv1x1_narrow_wgrad_launch(d, dz, x, in_scale, in_shift, (float*)workspace, pl.nsplit, &nblk, stream);
+        if (rc) return rc;
+        return adamml_launch_split_reduce((const float*)workspace, dw, dw_numel, groups * nblk, stream, 1, cin_true);
     }
     float* ws = nullptr;
     if (workspace && workspace_bytes >= (size_t)groups * pl.nsplit * dw_numel * sizeof(float)) ws = (float*)workspace;

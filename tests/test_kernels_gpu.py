@@ -81,6 +81,13 @@ CONV_CASES = [
     (1, 7, 7, 512, 2048, 1, 1, 0),
     (3, 7, 7, 512, 512, 3, 1, 1),
     (1, 5, 5, 320, 1280, 1, 1, 0),
+    # narrow 1x1 convs of the MobileNetV2s: the barrier-free streaming kernel (csrc/conv1x1_narrow.hip), every instance, ragged pixel counts
+    (2, 21, 19, 32, 192, 1, 1, 0),
+    (1, 33, 31, 96, 24, 1, 1, 0),
+    (2, 20, 20, 32, 16, 1, 1, 0),
+    (1, 18, 22, 144, 32, 1, 1, 0),
+    (1, 16, 16, 192, 32, 1, 1, 0),
+    (3, 17, 13, 24, 144, 1, 1, 0),
     (2, 40, 40, 64, 128, 3, 1, 1),          # wide 3x3 that is not 64 -> 64: the LDS-patch weight gradient (conv3x3_wgrad_kernel)
     (1, 66, 66, 128, 128, 3, 2, 1),         # wide stride-2 3x3: generic implicit-GEMM weight gradient
 ]
@@ -390,7 +397,7 @@ def _g(t, G):
     return t.view(G, t.shape[0] // G, *t.shape[1:])
 
 
-@pytest.mark.parametrize("case", [(2, 28, 28, 64, 256, 1, 1, 0), (2, 14, 14, 64, 64, 3, 1, 1), (2, 15, 15, 128, 128, 3, 2, 1),
+@pytest.mark.parametrize("case", [(2, 28, 28, 64, 256, 1, 1, 0), (2, 14, 14, 64, 64, 3, 1, 1), (2, 15, 15, 128, 128, 3, 2, 1), (2, 19, 17, 16, 96, 1, 1, 0), (1, 13, 21, 144, 24, 1, 1, 0),
                                   (2, 32, 32, 3, 64, 7, 2, 3), (1, 14, 14, 256, 512, 1, 2, 0), (2, 7, 7, 512, 2048, 1, 1, 0)])
 def test_conv_groups_equal_separate_launches(case):
     torch.manual_seed(10)
