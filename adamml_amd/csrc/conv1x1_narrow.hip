@@ -219,6 +219,247 @@ int narrow_launch(const N1P& p, int groups, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Data gradient of a narrow PROJECTION conv (K = 16 / 24 / 32 gradient channels -> 32 .. 192 channels of the expanded tensor) in the forms
+// adamml_conv_bwd_data_dual runs for the MobileNetV2s: DUAL -- the loader reads the masked gradient g and the raw conv output z and forms
+// dz = A g + B z + C per channel (the BatchNorm-backward "apply" of the projection's own BatchNorm, never a pass of its own), writing dz
+// once on the side for the weight gradient --, and EPI 1 -- the BatchNorm-fused epilogue of the tensor the gradient flows into (the
+// depthwise conv's output): g' = dx * act'(scale z_in + shift) stored, sum g' and sum g' zhat accumulated -- or EPI 2 (accumulate into dx) /
+// EPI 0 (plain store).  Same streaming structure as the forward kernel above.  The epilogue walks the staged tile with a CONSTANT
+// 8-channel chunk per lane (64 / CPR pixels per pass), so the per-channel sums stay in registers over all tiles of a wave; wide outputs are
+// produced in blocks of <= 96 channels (6 MFMA tiles) that reuse the B fragments.  conv_gemm_kernel's DUAL instance ran these layers at
+// 2.4-2.9 TB/s (round 5, tools/launch_table.py sound).
+struct ND1P {
+    const bf16_t* g;         // [groups * P][K]
+    const bf16_t* z;         // DUAL: [groups * P][K]
+    const float* aff;        // DUAL: [groups][3][K]
+    bf16_t* side;            // DUAL: dz out or null
+    const bf16_t* w;         // [COUT][K] (data-gradient pack)
+    bf16_t* dx;              // [groups * P][COUT]
+    const bf16_t* z_in;      // EPI 1: [groups * P][COUT]
+    const float* bn_vec;     // EPI 1: [groups][4][COUT]
+    double* stats;           // EPI 1: [groups][SLOTS][2 * COUT]
+    int bn_act, K;
+    long P;
+};
+
+template <int KS, int COUT, bool DUAL, int EPI>
+__global__ __launch_bounds__(256, 2) void conv1x1_narrow_dgrad_kernel(ND1P p) {
+    constexpr int KP = KS * 32;
+    constexpr int NCT = (COUT + 15) / 16;
+    constexpr int NCB = (NCT + 5) / 6;                                   // cout blocks of <= 6 tiles
+    constexpr int BT = (NCT + NCB - 1) / NCB;                            // tiles per block (the last block may hold fewer live channels)
+    constexpr int BW = BT * 16;                                          // block width (channels)
+    constexpr int WROW = KP * 2 + 16;
+    constexpr int SROW = BW * 2 + 8;
+    constexpr int TPX = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_w = smem;                                                        // [NCB * BW][WROW]
+    float* s_aff = reinterpret_cast<float*>(smem + NCB * BW * WROW);         // [3][KP]
+    float* s_bn = s_aff + 3 * KP;                                            // [4][NCB * BW]
+    float* s_fold = s_bn + 4 * NCB * BW;                                     // [4 waves][64 lanes][NCB][16]  (end of the kernel only)
+    char* s_stage = reinterpret_cast<char*>(s_fold + (EPI == 1 ? 4 * 64 * NCB * 16 : 0));     // [4 waves][32][SROW]
+    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    p.g += (size_t)g * p.P * p.K;
+    if (DUAL) { p.z += (size_t)g * p.P * p.K; p.aff += (size_t)g * 3 * p.K; if (p.side) p.side += (size_t)g * p.P * p.K; }
+    p.dx += (size_t)g * p.P * COUT;
+    if (EPI == 1) { p.z_in += (size_t)g * p.P * COUT; p.bn_vec += (size_t)g * 4 * COUT; }
+    for (int i = tid; i < NCB * BW * (KP / 8); i += 256) {
+        const int row = i / (KP / 8), ch = i - row * (KP / 8);
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < COUT && ch * 8 < p.K) v = *reinterpret_cast<const bf16x8*>(p.w + (size_t)row * p.K + ch * 8);
+        *reinterpret_cast<bf16x8*>(s_w + row * WROW + ch * 16) = v;
+    }
+    if (DUAL)
+        for (int i = tid; i < 3 * KP; i += 256) {
+            const int v = i / KP, c = i - v * KP;
+            s_aff[i] = c < p.K ? p.aff[v * p.K + c] : 0.f;               // (K positions beyond the tensor: A = B = C = 0 -> dz = 0)
+        }
+    if (EPI == 1)
+        for (int i = tid; i < 4 * NCB * BW; i += 256) {
+            const int v = i / (NCB * BW), c = i - v * (NCB * BW);
+            s_bn[i] = c < COUT ? p.bn_vec[v * COUT + c] : 0.f;
+        }
+    __syncthreads();
+    char* stg = s_stage + wave * (TPX * SROW);
+    const long ntile = (p.P + TPX - 1) / TPX;
+    const long wid = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
+    // ---- epilogue geometry of a block: lane -> (pixel sub-index pl, 8-channel chunk ch), PPI pixels per pass
+    constexpr int CPRB = BW / 8, PPI = 64 / CPRB, NI = (TPX + PPI - 1) / PPI;
+    const int epl = lane / CPRB, ech = lane - epl * CPRB;
+    const bool eact = lane < PPI * CPRB;
+    const float blo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, act_lo(p.bn_act))));
+    const float bhi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, act_hi(p.bn_act))));
+    f32x8 esum[NCB], esq[NCB];
+#pragma unroll
+    for (int b = 0; b < NCB; ++b)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { esum[b][i] = 0.f; esq[b][i] = 0.f; }
+
+    bf16x8 rg[KS][2], rzz[DUAL ? KS : 1][2], raux[EPI ? NCB : 1][EPI ? NI : 1];
+    auto issue = [&](long tile) {
+        const long p0 = tile * TPX;
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg) {
+            long px = p0 + pg * 16 + li;
+            px = px < p.P ? px : p.P - 1;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const int c = (k * 4 + lg) * 8;
+                const size_t off = (size_t)px * p.K + (c < p.K ? c : 0);
+                rg[k][pg] = *reinterpret_cast<const bf16x8*>(p.g + off);
+                if (DUAL) rzz[k][pg] = *reinterpret_cast<const bf16x8*>(p.z + off);
+            }
+        }
+    };
+    auto issue_aux = [&](long tile) {                                      // the epilogue's second operand (z_in, or the dx accumulated into), requested
+        const long p0 = tile * TPX;                                        // when the previous tile's epilogue has consumed its registers
+        if (EPI) {
+            const bf16_t* aux = EPI == 1 ? p.z_in : p.dx;
+#pragma unroll
+            for (int b = 0; b < NCB; ++b)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    long px = p0 + i * PPI + epl;
+                    px = px < p.P ? px : p.P - 1;
+                    const int c = b * BW + ech * 8;
+                    raux[b][i] = *reinterpret_cast<const bf16x8*>(aux + (size_t)px * COUT + (c < COUT ? c : 0));
+                }
+        }
+    };
+    issue(wid < ntile ? wid : ntile - 1);
+    issue_aux(wid < ntile ? wid : ntile - 1);
+
+    for (long t = wid; t < ntile; t += nw) {
+        const int npx = (int)(p.P - t * TPX < TPX ? p.P - t * TPX : TPX);
+        // ---- B fragments (dz formed here in the DUAL form, written once on the side)
+        bf16x8 fb[KS][2];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int c = (k * 4 + lg) * 8;
+#pragma unroll
+            for (int pg = 0; pg < 2; ++pg) {
+                bf16x8 v = rg[k][pg];
+                if (DUAL) {
+                    const f32x8 gv = bf8_to_f32(v), zv = bf8_to_f32(rzz[k][pg]);
+                    const f32x8 ca = load_f32x8(s_aff + c), cb = load_f32x8(s_aff + KP + c), cc = load_f32x8(s_aff + 2 * KP + c);
+                    f32x8 o;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = fmaf(ca[i], gv[i], fmaf(cb[i], zv[i], cc[i]));
+                    v = f32_to_bf8(o);
+                    if (p.side && c < p.K && pg * 16 + li < npx) *reinterpret_cast<bf16x8*>(p.side + ((size_t)t * TPX + pg * 16 + li) * p.K + c) = v;
+                }
+                if (c >= p.K) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                fb[k][pg] = v;
+            }
+        }
+        {
+            const long tn = t + nw;
+            issue(tn < ntile ? tn : ntile - 1);                           // (unconditional request of this wave's next tile)
+        }
+#pragma unroll
+        for (int b = 0; b < NCB; ++b) {
+            f32x4 acc[2][BT];
+#pragma unroll
+            for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+                for (int ct = 0; ct < BT; ++ct) acc[pg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+#pragma unroll
+                for (int ct = 0; ct < BT; ++ct) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(s_w + ((b * BT + ct) * 16 + li) * WROW + k * 64 + lg * 16);
+#pragma unroll
+                    for (int pg = 0; pg < 2; ++pg) acc[pg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[k][pg], acc[pg][ct], 0, 0, 0);
+                }
+#pragma unroll
+            for (int pg = 0; pg < 2; ++pg)
+#pragma unroll
+                for (int ct = 0; ct < BT; ++ct)
+                    *reinterpret_cast<bf16x4*>(stg + (pg * 16 + li) * SROW + (ct * 16 + lg * 4) * 2) = f32_to_bf4(acc[pg][ct]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int c0 = b * BW + ech * 8;                               // this lane's channels of the block
+            const bool cact = eact && c0 < COUT;
+            f32x8 sc, sh, mu, is;
+            if (EPI == 1) {
+                sc = load_f32x8(s_bn + c0); sh = load_f32x8(s_bn + NCB * BW + c0);
+                mu = load_f32x8(s_bn + 2 * NCB * BW + c0); is = load_f32x8(s_bn + 3 * NCB * BW + c0);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int px = i * PPI + epl;
+                if (cact && px < npx) {
+                    union { struct { s16x4_ a, b; } s; bf16x8 v; } u;
+                    u.s.a = *reinterpret_cast<const s16x4_*>(stg + px * SROW + ech * 16);
+                    u.s.b = *reinterpret_cast<const s16x4_*>(stg + px * SROW + ech * 16 + 8);
+                    f32x8 f = bf8_to_f32(u.v);
+                    bf16x8 v = u.v;
+                    if (EPI == 1) {
+                        const f32x8 zv = bf8_to_f32(raux[b][i]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) f[j] *= mask_act(fmaf(zv[j], sc[j], sh[j]), blo, bhi);
+                        v = f32_to_bf8(f);
+                        f = bf8_to_f32(v);
+                        esum[b] += f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) esq[b][j] += f[j] * (zv[j] - mu[j]) * is[j];
+                    } else if (EPI == 2) {
+                        f += bf8_to_f32(raux[b][i]);
+                        v = f32_to_bf8(f);
+                    }
+                    *reinterpret_cast<bf16x8*>(p.dx + ((size_t)t * TPX + px) * COUT + c0) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (staging reads done before the next block / tile overwrites the area)
+        }
+        {
+            const long tn = t + nw;
+            issue_aux(tn < ntile ? tn : ntile - 1);
+        }
+    }
+    if (EPI == 1 && p.stats) {
+        // per-lane partial sums of (block, 8 channels): to LDS, then one thread per channel folds the PPI lanes of a wave and the four waves
+        // in a fixed order (reproducible), one exact add per channel and workgroup
+        float* fo = s_fold + (size_t)(wave * 64 + lane) * NCB * 16;
+#pragma unroll
+        for (int b = 0; b < NCB; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { fo[b * 16 + j] = esum[b][j]; fo[b * 16 + 8 + j] = esq[b][j]; }
+        __syncthreads();
+        for (int i = tid; i < 2 * COUT; i += 256) {
+            const int which = i >= COUT, c = which ? i - COUT : i;
+            const int b = c / BW, cc = c - b * BW, ch = cc >> 3, j = cc & 7;
+            float v = 0.f;
+            for (int w = 0; w < 4; ++w)
+                for (int pl = 0; pl < PPI; ++pl) v += s_fold[(size_t)(w * 64 + pl * CPRB + ch) * NCB * 16 + b * 16 + which * 8 + j];
+            stat_publish(p.stats + (size_t)g * ADAMML_STAT_SLOTS * 2 * COUT + i, 2 * COUT, blockIdx.x & (ADAMML_STAT_SLOTS - 1), v);
+        }
+    }
+}
+
+template <int KS, int COUT, bool DUAL, int EPI>
+int narrow_dgrad_launch(const ND1P& p, int groups, hipStream_t stream) {
+    constexpr int KP = KS * 32, NCT = (COUT + 15) / 16, NCB = (NCT + 5) / 6, BT = (NCT + NCB - 1) / NCB, BW = BT * 16;
+    constexpr size_t lds = (size_t)NCB * BW * (KP * 2 + 16) + 3 * KP * 4 + 4 * NCB * BW * 4 + (EPI == 1 ? 4 * 64 * NCB * 16 * 4 : 0) + 4 * 32 * (BW * 2 + 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_narrow_dgrad_kernel<KS, COUT, DUAL, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv_bwd_data (narrow): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        }
+        attr_set = true;
+    }
+    const long ntile = (p.P + 31) / 32;
+    long nblk = (ntile + 3) / 4;
+    long cap = 768 / groups;
+    if (cap < 1) cap = 1;
+    if (nblk > cap) nblk = cap;
+    hipLaunchKernelGGL((conv1x1_narrow_dgrad_kernel<KS, COUT, DUAL, EPI>), dim3((unsigned)nblk, groups), dim3(256), lds, stream, p);
+    return adamml_check_launch("conv_bwd_data_dual (narrow 1x1 stream)");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Weight gradient of the same narrow 1x1 convs: dW[co][ci] = sum_p dz[p][co] * a[p][ci], a = act(scale x + shift) of the lazily normalised
 // input.  Both operands are pixel-major and NARROW (16 .. 192 channels): a 32-pixel tile of either is ONE contiguous run of memory.  A wave
 // keeps the whole dW (<= 24 MFMA tiles of 16 x 16) in registers over all its tiles; per tile it loads the two runs with 16-byte coalesced
@@ -461,4 +702,64 @@ int adamml_conv1x1_narrow_wgrad_launch(const adamml_conv_desc_t* d, const void* 
     if (co == 192 && ci == 32) return narrow_wgrad_launch<192, 32>(p, groups, (int)nblk, stream);
     if (co == 32 && ci == 192) return narrow_wgrad_launch<32, 192>(p, groups, (int)nblk, stream);
     return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_weight (narrow): no instance for Cout %d, Cin %d", co, ci);
+}
+
+// ---- DUAL data gradient of the projection convs: K = d->Cout gradient channels (<= 32) -> d->Cin in {32, 96, 144, 192}
+bool adamml_conv1x1_narrow_dual_supported(const adamml_conv_desc_t* d) {
+    static const int on = getenv("ADAMML_NARROW_STREAM") ? atoi(getenv("ADAMML_NARROW_STREAM")) : 1;
+    if (!on || d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->up > 1) return false;
+    return d->Cout % 8 == 0 && d->Cout <= 32 && (d->Cin == 32 || d->Cin == 96 || d->Cin == 144 || d->Cin == 192);
+}
+
+template <int COUT>
+static int narrow_dual_dispatch(const ND1P& p, int groups, int epi, hipStream_t stream) {
+    if (epi == 1) return narrow_dgrad_launch<1, COUT, true, 1>(p, groups, stream);
+    if (epi == 2) return narrow_dgrad_launch<1, COUT, true, 2>(p, groups, stream);
+    return narrow_dgrad_launch<1, COUT, true, 0>(p, groups, stream);
+}
+
+// d: the FORWARD descriptor of the projection conv (as adamml_conv_bwd_data_dual receives it)
+int adamml_conv1x1_narrow_dual_launch(const adamml_conv_desc_t* d, const void* g, const void* z, const float* aff, void* dz_side,
+                                      const void* w_dgrad_packed, void* dx, int accumulate, const void* z_in, const float* bn_vec, int act,
+                                      double* sums, hipStream_t stream) {
+    ND1P p;
+    p.g = (const bf16_t*)g; p.z = (const bf16_t*)z; p.aff = aff; p.side = (bf16_t*)dz_side; p.w = (const bf16_t*)w_dgrad_packed; p.dx = (bf16_t*)dx;
+    p.z_in = (const bf16_t*)z_in; p.bn_vec = bn_vec; p.stats = sums; p.bn_act = act; p.K = d->Cout;
+    p.P = (long)d->N * d->OH * d->OW;
+    if (p.P <= 0) return ADAMML_OK;
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    const int epi = z_in ? 1 : (accumulate ? 2 : 0);
+    switch (d->Cin) {
+        case 32: return narrow_dual_dispatch<32>(p, groups, epi, stream);
+        case 96: return narrow_dual_dispatch<96>(p, groups, epi, stream);
+        case 144: return narrow_dual_dispatch<144>(p, groups, epi, stream);
+        case 192: return narrow_dual_dispatch<192>(p, groups, epi, stream);
+    }
+    return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_dual (narrow): no instance for %d -> %d channels", d->Cout, d->Cin);
+}
+
+// ---- plain-loader data gradient of the EXPANSION convs (K = d->Cin = 96 / 144 / 192 gradient channels -> 16 / 24 / 32) with the BatchNorm-fused
+// epilogue (adamml_conv_bwd_data_bn) or accumulating into dx.  d: the data-gradient-shaped descriptor conv_launch works with.
+bool adamml_conv1x1_narrow_dgrad_epi_supported(const adamml_conv_desc_t* d) {
+    static const int on = getenv("ADAMML_NARROW_STREAM") ? atoi(getenv("ADAMML_NARROW_STREAM")) : 1;
+    if (!on || d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->up > 1) return false;
+    const int ks = narrow_ks(d->Cin), co = d->Cout;
+    return d->Cin % 8 == 0 && ((ks == 3 && co == 16) || (ks == 5 && (co == 24 || co == 32)) || (ks == 6 && co == 32));
+}
+
+int adamml_conv1x1_narrow_dgrad_epi_launch(const adamml_conv_desc_t* d, const void* dz, const void* w_packed, void* dx, const void* z_in,
+                                           const float* bn_vec, int act, double* sums, hipStream_t stream) {
+    ND1P p;
+    p.g = (const bf16_t*)dz; p.z = nullptr; p.aff = nullptr; p.side = nullptr; p.w = (const bf16_t*)w_packed; p.dx = (bf16_t*)dx;
+    p.z_in = (const bf16_t*)z_in; p.bn_vec = bn_vec; p.stats = sums; p.bn_act = act; p.K = d->Cin;
+    p.P = (long)d->N * d->OH * d->OW;
+    if (p.P <= 0) return ADAMML_OK;
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    const int ks = narrow_ks(d->Cin), co = d->Cout;
+    const bool bn = z_in != nullptr;
+    if (ks == 3 && co == 16) return bn ? narrow_dgrad_launch<3, 16, false, 1>(p, groups, stream) : narrow_dgrad_launch<3, 16, false, 2>(p, groups, stream);
+    if (ks == 5 && co == 24) return bn ? narrow_dgrad_launch<5, 24, false, 1>(p, groups, stream) : narrow_dgrad_launch<5, 24, false, 2>(p, groups, stream);
+    if (ks == 5 && co == 32) return bn ? narrow_dgrad_launch<5, 32, false, 1>(p, groups, stream) : narrow_dgrad_launch<5, 32, false, 2>(p, groups, stream);
+    if (ks == 6 && co == 32) return bn ? narrow_dgrad_launch<6, 32, false, 1>(p, groups, stream) : narrow_dgrad_launch<6, 32, false, 2>(p, groups, stream);
+    return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data (narrow): no instance for %d -> %d channels", d->Cin, d->Cout);
 }

@@ -1787,6 +1787,13 @@ int ilog2_exact(int v) {
 bool adamml_conv3x3_c64_supported(const adamml_conv_desc_t* d);
 bool adamml_conv1x1_narrow_fwd_supported(const adamml_conv_desc_t* d);
 bool adamml_conv1x1_narrow_wgrad_supported(const adamml_conv_desc_t* d, int cin_true);
+bool adamml_conv1x1_narrow_dual_supported(const adamml_conv_desc_t* d);
+bool adamml_conv1x1_narrow_dgrad_epi_supported(const adamml_conv_desc_t* d);
+int adamml_conv1x1_narrow_dgrad_epi_launch(const adamml_conv_desc_t* d, const void* dz, const void* w_packed, void* dx, const void* z_in,
+                                           const float* bn_vec, int act, double* sums, hipStream_t stream);
+int adamml_conv1x1_narrow_dual_launch(const adamml_conv_desc_t* d, const void* g, const void* z, const float* aff, void* dz_side,
+                                      const void* w_dgrad_packed, void* dx, int accumulate, const void* z_in, const float* bn_vec, int act,
+                                      double* sums, hipStream_t stream);
 int adamml_conv1x1_narrow_wgrad_launch(const adamml_conv_desc_t* d, const void* dz, const void* x, const float* in_scale, const float* in_shift,
                                        float* ws, int max_blocks_per_group, int* nblk_out, hipStream_t stream);
 int adamml_conv1x1_narrow_fwd_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
@@ -1825,6 +1832,10 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     // narrow 1x1 convs of the MobileNetV2s (plain forward / plain data gradient): the barrier-free streaming kernel (conv1x1_narrow.hip)
     if (!cls && !fadd && !res && !dual && !cat && !pf && !bn_z && adamml_conv1x1_narrow_fwd_supported(d))
         return adamml_conv1x1_narrow_fwd_launch(d, x, w_packed, in_scale, in_shift, y, stats, stream);
+    // ... their data gradients with the BatchNorm-fused epilogue (bn_z) or accumulating into the output
+    if (!cls && !fadd && !res && !dual && !cat && !pf && !in_scale && (bn_z ? stats != nullptr && !d->accumulate : d->accumulate != 0) &&
+        adamml_conv1x1_narrow_dgrad_epi_supported(d))
+        return adamml_conv1x1_narrow_dgrad_epi_launch(d, x, w_packed, y, bn_z, bn_vec, bn_act, stats, stream);
     ConvP p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_packed; p.in_scale = in_scale; p.in_shift = in_shift;
     p.y = (bf16_t*)y; p.stats = stats;
@@ -2176,6 +2187,8 @@ extern "C" int adamml_conv_bwd_data_dual(const adamml_conv_desc_t* d, const void
     if ((z_in != nullptr) != (bn_vec != nullptr) || (z_in != nullptr) != (sums != nullptr))
         return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_dual: incomplete BatchNorm epilogue operands");
     if (z_in && accumulate) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_dual: the BatchNorm epilogue does not accumulate");
+    if (adamml_conv1x1_narrow_dual_supported(d))             // projection convs of the MobileNetV2s: barrier-free streaming kernel (conv1x1_narrow.hip)
+        return adamml_conv1x1_narrow_dual_launch(d, g, z, aff, dz_side, w_dgrad_packed, dx, accumulate, z_in, bn_vec, act, sums, stream);
     adamml_conv_desc_t gd = *d;
     gd.N = d->N; gd.H = d->OH; gd.W = d->OW; gd.Cin = d->Cout;
     gd.OH = d->H; gd.OW = d->W; gd.Cout = d->Cin;

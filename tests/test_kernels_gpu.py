@@ -893,7 +893,10 @@ def test_maxpool_bwd_bn_fused_equals_unfused_sequence(N, H, W, C, G):
 
 
 @pytest.mark.parametrize("N,H,Cin,Cout,G,mode", [(4, 28, 64, 256, 1, "plain"), (6, 14, 128, 512, 3, "bn"), (4, 20, 64, 256, 2, "acc"),
-                                                  (2, 16, 144, 24, 1, "bn"), (5, 7, 128, 512, 5, "bn"), (3, 14, 256, 384, 1, "plain")])
+                                                  (2, 16, 144, 24, 1, "bn"), (5, 7, 128, 512, 5, "bn"), (3, 14, 256, 384, 1, "plain"),
+                                                  # projection convs of the MobileNetV2s: the narrow streaming kernel (csrc/conv1x1_narrow.hip), ragged pixel counts
+                                                  (3, 17, 32, 16, 2, "bn"), (2, 13, 96, 24, 3, "acc"), (2, 11, 192, 32, 1, "plain"), (1, 19, 144, 32, 2, "bn"),
+                                                  (2, 9, 192, 32, 5, "bn"), (1, 21, 96, 24, 1, "bn"), (2, 15, 32, 16, 1, "plain")])
 def test_conv_bwd_data_dual_equals_apply_then_dgrad(N, H, Cin, Cout, G, mode):
     """adamml_conv_bwd_data_dual (BatchNorm-backward apply folded into the loader of the 1x1 data gradient, dz as a side
     output) against adamml_bn_bwd_apply + adamml_conv_bwd_data[_bn].  The affine form A g + B z + C rounds differently
