@@ -2032,6 +2032,18 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     return adamml_check_launch("conv_fwd");
 }
 
+extern "C" int adamml_conv1x1_narrow_supported(const adamml_conv_desc_t* d, int kind) {
+    if (!d) return 0;
+    if (kind == 0) return adamml_conv1x1_narrow_fwd_supported(d) ? 1 : 0;
+    if (kind == 1) return adamml_conv1x1_narrow_wgrad_supported(d, d->Cin) ? 1 : 0;
+    if (kind == 2) return adamml_conv1x1_narrow_dual_supported(d) ? 1 : 0;
+    adamml_conv_desc_t g = *d;                                   // the data-gradient-shaped descriptor conv_launch dispatches on
+    g.H = d->OH; g.W = d->OW; g.Cin = d->Cout; g.OH = d->H; g.OW = d->W; g.Cout = d->Cin; g.accumulate = 0;
+    if (kind == 3) return adamml_conv1x1_narrow_fwd_supported(&g) ? 1 : 0;
+    if (kind == 4) return adamml_conv1x1_narrow_dgrad_epi_supported(&g) ? 1 : 0;
+    return 0;
+}
+
 extern "C" int adamml_conv_fused_input_supported(const adamml_conv_desc_t* d) {
     return d && adamml_conv3x3_c64_supported(d) ? 1 : 0;
 }

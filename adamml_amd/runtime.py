@@ -378,13 +378,20 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
     in_b, out_b = 2.0 * G * d.N * d.H * d.W * cs.cin_true, 2.0 * G * count * C
     w_b = 2.0 * C * cs.kh * cs.kw * (1 if cs.depthwise else cs.cin_true)
     # device kernel behind adamml_conv_fwd / adamml_conv_bwd_data[_bn] for this layer (bench.py groups launches by it)
-    kern = None
+    kern = kern_f = kern_dual = kern_acc = kern_bn = None
     if not cs.depthwise:
-        kern = "conv3x3_c64_kernel" if hip.load().adamml_conv_fused_input_supported(byref(d)) else "conv_gemm_kernel"
+        lib = hip.load()
+        kern = "conv3x3_c64_kernel" if lib.adamml_conv_fused_input_supported(byref(d)) else "conv_gemm_kernel"
+        # the narrow 1x1 layers of the MobileNetV2s run on the streaming kernels of csrc/conv1x1_narrow.hip
+        nar = [bool(lib.adamml_conv1x1_narrow_supported(byref(d), k)) for k in range(5)] if cs.kh * cs.kw == 1 else [False] * 5
+        kern_f = "conv1x1_narrow_fwd_kernel" if nar[0] else kern
+        kern_dual = "conv1x1_narrow_dgrad_kernel" if nar[2] else kern
+        kern_acc = ("conv1x1_narrow_dgrad_kernel" if nar[4] else kern, "conv1x1_narrow_fwd_kernel" if nar[3] else kern)      # [accumulating?]
+        kern_bn = "conv1x1_narrow_dgrad_kernel" if nar[4] else kern
     role_f = None if cs.depthwise else (R_KXK if cs.kh * cs.kw > 1 else R_1X1)
     role_b = None if cs.depthwise else (R_KXK if (cs.kh * cs.kw > 1 or cs.stride > 1) else R_1X1)
     role_bf = role_b if role_b != R_1X1 else R_FUSED          # data gradient with a fused BatchNorm-backward / residual epilogue
-    hip.next_meta = (2 * macs, in_b + out_b + w_b, "conv_stem_kernel" if stem else kern, role_f)
+    hip.next_meta = (2 * macs, in_b + out_b + w_b, "conv_stem_kernel" if stem else kern_f, role_f)
     if rt.training:
         stats = rt.fwd_arena.take(G * 2 * C * STAT_SLOTS)
         if stem:
@@ -417,7 +424,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                 return
             if DUAL_DGRAD and act == ACT_NONE and not cs.depthwise and not stem and out.pool_grad is None and x.requires_grad \
                     and rt.training and hip.load().adamml_conv_bwd_data_dual_supported(byref(d)):
-                _conv1x1_backward_dual(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern)
+                _conv1x1_backward_dual(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern_dual)
                 return
             dz = _bn_backward(rt, out, y, vec, bn, act, count)
             if cs.weight.requires_grad:
@@ -440,7 +447,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                 if x.grad is None:
                     x.grad = torch.empty_like(x.data)
                     acc = 0
-                hip.next_meta = (2 * macs, in_b * (1 + acc) + out_b + w_b, kern, role_b)
+                hip.next_meta = (2 * macs, in_b * (1 + acc) + out_b + w_b, kern if cs.depthwise else kern_acc[0 if acc else 1], role_b)
                 tgt = x.src if x.src is not None else x
                 if cs.depthwise and DW_BNZ and sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None \
                         and hip.load().adamml_dwconv_bwd_data_bn_supported(byref(d)):
@@ -485,7 +492,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                     x.res_done = True
                 elif sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None:
                     sums = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS)
-                    hip.next_meta = (2 * macs, 2 * in_b + out_b + w_b, kern, role_bf)
+                    hip.next_meta = (2 * macs, 2 * in_b + out_b + w_b, kern_bn, role_bf)
                     call("adamml_conv_bwd_data_bn", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), ptr(tgt.data), ptr(tgt.vec),
                          tgt.act, ptr(sums))
                     tgt.pre_sums = sums

@@ -75,6 +75,12 @@ ADAMML_API int adamml_conv_fwd(const adamml_conv_desc_t* d, const void* x, const
  * 3x3 / stride 1 / pad 1 / 64 -> 64 channels), so the caller need not materialise the normalised input first; 0 when the
  * implicit-GEMM loader would re-apply it once per tap. */
 ADAMML_API int adamml_conv_fused_input_supported(const adamml_conv_desc_t* d);
+/* 1 when the 1x1 conv of FORWARD descriptor d is served by the barrier-free streaming kernels of the narrow MobileNetV2 layers
+ * (csrc/conv1x1_narrow.hip; models/policy_net.py:63-95, models/sound_mobilenet_v2.py:43-69) instead of the tile-loop implicit GEMM,
+ * for kind 0: adamml_conv_fwd, 1: adamml_conv_bwd_weight (with a workspace), 2: adamml_conv_bwd_data_dual, 3: adamml_conv_bwd_data
+ * without accumulation, 4: adamml_conv_bwd_data_bn / adamml_conv_bwd_data accumulating.  Results are identical either way; callers
+ * use it to label launches with the device kernel that runs (bench.py's roofline groups launches by kernel). */
+ADAMML_API int adamml_conv1x1_narrow_supported(const adamml_conv_desc_t* d, int kind);
 /* Forward 1x1 / stride-1 conv with BatchNorm + residual add + activation in its epilogue (a bottleneck's conv3 + bn3 + add +
  * ReLU, models/resnet.py:104-112; a MobileNetV2 projection + add) -- for the cases where the BatchNorm vectors are known before
  * the launch: eval mode, or train mode with statistics from adamml_gram_stats.  bn_vec [groups][4][Cout] (scale, shift, ..) of

@@ -39,6 +39,13 @@ def role(name):
         if flag(3) or flag(4) or flag(5) or flag(6) or a[10].lstrip("(int)") == "1":
             return "conv1x1_fused_streaming"
         return "conv1x1_streaming"
+    if b == "conv1x1_narrow_fwd_kernel":
+        return "conv1x1_streaming"
+    if b == "conv1x1_narrow_dgrad_kernel":                  # <KS, COUT, DUAL, EPI>: DUAL loader or BatchNorm-fused epilogue -> fused
+        a = [t.strip() for t in re.search(r"conv1x1_narrow_dgrad_kernel<([^>]*)>", name).group(1).split(",")]
+        return "conv1x1_fused_streaming" if (a[2] in ("true", "1") or a[3].lstrip("(int)") == "1") else "conv1x1_streaming"
+    if b == "conv1x1_narrow_wgrad_kernel":
+        return "weight_gradient"
     if b in ("conv3x3_c64_kernel", "conv_stem_kernel"):
         return "convKxK_mfma"
     if b == "alg_stream_kernel":
