@@ -2066,6 +2066,26 @@ extern "C" int adamml_conv_fwd_bn_add(const adamml_conv_desc_t* d, const void* x
     return conv_launch(d, x, w_packed, in_scale, in_shift, out, nullptr, nullptr, nullptr, 0, stream, nullptr, nullptr, nullptr, nullptr, &f);
 }
 
+bool adamml_conv1x1_fadd_next_supported(const adamml_conv_desc_t* d, int next_cout);
+int adamml_conv1x1_fadd_next_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
+                                    const float* bn_vec, const void* idn, const float* id_scale, const float* id_shift, int id_gstride, int act,
+                                    void* out, uint8_t* mask_out, const void* w1_packed, void* y1, double* stats1, hipStream_t stream);
+
+extern "C" int adamml_conv_fwd_bn_add_next_supported(const adamml_conv_desc_t* d, int next_cout) {
+    return d && next_cout > 0 && adamml_conv_fwd_bn_add_supported(d) && adamml_conv1x1_fadd_next_supported(d, next_cout) ? 1 : 0;
+}
+
+extern "C" int adamml_conv_fwd_bn_add_next(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
+                                           const float* in_shift, const float* bn_vec, const void* idn, const float* id_scale,
+                                           const float* id_shift, int id_gstride, int act, void* out, uint8_t* mask_out, const void* w_next,
+                                           void* y_next, double* stats_next, hipStream_t stream) {
+    if (!d || !x || !w_packed || !bn_vec || !out || !w_next || !y_next) return adamml_set_error(ADAMML_EINVAL, "conv_fwd_bn_add_next: null argument");
+    if (!adamml_conv_fwd_bn_add_next_supported(d, 64))
+        return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd_bn_add_next: 1x1 / stride-1, 64 -> 256 channels, next conv 256 -> 64 only");
+    return adamml_conv1x1_fadd_next_launch(d, x, w_packed, in_scale, in_shift, bn_vec, idn, id_scale, id_shift, id_gstride, act, out, mask_out,
+                                           w_next, y_next, stats_next, stream);
+}
+
 extern "C" int adamml_conv_fwd_bn_add_tpool_supported(const adamml_conv_desc_t* d, int frames, int act, int lazy_input) {
     if (!adamml_conv_fwd_bn_add_supported(d)) return 0;
     if (!(frames == 2 || frames == 4 || frames == 8) || d->N % frames || d->Cout % 128 || act != ADAMML_ACT_RELU) return 0;

@@ -34,6 +34,7 @@ SIGNATURES = {
     "adamml_conv_fwd": [_DESC, _P, _P, _P, _P, _P, _P, _P],
     "adamml_conv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
     "adamml_conv_fwd_bn_add": [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "adamml_conv_fwd_bn_add_next": [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "adamml_conv_fwd_bn_add_tpool": [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "adamml_temporal_pool_bwd_code": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "adamml_copy2d": [_P, _Z, _P, _Z, _Z, _Z, _P],
@@ -138,6 +139,8 @@ def load():
     lib.adamml_conv1x1_narrow_supported.restype = c_int
     lib.adamml_conv_fwd_bn_add_supported.argtypes = [_DESC]
     lib.adamml_conv_fwd_bn_add_supported.restype = c_int
+    lib.adamml_conv_fwd_bn_add_next_supported.argtypes = [_DESC, c_int]
+    lib.adamml_conv_fwd_bn_add_next_supported.restype = c_int
     lib.adamml_conv_fwd_bn_add_tpool_supported.argtypes = [_DESC, _I, _I, _I]
     lib.adamml_conv_fwd_bn_add_tpool_supported.restype = c_int
     lib.adamml_conv_bwd_data_dual_supported.argtypes = [_DESC]

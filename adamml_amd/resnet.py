@@ -106,7 +106,7 @@ class ResNet(HipBackbone, MeanStdMixin, StockDDPAware):
                 self._mark_grads_ready_after(tape, [self.layer3])
             elif li == 3:
                 self._mark_grads_ready_after(tape, [self.layer4, self.fc])
-            for b in layer:
+            for bi, b in enumerate(layer):
                 # the downsample branch is issued FIRST so that its data gradient runs LAST in the reversed tape: it then
                 # accumulates into the gradient conv1 already wrote, and a stride-2 1x1 only touches a quarter of the pixels
                 idn = conv_bn(rt, h, b._csd, b.downsample[1], ACT_NONE) if b._csd is not None else h
@@ -120,7 +120,9 @@ class ResNet(HipBackbone, MeanStdMixin, StockDDPAware):
                     # behind the last block of a stage the temporal max-pool runs in that kernel's epilogue as well
                     pooled = (b is layer[-1] and li < 3 and not self.without_t_stride and
                               conv_bn_add_tpool_supported(rt, o, b._cs3, idn, ACT_RELU, frames, self.pooling_method))
-                    h = conv_bn_add(rt, o, b._cs3, b.bn3, idn, ACT_RELU, idn_sole=b._csd is not None, tpool=frames if pooled else 0)
+                    # (within a stage the next block's conv1 is the only conv of the block output: it can run inside this kernel)
+                    nxt = layer[bi + 1]._cs1 if (bi + 1 < len(layer) and not pooled) else None
+                    h = conv_bn_add(rt, o, b._cs3, b.bn3, idn, ACT_RELU, idn_sole=b._csd is not None, tpool=frames if pooled else 0, next_cs=nxt)
                 else:
                     o = conv_bn(rt, o, b._cs3, b.bn3, ACT_NONE, sole_consumer=True)
                     h = add_act(rt, o, idn, ACT_RELU, idn_sole=b._csd is not None)

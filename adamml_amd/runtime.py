@@ -34,7 +34,7 @@ class Lazy:
     """Activation tensor [G*N,H,W,C] bf16 (G BatchNorm groups, group-major) whose value is act(scale*data + shift)
     (scale None -> data); group g uses scale + g*gs, shift + g*gs (gs == 0: one pair for all groups)."""
     __slots__ = ("data", "scale", "shift", "gs", "act", "grad", "requires_grad", "vec", "src", "pre_sums", "res", "res_done", "pool_grad", "alg", "sums_partial",
-                 "recompute", "_shape", "alg_in", "prod")
+                 "recompute", "_shape", "alg_in", "prod", "next_pre")
 
     def __init__(self, data, scale=None, shift=None, act=ACT_NONE, requires_grad=True, gs=0):
         self.data, self.scale, self.shift, self.act, self.gs = data, scale, shift, act, gs
@@ -51,6 +51,7 @@ class Lazy:
         self.recompute = None       # data is None: the raw tensor was never written (conv_bn_add); recompute() materialises it
         self.alg_in = None          # (lazy input of the conv that produced this tensor, its descriptor): algebraic backward only
         self.prod = None            # P = g'^T a [G, C, Cin] already accumulated by the producer of .grad (adamml_conv_bwd_data_res_prod)
+        self.next_pre = None        # (ConvState, raw output, statistics) of a conv of THIS tensor that its producer already ran (conv_bn_add next_cs)
         self._shape = None
 
     @property
@@ -366,7 +367,9 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
     if x.shape[0] % G:
         raise RuntimeError("conv_bn: %d images do not split into %d BatchNorm groups" % (x.shape[0], G))
     dev = x.data.device
-    y = torch.empty(G * d.N, d.OH, d.OW, d.Cout, dtype=torch.bfloat16, device=dev)
+    pre = x.next_pre if (x.next_pre is not None and x.next_pre[0] is cs and rt.training) else None     # forward already run by the producer of x
+    x.next_pre = None
+    y = pre[1] if pre is not None else torch.empty(G * d.N, d.OH, d.OW, d.Cout, dtype=torch.bfloat16, device=dev)
     C = d.Cout
     count = d.N * d.OH * d.OW               # elements per channel per group
     fwd = "adamml_dwconv_fwd" if cs.depthwise else "adamml_conv_fwd"
@@ -392,7 +395,11 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
     role_b = None if cs.depthwise else (R_KXK if (cs.kh * cs.kw > 1 or cs.stride > 1) else R_1X1)
     role_bf = role_b if role_b != R_1X1 else R_FUSED          # data gradient with a fused BatchNorm-backward / residual epilogue
     hip.next_meta = (2 * macs, in_b + out_b + w_b, "conv_stem_kernel" if stem else kern_f, role_f)
-    if rt.training:
+    if pre is not None:
+        hip.next_meta = (0.0, 0.0)
+        vec = _bn_vectors(rt, bn, pre[2], count, C, dev)
+        rt.touched_bns.append(bn)
+    elif rt.training:
         stats = rt.fwd_arena.take(G * 2 * C * STAT_SLOTS)
         if stem:
             call("adamml_conv_stem_fwd", byref(d), ptr(x.data), ptr(cs.w_stem), ptr(y), ptr(stats))
@@ -856,7 +863,10 @@ def conv_bn_add_tpool_supported(rt, x, cs, idn, act, frames, mode):
     return bool(hip.load().adamml_conv_fwd_bn_add_tpool_supported(byref(d), frames, act, 1 if x.scale is not None else 0))
 
 
-def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False, tpool=0):
+FADD_NEXT = os.environ.get("ADAMML_FADD_NEXT", "1") != "0"     # conv3 + bn3 + add + ReLU and the NEXT block's conv1 in one streaming kernel (A/B aid)
+
+
+def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False, tpool=0, next_cs=None):
     """out = act(BatchNorm(conv1x1(x)) + value(idn)) in ONE kernel whose epilogue normalises, adds and activates
     (adamml_conv_fwd_bn_add): the raw conv output is never written to HBM nor re-read by a separate add pass.
     tpool = T > 0 (caller checked conv_bn_add_tpool_supported): the block output feeds only TemporalPooling(max) over the T frames of a
@@ -914,11 +924,29 @@ def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False, tpool=0):
         out_t = torch.empty(G * d.N, d.OH, d.OW, C, dtype=torch.bfloat16, device=dev)
         mask_t = torch.empty(G * d.N, d.OH, d.OW, C // 8, dtype=torch.uint8, device=dev) if (need_grad and act != ACT_NONE) else None
         hip.next_meta = (2 * macs, in_b + (2 if idn is not None else 1) * out_b + w_b + (out_b / 16 if mask_t is not None else 0), kern, R_FUSED)
-        call("adamml_conv_fwd_bn_add", byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(vec),
-             ptr(idn.data) if idn is not None else None, ptr(idn.scale) if idn is not None else None,
-             ptr(idn.shift) if idn is not None else None, idn.gs if idn is not None else 0, act, ptr(out_t), ptr(mask_t))
+        nxt = None
+        if (FADD_NEXT and next_cs is not None and rt.training and next_cs.kh * next_cs.kw == 1 and next_cs.stride == 1
+                and not next_cs.depthwise and next_cs.cin == C and hip.load().adamml_conv_fwd_bn_add_next_supported(byref(d), next_cs.weight.shape[0])):
+            # the NEXT block's conv1 consumes the block-output tile while it is still in LDS (csrc/conv1x1_fadd_next.hip): conv_bn(out, next_cs)
+            # finds its raw output and statistics here and launches nothing
+            Cn = next_cs.weight.shape[0]
+            y_n = torch.empty(G * d.N, d.OH, d.OW, Cn, dtype=torch.bfloat16, device=dev)
+            st_n = rt.fwd_arena.take(G * 2 * Cn * STAT_SLOTS)
+            hip.next_meta = (2 * macs + 2.0 * count * G * C * Cn, in_b + (2 if idn is not None else 1) * out_b + w_b + 2.0 * G * count * Cn + 2.0 * C * Cn
+                             + (out_b / 16 if mask_t is not None else 0), "conv1x1_fadd_next_kernel", R_FUSED)
+            call("adamml_conv_fwd_bn_add_next", byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(vec),
+                 ptr(idn.data) if idn is not None else None, ptr(idn.scale) if idn is not None else None,
+                 ptr(idn.shift) if idn is not None else None, idn.gs if idn is not None else 0, act, ptr(out_t), ptr(mask_t),
+                 ptr(next_cs.w_fwd), ptr(y_n), ptr(st_n))
+            nxt = (next_cs, y_n, st_n)
+        else:
+            call("adamml_conv_fwd_bn_add", byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(vec),
+                 ptr(idn.data) if idn is not None else None, ptr(idn.scale) if idn is not None else None,
+                 ptr(idn.shift) if idn is not None else None, idn.gs if idn is not None else 0, act, ptr(out_t), ptr(mask_t))
         full_shape = tuple(out_t.shape)
     out = Lazy(out_t)
+    if not tpool:
+        out.next_pre = nxt
     if not need_grad:
         return out
     # the raw conv output as a (never materialised) lazy tensor: the generic residual machinery only needs its BatchNorm vectors

@@ -91,6 +91,16 @@ ADAMML_API int adamml_conv_fwd_bn_add_supported(const adamml_conv_desc_t* d);
 ADAMML_API int adamml_conv_fwd_bn_add(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
                            const float* bn_vec, const void* idn, const float* id_scale, const float* id_shift, int id_gstride, int act,
                            void* out, uint8_t* mask_out, hipStream_t stream);
+/* conv3 + bn3 + residual add + activation of a bottleneck AND the 1x1 conv1 of the NEXT bottleneck in one barrier-free streaming
+ * kernel (csrc/conv1x1_fadd_next.hip; models/resnet.py:104-112 then :94-96 of the next block): the block output `out` (+ mask_out) is
+ * written as by adamml_conv_fwd_bn_add, and its tile -- still in LDS -- is multiplied with w_next [next_cout][Cout] (forward pack) into
+ * y_next [same pixels][next_cout] with the per-channel sums of the stored values in stats_next ([groups][SLOTS][2*next_cout], caller
+ * zeroes; may be NULL), exactly what adamml_conv_fwd(out -> y_next) would produce (bit-identical y_next), without re-reading `out`.
+ * ResNet-50 layer 1 only: Cin = 64, Cout = 256, next_cout = 64 (the weights of both convs are LDS-resident). */
+ADAMML_API int adamml_conv_fwd_bn_add_next_supported(const adamml_conv_desc_t* d, int next_cout);
+ADAMML_API int adamml_conv_fwd_bn_add_next(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
+                                const float* bn_vec, const void* idn, const float* id_scale, const float* id_shift, int id_gstride, int act,
+                                void* out, uint8_t* mask_out, const void* w_next, void* y_next, double* stats_next, hipStream_t stream);
 /* The same conv + BatchNorm + add + ReLU when the block output feeds ONLY a temporal max-pool (the last block of a ResNet stage:
  * models/resnet.py:205-209 -> models/common.py:4-33, kernel 3 / stride 2 / pad 1 over the `frames` frames of a clip; d->N = clips * frames
  * per group): the epilogue pools over the frames and writes pooled [groups * clips * frames / 2][OH*OW][Cout] and, when `code` is given,

@@ -1108,6 +1108,57 @@ def test_conv_fwd_bn_add_and_gram_statistics(G, N, H, Cin, Cout, lazy_idn, act):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("G,N,H,lazy_idn,with_idn", [(3, 2, 28, False, True), (1, 1, 13, True, True), (5, 1, 9, False, False), (2, 3, 15, True, True)])
+def test_conv_fwd_bn_add_next_equals_the_two_launches(G, N, H, lazy_idn, with_idn):
+    """adamml_conv_fwd_bn_add_next (csrc/conv1x1_fadd_next.hip: conv3 + bn3 + add + ReLU of a layer-1 bottleneck and conv1 of the NEXT
+    bottleneck from the LDS-resident block-output tile) against adamml_conv_fwd_bn_add followed by adamml_conv_fwd: the block output, its
+    1-bit mask and the next conv's output must be BIT-IDENTICAL (same K order, rounding points and epilogue expression), the statistics of
+    the next conv's output equal up to summation order; ragged pixel counts (P % 16 != 0), lazy and plain identities, no identity."""
+    torch.manual_seed(G * 100 + H)
+    Cin, Cout, Cn = 64, 256, 64
+    x = (torch.randn(G * N, H, H, Cin, device=DEV) * 1.5).to(torch.bfloat16)
+    xvec = torch.rand(G, 4, Cin, device=DEV) + 0.5
+    xvec[:, 1] -= 0.7
+    w3 = torch.randn(Cout, Cin, 1, 1, device=DEV) * (2.0 / Cin) ** 0.5
+    w1 = torch.randn(Cn, Cout, 1, 1, device=DEV) * (2.0 / Cout) ** 0.5
+    w3p, w1p = pack(w3, Cin, 0), pack(w1, Cout, 0)
+    vec = torch.rand(G, 4, Cout, device=DEV) + 0.5
+    vec[:, 1] -= 1.0
+    idn = (torch.randn(G * N, H, H, Cout, device=DEV)).to(torch.bfloat16) if with_idn else None
+    ivec = torch.rand(G, 4, Cout, device=DEV) + 0.5
+    isc, ish, igs = (ptr(ivec[0, 0]), ptr(ivec[0, 1]), 4 * Cout) if (lazy_idn and with_idn) else (None, None, 0)
+    d3 = ConvDesc(N, H, H, Cin, H, H, Cout, 1, 1, 1, 0, 1, 1, 0, G, 4 * Cin)
+    d1 = ConvDesc(N, H, H, Cout, H, H, Cn, 1, 1, 1, 0, 1, 0, 0, G, 0)
+    assert hip.load().adamml_conv_fwd_bn_add_next_supported(byref(d3), Cn) == 1
+    assert hip.load().adamml_conv_fwd_bn_add_next_supported(byref(d1), Cn) == 0
+    # the two launches
+    want = torch.empty(G * N, H, H, Cout, dtype=torch.bfloat16, device=DEV)
+    want_mask = torch.zeros(G * N, H, H, Cout // 8, dtype=torch.uint8, device=DEV)
+    call("adamml_conv_fwd_bn_add", byref(d3), ptr(x), ptr(w3p), ptr(xvec[0, 0]), ptr(xvec[0, 1]), ptr(vec), ptr(idn), isc, ish, igs, 1, ptr(want), ptr(want_mask))
+    want_y = torch.empty(G * N, H, H, Cn, dtype=torch.bfloat16, device=DEV)
+    want_st = torch.zeros(G, STAT_SLOTS, 2 * Cn, dtype=torch.float64, device=DEV)
+    call("adamml_conv_fwd", byref(d1), ptr(want), ptr(w1p), None, None, ptr(want_y), ptr(want_st))
+    # one launch
+    got = torch.zeros_like(want)
+    got_mask = torch.zeros_like(want_mask)
+    got_y = torch.zeros_like(want_y)
+    got_st = torch.zeros_like(want_st)
+    call("adamml_conv_fwd_bn_add_next", byref(d3), ptr(x), ptr(w3p), ptr(xvec[0, 0]), ptr(xvec[0, 1]), ptr(vec), ptr(idn), isc, ish, igs, 1, ptr(got), ptr(got_mask),
+         ptr(w1p), ptr(got_y), ptr(got_st))
+    assert torch.equal(got, want)
+    assert torch.equal(got_mask, want_mask)
+    assert torch.equal(got_y, want_y)
+    assert torch.allclose(ssum(got_st), ssum(want_st), rtol=1e-5, atol=1e-3)
+    yf = got_y.float().reshape(G, -1, Cn).double()
+    assert torch.allclose(ssum(got_st)[:, :Cn], yf.sum(1), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(ssum(got_st)[:, Cn:], (yf * yf).sum(1), rtol=1e-4, atol=1e-3)
+    # without a mask and without statistics
+    got2, y2 = torch.zeros_like(want), torch.zeros_like(want_y)
+    call("adamml_conv_fwd_bn_add_next", byref(d3), ptr(x), ptr(w3p), ptr(xvec[0, 0]), ptr(xvec[0, 1]), ptr(vec), ptr(idn), isc, ish, igs, 1, ptr(got2), None,
+         ptr(w1p), ptr(y2), None)
+    assert torch.equal(got2, want) and torch.equal(y2, want_y)
+
+
 @pytest.mark.parametrize("C,P,G,lazy,act", [(64, 3136, 3, True, 1), (64, 777, 1, False, 0), (128, 1570, 2, True, 1), (128, 31, 5, True, 2),
                                             (64, 70001, 2, True, 1), (256, 1570, 2, True, 1), (256, 141120, 5, True, 1), (256, 45, 1, False, 0)])
 def test_gram_colsum_kernel(C, P, G, lazy, act):
