@@ -65,6 +65,7 @@ SIGNATURES = {
     "adamml_dwconv_bwd_data": [_DESC, _P, _P, _P, _I, _P],
     "adamml_dwconv_bwd_data_bn": [_DESC, _P, _P, _P, _P, _P, _I, _P, _P],
     "adamml_dwconv_bwd_weight": [_DESC, _P, _P, _P, _P, _P, _P, _Z, _P],
+    "adamml_dwconv_bwd_fused": [_DESC, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _P],
     "adamml_stats_collapse": [_P, _P, _I, _I, _P],
     "adamml_bn_finalize": [_P, _I, _I, _D, _P, _P, _P, _P, _F, _F, _P, _I, _P],
     "adamml_bn_eval_affine": [_P, _P, _P, _P, _F, _P, _P, _I, _P],
@@ -151,6 +152,10 @@ def load():
     lib.adamml_temporal_pool_bwd_res_supported.restype = c_int
     lib.adamml_dwconv_bwd_data_bn_supported.argtypes = [_DESC]
     lib.adamml_dwconv_bwd_data_bn_supported.restype = c_int
+    lib.adamml_dwconv_bwd_fused_supported.argtypes = [_DESC]
+    lib.adamml_dwconv_bwd_fused_supported.restype = c_int
+    lib.adamml_dwconv_bwd_fused_workspace.argtypes = [_DESC]
+    lib.adamml_dwconv_bwd_fused_workspace.restype = c_size_t
     lib.adamml_conv_stem_supported.argtypes = [_DESC]
     lib.adamml_conv_stem_supported.restype = c_int
     lib.adamml_plan_run.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int]

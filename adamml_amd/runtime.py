@@ -433,6 +433,23 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                     and rt.training and hip.load().adamml_conv_bwd_data_dual_supported(byref(d)):
                 _conv1x1_backward_dual(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern_dual)
                 return
+            if cs.depthwise and DW_FUSED and out.pool_grad is None and out.pre_sums is not None and rt.training and sole_consumer \
+                    and cs.weight.requires_grad and x.requires_grad and x.grad is None and x.src is None and x.vec is not None \
+                    and x.pre_sums is None and x.scale is not None and x.scale.data_ptr() == x.vec.data_ptr() \
+                    and hip.load().adamml_dwconv_bwd_fused_supported(byref(d)):
+                # g is already masked by this conv's activation (out.pre_sums: the projection's data gradient did that), so
+                # dz = A g + B z + C in the loader; apply + weight gradient + data gradient (mask / sums of the expansion) in one pass
+                g, coef = _bn_backward(rt, out, y, vec, bn, act, count, defer_apply=True)
+                aff = torch.empty(G, 3, C, dtype=torch.float32, device=dev)
+                call("adamml_bn_bwd_affine", ptr(coef), ptr(vec), ptr(aff), C, G)
+                x.grad = torch.empty_like(x.data)
+                sums = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS)
+                ws = hip.scratch(hip.load().adamml_dwconv_bwd_fused_workspace(byref(d)), dev)
+                hip.next_meta = (4 * macs, 2 * in_b + 2 * out_b + 2 * w_b, "dwconv_bwd_fused_kernel", None)
+                call("adamml_dwconv_bwd_fused", byref(d), ptr(g), ptr(y), ptr(aff), ptr(cs.w_fwd), ptr(x.data), ptr(x.vec), x.act, ptr(x.grad),
+                     ptr(sums), ptr(cs.weight.grad), ptr(ws), ws.numel() * 4)
+                x.pre_sums = sums
+                return
             dz = _bn_backward(rt, out, y, vec, bn, act, count)
             if cs.weight.requires_grad:
                 with _on_wgrad_stream(rt, (dz, x.data, x.scale)):
@@ -631,6 +648,7 @@ def _gram_colsum(rt, x, d):
 
 RES_PROD = os.environ.get("ADAMML_RES_PROD", "1") != "0"     # g'^T a accumulated inside the residual-backward data gradient (A/B aid)
 POOL_ZSEL = os.environ.get("ADAMML_POOL_ZSEL", "1") != "0"   # stem BatchNorm-backward sums over the pool windows (g_y, z_sel) (A/B aid)
+DW_FUSED = os.environ.get("ADAMML_DW_BWD_FUSED", "1") != "0"    # whole stride-1 depthwise backward in one pass (csrc/dwconv_bwd_fused.hip; A/B aid)
 DW_BNZ = os.environ.get("ADAMML_DW_BNZ", "1") != "0"         # BatchNorm-backward sums of the expansion inside the depthwise data gradient (A/B aid)
 GRAM_KERNEL = os.environ.get("ADAMML_GRAM_KERNEL", "1") != "0"     # dedicated Gram + column-sum kernel (A/B aid)
 ALG_BN = os.environ.get("ADAMML_ALG_BN", "1") != "0"     # algebraic BatchNorm backward through expanding 1x1 convs (A/B aid)

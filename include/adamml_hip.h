@@ -238,6 +238,19 @@ ADAMML_API int adamml_dwconv_bwd_data_bn_supported(const adamml_conv_desc_t* d);
 ADAMML_API int adamml_dwconv_bwd_data_bn(const adamml_conv_desc_t* d, const void* dz, const float* w_tapmajor, void* dx, const void* z_in,
                               const float* bn_vec, int act, double* sums, hipStream_t stream);
 ADAMML_API size_t adamml_dwconv_bwd_weight_workspace(const adamml_conv_desc_t* d);
+/* The whole backward of a stride-1 depthwise conv + train-mode BatchNorm + ReLU6 in one pass (models/sound_mobilenet_v2.py:58-61,
+ * models/policy_net.py:80-83; replaces adamml_bn_bwd_apply + adamml_dwconv_bwd_weight + adamml_dwconv_bwd_data_bn: four passes over the
+ * block's widest tensor instead of eight).  g = gradient w.r.t. the ACTIVATED depthwise output, already masked by its activation (the
+ * projection's data gradient does that), z = the raw depthwise output, aff = [groups][3][C] from adamml_bn_bwd_affine
+ * (dz = A g + B z + C, rounded to bf16 as the per-layer form stores it); x = the RAW expansion output the conv read through its lazy
+ * BatchNorm, x_vec = [groups][4][C] its BatchNorm vectors, x_act its activation.  Outputs: dx = gradient w.r.t. the activated expansion
+ * output, masked (same taps, same order as adamml_dwconv_bwd_data_bn), sums [groups][SLOTS][2C] += sum(dx), sum(dx xhat), and
+ * dw [C][3][3] += the weight gradient (split partials in `workspace`, adamml_dwconv_bwd_fused_workspace bytes). */
+ADAMML_API int adamml_dwconv_bwd_fused_supported(const adamml_conv_desc_t* d);
+ADAMML_API size_t adamml_dwconv_bwd_fused_workspace(const adamml_conv_desc_t* d);
+ADAMML_API int adamml_dwconv_bwd_fused(const adamml_conv_desc_t* d, const void* g, const void* z, const float* aff, const float* w_tapmajor,
+                            const void* x, const float* x_vec, int x_act, void* dx, double* sums, float* dw, void* workspace,
+                            size_t workspace_bytes, hipStream_t stream);
 /* 3x3 / stride-2 / pad-1 stem of a ONE-channel fp32 image -- the first conv of the Sound-MobileNetV2 and of the policy MobileNetV2 on a
  * log-spectrogram (models/sound_mobilenet_v2.py:96, models/policy_net.py:108 with input_channels = 1) -- reading the caller's fp32 tensor
  * directly: image n of BatchNorm group g at x + g * group_stride + n * image_stride floats (for the [B, S, H, W] input of

@@ -488,6 +488,52 @@ def test_dwconv_bwd_data_bn_equals_dgrad_then_reduce(N, H, W, C, s, G):
     assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-5
 
 
+@pytest.mark.parametrize("N,H,W,C,G", [(2, 20, 20, 96, 1), (3, 9, 14, 24, 2), (1, 40, 40, 192, 5), (2, 7, 7, 960, 1), (1, 50, 22, 384, 2),
+                                       (2, 1, 5, 16, 1), (2, 3, 1, 32, 3), (1, 64, 64, 144, 2), (5, 8, 8, 576, 1)])
+def test_dwconv_bwd_fused_equals_apply_wgrad_dgrad(N, H, W, C, G):
+    """adamml_dwconv_bwd_fused (BatchNorm-backward apply + weight gradient + data gradient with the expansion's mask and sums, one pass)
+    against the per-layer form on the same dz = bf16(A g + B z + C): adamml_dwconv_bwd_data_bn (dx bit-identical, sums up to summation
+    order) and adamml_dwconv_bwd_weight (up to summation order)."""
+    torch.manual_seed(N * 11 + H + C)
+    w = torch.randn(C, 1, 3, 3, device=DEV) * 0.4
+    wp = pack(w, C, 2)
+    d = ConvDesc(N, H, W, C, H, W, C, 3, 3, 1, 1, 1, 2, 0, G, 4 * C)
+    assert hip.load().adamml_dwconv_bwd_fused_supported(byref(d)) == 1
+    g = torch.randn(G * N, H, W, C, device=DEV).to(torch.bfloat16)
+    g = g * (torch.rand_like(g, dtype=torch.float32) > 0.3).to(torch.bfloat16)        # masked gradient: exact zeros
+    z = (torch.randn(G * N, H, W, C, device=DEV) * 1.5).to(torch.bfloat16)
+    aff = torch.randn(G, 3, C, device=DEV) * 0.5
+    x = (torch.randn(G * N, H, W, C, device=DEV) * 2).to(torch.bfloat16)
+    xvec = torch.rand(G, 4, C, device=DEV) + 0.5
+    xvec[:, 1] += 1.0                                                   # ReLU6: a share of pixels below 0 and above 6
+    # dz as the kernel forms it: fmaf(A, g, fmaf(B, z, C)) -- each fma emulated in fp64 (products of fp32 numbers are exact there)
+    A, B, Cc = (aff[:, k].double().view(G, 1, 1, 1, C) for k in range(3))
+    inner = (B * _g(z, G).double() + Cc).float().double()
+    dz = (A * _g(g, G).double() + inner).float().to(torch.bfloat16).view_as(z).contiguous()
+    dx_ref = torch.empty_like(x)
+    s_ref = torch.zeros(G, STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
+    call("adamml_dwconv_bwd_data_bn", byref(d), ptr(dz), ptr(wp), ptr(dx_ref), ptr(x), ptr(xvec), 2, ptr(s_ref))
+    dw_ref = torch.zeros_like(w)
+    ws = hip.wgrad_workspace(d, 0, DEV, depthwise=True)
+    call("adamml_dwconv_bwd_weight", byref(d), ptr(dz), ptr(x), ptr(xvec[0, 0]), ptr(xvec[0, 1]), ptr(dw_ref), ptr(ws), ws.numel() * 4)
+    dx = torch.full_like(x, 7.0)
+    sums = torch.zeros_like(s_ref)
+    dw = torch.zeros_like(w)
+    ws = hip.scratch(hip.load().adamml_dwconv_bwd_fused_workspace(byref(d)), DEV)
+    call("adamml_dwconv_bwd_fused", byref(d), ptr(g), ptr(z), ptr(aff), ptr(wp), ptr(x), ptr(xvec), 2, ptr(dx), ptr(sums), ptr(dw), ptr(ws),
+         ws.numel() * 4)
+    assert torch.equal(dx, dx_ref)
+    frac = (dx_ref == 0).float().mean().item()
+    assert 0.02 < frac < 0.98                                          # the mask is exercised both ways
+    a, b = ssum(sums), ssum(s_ref)
+    assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-5
+    close(dw, dw_ref, rtol=1e-3, atol_frac=1e-4, what="fused dw wgrad")
+    # accumulation into dw, as the per-layer form
+    call("adamml_dwconv_bwd_fused", byref(d), ptr(g), ptr(z), ptr(aff), ptr(wp), ptr(x), ptr(xvec), 2, ptr(dx), ptr(sums), ptr(dw), ptr(ws),
+         ws.numel() * 4)
+    close(dw, 2 * dw_ref, rtol=1e-3, atol_frac=1e-4, what="fused dw wgrad, accumulated")
+
+
 @pytest.mark.parametrize("case", [(2, 20, 20, 96, 1), (2, 21, 21, 144, 2)])
 def test_dwconv_groups_equal_separate_launches(case):
     torch.manual_seed(11)
