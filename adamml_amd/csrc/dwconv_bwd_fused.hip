@@ -33,6 +33,59 @@ struct DwBP {
     size_t gz, gx;          // group strides (elements) of g / z and of x / dx
 };
 
+// Epilogue shared by the two walkers: the threads that share a channel chunk (thread ids congruent modulo nchunk) add in turn -- a fixed
+// order (common.h: reproducible reductions) --, the weight-gradient tile first (one [C][9] partial per workgroup), then, in the same LDS,
+// the two statistics rows (published exactly).
+__device__ __forceinline__ void fold_publish(const DwBP& p, float* dsm, const f32x4 (&accw)[9], const f32x4& s, const f32x4& q, bool any, int c) {
+    const int C = p.C, nchunk = C >> 2;
+    __syncthreads();                        // (the constants are dead: their LDS becomes the fold area)
+    for (int i = threadIdx.x; i < 9 * C; i += NT) dsm[i] = 0.f;
+    __syncthreads();
+    const int nturn = (NT + nchunk - 1) / nchunk;
+    for (int r = 0; r < nturn; ++r) {
+        if (any && (int)threadIdx.x / nchunk == r) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dsm[t * C + c + i] += accw[t][i];
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 9 * C; i += NT) {
+        const int t = i / C, cc2 = i - t * C;
+        p.ws[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 9 * C + (size_t)cc2 * 9 + t] = dsm[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += NT) dsm[i] = 0.f;
+    __syncthreads();
+    for (int r = 0; r < nturn; ++r) {
+        if (any && (int)threadIdx.x / nchunk == r) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dsm[c + i] += s[i]; dsm[C + c + i] += q[i]; }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 2 * C; i += NT) {
+        const float v = dsm[i];
+        if (v != 0.f) stat_publish(p.stats + i, 2 * (size_t)C, blockIdx.x & (ADAMML_STAT_SLOTS - 1), v);
+    }
+}
+
+// Group offsets, then the per-channel constants into LDS: [16][C] = the nine taps (REVERSED order when flip), A / B / C, the expansion's
+// scale / shift / mean / invstd.
+__device__ __forceinline__ void group_and_constants(DwBP& p, float* dsm, bool flip) {
+    const size_t g = blockIdx.y;
+    p.g += g * p.gz; p.z += g * p.gz; p.x += g * p.gx; p.dx += g * p.gx;
+    p.aff += g * 3 * p.C; p.xvec += g * 4 * p.C;
+    p.stats += g * ADAMML_STAT_SLOTS * 2 * p.C;
+    const int C = p.C;
+    for (int i = threadIdx.x; i < 16 * C; i += NT) {
+        const int r = i / C, cc2 = i - r * C;
+        dsm[i] = r < 9 ? p.w[(size_t)(flip ? 8 - r : r) * C + cc2] : r < 12 ? p.aff[(size_t)(r - 9) * C + cc2] : p.xvec[(size_t)(r - 12) * C + cc2];
+    }
+    __syncthreads();
+}
+
 // Per-channel constants live in LDS ([16][C] fp32: the nine taps reversed, A / B / C, the expansion's scale / shift / mean / invstd) and
 // are re-read where they are used -- 16 ds_read_b128 per row step against ~800 VALU lane-operations -- instead of pinning 64 registers;
 // the dz window is kept as packed bf16 (it IS bf16: the value the per-layer kernels exchange) and unpacked one window row at a time.
@@ -41,19 +94,9 @@ __global__ __launch_bounds__(NT, 2) void dwconv_bwd_fused_kernel(DwBP p) {
     static_assert(S == 1, "stride-1 walker");
     constexpr int NCOL = SEGW + 2;          // dz columns feeding them
     extern __shared__ __attribute__((aligned(16))) float dsm[];          // [16][C] constants during the walk; then [9][C] weight-gradient fold, [2][C] statistics fold
-    {
-        const size_t g = blockIdx.y;
-        p.g += g * p.gz; p.z += g * p.gz; p.x += g * p.gx; p.dx += g * p.gx;
-        p.aff += g * 3 * p.C; p.xvec += g * 4 * p.C;
-        p.stats += g * ADAMML_STAT_SLOTS * 2 * p.C;
-    }
+    group_and_constants(p, dsm, true);
     const int C = p.C;
     const int nchunk = C >> 2;
-    for (int i = threadIdx.x; i < 16 * C; i += NT) {
-        const int r = i / C, cc2 = i - r * C;
-        dsm[i] = r < 9 ? p.w[(size_t)(8 - r) * C + cc2] : r < 12 ? p.aff[(size_t)(r - 9) * C + cc2] : p.xvec[(size_t)(r - 12) * C + cc2];
-    }
-    __syncthreads();
     const int gid = blockIdx.x * NT + threadIdx.x;
     const int nthreads = gridDim.x * NT;
     const int chunk = gid % nchunk;
@@ -202,39 +245,179 @@ __global__ __launch_bounds__(NT, 2) void dwconv_bwd_fused_kernel(DwBP p) {
         }
 #undef DWB_STEP
     }
-    __syncthreads();                        // (the constants are dead: their LDS becomes the fold area)
-    for (int i = threadIdx.x; i < 9 * C; i += NT) dsm[i] = 0.f;
-    __syncthreads();
-    // the threads that share a channel chunk (thread ids congruent modulo nchunk) add in turn: a fixed order (common.h: reproducible
-    // reductions); the weight-gradient tile first, then (same LDS) the two statistics rows
-    const int nturn = (NT + nchunk - 1) / nchunk;
-    for (int r = 0; r < nturn; ++r) {
-        if (any && (int)threadIdx.x / nchunk == r) {
+    fold_publish(p, dsm, accw, s, q, any, c);
+}
+
+// Stride 2 (pad 1): a thread owns 4 channels x a strip QW 2x2 input quads wide and walks down the quad
+// rows.  Quad (k, j) -- input rows 2k, 2k+1, columns 2j, 2j+1 -- exchanges with exactly the four dz pixels (k + a, j + b), a, b in {0, 1}
+// (pixel (0,0) through one tap, (0,1) and (1,0) through two, (1,1) through four: dwconv_bwd_data_s2_kernel, same tap order), so a strip
+// needs dz columns QW js .. QW js + QW and a TWO-row window of dz: row k + 1 of one step is row k of the next.  dz is a quarter of the block's
+// pixels; the full-resolution tensors x (read once: mask, xhat and the weight gradient's operand) and dx (written once) are the traffic.
+template <int QW>                           // QW = quads (column pairs) per thread
+__global__ __launch_bounds__(NT, 2) void dwconv_bwd_fused_s2_kernel(DwBP p) {
+    constexpr int NDZ = QW + 1;             // dz columns feeding them
+    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    group_and_constants(p, dsm, false);
+    const int C = p.C;
+    const int nchunk = C >> 2;
+    const int gid = blockIdx.x * NT + threadIdx.x;
+    const int nthreads = gridDim.x * NT;
+    const int chunk = gid % nchunk;
+    const long ntasks = (long)nchunk * p.nseg * p.nrb * p.N;
+    const int c = chunk * 4;
+    auto opaque = [](int b) { asm volatile("" : "+v"(b)); return b; };
+    auto K = [&](int b, int r) { return *reinterpret_cast<const f32x4*>(dsm + b + r * C); };
+    f32x4 accw[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t) accw[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    bool any = false;
+    const float lo = act_lo(p.xact), hi = act_hi(p.xact);
+    const char* gb = reinterpret_cast<const char*>(p.g);
+    const char* zb = reinterpret_cast<const char*>(p.z);
+    const char* xb = reinterpret_cast<const char*>(p.x);
+    char* db = reinterpret_cast<char*>(p.dx);
+    for (long task = gid; task < ntasks; task += nthreads) {
+        int tsk = (int)(task / nchunk);
+        const int seg = tsk % p.nseg;
+        tsk /= p.nseg;
+        const int rb = tsk % p.nrb, n = tsk / p.nrb;
+        any = true;
+        const int j0 = seg * QW;                            // first dz column / quad column
+        const int kb = rb * p.rows_per_thread;              // quad rows kb .. ke - 1
+        const int ke = min((p.H + 1) >> 1, kb + p.rows_per_thread);
+        bool zok[NDZ], xok[2 * QW];
+        unsigned zcol[NDZ], xcol[2 * QW];                    // byte offsets of the columns (an invalid one reads column 0: never used)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dsm[t * C + c + i] += accw[t][i];
+        for (int j = 0; j < NDZ; ++j) { zok[j] = j0 + j < p.OW; zcol[j] = zok[j] ? (unsigned)(j0 + j) * C * 2u : 0u; }
+#pragma unroll
+        for (int j = 0; j < 2 * QW; ++j) { xok[j] = 2 * j0 + j < p.W; xcol[j] = xok[j] ? (unsigned)(2 * j0 + j) * C * 2u : 0u; }
+        const unsigned zoff = ((unsigned)n * p.OH * p.OW * C + c) * 2u, zstride = (unsigned)p.OW * C * 2u;
+        const unsigned xoff = ((unsigned)n * p.H * p.W * C + c) * 2u, xstride = (unsigned)p.W * C * 2u;
+
+        struct Raw { bf16x4 g[NDZ], z[NDZ]; };
+        struct XRow { bf16x4 v[2 * QW]; };
+        auto load_dz = [&](int r, Raw& raw) {               // unconditional, clamped (see the stride-1 walker)
+            const unsigned ro = zoff + (unsigned)min(r, p.OH - 1) * zstride;
+#pragma unroll
+            for (int j = 0; j < NDZ; ++j) {
+                raw.g[j] = *reinterpret_cast<const bf16x4*>(gb + (ro + zcol[j]));
+                raw.z[j] = *reinterpret_cast<const bf16x4*>(zb + (ro + zcol[j]));
+            }
+        };
+        auto load_x = [&](int r, XRow& xr) {
+            const unsigned ro = xoff + (unsigned)min(r, p.H - 1) * xstride;
+#pragma unroll
+            for (int j = 0; j < 2 * QW; ++j) xr.v[j] = *reinterpret_cast<const bf16x4*>(xb + (ro + xcol[j]));
+        };
+        auto mkdz = [&](int r, const Raw& raw, f32x4 (&dst)[NDZ]) {
+            const bool rok = r < p.OH;
+            const int kb2 = opaque(c);
+            const f32x4 ca = K(kb2, 9), cb = K(kb2, 10), cc = K(kb2, 11);
+#pragma unroll
+            for (int j = 0; j < NDZ; ++j) {
+                const f32x4 gv = bf4_to_f32(raw.g[j]), zv = bf4_to_f32(raw.z[j]);
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = fmaf(ca[i], gv[i], fmaf(cb[i], zv[i], cc[i]));
+                o = bf4_to_f32(f32_to_bf4(o));
+                const bool ok = rok && zok[j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = ok ? o[i] : 0.f;
+                dst[j] = o;
+            }
+        };
+        // one quad row: d0 = dz row k, d1 = dz row k + 1, x0 / x1 = input rows 2k, 2k + 1
+        auto emit = [&](int k, const f32x4 (&d0)[NDZ], const f32x4 (&d1)[NDZ], const XRow& x0, const XRow& x1) {
+            const int kc = opaque(c);
+            const f32x4 bsc = K(kc, 12), bsh = K(kc, 13), bmu = K(kc, 14), bis = K(kc, 15);
+            const bool r1ok = 2 * k + 1 < p.H;
+            const unsigned ro0 = xoff + (unsigned)(2 * k) * xstride, ro1 = ro0 + xstride;
+#pragma unroll
+            for (int jq = 0; jq < QW; ++jq) {
+                f32x4 acc[2][2], a[2][2], xv[2][2];
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        xv[dy][dx] = bf4_to_f32(dy ? x1.v[2 * jq + dx] : x0.v[2 * jq + dx]);
+                        const bool ok = xok[2 * jq + dx] && (dy == 0 || r1ok);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a[dy][dx][i] = ok ? clamp_act(fmaf(xv[dy][dx][i], bsc[i], bsh[i]), lo, hi) : 0.f;
+                    }
+                const f32x4 g00 = d0[jq], g01 = d0[jq + 1], g10 = d1[jq], g11 = d1[jq + 1];
+                {
+                    // input (2k + dy, 2j + dx) <- dz (k + a, j + b) through tap (kh, kw) = (dy + 1 - 2a, dx + 1 - 2b), ascending (kh, kw)
+                    // (explicit fused multiply-adds from zero, as dwconv_bwd_data_s2_kernel: contraction may fuse either product of a sum)
+                    auto fma4 = [](const f32x4& u, const f32x4& v, const f32x4& w) {
+                        f32x4 r;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(u[i], v[i], w[i]);
+                        return r;
+                    };
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    {
+                        const int kw2 = opaque(c);
+                        const f32x4 w1 = K(kw2, 1), w3 = K(kw2, 3), w4 = K(kw2, 4), w5 = K(kw2, 5), w7 = K(kw2, 7);
+                        acc[0][0] = fma4(g00, w4, zero);
+                        acc[0][1] = fma4(g00, w5, fma4(g01, w3, zero));
+                        acc[1][0] = fma4(g00, w7, fma4(g10, w1, zero));
+                    }
+                    {
+                        const int kw3 = opaque(c);
+                        const f32x4 w0 = K(kw3, 0), w2 = K(kw3, 2), w6 = K(kw3, 6), w8 = K(kw3, 8);
+                        acc[1][1] = fma4(g00, w8, fma4(g01, w6, fma4(g10, w2, fma4(g11, w0, zero))));
+                    }
+                }
+                accw[4] += a[0][0] * g00;
+                accw[3] += a[0][1] * g01;
+                accw[5] += a[0][1] * g00;
+                accw[1] += a[1][0] * g10;
+                accw[7] += a[1][0] * g00;
+                accw[0] += a[1][1] * g11;
+                accw[2] += a[1][1] * g10;
+                accw[6] += a[1][1] * g01;
+                accw[8] += a[1][1] * g00;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        // (a pixel outside the image has a = 0: its mask, its value and its sums vanish; only the store is predicated)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[dy][dx][i] *= (a[dy][dx][i] > lo && a[dy][dx][i] < hi) ? 1.f : 0.f;
+                        const bf16x4 ob = f32_to_bf4(acc[dy][dx]);
+                        if (xok[2 * jq + dx] && (dy == 0 || r1ok)) *reinterpret_cast<bf16x4*>(db + ((dy ? ro1 : ro0) + xcol[2 * jq + dx])) = ob;
+                        const f32x4 rv = bf4_to_f32(ob);
+                        s += rv;
+                        q += rv * ((xv[dy][dx] - bmu) * bis);
+                    }
+            }
+        };
+
+        f32x4 win[2][NDZ];
+        Raw nxt;
+        XRow xa, xb2, xna, xnb;
+        { Raw r; load_dz(kb, r); mkdz(kb, r, win[0]); }
+        load_dz(kb + 1, nxt);
+        load_x(2 * kb, xna);
+        load_x(2 * kb + 1, xnb);
+#define DWB2_STEP(KQ, A, B)                                     \
+        {                                                       \
+            mkdz((KQ) + 1, nxt, win[B]);                        \
+            xa = xna; xb2 = xnb;                                \
+            load_dz((KQ) + 2, nxt);                             \
+            load_x(2 * (KQ) + 2, xna);                          \
+            load_x(2 * (KQ) + 3, xnb);                          \
+            emit((KQ), win[A], win[B], xa, xb2);                \
         }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < 9 * C; i += NT) {
-        const int t = i / C, cc2 = i - t * C;
-        p.ws[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 9 * C + (size_t)cc2 * 9 + t] = dsm[i];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += NT) dsm[i] = 0.f;
-    __syncthreads();
-    for (int r = 0; r < nturn; ++r) {
-        if (any && (int)threadIdx.x / nchunk == r) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { dsm[c + i] += s[i]; dsm[C + c + i] += q[i]; }
+        for (int k = kb; k < ke; k += 2) {
+            DWB2_STEP(k, 0, 1);
+            if (k + 1 >= ke) break;
+            DWB2_STEP(k + 1, 1, 0);
         }
-        __syncthreads();
+#undef DWB2_STEP
     }
-    for (int i = threadIdx.x; i < 2 * C; i += NT) {
-        const float v = dsm[i];
-        if (v != 0.f) stat_publish(p.stats + i, 2 * (size_t)C, blockIdx.x & (ADAMML_STAT_SLOTS - 1), v);
-    }
+    fold_publish(p, dsm, accw, s, q, any, c);
 }
 
 // pixels per thread: 3 (256 registers, none spilled; 4 spills 78 of them, 2 re-reads every halo column)
@@ -243,17 +426,24 @@ int fused_segw() {
     return v == 2 ? 2 : 3;
 }
 
+int fused_qw() {
+    static const int v = getenv("ADAMML_DWB_QW") ? atoi(getenv("ADAMML_DWB_QW")) : 2;              // A/B aid
+    return v == 1 ? 1 : 2;
+}
+
 int fused_blocks(const adamml_conv_desc_t* d, int* rows_per_thread, int* nseg, int* nrb) {
     const long nchunk = d->Cin / 4;
-    *nseg = ceil_div(d->W, fused_segw());
+    // stride 1: strips of fused_segw() pixels, walked down the image rows; stride 2: strips two quads wide, walked down the quad rows
+    const int rows = d->stride == 2 ? (d->H + 1) / 2 : d->H;
+    *nseg = d->stride == 2 ? ceil_div((d->W + 1) / 2, fused_qw()) : ceil_div(d->W, fused_segw());
     const int groups = d->groups < 1 ? 1 : d->groups;
     static const long min_blocks = getenv("ADAMML_DWB_MIN_BLOCKS") ? atol(getenv("ADAMML_DWB_MIN_BLOCKS")) : 256;       // A/B aids
     static const int max_rows = getenv("ADAMML_DWB_MAX_ROWS") ? atoi(getenv("ADAMML_DWB_MAX_ROWS")) : 24;
-    int nb_rows = ceil_div(d->H, max_rows);
-    while (ceil_div(d->H, nb_rows) > 3 && (long)groups * d->N * nb_rows * *nseg * nchunk < min_blocks * NT) ++nb_rows;
-    const int rpt = ceil_div(d->H, nb_rows);
+    int nb_rows = ceil_div(rows, max_rows);
+    while (ceil_div(rows, nb_rows) > 3 && (long)groups * d->N * nb_rows * *nseg * nchunk < min_blocks * NT) ++nb_rows;
+    const int rpt = ceil_div(rows, nb_rows);
     *rows_per_thread = rpt;
-    *nrb = ceil_div(d->H, rpt);
+    *nrb = ceil_div(rows, rpt);
     const long threads = (long)d->N * *nrb * *nseg * nchunk;
     const long nb = (threads + NT - 1) / NT;
     // NT * nblk must be a multiple of nchunk (a thread keeps its channel chunk across tasks): 45 | nblk covers every C / 4 of the
@@ -272,8 +462,9 @@ int fused_blocks(const adamml_conv_desc_t* d, int* rows_per_thread, int* nseg, i
 
 extern "C" int adamml_dwconv_bwd_fused_supported(const adamml_conv_desc_t* d) {
     static const bool on = !(getenv("ADAMML_DW_BWD_FUSED") && atoi(getenv("ADAMML_DW_BWD_FUSED")) == 0);                // A/B aid
-    return on && d && d->KH == 3 && d->KW == 3 && d->Cin == d->Cout && d->Cin % 8 == 0 && d->Cin <= 960 && d->pad == 1 && d->stride == 1 &&
-           d->OH == d->H && d->OW == d->W ? 1 : 0;
+    return on && d && d->KH == 3 && d->KW == 3 && d->Cin == d->Cout && d->Cin % 8 == 0 && d->Cin <= 960 && d->pad == 1 &&
+           ((d->stride == 1 && d->OH == d->H && d->OW == d->W) || (d->stride == 2 && d->OH == (d->H - 1) / 2 + 1 && d->OW == (d->W - 1) / 2 + 1)) &&
+           (size_t)d->N * d->H * d->W * d->Cin * 2 < ((size_t)1 << 32) ? 1 : 0;       // (32-bit byte offsets within a group)
 }
 
 extern "C" size_t adamml_dwconv_bwd_fused_workspace(const adamml_conv_desc_t* d) {
@@ -286,7 +477,7 @@ extern "C" int adamml_dwconv_bwd_fused(const adamml_conv_desc_t* d, const void* 
                                        const void* x, const float* x_vec, int x_act, void* dx, double* sums, float* dw, void* workspace,
                                        size_t workspace_bytes, hipStream_t stream) {
     if (!adamml_dwconv_bwd_fused_supported(d))
-        return adamml_set_error(ADAMML_EUNSUPPORTED, "dwconv_bwd_fused: 3x3 depthwise, pad 1, stride 1, C %% 8 == 0");
+        return adamml_set_error(ADAMML_EUNSUPPORTED, "dwconv_bwd_fused: 3x3 depthwise, pad 1, stride 1 / 2, C %% 8 == 0, C <= 960, a group below 4 GB");
     if (!g || !z || !aff || !w || !x || !x_vec || !dx || !sums || !dw || !workspace)
         return adamml_set_error(ADAMML_EINVAL, "dwconv_bwd_fused: null argument");
     DwBP p;
@@ -300,7 +491,9 @@ extern "C" int adamml_dwconv_bwd_fused(const adamml_conv_desc_t* d, const void* 
     if (workspace_bytes < (size_t)groups * nblk * 9 * p.C * sizeof(float))
         return adamml_set_error(ADAMML_EINVAL, "dwconv_bwd_fused: workspace too small (adamml_dwconv_bwd_fused_workspace)");
     p.gz = (size_t)d->N * d->OH * d->OW * d->Cin; p.gx = P * d->Cin;
-    if (fused_segw() == 2) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<1, 2>), dim3(nblk, groups), dim3(NT), 16 * p.C * sizeof(float), stream, p);
+    if (d->stride == 2 && fused_qw() == 1) hipLaunchKernelGGL(dwconv_bwd_fused_s2_kernel<1>, dim3(nblk, groups), dim3(NT), 16 * p.C * sizeof(float), stream, p);
+    else if (d->stride == 2) hipLaunchKernelGGL(dwconv_bwd_fused_s2_kernel<2>, dim3(nblk, groups), dim3(NT), 16 * p.C * sizeof(float), stream, p);
+    else if (fused_segw() == 2) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<1, 2>), dim3(nblk, groups), dim3(NT), 16 * p.C * sizeof(float), stream, p);
     else hipLaunchKernelGGL((dwconv_bwd_fused_kernel<1, 3>), dim3(nblk, groups), dim3(NT), 16 * p.C * sizeof(float), stream, p);
     int rc = adamml_check_launch("dwconv_bwd_fused");
     if (rc) return rc;

@@ -370,15 +370,23 @@ __global__ __launch_bounds__(NT) void dwconv_bwd_data_s2_kernel(DwP p) {   // p.
                     if (!BNZ && p.accumulate) acc[dy][dx] = bf8_to_f32(prev[dy][dx]);
                 }
             // input (2k + dy, 2j + dx) <- dz (k + a, j + b) through tap (kh, kw) = (dy + 1 - 2a, dx + 1 - 2b), ascending (kh, kw)
-            acc[0][0] += g[0][0] * wt[4];
-            acc[0][1] += g[0][1] * wt[3];
-            acc[0][1] += g[0][0] * wt[5];
-            acc[1][0] += g[1][0] * wt[1];
-            acc[1][0] += g[0][0] * wt[7];
-            acc[1][1] += g[1][1] * wt[0];
-            acc[1][1] += g[1][0] * wt[2];
-            acc[1][1] += g[0][1] * wt[6];
-            acc[1][1] += g[0][0] * wt[8];
+            // (explicit fused multiply-adds: left to contraction, a sum of two products may fuse either one, and the one-pass backward of
+            // csrc/dwconv_bwd_fused.hip must round exactly as this kernel does)
+            auto fma8 = [](const f32x8& a, const f32x8& b, const f32x8& c) {
+                f32x8 r;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) r[i] = __builtin_fmaf(a[i], b[i], c[i]);
+                return r;
+            };
+            acc[0][0] = fma8(g[0][0], wt[4], acc[0][0]);
+            acc[0][1] = fma8(g[0][1], wt[3], acc[0][1]);
+            acc[0][1] = fma8(g[0][0], wt[5], acc[0][1]);
+            acc[1][0] = fma8(g[1][0], wt[1], acc[1][0]);
+            acc[1][0] = fma8(g[0][0], wt[7], acc[1][0]);
+            acc[1][1] = fma8(g[1][1], wt[0], acc[1][1]);
+            acc[1][1] = fma8(g[1][0], wt[2], acc[1][1]);
+            acc[1][1] = fma8(g[0][1], wt[6], acc[1][1]);
+            acc[1][1] = fma8(g[0][0], wt[8], acc[1][1]);
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll

@@ -488,20 +488,22 @@ def test_dwconv_bwd_data_bn_equals_dgrad_then_reduce(N, H, W, C, s, G):
     assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-5
 
 
+@pytest.mark.parametrize("st", [1, 2])
 @pytest.mark.parametrize("N,H,W,C,G", [(2, 20, 20, 96, 1), (3, 9, 14, 24, 2), (1, 40, 40, 192, 5), (2, 7, 7, 960, 1), (1, 50, 22, 384, 2),
-                                       (2, 1, 5, 16, 1), (2, 3, 1, 32, 3), (1, 64, 64, 144, 2), (5, 8, 8, 576, 1)])
-def test_dwconv_bwd_fused_equals_apply_wgrad_dgrad(N, H, W, C, G):
+                                       (2, 1, 5, 16, 1), (2, 3, 1, 32, 3), (1, 64, 64, 144, 2), (5, 8, 8, 576, 1), (2, 21, 19, 144, 2)])
+def test_dwconv_bwd_fused_equals_apply_wgrad_dgrad(N, H, W, C, G, st):
     """adamml_dwconv_bwd_fused (BatchNorm-backward apply + weight gradient + data gradient with the expansion's mask and sums, one pass)
     against the per-layer form on the same dz = bf16(A g + B z + C): adamml_dwconv_bwd_data_bn (dx bit-identical, sums up to summation
     order) and adamml_dwconv_bwd_weight (up to summation order)."""
     torch.manual_seed(N * 11 + H + C)
     w = torch.randn(C, 1, 3, 3, device=DEV) * 0.4
     wp = pack(w, C, 2)
-    d = ConvDesc(N, H, W, C, H, W, C, 3, 3, 1, 1, 1, 2, 0, G, 4 * C)
+    OH, OW = (H - 1) // st + 1, (W - 1) // st + 1
+    d = ConvDesc(N, H, W, C, OH, OW, C, 3, 3, st, 1, 1, 2, 0, G, 4 * C)
     assert hip.load().adamml_dwconv_bwd_fused_supported(byref(d)) == 1
-    g = torch.randn(G * N, H, W, C, device=DEV).to(torch.bfloat16)
+    g = torch.randn(G * N, OH, OW, C, device=DEV).to(torch.bfloat16)
     g = g * (torch.rand_like(g, dtype=torch.float32) > 0.3).to(torch.bfloat16)        # masked gradient: exact zeros
-    z = (torch.randn(G * N, H, W, C, device=DEV) * 1.5).to(torch.bfloat16)
+    z = (torch.randn(G * N, OH, OW, C, device=DEV) * 1.5).to(torch.bfloat16)
     aff = torch.randn(G, 3, C, device=DEV) * 0.5
     x = (torch.randn(G * N, H, W, C, device=DEV) * 2).to(torch.bfloat16)
     xvec = torch.rand(G, 4, C, device=DEV) + 0.5
