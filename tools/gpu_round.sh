@@ -33,6 +33,8 @@ timeout 600 python tools/bench_conv.py 2>&1 | grep -v amdgpu > $out/bench_conv.t
 timeout 600 python tools/bench_fused.py 2>&1 | grep -v amdgpu > $out/bench_fused.txt
 timeout 600 python tools/bench_dw.py 2>&1 | grep -v amdgpu > $out/bench_dw.txt
 timeout 600 python tools/bench_elementwise.py 2>&1 | grep -v amdgpu > $out/bench_elementwise.txt
+timeout 300 python tools/bench_dw_bwd.py 2>&1 | grep -v amdgpu > $out/bench_dw_bwd.txt
+timeout 300 python tools/bench_fadd_next.py 2>&1 | grep -v amdgpu > $out/bench_fadd_next.txt
 timeout 600 python tools/launch_table.py resnet 72 60 2>&1 | grep -v amdgpu > $out/launch_table_resnet.txt
 timeout 600 python tools/launch_table.py sound 72 40 2>&1 | grep -v amdgpu > $out/launch_table_sound.txt
 timeout 600 python tools/launch_table.py policy_rgb 72 400 2>&1 | grep -v "amdgpu\|Warning\|warnings.warn" > $out/launch_table_policy_rgb.txt

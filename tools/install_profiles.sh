@@ -13,6 +13,8 @@ cp $g/$tag/bench_conv.txt profiles/${r}_per_layer_bench_conv.txt
 cp $g/$tag/bench_dw.txt profiles/${r}_per_layer_bench_dw.txt
 cp $g/$tag/bench_fused.txt profiles/${r}_per_layer_bench_fused.txt
 cp $g/$tag/bench_elementwise.txt profiles/${r}_bench_elementwise.txt
+[ -f $g/$tag/bench_dw_bwd.txt ] && cp $g/$tag/bench_dw_bwd.txt profiles/${r}_per_layer_bench_dw_bwd.txt
+[ -f $g/$tag/bench_fadd_next.txt ] && cp $g/$tag/bench_fadd_next.txt profiles/${r}_per_layer_bench_fadd_next.txt
 cp $g/$tag/launch_table_resnet.txt profiles/${r}_launch_table_resnet.txt
 cp $g/$tag/launch_table_sound.txt profiles/${r}_launch_table_sound.txt
 cp $g/$tag/launch_table_policy_rgb.txt profiles/${r}_launch_table_policy_rgb.txt

@@ -48,7 +48,7 @@ def role(name):
         return "weight_gradient"
     if b in ("conv3x3_c64_kernel", "conv_stem_kernel"):
         return "convKxK_mfma"
-    if b == "alg_stream_kernel":
+    if b in ("alg_stream_kernel", "conv1x1_fadd_next_kernel"):
         return "conv1x1_fused_streaming"
     if b in ("conv_wgrad_kernel", "conv_wgrad_glds_kernel", "conv3x3_wgrad_kernel", "conv3x3_c64_wgrad_kernel", "conv_stem_wgrad_kernel",
              "wgrad_reduce_kernel", "stem_wgrad_reduce_kernel", "gram_colsum_kernel", "gram_reduce_kernel"):
