@@ -259,6 +259,176 @@ __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_next_kernel(FNP p) {
     }
 }
 
+
+// ---- the same conv3 + bn3 + add + ReLU when the block output feeds ONLY the temporal max-pool (last block of the stage: models/resnet.py
+// :205-209 -> models/common.py:4-33, kernel 3 / stride 2 / pad 1 over the T frames of a clip).  A wave takes a (clip, 16-pixel block) task
+// and streams the T frames of that block in order; every lane keeps, for its 8 (pixel, 8-channel chunk) slots, the running maximum of the
+// open window and the 2-bit tap of its FIRST maximum in registers: an even frame 2 to is tap 1 of window `to`, the odd frame 2 to + 1 is
+// tap 2 of window `to` -- which is then complete and stored, pooled value + code -- and tap 0 of window to + 1.  Values, tie rule and the
+// "maximum <= 0 -> code 3" rule are conv_gemm_kernel's TP epilogue: pooled and code are bit-identical; the full-rate block output never
+// exists in HBM.  conv_gemm's TP instance ran this launch at 3.9 TB/s (its 128-row tile holds 16 pixels x 8 frames: 16 short runs).
+struct FTP {
+    const bf16_t* x; const float* in_scale; const float* in_shift; const bf16_t* w3; const float* bn_vec;
+    const bf16_t* idn; const float* id_scale; const float* id_shift;
+    bf16_t* pooled;          // [groups * clips * T / 2][HW][256]
+    uint16_t* code;          // [groups * clips * T / 2][HW][32] or null
+    int in_act, in_gs, id_gs, act, T, HW, clips;
+};
+
+__global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_tpool_kernel(FTP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_w3 = smem;
+    float* s_vec = reinterpret_cast<float*>(s_w3 + CB * W3ROW);              // [2][64]
+    float* s_bn = s_vec + 2 * C3IN;                                          // [4][256]: scale3, shift3, id scale, id shift
+    char* s_stage = reinterpret_cast<char*>(s_bn + 4 * CB);                  // [8 waves][16][SROW]
+    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int To = p.T >> 1;
+    {
+        const size_t P = (size_t)p.clips * p.T * p.HW, Pp = (size_t)p.clips * To * p.HW;
+        p.x += (size_t)g * P * C3IN;
+        p.idn += (size_t)g * P * CB;
+        p.pooled += (size_t)g * Pp * CB;
+        if (p.code) p.code += (size_t)g * Pp * (CB / 8);
+    }
+    for (int i = tid; i < CB * (C3IN / 8); i += NW * 64) {
+        const int row = i / (C3IN / 8), ch = i - row * (C3IN / 8);
+        *reinterpret_cast<bf16x8*>(s_w3 + row * W3ROW + ch * 16) = *reinterpret_cast<const bf16x8*>(p.w3 + (size_t)row * C3IN + ch * 8);
+    }
+    for (int i = tid; i < C3IN; i += NW * 64) {
+        s_vec[i] = p.in_scale ? p.in_scale[(size_t)g * p.in_gs + i] : 1.f;
+        s_vec[C3IN + i] = p.in_scale ? p.in_shift[(size_t)g * p.in_gs + i] : 0.f;
+    }
+    for (int i = tid; i < CB; i += NW * 64) {
+        s_bn[i] = p.bn_vec[(size_t)g * 4 * CB + i];
+        s_bn[CB + i] = p.bn_vec[(size_t)g * 4 * CB + CB + i];
+        s_bn[2 * CB + i] = p.id_scale ? p.id_scale[(size_t)g * p.id_gs + i] : 1.f;
+        s_bn[3 * CB + i] = p.id_scale ? p.id_shift[(size_t)g * p.id_gs + i] : 0.f;
+    }
+    __syncthreads();
+    auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    const float alo = uniform(p.in_scale ? act_lo(p.in_act) : -INFINITY), ahi = uniform(p.in_scale ? act_hi(p.in_act) : INFINITY);
+    const float rlo = uniform(act_lo(p.act)), rhi = uniform(act_hi(p.act));
+    const bool lazy = p.in_scale != nullptr;
+    char* stg = s_stage + wave * (TPX * SROW);
+    const int tpf = (p.HW + TPX - 1) / TPX;                                  // pixel blocks per frame
+    const long ntask = (long)p.clips * tpf;
+    const long wid = (long)blockIdx.x * NW + wave, nw = (long)gridDim.x * NW;
+    const int epl = lane >> 4, ech = lane & 15;
+
+    bf16x8 rx[2], raux[2][4];
+    // frame t of task `task`: first pixel (within the group) and the number of live pixels of the block
+    auto frame_base = [&](long task, int t, int& npx) {
+        const int clip = (int)(task / tpf), blk = (int)(task - (long)clip * tpf);
+        npx = p.HW - blk * TPX < TPX ? p.HW - blk * TPX : TPX;
+        return ((long)clip * p.T + t) * p.HW + (long)blk * TPX;
+    };
+    auto issue = [&](long task, int t) {
+        int npx;
+        const long base = frame_base(task, t, npx);
+        const long px = base + (li < npx ? li : npx - 1);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) rx[k] = *reinterpret_cast<const bf16x8*>(p.x + (size_t)px * C3IN + (k * 4 + lg) * 8);
+    };
+    auto issue_aux = [&](long task, int t) {
+        int npx;
+        const long base = frame_base(task, t, npx);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = i * 4 + epl;
+                raux[b][i] = *reinterpret_cast<const bf16x8*>(p.idn + (size_t)(base + (q < npx ? q : npx - 1)) * CB + b * 128 + ech * 8);
+            }
+    };
+    {
+        const long t0 = wid < ntask ? wid : ntask - 1;
+        issue(t0, 0);
+        issue_aux(t0, 0);
+    }
+    for (long task = wid; task < ntask; task += nw) {
+        const int clip = (int)(task / tpf), blk = (int)(task - (long)clip * tpf);
+        const int npx = p.HW - blk * TPX < TPX ? p.HW - blk * TPX : TPX;
+        f32x8 best[2][4];
+        unsigned code[2][4];
+        for (int t = 0; t < p.T; ++t) {
+            // the (task, frame) after this one, clamped to the last: its rows are requested while this frame is computed
+            long ntask_ = task;
+            int nt = t + 1;
+            if (nt == p.T) { nt = 0; ntask_ = task + nw < ntask ? task + nw : task; if (ntask_ == task) nt = p.T - 1; }
+            bf16x8 fb[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                fb[k] = rx[k];
+                if (lazy) {
+                    const f32x8 sc = load_f32x8(s_vec + k * 32 + lg * 8), sh = load_f32x8(s_vec + C3IN + k * 32 + lg * 8);
+                    f32x8 v = bf8_to_f32(fb[k]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = clamp_act(fmaf(v[i], sc[i], sh[i]), alo, ahi);
+                    fb[k] = f32_to_bf8(v);
+                }
+            }
+            issue(ntask_, nt);
+            const unsigned tapbits = (t & 1) ? 0xAAAAu : 0x5555u;            // this frame's tap in the open window: 2 (odd frame) or 1
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                f32x4 acc[8];
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int ct = 0; ct < 8; ++ct) {
+                        const bf16x8 fa = *reinterpret_cast<const bf16x8*>(s_w3 + ((b * 8 + ct) * 16 + li) * W3ROW + k * 64 + lg * 16);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[k], acc[ct], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct)
+                    *reinterpret_cast<bf16x4*>(stg + li * SROW + (b * 128 + ct * 16 + lg * 4) * 2) = f32_to_bf4(acc[ct]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int c0 = b * 128 + ech * 8;
+                const f32x8 sc = load_f32x8(s_bn + c0), sh = load_f32x8(s_bn + CB + c0), isc = load_f32x8(s_bn + 2 * CB + c0), ish = load_f32x8(s_bn + 3 * CB + c0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int px = i * 4 + epl;
+                    f32x8 f = bf8_to_f32(*reinterpret_cast<const bf16x8*>(stg + px * SROW + c0 * 2));
+                    const f32x8 w = bf8_to_f32(raux[b][i]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = clamp_act(fmaf(f[j], sc[j], sh[j]) + fmaf(w[j], isc[j], ish[j]), rlo, rhi);
+                    const f32x8 v = bf8_to_f32(f32_to_bf8(f));              // the value the unfused path stores and the pool re-reads
+                    if (t == 0) {                                           // window 0 has no tap 0: the scan starts at tap 1
+                        best[b][i] = v;
+                        code[b][i] = 0x5555u;
+                    } else {
+                        unsigned cd = code[b][i];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (v[j] > best[b][i][j]) { best[b][i][j] = v[j]; cd = (cd & ~(3u << (2 * j))) | (tapbits & (3u << (2 * j))); }   // first maximum in scan order
+                        code[b][i] = cd;
+                    }
+                    if (t & 1) {
+                        // window t >> 1 is complete
+                        if (px < npx) {
+                            unsigned cd = code[b][i];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (!(best[b][i][j] > rlo && best[b][i][j] < rhi)) cd |= 3u << (2 * j);       // act'(maximum) == 0: no gradient through this window
+                            const size_t po = (((size_t)clip * To + (t >> 1)) * p.HW + (size_t)blk * TPX + px) * CB + c0;
+                            *reinterpret_cast<bf16x8*>(p.pooled + po) = f32_to_bf8(best[b][i]);
+                            if (p.code) p.code[po >> 3] = (uint16_t)cd;
+                        }
+                        best[b][i] = v;                                     // tap 0 of the next window
+                        code[b][i] = 0u;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the staged block is consumed before the next one overwrites it)
+            }
+            issue_aux(ntask_, nt);
+        }
+    }
+}
+
 }  // namespace
 
 // d: the forward descriptor of conv3 (1x1, 64 -> 256); next_cout: output channels of the next block's conv1 (64) or 0
@@ -294,4 +464,38 @@ int adamml_conv1x1_fadd_next_launch(const adamml_conv_desc_t* d, const void* x, 
     if (w1_packed) hipLaunchKernelGGL(conv1x1_fadd_next_kernel<true>, dim3((unsigned)nblk, groups), dim3(NW * 64), LDS_BYTES, stream, p);
     else hipLaunchKernelGGL(conv1x1_fadd_next_kernel<false>, dim3((unsigned)nblk, groups), dim3(NW * 64), LDS_BYTES, stream, p);
     return adamml_check_launch("conv_fwd_bn_add_next");
+}
+
+// d: the forward descriptor of conv3 (1x1, 64 -> 256, N = clips * frames images per group)
+bool adamml_conv1x1_fadd_tpool_supported(const adamml_conv_desc_t* d, int frames) {
+    static const int on = getenv("ADAMML_FADD_TPOOL_STREAM") ? atoi(getenv("ADAMML_FADD_TPOOL_STREAM")) : 1;      // A/B aid
+    return on && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->up <= 1 && d->Cin == C3IN && d->Cout == CB &&
+           (frames == 2 || frames == 4 || frames == 8) && d->N % frames == 0;
+}
+
+int adamml_conv1x1_fadd_tpool_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
+                                     const float* bn_vec, const void* idn, const float* id_scale, const float* id_shift, int id_gstride, int act,
+                                     int frames, void* pooled, uint16_t* code, hipStream_t stream) {
+    FTP p;
+    p.x = (const bf16_t*)x; p.in_scale = in_scale; p.in_shift = in_scale ? in_shift : nullptr; p.w3 = (const bf16_t*)w_packed; p.bn_vec = bn_vec;
+    p.idn = (const bf16_t*)idn; p.id_scale = id_scale; p.id_shift = id_scale ? id_shift : nullptr;
+    p.pooled = (bf16_t*)pooled; p.code = code;
+    p.in_act = d->act; p.in_gs = d->in_gstride; p.id_gs = id_gstride; p.act = act;
+    p.T = frames; p.HW = d->H * d->W; p.clips = d->N / frames;
+    if (p.clips <= 0 || p.HW <= 0) return ADAMML_OK;
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    constexpr int LDS_TP = CB * W3ROW + 2 * C3IN * 4 + 4 * CB * 4 + NW * TPX * SROW;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fadd_tpool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TP);
+        if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv_fwd_bn_add_tpool: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const long ntask = (long)p.clips * ((p.HW + TPX - 1) / TPX);
+    long nblk = (ntask + NW - 1) / NW;
+    long cap = 256 / groups;                                             // one workgroup per CU over all groups
+    if (cap < 1) cap = 1;
+    if (nblk > cap) nblk = cap;
+    hipLaunchKernelGGL(conv1x1_fadd_tpool_kernel, dim3((unsigned)nblk, groups), dim3(NW * 64), LDS_TP, stream, p);
+    return adamml_check_launch("conv_fwd_bn_add_tpool");
 }

@@ -2086,6 +2086,12 @@ extern "C" int adamml_conv_fwd_bn_add_next(const adamml_conv_desc_t* d, const vo
                                            w_next, y_next, stats_next, stream);
 }
 
+// csrc/conv1x1_fadd_next.hip: the streaming form for layer 1 (64 -> 256)
+bool adamml_conv1x1_fadd_tpool_supported(const adamml_conv_desc_t* d, int frames);
+int adamml_conv1x1_fadd_tpool_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
+                                     const float* bn_vec, const void* idn, const float* id_scale, const float* id_shift, int id_gstride, int act,
+                                     int frames, void* pooled, uint16_t* code, hipStream_t stream);
+
 extern "C" int adamml_conv_fwd_bn_add_tpool_supported(const adamml_conv_desc_t* d, int frames, int act, int lazy_input) {
     if (!adamml_conv_fwd_bn_add_supported(d)) return 0;
     if (!(frames == 2 || frames == 4 || frames == 8) || d->N % frames || d->Cout % 128 || act != ADAMML_ACT_RELU) return 0;
@@ -2102,6 +2108,9 @@ extern "C" int adamml_conv_fwd_bn_add_tpool(const adamml_conv_desc_t* d, const v
     if (!adamml_conv_fwd_bn_add_tpool_supported(d, frames, act, in_scale != nullptr))
         return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd_bn_add_tpool: 1x1 / stride-1 conv, Cout %% 128 == 0, ReLU, 2 / 4 / 8 frames per clip");
     if (!bn_vec || !idn || !pooled) return adamml_set_error(ADAMML_EINVAL, "conv_fwd_bn_add_tpool: null argument");
+    if (adamml_conv1x1_fadd_tpool_supported(d, frames))
+        return adamml_conv1x1_fadd_tpool_launch(d, x, w_packed, in_scale, in_shift, bn_vec, idn, id_scale, id_shift, id_gstride, act, frames, pooled, code,
+                                                stream);
     FaddEpi f{bn_vec, idn, id_scale, id_shift, id_gstride, act, nullptr, frames, pooled, code};
     // (`pooled` doubles as the kernel's y pointer: the full-rate output is never written)
     return conv_launch(d, x, w_packed, in_scale, in_shift, pooled, nullptr, nullptr, nullptr, 0, stream, nullptr, nullptr, nullptr, nullptr, &f);

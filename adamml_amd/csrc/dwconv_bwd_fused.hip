@@ -426,10 +426,9 @@ int fused_segw() {
     return v == 2 ? 2 : 3;
 }
 
-int fused_qw() {
-    static const int v = getenv("ADAMML_DWB_QW") ? atoi(getenv("ADAMML_DWB_QW")) : 2;              // A/B aid
-    return v == 1 ? 1 : 2;
-}
+// quads per thread at stride 2: 1 (191 registers; 2 quads = 256 + 8 spilled for the same time over the net's four stride-2 layers --
+// 1.185 against 1.179 ms -- so that instance is not built)
+constexpr int fused_qw() { return 1; }
 
 int fused_blocks(const adamml_conv_desc_t* d, int* rows_per_thread, int* nseg, int* nrb) {
     const long nchunk = d->Cin / 4;
@@ -491,8 +490,7 @@ extern "C" int adamml_dwconv_bwd_fused(const adamml_conv_desc_t* d, const void* 
     if (workspace_bytes < (size_t)groups * nblk * 9 * p.C * sizeof(float))
         return adamml_set_error(ADAMML_EINVAL, "dwconv_bwd_fused: workspace too small (adamml_dwconv_bwd_fused_workspace)");
     p.gz = (size_t)d->N * d->OH * d->OW * d->Cin; p.gx = P * d->Cin;
-    if (d->stride == 2 && fused_qw() == 1) hipLaunchKernelGGL(dwconv_bwd_fused_s2_kernel<1>, dim3(nblk, groups), dim3(NT), 16 * p.C * sizeof(float), stream, p);
-    else if (d->stride == 2) hipLaunchKernelGGL(dwconv_bwd_fused_s2_kernel<2>, dim3(nblk, groups), dim3(NT), 16 * p.C * sizeof(float), stream, p);
+    if (d->stride == 2) hipLaunchKernelGGL(dwconv_bwd_fused_s2_kernel<fused_qw()>, dim3(nblk, groups), dim3(NT), 16 * p.C * sizeof(float), stream, p);
     else if (fused_segw() == 2) hipLaunchKernelGGL((dwconv_bwd_fused_kernel<1, 2>), dim3(nblk, groups), dim3(NT), 16 * p.C * sizeof(float), stream, p);
     else hipLaunchKernelGGL((dwconv_bwd_fused_kernel<1, 3>), dim3(nblk, groups), dim3(NT), 16 * p.C * sizeof(float), stream, p);
     int rc = adamml_check_launch("dwconv_bwd_fused");

@@ -606,3 +606,7 @@ def test_parity_bounds_table_respects_the_stated_tolerances():
         assert case + ".logits" in t and case + ".stats" in t and case + ".head" in t
     src = open(os.path.join(ROOT, "tests", "test_parity_fullsize_gpu.py")).read()
     assert "_tol=" not in src and "max_tol" not in src          # no scattered literals left in the full-size file
+    # the 20-step trajectory reads the table too (round 5: its literals vetoed a data-gradient kernel that rounds dz in its loader)
+    assert pb.CEILINGS["traj_emu"] <= 5e-2 and pb.CEILINGS["traj_ref_mean"] <= 0.10
+    assert all(k in t for k in ("traj_c2.loss_vs_emu_max", "traj_c2.loss_vs_ref_max", "traj_c2.loss_vs_ref_mean", "traj_c2.final_logits", "traj_c2.fc_update"))
+    assert "<= 0.0" not in open(os.path.join(ROOT, "tests", "test_train_trajectory_gpu.py")).read()

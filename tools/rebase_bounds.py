@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests import parity_bounds as pb  # noqa: E402
 
-FILES = ["tests/test_parity_fullsize_gpu.py", "tests/test_syncbn_gpu.py"]
+FILES = ["tests/test_parity_fullsize_gpu.py", "tests/test_syncbn_gpu.py", "tests/test_train_trajectory_gpu.py"]
 
 
 def main():
