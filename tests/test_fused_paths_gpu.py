@@ -1,0 +1,56 @@
+"""The fused forms of round 5 must be the ones that RUN in a main-net-stage training step of the RGB + Audio model -- a `*_supported`
+query that silently starts answering no would leave every parity test green on the per-layer fallback.  One step of the C2 golden case
+under the launch profiler (adamml_amd/hip.py: LaunchProfiler), entry points counted by name:
+
+  * every depthwise conv of the Sound-MobileNetV2 (17 inverted residuals, models/sound_mobilenet_v2.py:43-69) runs its backward through
+    adamml_dwconv_bwd_fused -- no adamml_dwconv_bwd_weight / adamml_dwconv_bwd_data[_bn] launch is left in the step;
+  * the two block boundaries of ResNet-50 layer 1 run adamml_conv_fwd_bn_add_next (models/resnet.py:104-112 + :94-96 of the next block) and
+    the stage ends go through adamml_conv_fwd_bn_add_tpool;
+  * the projection convs run their data gradient through adamml_conv_bwd_data_dual."""
+import collections
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from adamml_amd import synth  # noqa: E402
+from tests.golden_cases import CASES  # noqa: E402
+from tests.oracle_harness import manifest, case_inputs  # noqa: E402
+from tests.test_launch_plan_gpu import _build  # noqa: E402
+
+DEV = "cuda"
+
+
+def test_round5_fused_entry_points_run_in_the_training_step():
+    from adamml_amd import hip
+    c = CASES["adamml_c2"]
+    model = _build(c, 0.0)
+    model.load_state_dict(synth.synth_state_dict(manifest(c), seed=1234))
+    model.to(DEV)
+    model.freeze_policy_net()
+    model.train()
+    xs, target = case_inputs(c)
+    xs, target = [t.to(DEV) for t in xs], target.to(DEV)
+    expo = synth.synth_gumbel_exponential(c["S"], 2, c["B"], seed=11).to(DEV)
+
+    def step():
+        logits, _ = model(xs, gumbel_exponential=expo)
+        F.cross_entropy(logits, target).backward()
+
+    step()
+    torch.cuda.synchronize()
+    hip.profiler = hip.LaunchProfiler()
+    try:
+        step()
+        torch.cuda.synchronize()
+        names = collections.Counter(r[0] for r in hip.profiler.records)
+    finally:
+        hip.profiler = None
+    print({k: v for k, v in names.items() if any(t in k for t in ("dwconv", "bn_add", "dual", "bn_bwd_apply"))})
+    assert names["adamml_dwconv_bwd_fused"] == 17
+    assert names["adamml_dwconv_bwd_weight"] == 0 and names["adamml_dwconv_bwd_data_bn"] == 0 and names["adamml_dwconv_bwd_data"] == 0
+    assert names["adamml_conv_fwd_bn_add_next"] == 2
+    assert names["adamml_conv_fwd_bn_add_tpool"] >= 2
+    assert names["adamml_conv_bwd_data_dual"] >= 17
