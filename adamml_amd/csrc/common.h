@@ -23,6 +23,7 @@ int adamml_set_error(int code, const char* fmt, ...);
 int adamml_check_launch(const char* what);
 // dw[perm(i)] += sum_{s<nsplit} ws[s*n + i]; taps > 1: ws is [co][tap][cin], dw [co][cin][tap]   (conv_gemm.hip)
 int adamml_launch_split_reduce(const float* ws, float* dw, size_t n, int nsplit, hipStream_t stream, int taps = 1, int cin = 1);
+int adamml_launch_split_reduce_grouped(const float* ws, float* out, size_t n, int nsplit, int groups, int cin, hipStream_t stream);
 
 // Activations as a clamp to [lo, hi] with wave-uniform bounds (none: [-inf, inf], ReLU: [0, inf], ReLU6: [0, 6]):
 // branch-free per element (the runtime `act` is folded into two scalars once per call site).

@@ -2502,6 +2502,12 @@ int adamml_launch_split_reduce(const float* ws, float* dw, size_t n, int nsplit,
     return adamml_check_launch("split_reduce");
 }
 
+// per-group form: ws [groups][nsplit][n] -> out [groups][n], OVERWRITTEN (the products of the algebraic BatchNorm backward)
+int adamml_launch_split_reduce_grouped(const float* ws, float* out, size_t n, int nsplit, int groups, int cin, hipStream_t stream) {
+    launch_wgrad_reduce(ws, out, n, nsplit, 1, cin, 1, groups, stream);
+    return adamml_check_launch("split_reduce");
+}
+
 extern "C" size_t adamml_conv_bwd_weight_workspace(const adamml_conv_desc_t* d, int cin_true) {
     WgradPlan pl;
     if (!d || wgrad_plan(d, cin_true, &pl)) return 0;

@@ -37,6 +37,7 @@ SIGNATURES = {
     "adamml_conv_fwd_bn_add_next": [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "adamml_conv_fwd_bn_add_tpool": [_DESC, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "adamml_temporal_pool_bwd_code": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "adamml_temporal_pool_bwd_code_prod": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _Z, _I, _I, _I, _I, _I, _I, _P],
     "adamml_copy2d": [_P, _Z, _P, _Z, _Z, _Z, _P],
     "adamml_gram_stats": [_P, _P, _P, _P, _I, _I, _I, _P],
     "adamml_gram_colsum": [_P, _P, _P, _I, _I, _P, _P, _Z, _I, _I, _P, _Z, _P],
@@ -152,6 +153,10 @@ def load():
     lib.adamml_temporal_pool_bwd_res_supported.restype = c_int
     lib.adamml_dwconv_bwd_data_bn_supported.argtypes = [_DESC]
     lib.adamml_dwconv_bwd_data_bn_supported.restype = c_int
+    lib.adamml_temporal_pool_bwd_code_prod_supported.argtypes = [c_int, c_int, c_int]
+    lib.adamml_temporal_pool_bwd_code_prod_supported.restype = c_int
+    lib.adamml_temporal_pool_bwd_code_prod_workspace.argtypes = [c_int, c_int, c_int, c_int, c_int, c_int]
+    lib.adamml_temporal_pool_bwd_code_prod_workspace.restype = c_size_t
     lib.adamml_dwconv_bwd_fused_supported.argtypes = [_DESC]
     lib.adamml_dwconv_bwd_fused_supported.restype = c_int
     lib.adamml_dwconv_bwd_fused_workspace.argtypes = [_DESC]

@@ -646,6 +646,7 @@ def _gram_colsum(rt, x, d):
     return Gm, sv
 
 
+TPOOL_PROD = os.environ.get("ADAMML_TPOOL_BWD_PROD", "1") != "0"   # temporal-pool backward + the product g'^T a in one pass (A/B aid)
 RES_PROD = os.environ.get("ADAMML_RES_PROD", "1") != "0"     # g'^T a accumulated inside the residual-backward data gradient (A/B aid)
 POOL_ZSEL = os.environ.get("ADAMML_POOL_ZSEL", "1") != "0"   # stem BatchNorm-backward sums over the pool windows (g_y, z_sel) (A/B aid)
 DW_FUSED = os.environ.get("ADAMML_DW_BWD_FUSED", "1") != "0"    # whole stride-1 depthwise backward in one pass (csrc/dwconv_bwd_fused.hip; A/B aid)
@@ -1002,7 +1003,19 @@ def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False, tpool=0, next_cs=None):
                 return
             gx = torch.empty(full_shape, dtype=torch.bfloat16, device=dev)
             sa = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS)
-            call("adamml_temporal_pool_bwd_code", ptr(g), ptr(code_t), ptr(gx), ptr(sa), d.N // tpool, tpool, d.OH * d.OW, C, G)
+            lib = hip.load()
+            if TPOOL_PROD and z.alg and x.requires_grad and cs.weight.requires_grad and _alg_supported(cs, d) \
+                    and lib.adamml_temporal_pool_bwd_code_prod_supported(tpool, C, d.Cin):
+                # the expanded gradient AND the product g'^T a the algebraic backward of conv3 needs first, from one pass (the product
+                # kernel read the 4.6 GB of g' back)
+                P = torch.empty(G, C, d.Cin, dtype=torch.float32, device=dev)
+                ws = hip.scratch(lib.adamml_temporal_pool_bwd_code_prod_workspace(d.N // tpool, tpool, d.OH * d.OW, C, d.Cin, G), dev)
+                hip.next_meta = (2 * macs, in_b + 1.5 * out_b + out_b / 16, "tpool_bwd_prod_kernel", R_WGRAD)
+                call("adamml_temporal_pool_bwd_code_prod", ptr(g), ptr(code_t), ptr(gx), ptr(sa), ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act,
+                     ptr(P), ptr(ws), ws.numel() * 4, d.N // tpool, tpool, d.OH * d.OW, C, d.Cin, G)
+                z.prod = P
+            else:
+                call("adamml_temporal_pool_bwd_code", ptr(g), ptr(code_t), ptr(gx), ptr(sa), d.N // tpool, tpool, d.OH * d.OW, C, G)
             z.pre_sums, z.sums_partial = sa, True
             blk.res_done = True
             blk.grad = gx

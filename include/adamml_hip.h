@@ -350,6 +350,17 @@ ADAMML_API int adamml_temporal_pool_bwd_res(const void* g_y, const void* out, in
  * backward derives it, adamml_alg_sumfix).  Bit-identical to adamml_temporal_pool_bwd_res(z_a = NULL) on the block output. */
 ADAMML_API int adamml_temporal_pool_bwd_code(const void* g_y, const uint16_t* code, void* g2, double* sums_a, int NB, int T, int HW, int C, int groups,
                                   hipStream_t stream);
+/* adamml_temporal_pool_bwd_code AND the first product its output feeds, in one pass (round 5): while a tile of the expanded gradient g2
+ * is on chip it is multiplied with the matching tile of the block's conv3 input a [groups*NB*T, HW, Cin] (raw, with its lazy
+ * BatchNorm in_scale / in_shift / in_act): prod [groups][C][Cin] = g2^T a per group, OVERWRITTEN -- the product
+ * adamml_conv_bwd_weight_grouped(dz = g2) computes for the algebraic BatchNorm backward of conv3 (adamml_alg_sumfix needs it before the
+ * coefficients exist), without reading g2 back.  g2 bit-identical, sums_a as adamml_temporal_pool_bwd_code.
+ * (T, C, Cin) = (8, 256, 64): the end of ResNet-50 stage 1. */
+ADAMML_API int adamml_temporal_pool_bwd_code_prod_supported(int T, int C, int Cin);
+ADAMML_API size_t adamml_temporal_pool_bwd_code_prod_workspace(int NB, int T, int HW, int C, int Cin, int groups);
+ADAMML_API int adamml_temporal_pool_bwd_code_prod(const void* g_y, const uint16_t* code, void* g2, double* sums_a, const void* a, const float* in_scale,
+                                       const float* in_shift, int in_gstride, int in_act, float* prod, void* workspace, size_t workspace_bytes,
+                                       int NB, int T, int HW, int C, int Cin, int groups, hipStream_t stream);
 
 /* AdaptiveAvgPool2d(1) on a lazy input -> fp32 [groups*N,C] (resnet.py:212, sound_mobilenet_v2.py:157, policy_net.py:147) */
 ADAMML_API int adamml_gap_fwd(const void* x, const float* scale, const float* shift, int gstride, int act, float* out, int N, int HW,

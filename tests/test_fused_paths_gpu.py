@@ -6,7 +6,8 @@ under the launch profiler (adamml_amd/hip.py: LaunchProfiler), entry points coun
     adamml_dwconv_bwd_fused -- no adamml_dwconv_bwd_weight / adamml_dwconv_bwd_data[_bn] launch is left in the step;
   * the two block boundaries of ResNet-50 layer 1 run adamml_conv_fwd_bn_add_next (models/resnet.py:104-112 + :94-96 of the next block) and
     the stage ends go through adamml_conv_fwd_bn_add_tpool;
-  * the projection convs run their data gradient through adamml_conv_bwd_data_dual."""
+  * the projection convs run their data gradient through adamml_conv_bwd_data_dual;
+  * the backward of the temporal pool behind stage 1 is adamml_temporal_pool_bwd_code_prod."""
 import collections
 
 import pytest
@@ -48,9 +49,11 @@ def test_round5_fused_entry_points_run_in_the_training_step():
         names = collections.Counter(r[0] for r in hip.profiler.records)
     finally:
         hip.profiler = None
-    print({k: v for k, v in names.items() if any(t in k for t in ("dwconv", "bn_add", "dual", "bn_bwd_apply"))})
+    print({k: v for k, v in names.items() if any(t in k for t in ("dwconv", "bn_add", "dual", "bn_bwd_apply", "temporal_pool"))})
     assert names["adamml_dwconv_bwd_fused"] == 17
     assert names["adamml_dwconv_bwd_weight"] == 0 and names["adamml_dwconv_bwd_data_bn"] == 0 and names["adamml_dwconv_bwd_data"] == 0
     assert names["adamml_conv_fwd_bn_add_next"] == 2
     assert names["adamml_conv_fwd_bn_add_tpool"] >= 2
     assert names["adamml_conv_bwd_data_dual"] >= 17
+    # the temporal pool behind stage 1 hands the algebraic backward of conv3 its product (one pass; stage 2 keeps the two launches)
+    assert names["adamml_temporal_pool_bwd_code_prod"] == 1 and names["adamml_temporal_pool_bwd_code"] >= 1

@@ -1352,6 +1352,50 @@ def test_conv_fwd_bn_add_tpool_equals_add_then_pool(T, clips, H, Cin, Cout, G, l
     assert torch.allclose(cs[:, :Cout], cr[:, :Cout], rtol=1e-6, atol=1e-6 * cr.abs().max().item())
 
 
+@pytest.mark.parametrize("clips,H,G,lazy", [(3, 56, 2, True), (2, 13, 1, True), (5, 9, 3, False), (1, 7, 5, True)])
+def test_temporal_pool_bwd_code_prod_equals_expand_then_product(clips, H, G, lazy):
+    """adamml_temporal_pool_bwd_code_prod (stage-1 end of ResNet-50: T = 8, C = 256, Cin = 64) == adamml_temporal_pool_bwd_code followed by
+    adamml_conv_bwd_weight_grouped(dz = g2): the expanded gradient bit-identical, sum(g2) and the product g2^T a up to summation order
+    (the product also against fp64); 56^2 (98 full 32-pixel blocks) and sizes whose last block is ragged."""
+    from adamml_amd.runtime import ACT_RELU
+    torch.manual_seed(clips * 10 + H)
+    T, C, Cin, To = 8, 256, 64, 4
+    Q = H * H
+    assert hip.load().adamml_temporal_pool_bwd_code_prod_supported(T, C, Cin) == 1
+    gy = torch.randn(G * clips * To, H, H, C, device=DEV).to(torch.bfloat16)
+    code = torch.randint(0, 1 << 16, (G * clips * To, H, H, C // 8), device=DEV, dtype=torch.int32).to(torch.int16)
+    a = (torch.randn(G * clips * T, H, H, Cin, device=DEV) * 1.5).to(torch.bfloat16)
+    avec = torch.rand(G, 4, Cin, device=DEV) + 0.5
+    avec[:, 1] -= 0.6
+    sc, sh = (avec[0, 0], avec[0, 1]) if lazy else (None, None)
+    # reference: expand, then the grouped product kernel
+    g2_ref = torch.empty(G * clips * T, H, H, C, dtype=torch.bfloat16, device=DEV)
+    s_ref = torch.zeros(G, STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
+    call("adamml_temporal_pool_bwd_code", ptr(gy), ptr(code), ptr(g2_ref), ptr(s_ref), clips, T, Q, C, G)
+    d = ConvDesc(clips * T, H, H, Cin, H, H, C, 1, 1, 1, 0, 1, ACT_RELU if lazy else 0, 0, G, 4 * Cin if lazy else 0)
+    P_ref = torch.empty(G, C, Cin, device=DEV)
+    ws = hip.wgrad_workspace(d, Cin, DEV)
+    call("adamml_conv_bwd_weight_grouped", byref(d), ptr(g2_ref), None, None, 0, 0, ptr(a), ptr(sc), ptr(sh), ptr(P_ref), Cin, ptr(ws), ws.numel() * 4)
+    g2 = torch.full_like(g2_ref, float("nan"))
+    s = torch.zeros_like(s_ref)
+    P = torch.full_like(P_ref, float("nan"))
+    ws2 = hip.scratch(hip.load().adamml_temporal_pool_bwd_code_prod_workspace(clips, T, Q, C, Cin, G), DEV)
+    call("adamml_temporal_pool_bwd_code_prod", ptr(gy), ptr(code), ptr(g2), ptr(s), ptr(a), ptr(sc), ptr(sh), 4 * Cin if lazy else 0,
+         ACT_RELU if lazy else 0, ptr(P), ptr(ws2), ws2.numel() * 4, clips, T, Q, C, Cin, G)
+    assert torch.equal(g2, g2_ref)
+    cs_, cr = ssum(s), ssum(s_ref)
+    assert torch.allclose(cs_[:, :C], cr[:, :C], rtol=1e-6, atol=1e-6 * cr.abs().max().item())
+    assert (cs_[:, C:] == 0).all()
+    av = _g(a, G).float()
+    if lazy:
+        av = torch.relu(av * avec[:, 0].view(G, 1, 1, 1, Cin) + avec[:, 1].view(G, 1, 1, 1, Cin))
+    av = av.to(torch.bfloat16).double().reshape(G, -1, Cin)
+    P64 = _g(g2_ref, G).double().reshape(G, -1, C).transpose(1, 2) @ av
+    scale = P64.abs().max().item()
+    e64, ekern = (P.double() - P64).abs().max().item() / scale, (P - P_ref).abs().max().item() / scale
+    assert e64 <= 2e-4 and ekern <= 5e-5, (e64, ekern)
+
+
 @pytest.mark.parametrize("B,G,H,W,C", [(3, 2, 64, 64, 32), (2, 5, 96, 80, 32), (1, 1, 33, 47, 32), (4, 3, 256, 256, 32)])
 def test_conv_stem1_reads_the_fp32_spectrogram_directly(B, G, H, W, C):
     """adamml_conv_stem1_fwd / adamml_conv_stem1_bwd_weight: the 3x3 / stride-2 / pad-1 stem of the MobileNetV2s on a one-channel input
