@@ -51,7 +51,7 @@ def role(name):
     if b in ("alg_stream_kernel", "conv1x1_fadd_next_kernel"):
         return "conv1x1_fused_streaming"
     if b in ("conv_wgrad_kernel", "conv_wgrad_glds_kernel", "conv3x3_wgrad_kernel", "conv3x3_c64_wgrad_kernel", "conv_stem_wgrad_kernel",
-             "wgrad_reduce_kernel", "stem_wgrad_reduce_kernel", "gram_colsum_kernel", "gram_reduce_kernel"):
+             "wgrad_reduce_kernel", "stem_wgrad_reduce_kernel", "gram_colsum_kernel", "gram_reduce_kernel", "tpool_bwd_prod_kernel"):
         return "weight_gradient"
     return None
 
