@@ -117,6 +117,11 @@ out.append("Per-layer tables of the same build (B = 72 shapes): `%s_per_layer_be
            " `tools/bench_conv.py`), `%s_per_layer_bench_fused.txt` (RES / DUAL forms), `%s_per_layer_bench_dw.txt` (depthwise), `%s_bench_elementwise.txt` (BatchNorm / residual passes"
            " against a plain copy), `%s_launch_table_resnet.txt` / `%s_launch_table_sound.txt` (every launch of one backbone step with its excess over a 5.3 TB/s / 800 TFLOP/s floor;"
            " `tools/launch_table.py`), `%s_bench_nets.txt` (each backbone alone), `%s_kernel_resources.txt` (registers / spills / LDS of every kernel instance, `tools/kernel_resources.py`)." % ((R,) * 8))
+if os.path.exists("profiles/%s_per_layer_bench_dw_bwd.txt" % R):
+    out.append("")
+    out.append("Round-5 fused forms against the launches they replace, same build: `%s_per_layer_bench_dw_bwd.txt` (one-pass depthwise backward, stride 1 and 2;"
+               " `tools/bench_dw_bwd.py`), `%s_per_layer_bench_fadd_next.txt` (conv3 + add + ReLU + the next block's conv1; `tools/bench_fadd_next.py`)."
+               "  `tools/bench_fadd_tpool.py` and `tools/bench_tpool_bwd.py` time the two temporal-pool kernels the same way." % (R, R))
 if os.path.exists("profiles/%s_bench_deterministic.json" % R):
     ab = [json.loads(l) for l in open("profiles/%s_bench_deterministic.json" % R) if l.strip()]
     out.append("")
