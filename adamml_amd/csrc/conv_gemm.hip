@@ -1801,6 +1801,10 @@ int adamml_conv1x1_narrow_fwd_launch(const adamml_conv_desc_t* d, const void* x,
 int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
                               const float* in_shift, void* y, double* stats, const void* bn_z, const float* bn_vec, int bn_act,
                               hipStream_t stream);
+// wide 1x1 convs of ResNet layers 3-4 (conv1x1_wide.hip)
+bool adamml_conv1x1_wide_expand_supported(const adamml_conv_desc_t* d);
+int adamml_conv1x1_wide_expand_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
+                                      void* y, double* stats, hipStream_t stream);
 
 bool adamml_conv3x3_c64_wgrad_supported(const adamml_conv_desc_t* d, int cin_true);
 int adamml_conv3x3_c64_wgrad_blocks(const adamml_conv_desc_t* d, int* tpb_out);
@@ -1832,6 +1836,10 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     // narrow 1x1 convs of the MobileNetV2s (plain forward / plain data gradient): the barrier-free streaming kernel (conv1x1_narrow.hip)
     if (!cls && !fadd && !res && !dual && !cat && !pf && !bn_z && adamml_conv1x1_narrow_fwd_supported(d))
         return adamml_conv1x1_narrow_fwd_launch(d, x, w_packed, in_scale, in_shift, y, stats, stream);
+    // expanding 1x1 convs of ResNet layers 3-4 (K = 256 / 512 -> >= 2 K channels; plain forward, stride-2 downsample forward, plain or
+    // accumulating data gradient): activation-stationary streaming kernel (conv1x1_wide.hip)
+    if (!cls && !fadd && !res && !dual && !cat && !pf && !bn_z && adamml_conv1x1_wide_expand_supported(d))
+        return adamml_conv1x1_wide_expand_launch(d, x, w_packed, in_scale, in_shift, y, stats, stream);
     // ... their data gradients with the BatchNorm-fused epilogue (bn_z) or accumulating into the output
     if (!cls && !fadd && !res && !dual && !cat && !pf && !in_scale && (bn_z ? stats != nullptr && !d->accumulate : d->accumulate != 0) &&
         adamml_conv1x1_narrow_dgrad_epi_supported(d))
@@ -2042,6 +2050,16 @@ extern "C" int adamml_conv1x1_narrow_supported(const adamml_conv_desc_t* d, int 
     if (kind == 3) return adamml_conv1x1_narrow_fwd_supported(&g) ? 1 : 0;
     if (kind == 4) return adamml_conv1x1_narrow_dgrad_epi_supported(&g) ? 1 : 0;
     return 0;
+}
+
+extern "C" int adamml_conv1x1_wide_supported(const adamml_conv_desc_t* d, int kind) {
+    if (!d) return 0;
+    if (kind == 0) { adamml_conv_desc_t f = *d; f.accumulate = 0; return adamml_conv1x1_wide_expand_supported(&f) ? 1 : 0; }
+    if (kind != 3 && kind != 4) return 0;
+    if (d->stride != 1) return 0;                                // (strided data gradients run by parity class: conv_dgrad_stride2)
+    adamml_conv_desc_t g = *d;                                   // the data-gradient-shaped descriptor conv_launch dispatches on
+    g.H = d->OH; g.W = d->OW; g.Cin = d->Cout; g.OH = d->H; g.OW = d->W; g.Cout = d->Cin; g.accumulate = kind == 4; g.up = 1; g.pad = 0;
+    return adamml_conv1x1_wide_expand_supported(&g) ? 1 : 0;
 }
 
 extern "C" int adamml_conv_fused_input_supported(const adamml_conv_desc_t* d) {

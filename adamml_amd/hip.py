@@ -139,6 +139,8 @@ def load():
     lib.adamml_conv_fused_input_supported.restype = c_int
     lib.adamml_conv1x1_narrow_supported.argtypes = [_DESC, c_int]
     lib.adamml_conv1x1_narrow_supported.restype = c_int
+    lib.adamml_conv1x1_wide_supported.argtypes = [_DESC, c_int]
+    lib.adamml_conv1x1_wide_supported.restype = c_int
     lib.adamml_conv_fwd_bn_add_supported.argtypes = [_DESC]
     lib.adamml_conv_fwd_bn_add_supported.restype = c_int
     lib.adamml_conv_fwd_bn_add_next_supported.argtypes = [_DESC, c_int]

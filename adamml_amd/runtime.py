@@ -391,6 +391,12 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
         kern_dual = "conv1x1_narrow_dgrad_kernel" if nar[2] else kern
         kern_acc = ("conv1x1_narrow_dgrad_kernel" if nar[4] else kern, "conv1x1_narrow_fwd_kernel" if nar[3] else kern)      # [accumulating?]
         kern_bn = "conv1x1_narrow_dgrad_kernel" if nar[4] else kern
+        if cs.kh * cs.kw == 1 and d.Cin >= 256:
+            # the wide 1x1 layers of ResNet layers 3-4 run on the activation-stationary streaming kernels of csrc/conv1x1_wide.hip
+            wide = [bool(lib.adamml_conv1x1_wide_supported(byref(d), k)) for k in (0, 3, 4)]
+            if wide[0]:
+                kern_f = "wide_expand_kernel"
+            kern_acc = ("wide_expand_kernel" if wide[2] else kern_acc[0], "wide_expand_kernel" if wide[1] else kern_acc[1])
     role_f = None if cs.depthwise else (R_KXK if cs.kh * cs.kw > 1 else R_1X1)
     role_b = None if cs.depthwise else (R_KXK if (cs.kh * cs.kw > 1 or cs.stride > 1) else R_1X1)
     role_bf = role_b if role_b != R_1X1 else R_FUSED          # data gradient with a fused BatchNorm-backward / residual epilogue

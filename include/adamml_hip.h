@@ -81,6 +81,12 @@ ADAMML_API int adamml_conv_fused_input_supported(const adamml_conv_desc_t* d);
  * without accumulation, 4: adamml_conv_bwd_data_bn / adamml_conv_bwd_data accumulating.  Results are identical either way; callers
  * use it to label launches with the device kernel that runs (bench.py's roofline groups launches by kernel). */
 ADAMML_API int adamml_conv1x1_narrow_supported(const adamml_conv_desc_t* d, int kind);
+/* The same question for the activation-stationary streaming kernels of the WIDE 1x1 convs of ResNet-50 layers 3-4 (csrc/conv1x1_wide.hip;
+ * models/resnet.py:94-113 at the widths of models/resnet.py:150-154): 1 when the launch of FORWARD descriptor d behind kind 0:
+ * adamml_conv_fwd, 3: adamml_conv_bwd_data without accumulation, 4: adamml_conv_bwd_data accumulating runs there instead of on the
+ * tile-loop implicit GEMM (other kinds: 0).  Outputs are bit-identical either way (same K order and rounding points); the forward
+ * statistics differ in summation order only.  ADAMML_WIDE_STREAM=0 in the environment disables the kernels (A/B aid; read at every call). */
+ADAMML_API int adamml_conv1x1_wide_supported(const adamml_conv_desc_t* d, int kind);
 /* Forward 1x1 / stride-1 conv with BatchNorm + residual add + activation in its epilogue (a bottleneck's conv3 + bn3 + add +
  * ReLU, models/resnet.py:104-112; a MobileNetV2 projection + add) -- for the cases where the BatchNorm vectors are known before
  * the launch: eval mode, or train mode with statistics from adamml_gram_stats.  bn_vec [groups][4][Cout] (scale, shift, ..) of

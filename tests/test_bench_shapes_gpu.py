@@ -30,6 +30,17 @@ SIGNATURES = [
     (256, 512, 1, 2, 4, 56),      # layer2.0.downsample
     (512, 128, 1, 1, 4, 28),      # layer2.1-3.conv1
     (128, 128, 3, 1, 4, 28),      # layer2.1-3.conv2
+    # round 6: layers 3-4 (models/resnet.py:150-154) -- where the wide 1x1 streaming kernels (csrc/conv1x1_wide.hip) run -- and two narrow 1x1
+    # convs of the MobileNetV2s (csrc/conv1x1_narrow.hip: Sound-MobileNetV2 16 -> 96 at 128^2, policy-rgb 96 -> 24 at 40^2 x 4 frames)
+    (512, 256, 1, 1, 2, 28),      # layer3.0.conv1 (T 4 -> 2)
+    (256, 1024, 1, 1, 2, 14),     # layer3.*.conv3
+    (1024, 256, 1, 1, 2, 14),     # layer3.1-5.conv1
+    (256, 256, 3, 1, 2, 14),      # layer3.1-5.conv2
+    (512, 1024, 1, 2, 2, 28),     # layer3.0.downsample
+    (512, 2048, 1, 1, 1, 7),      # layer4.*.conv3
+    (2048, 512, 1, 1, 1, 7),      # layer4.1-2.conv1
+    (16, 96, 1, 1, 1, 128),       # sound features.2 expansion
+    (96, 24, 1, 1, 4, 40),        # policy-rgb features.2 projection
 ]
 
 
@@ -105,6 +116,37 @@ def test_conv_at_benchmark_shape(sig):
     assert e_y <= 4.5e-3 * y_scale and e_dx <= 4.5e-3 * dx_scale        # 2^-8 (bf16 output rounding) + fp32 accumulation-order noise
     assert e_dw <= 1e-5                 # measured 5.6e-7 .. 1.3e-6
     assert st_err <= 1e-6               # fp32 workgroup partials of exactly representable products, folded exactly
+
+
+# ---- the fused kernels of round 5 at the geometry the benchmark runs them (round-5 review: they were tested at <= 3 frames per group, where
+# no wave runs its steady-state loop twice; 32-bit lane offsets against uniform 64-bit bases over 4.6 GB tensors only show at B = 72).
+# Each is the EQUALITY statement of tests/test_kernels_gpu.py -- fused launch == the launches it replaces, bit for bit (sums / products up
+# to summation order) -- called with the benchmark's own sizes: 5 groups x 576 (288) frames at 56^2 / 28^2, 5 x 72 spectrogram maps.
+def test_fadd_next_at_benchmark_shape():
+    """adamml_conv_fwd_bn_add_next (csrc/conv1x1_fadd_next.hip), layer 1: conv3 + bn3 + add + ReLU + the next conv1, 5 x 576 frames at 56^2."""
+    from tests.test_kernels_gpu import test_conv_fwd_bn_add_next_equals_the_two_launches as eq
+    eq(G, B * 8, 56, False, True)
+    eq(G, B * 8, 56, True, True)
+
+
+@pytest.mark.parametrize("T,H,Cin,Cout", [(8, 56, 64, 256), (4, 28, 128, 512)])
+def test_fadd_tpool_at_benchmark_shape(T, H, Cin, Cout):
+    """adamml_conv_fwd_bn_add_tpool (the streaming form at layer 1, conv_gemm_kernel's TP instance at layer 2): 72 clips x T frames x 5 groups."""
+    from tests.test_kernels_gpu import test_conv_fwd_bn_add_tpool_equals_add_then_pool as eq
+    eq(T, B, H, Cin, Cout, G, True)
+
+
+def test_tpool_bwd_prod_at_benchmark_shape():
+    """adamml_temporal_pool_bwd_code_prod (csrc/tpool_bwd_prod.hip): stage-1 pool backward + the product g'^T a, 72 clips x 8 frames x 5 groups at 56^2."""
+    from tests.test_kernels_gpu import test_temporal_pool_bwd_code_prod_equals_expand_then_product as eq
+    eq(B, 56, G, True)
+
+
+@pytest.mark.parametrize("H,C,st", [(128, 96, 2), (64, 144, 1), (128, 32, 1), (64, 144, 2)])
+def test_dwconv_bwd_fused_at_benchmark_shape(H, C, st):
+    """adamml_dwconv_bwd_fused (csrc/dwconv_bwd_fused.hip) on the byte-heavy depthwise layers of the Sound-MobileNetV2: 72 maps x 5 groups."""
+    from tests.test_kernels_gpu import test_dwconv_bwd_fused_equals_apply_wgrad_dgrad as eq
+    eq(B, H, H, C, G, st)
 
 
 def test_eval_forward_b72_equals_chunks_of_four():

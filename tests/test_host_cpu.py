@@ -598,10 +598,23 @@ def test_parity_bounds_table_respects_the_stated_tolerances():
     assert len(t) >= 40
     assert pb.CEILINGS["logits"] <= 4e-2 and pb.CEILINGS["plog"] <= 8e-2 and pb.CEILINGS["stats"] <= 3e-2 and pb.CEILINGS["replay_p90"] <= 0.13
     for k, e in t.items():
-        ceil = pb.CEILINGS[e["cat"]]
+        # every entry has its OWN ceiling <= the category's (round-5 advisor finding: a category-wide ceiling let a tight entry drift)
+        ceil = e["ceil"]
+        assert ceil <= pb.CEILINGS[e["cat"]] * (1 + 1e-9), (k, e)
         assert 0 < e["measured"] <= ceil, (k, e)
         assert e["bound"] <= ceil * (1 + 1e-9), (k, e)
         assert abs(e["bound"] - min(pb.FACTOR * e["measured"], ceil)) <= 2e-3 * e["bound"], (k, e)
+    # the re-base refuses a figure above an entry's ceiling and, without --allow-growth, one that grew by more than 10 %
+    old = t["c4.train_main.logits"]
+    with pytest.raises(SystemExit):
+        pb.rebased_entry("logits", 1.2 * old["measured"], old, False, "c4.train_main.logits")
+    assert pb.rebased_entry("logits", 1.2 * old["measured"], old, True, "x")["ceil"] == old["ceil"]
+    with pytest.raises(SystemExit):
+        pb.rebased_entry("logits", 2.5 * old["measured"], old, True, "c4.train_main.logits")        # (above its own ceiling although below the category's 4e-2)
+    # the emulation fixtures of the full-size cases exist and the emulation-relative gate has its constants
+    for name in ("resnet50_c1", "adamml_c2", "adamml_c4", "adamml_c5"):
+        assert os.path.exists(os.path.join(ROOT, "tests", "golden", name + "_bf16emu.npz")), name
+    assert pb.EMU_K <= 2.0 and all(pb.EMU_FLOOR[c] <= 0.25 * pb.CEILINGS[c] * (1 + 1e-9) for c in pb.EMU_FLOOR)
     for case in ("c1.train", "c2.train_main", "c2.train_policy", "c4.train_main", "c5.train_main", "c5.train_policy"):
         assert case + ".logits" in t and case + ".stats" in t and case + ".head" in t
     src = open(os.path.join(ROOT, "tests", "test_parity_fullsize_gpu.py")).read()

@@ -90,6 +90,14 @@ CONV_CASES = [
     (3, 17, 13, 24, 144, 1, 1, 0),
     (2, 40, 40, 64, 128, 3, 1, 1),          # wide 3x3 that is not 64 -> 64: the LDS-patch weight gradient (conv3x3_wgrad_kernel)
     (1, 66, 66, 128, 128, 3, 2, 1),         # wide stride-2 3x3: generic implicit-GEMM weight gradient
+    # wide 1x1 convs of ResNet layers 3-4 at >= 2048 pixels: the activation-stationary streaming kernels (csrc/conv1x1_wide.hip) --
+    # forward K = 256 / 512 (also stride 2), and as the data gradient of the reducing convs (1024 -> 256, 2048 -> 512); ragged pixel counts
+    (3, 28, 28, 256, 1024, 1, 1, 0),
+    (2, 33, 33, 256, 512, 1, 1, 0),
+    (1, 47, 47, 512, 2048, 1, 1, 0),
+    (3, 57, 57, 512, 1024, 1, 2, 0),
+    (3, 28, 28, 1024, 256, 1, 1, 0),
+    (1, 47, 47, 2048, 512, 1, 1, 0),
 ]
 
 
@@ -451,6 +459,66 @@ def test_conv_groups_equal_separate_launches(case):
             call("adamml_conv_bwd_weight", byref(d1), ptr(_g(dz, G)[g]), ptr(_g(xh, G)[g]), ptr(scale[g]) if lazy else None,
                  ptr(shift[g]) if lazy else None, ptr(dw1), Cin, ptr(ws), ws.numel() * 4 if use_ws else 0)
         close(dw, dw1, rtol=1e-3, atol_frac=1e-4, what="grouped wgrad (ws=%s)" % use_ws)
+
+
+@pytest.mark.parametrize("G,N,H,Cin,Cout,stride", [(3, 3, 28, 256, 1024, 1), (2, 1, 47, 512, 2048, 1), (1, 2, 33, 256, 512, 1), (2, 3, 57, 512, 1024, 2),
+                                                   (5, 4, 28, 256, 1024, 1)])
+def test_conv1x1_wide_stream_equals_conv_gemm(G, N, H, Cin, Cout, stride):
+    """csrc/conv1x1_wide.hip (activation-stationary streaming form of the wide 1x1 convs of ResNet layers 3-4, models/resnet.py:94-113)
+    against conv_gemm_kernel on the same operands (ADAMML_WIDE_STREAM is read at every call): forward with a lazy and with a plain
+    input -- outputs bit-identical, statistics up to summation order --, and, for the stride-1 shapes, the plain and the accumulating
+    data gradient of the REDUCING conv with these channel counts swapped (Cout -> Cin), bit-identical."""
+    import os
+    torch.manual_seed(21)
+    OH = (H - 1) // stride + 1
+    xh = nhwc(torch.randn(G * N, Cin, H, H, device=DEV))
+    w = torch.randn(Cout, Cin, 1, 1, device=DEV) * (2.0 / Cin) ** 0.5
+    wf = pack(w, Cin, 0)
+    scale = torch.rand(G, Cin, device=DEV) + 0.5
+    shift = torch.randn(G, Cin, device=DEV) * 0.3
+
+    def both(fn):
+        outs = []
+        for on in ("1", "0"):
+            os.environ["ADAMML_WIDE_STREAM"] = on
+            try:
+                outs.append(fn())
+            finally:
+                os.environ.pop("ADAMML_WIDE_STREAM", None)
+        return outs
+
+    for lazy in (True, False):
+        d = ConvDesc(N, H, H, Cin, OH, OH, Cout, 1, 1, stride, 0, 1, 1 if lazy else 0, 0, G, Cin if lazy else 0)
+        assert hip.load().adamml_conv1x1_wide_supported(byref(d), 0) == 1
+
+        def fwd():
+            y = torch.empty(G * N, OH, OH, Cout, dtype=torch.bfloat16, device=DEV)
+            st = torch.zeros(G, STAT_SLOTS, 2 * Cout, dtype=torch.float64, device=DEV)
+            call("adamml_conv_fwd", byref(d), ptr(xh), ptr(wf), ptr(scale) if lazy else None, ptr(shift) if lazy else None, ptr(y), ptr(st))
+            return y, ssum(st)
+        (y1, s1), (y0, s0) = both(fwd)
+        assert torch.equal(y1, y0), "forward (lazy=%s)" % lazy
+        assert torch.allclose(s1, s0, rtol=1e-5, atol=1e-3)
+        yf = y1.float().reshape(G, -1, Cout).double()
+        assert torch.allclose(s1[:, :Cout], yf.sum(1), rtol=1e-5, atol=1e-3) and torch.allclose(s1[:, Cout:], (yf * yf).sum(1), rtol=1e-5, atol=1e-3)
+    if stride != 1:
+        return
+    # data gradient of the conv Cout -> Cin (its gradient tensor has Cin channels, its input Cout): dx [.., Cout] = dz [.., Cin] . W
+    wr = torch.randn(Cin, Cout, 1, 1, device=DEV) * (2.0 / Cout) ** 0.5
+    wd = pack(wr, Cout, 1)
+    dz = nhwc(torch.randn(G * N, Cin, H, H, device=DEV))
+    dr = ConvDesc(N, H, H, Cout, H, H, Cin, 1, 1, 1, 0, 1, 0, 0, G, 0)
+    assert hip.load().adamml_conv1x1_wide_supported(byref(dr), 3) == 1 and hip.load().adamml_conv1x1_wide_supported(byref(dr), 4) == 1
+    base = nhwc(torch.randn(G * N, Cout, H, H, device=DEV))
+    for acc in (0, 1):
+        def dgrad():
+            dx = base.clone()
+            call("adamml_conv_bwd_data", byref(dr), ptr(dz), ptr(wd), ptr(dx), acc)
+            return dx
+        dx1, dx0 = both(dgrad)
+        assert torch.equal(dx1, dx0), "data gradient (acc=%d)" % acc
+    ref = torch.einsum("nhwk,kc->nhwc", dz.float(), rb(wr)[:, :, 0, 0]) + base.float()
+    close(dx1.float(), ref, rtol=2e-2, atol_frac=2e-2, what="wide data gradient vs fp32")
 
 
 @pytest.mark.parametrize("N,H,W,C,s,G", [(2, 20, 20, 96, 1, 1), (2, 21, 19, 144, 2, 2), (1, 16, 16, 32, 2, 3), (3, 9, 14, 24, 1, 2),

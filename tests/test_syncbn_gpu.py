@@ -47,7 +47,7 @@ STAGES = {
 }
 
 
-def _step(model, ddp, rank, world, nvid=B, px=64):
+def _step(model, ddp, rank, world, nvid=B, px=64, reduce=True):
     from adamml_amd import synth
     dev = torch.device("cuda", torch.cuda.current_device())
     xs = [t[rank::world].to(dev) for t in synth.synth_inputs(["rgb", "sound"], nvid, S, 8, px, seed=5)]
@@ -61,7 +61,8 @@ def _step(model, ddp, rank, world, nvid=B, px=64):
     loss = F.cross_entropy(out, tgt)
     loss.backward()
     if ddp is not None:
-        ddp.reduce_gradients()
+        if reduce:
+            ddp.reduce_gradients()
         lt = loss.detach().clone()
         dist.all_reduce(lt)
         loss = lt / world
@@ -76,6 +77,28 @@ def _step(model, ddp, rank, world, nvid=B, px=64):
             "sound_fc_grad": model.main_net.nets[1].classifier[1].weight.grad.detach().cpu().clone(),
             "bn_grads": {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if k in BN_GRAD_KEYS},
             "stats": {k: v.detach().cpu().clone() for k, v in sd.items() if k.endswith(("running_mean", "running_var"))}}
+
+
+def _exchange_linearity(model, ddp, rank, world, nvid, px, averaged):
+    """The gradient exchange is LINEAR, so it has a tight statement that no ReLU / max-pool decision can blur (round-5 advisor finding:
+    a 0.7-0.9 rel-L2 figure against the full-batch step cannot tell a wrong average from chaotic amplification).  The same step is taken
+    again WITHOUT the exchange (same inputs, same weights, SyncBatchNorm still on: every sum is order-fixed, so each rank reproduces its
+    local gradients bit for bit), the local flat gradients are summed by ONE plain all-reduce and divided by the world size, and the
+    result must equal what the bucketed asynchronous path (slices all-reduced from inside backward + gaps + one 1/world scale) left in
+    the parameters' .grad -- per stage, to fp32 summation order.  A missed bucket, a doubly reduced slice or a wrong factor reads >= 0.3."""
+    ov, ddp.overlap = ddp.overlap, False
+    try:
+        _step(model, ddp, rank, world, nvid, px, reduce=False)
+    finally:
+        ddp.overlap = ov
+    named = dict(model.named_parameters())
+    out = {}
+    for st, pre in STAGES.items():
+        loc = torch.cat([named[k].grad.detach().flatten() for k in named if k.startswith(pre) and named[k].grad is not None]).clone()
+        dist.all_reduce(loc)
+        loc /= world
+        out[st] = _rel(averaged["stage_grads"][st], loc.cpu())
+    return out
 
 
 def _worker(rank, world, port, ret, backend, nvid, px=64):
@@ -94,6 +117,7 @@ def _worker(rank, world, port, ret, backend, nvid, px=64):
         ddp = HipDDP(model, sync_bn=True)
         interleave.stats["collectives"] = interleave.stats["coalesced_vectors"] = 0
         r = _step(model, ddp, rank, world, nvid, px)
+        r["lin"] = _exchange_linearity(model, ddp, rank, world, nvid, px, r)
         if rank == 0:
             ret["r"] = plain(r)
             ret["exchange"] = dict(interleave.stats)
@@ -117,8 +141,15 @@ TOL = {"first_layer_stats": 1e-6,      # measured 1.8e-7: fp32 rounding of per-w
        "grad_rel_l2": 0.94}          # measured 0.721 (cosine 0.743) over all 25.8 M main-net gradient elements, see _compare
 
 
+def _check_linearity(two):
+    for st, e in two["lin"].items():
+        print("  gradient exchange of stage %-8s: bucketed asynchronous average vs one plain all-reduce of the local gradients: rel L2 %.2e" % (st, e))
+        assert e <= 1e-5, (st, e)
+
+
 def _compare(two, one, world, tol=TOL):
     assert torch.equal(two["sel"], one["sel"][0::world])                 # rank 0 holds videos 0, N, 2N.. and takes the same decisions
+    _check_linearity(two)
     errs = {k: _rel(two["stats"][k], v) for k, v in one["stats"].items()}
     first = max(e for k, e in errs.items() if k.startswith(FIRST_LAYER_STATS))
     ranked = sorted(errs.values())
@@ -171,18 +202,25 @@ TOL_BY_WORLD = {
 }
 
 
-def _compare_224(two, one, world, key, assert_grads=True):
+def _compare_224(two, one, world, key):
     """The well-conditioned form (224^2: >= 196 samples per BatchNorm channel even in layer 4): per-stage gradient figures from the
-    heads down, each against its own table entry (tests/parity_bounds.json, `key`.*), instead of one number over 25.8 M elements."""
-    from tests.parity_bounds import check
+    heads down, each against its own table entry (tests/parity_bounds.json, `key`.*), instead of one number over 25.8 M elements.
+    Asserted for every transport and world size: the LINEAR statement (_exchange_linearity, <= 1e-5 per stage) and a cosine >= 0.5 per
+    stage against the full-batch step; the rel-L2 figures against the full-batch step have table entries for the ResNet-50 stages of a
+    world size that was measured (key present) -- the random-weight Sound-MobileNetV2 trunk's figure (0.73 at two ranks: ~1.09x
+    amplification per layer over 52 layers) is PRINTED only: a bound of 0.95 on a quantity that reads 1.0 for a zero gradient was no gate."""
+    from tests.parity_bounds import check, table
     assert torch.equal(two["sel"], one["sel"][0::world])
+    _check_linearity(two)
+    have = (key + ".stats") in table() or os.environ.get("ADAMML_REBASE")
+    base = key if have else "nrank2_224"         # (statistics / loss / heads: the two-rank entries hold for any world -- fp64 / fp32 sums, no transport factor)
     errs = {k: _rel(two["stats"][k], v) for k, v in one["stats"].items()}
     ranked = sorted(errs.values())
-    check(key + ".first_stats", max(e for k, e in errs.items() if k.startswith(FIRST_LAYER_STATS)), "first-layer running statistics", cat="nrank_first_stats")
-    check(key + ".stats", ranked[-1], max(errs, key=errs.get), cat="nrank_stats")
-    check(key + ".stats_p90", ranked[int(0.9 * (len(ranked) - 1))], cat="nrank_stats")
-    check(key + ".loss", abs(two["loss"] - one["loss"]) / abs(one["loss"]), "%.6f vs %.6f" % (two["loss"], one["loss"]), cat="nrank_loss")
-    check(key + ".head", max(_rel(two["fc_grad"], one["fc_grad"]), _rel(two["sound_fc_grad"], one["sound_fc_grad"])),
+    check(base + ".first_stats", max(e for k, e in errs.items() if k.startswith(FIRST_LAYER_STATS)), "first-layer running statistics", cat="nrank_first_stats")
+    check(base + ".stats", ranked[-1], max(errs, key=errs.get), cat="nrank_stats")
+    check(base + ".stats_p90", ranked[int(0.9 * (len(ranked) - 1))], cat="nrank_stats")
+    check(base + ".loss", abs(two["loss"] - one["loss"]) / abs(one["loss"]), "%.6f vs %.6f" % (two["loss"], one["loss"]), cat="nrank_loss")
+    check(base + ".head", max(_rel(two["fc_grad"], one["fc_grad"]), _rel(two["sound_fc_grad"], one["sound_fc_grad"])),
           "classifier-head gradients (resnet fc, sound classifier)", cat="nrank_head")
     for k in BN_GRAD_KEYS:                               # (a world-times-too-large SyncBN gamma / beta gradient would read 1.0)
         e = _rel(two["bn_grads"][k], one["bn_grads"][k])
@@ -192,11 +230,11 @@ def _compare_224(two, one, world, key, assert_grads=True):
         a, b = two["stage_grads"][st], one["stage_grads"][st]
         e = _rel(a, b)
         cos = F.cosine_similarity(a.double(), b.double(), dim=0).item()
-        if assert_grads:
-            check("%s.grad_%s" % (key, st), e, "%d elements, cosine %.3f" % (a.numel(), cos), cat="nrank_grad_mbv2" if st == "mbv2" else "nrank_grad")
-            assert cos >= 0.5, (st, cos)                 # (a zero or sign-flipped averaged gradient reads rel L2 1.0 / cosine <= 0)
-        else:                                            # first contact with real peers: printed, not asserted
-            print("  [first contact] gradients of stage %-8s rel L2 %.3f cosine %.3f over %d elements" % (st, e, cos, a.numel()))
+        assert cos >= 0.5, (st, cos)                     # (a zero or sign-flipped averaged gradient reads rel L2 1.0 / cosine <= 0)
+        if have and st != "mbv2":
+            check("%s.grad_%s" % (key, st), e, "%d elements, cosine %.3f" % (a.numel(), cos), cat="nrank_grad")
+        else:                                            # unmeasured world size / the chaotic trunk: printed
+            print("  gradients of stage %-8s vs the full-batch step: rel L2 %.3f cosine %.3f over %d elements (printed)" % (st, e, cos, a.numel()))
 
 
 def _n_rank(world, backend, nvid, px=64):
@@ -211,9 +249,10 @@ def _n_rank(world, backend, nvid, px=64):
     torch.cuda.set_device(0)
     one = _step(_build(), None, 0, 1, nvid, px)
     if px == 224:
-        # statistics, loss and head gradients are asserted with the gloo-measured table entries (the exchange sums fp64 vectors and
-        # fp32 buckets: no transport-dependent factor); with real peers the per-stage gradient figures are PRINTED on first contact
-        _compare_224(got, one, world, "nrank%d_224" % (2 if backend == "nccl" else world), assert_grads=backend != "nccl")
+        # keyed by the ACTUAL world size; a world size without table entries uses the two-rank entries for statistics, loss and head
+        # gradients (the exchange sums fp64 vectors and fp32 buckets: no transport-dependent factor) and prints the per-stage figures
+        # against the full-batch step -- the gradient exchange itself is asserted tightly for every transport and world (_exchange_linearity)
+        _compare_224(got, one, world, "nrank%d_224" % world)
         return
     _compare(got, one, world, TOL_BY_WORLD.get(world) or _loose(TOL, 3.0))
 
@@ -241,7 +280,7 @@ def test_two_rank_syncbn_step_at_224_per_stage_gradients():
 def test_n_rank_rccl_step_equals_full_batch():
     """configs[2] with real peers: min(8, device_count) RCCL ranks, 2 videos each at 224^2, SyncBatchNorm + bucketed asynchronous
     gradient all-reduce, against the one-process step on the concatenated batch.  Asserted: `communicator_ranks`, the exchange counts,
-    running statistics, loss and head gradients (the two-rank 224^2 table entries, no transport factor); the per-stage gradient
-    figures are printed on first contact."""
+    running statistics, loss and head gradients (the two-rank 224^2 table entries, no transport factor), the gradient exchange per
+    stage to fp32 summation order (_exchange_linearity) and a cosine >= 0.5 per stage against the full-batch step."""
     world = min(8, torch.cuda.device_count())
     _n_rank(world, "nccl", 2 * world, px=224)

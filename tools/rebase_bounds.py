@@ -5,7 +5,11 @@ to gpurun_out/parity_bounds.json (the only directory that travels back).  A figu
 regression, not a re-base: the tool exits non-zero and leaves the table alone.  Exact (bit-identity, decisions, integer) asserts of the
 same tests stay hard asserts during the run.
 
-usage: python tools/rebase_bounds.py [pytest selection ...]      (default: the files that read the table)"""
+Every entry carries its OWN ceiling (min(category ceiling, 2 x the figure it was created with)); a figure above it, or one that grew by more
+than 10 % over the committed figure without --allow-growth, is refused (round-5 advisor finding: a category-wide ceiling let a tight entry
+drift).
+
+usage: python tools/rebase_bounds.py [--allow-growth] [pytest selection ...]      (default: the files that read the table)"""
 import json
 import os
 import subprocess
@@ -19,7 +23,9 @@ FILES = ["tests/test_parity_fullsize_gpu.py", "tests/test_syncbn_gpu.py", "tests
 
 
 def main():
-    sel = sys.argv[1:] or FILES
+    args = [a for a in sys.argv[1:] if a != "--allow-growth"]
+    allow_growth = "--allow-growth" in sys.argv[1:]
+    sel = args or FILES
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     rec_path = os.path.join(out_dir, "rebase_measured.json")
@@ -39,9 +45,9 @@ def main():
     print("%-46s %12s %12s %12s %12s" % ("entry", "was", "measured", "bound", "ceiling"))
     for k in sorted(measured):
         cat = measured[k]["cat"] or (old[k]["cat"] if k in old else pb_category(k))
-        ent = pb.rebased_entry(cat, measured[k]["value"])
-        print("%-46s %12s %12.4e %12.3e %12.1e" % (k, "%.4e" % old[k]["measured"] if k in old else "new", measured[k]["value"], ent["bound"],
-                                                    pb.CEILINGS[cat]))
+        ent = pb.rebased_entry(cat, measured[k]["value"], old.get(k), allow_growth, k)
+        print("%-46s %12s %12.4e %12.3e %12.3e" % (k, "%.4e" % old[k]["measured"] if k in old else "new", measured[k]["value"], ent["bound"],
+                                                    ent["ceil"]))
         new[k] = ent
     stale = sorted(set(old) - set(measured))
     if stale and sel == FILES:
