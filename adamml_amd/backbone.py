@@ -261,6 +261,46 @@ def _check_groups(x, groups):
         raise RuntimeError("backbone call: %d images do not split into %d groups" % (x.shape[0], groups))
 
 
+class NotifyingSequential(nn.Sequential):
+    """nn.Sequential whose item edits (`net.classifier[1] = nn.Linear(...)`, del / append / insert / extend) are reported to the backbone
+    that owns it, exactly as an attribute assignment on the backbone is (HipBackbone.__setattr__): the flat parameter buffers and the
+    optimizers re-home the new parameters at the NEXT call instead of at the every-32nd-call walk (round-5 advisor finding).  Same
+    state_dict names as a plain nn.Sequential."""
+
+    def _notify(self):
+        owner = self.__dict__.get("_owner_ref")
+        owner = owner() if owner is not None else None
+        if owner is not None:
+            owner._params_changed()
+
+    def bind_owner(self, owner):
+        self.__dict__["_owner_ref"] = weakref.ref(owner)
+        return self
+
+    def __setitem__(self, idx, module):
+        super().__setitem__(idx, module)
+        self._notify()
+
+    def __delitem__(self, idx):
+        super().__delitem__(idx)
+        self._notify()
+
+    def append(self, module):
+        r = super().append(module)
+        self._notify()
+        return r
+
+    def insert(self, index, module):
+        r = super().insert(index, module)
+        self._notify()
+        return r
+
+    def extend(self, sequential):
+        r = super().extend(sequential)
+        self._notify()
+        return r
+
+
 class HipBackbone(nn.Module):
     """Base of ResNet / MobileNetV2 backbones executed by libadamml_hip."""
 

@@ -74,6 +74,19 @@ __device__ __forceinline__ f32x4 transform4(bf16x4 raw, const float* scale, cons
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: raise it once per (kernel, device), thread-safely.
+// `done` = the call site's own bit set (one bit per device).  A process-wide `static bool` (rounds 4-5) left the limit at 64 KB on every
+// device but the first one a process drives, and was a data race between threads (round-5 advisor finding).
+struct AdamLdsOnce {
+    unsigned long long done = 0;
+    bool test(int dev) const { return dev >= 0 && dev < 64 && (__atomic_load_n(&done, __ATOMIC_ACQUIRE) >> dev) & 1ull; }
+    void set(int dev) { if (dev >= 0 && dev < 64) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELEASE); }
+};
+static inline int adamml_current_device() {
+    int dev = -1;
+    return hipGetDevice(&dev) == hipSuccess ? dev : -1;
+}
+
 // ---- reproducible per-channel reductions (BatchNorm statistics, BatchNorm-backward sums) ---------------------------------------
 // A sum over millions of pixels is accumulated in two stages, and both are ORDER-FIXED, so that two runs on the same input produce
 // the same bits (a 1-ulp difference of a BatchNorm scale is amplified by the bf16 rounding downstream into visibly different

@@ -449,12 +449,13 @@ int adamml_conv1x1_fadd_next_launch(const adamml_conv_desc_t* d, const void* x, 
     p.P = (long)d->N * d->H * d->W;
     if (p.P <= 0) return ADAMML_OK;
     const int groups = d->groups < 1 ? 1 : d->groups;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AdamLdsOnce attr_once;                    // (per device: common.h)
+    const int attr_dev = adamml_current_device();
+    if (!attr_once.test(attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fadd_next_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fadd_next_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv_fwd_bn_add_next: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-        attr_set = true;
+        attr_once.set(attr_dev);
     }
     const long ntile = (p.P + TPX - 1) / TPX;
     long nblk = (ntile + NW - 1) / NW;
@@ -485,11 +486,12 @@ int adamml_conv1x1_fadd_tpool_launch(const adamml_conv_desc_t* d, const void* x,
     if (p.clips <= 0 || p.HW <= 0) return ADAMML_OK;
     const int groups = d->groups < 1 ? 1 : d->groups;
     constexpr int LDS_TP = CB * W3ROW + 2 * C3IN * 4 + 4 * CB * 4 + NW * TPX * SROW;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AdamLdsOnce attr_once;                    // (per device: common.h)
+    const int attr_dev = adamml_current_device();
+    if (!attr_once.test(attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fadd_tpool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TP);
         if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv_fwd_bn_add_tpool: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-        attr_set = true;
+        attr_once.set(attr_dev);
     }
     const long ntask = (long)p.clips * ((p.HW + TPX - 1) / TPX);
     long nblk = (ntask + NW - 1) / NW;

@@ -200,13 +200,14 @@ template <int KS, int COUT>
 int narrow_launch(const N1P& p, int groups, hipStream_t stream) {
     constexpr int KP = KS * 32, NCT = (COUT + 15) / 16, CW = NCT * 16;
     constexpr size_t lds = (size_t)CW * (KP * 2 + 16) + 2 * KP * 4 + 4 * 2 * CW * 4 + 4 * 32 * (CW * 2 + 8);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AdamLdsOnce attr_once;                    // (per device: common.h)
+    const int attr_dev = adamml_current_device();
+    if (!attr_once.test(attr_dev)) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_narrow_fwd_kernel<KS, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv1x1 (narrow): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         }
-        attr_set = true;
+        attr_once.set(attr_dev);
     }
     const long ntile = (p.P + 31) / 32;
     long nblk = (ntile + 3) / 4;
@@ -442,13 +443,14 @@ template <int KS, int COUT, bool DUAL, int EPI>
 int narrow_dgrad_launch(const ND1P& p, int groups, hipStream_t stream) {
     constexpr int KP = KS * 32, NCT = (COUT + 15) / 16, NCB = (NCT + 5) / 6, BT = (NCT + NCB - 1) / NCB, BW = BT * 16;
     constexpr size_t lds = (size_t)NCB * BW * (KP * 2 + 16) + 3 * KP * 4 + 4 * NCB * BW * 4 + (EPI == 1 ? 4 * 64 * NCB * 16 * 4 : 0) + 4 * 32 * (BW * 2 + 8);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AdamLdsOnce attr_once;                    // (per device: common.h)
+    const int attr_dev = adamml_current_device();
+    if (!attr_once.test(attr_dev)) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_narrow_dgrad_kernel<KS, COUT, DUAL, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv_bwd_data (narrow): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         }
-        attr_set = true;
+        attr_once.set(attr_dev);
     }
     const long ntile = (p.P + 31) / 32;
     long nblk = (ntile + 3) / 4;
@@ -624,13 +626,14 @@ int narrow_wgrad_launch(const NW1P& p, int groups, int nblk, hipStream_t stream)
     constexpr int MT = (COUT + 15) / 16, NT = (CIN + 15) / 16;
     constexpr size_t stage = (size_t)4 * 32 * ((MT * 32 + 8) + (NT * 32 + 8)), foldb = (size_t)MT * 16 * NT * 16 * 4;
     constexpr size_t lds = 2 * NT * 16 * 4 + (stage > foldb ? stage : foldb);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AdamLdsOnce attr_once;                    // (per device: common.h)
+    const int attr_dev = adamml_current_device();
+    if (!attr_once.test(attr_dev)) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_narrow_wgrad_kernel<COUT, CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv_bwd_weight (narrow): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         }
-        attr_set = true;
+        attr_once.set(attr_dev);
     }
     hipLaunchKernelGGL((conv1x1_narrow_wgrad_kernel<COUT, CIN>), dim3((unsigned)nblk, groups), dim3(256), lds, stream, p);
     return adamml_check_launch("conv_bwd_weight (narrow 1x1 stream)");

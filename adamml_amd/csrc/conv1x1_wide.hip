@@ -1,20 +1,34 @@
-// Activation-stationary streaming kernels for the WIDE 1x1 convolutions of ResNet-50 layers 3-4 (models/resnet.py:94-113 over the
-// stages built at models/resnet.py:150-154: conv3 256 -> 1024 / 512 -> 2048, the stride-2 downsample convs 512 -> 1024 / 1024 -> 2048, and
-// -- as data gradients -- conv1 1024 <- 256 / 2048 <- 512), gfx950.
+// Activation-stationary kernel for the WIDE expanding 1x1 convolutions of ResNet-50 layers 2-3 (models/resnet.py:94-113 at the widths of
+// models/resnet.py:148-152: layer-3 conv3 256 -> 1024, the stride-2 downsample conv 256 -> 512 of layer 2, and -- as data gradients -- the
+// conv1 of layer 3, 1024 <- 256 / 512 <- 256), gfx950.
 //
 // conv_gemm_kernel walks 128 x 128 output tiles: with K = 256 a tile is 8 K steps behind 16 workgroup barriers, an LDS-staged epilogue and
-// a statistics fold, and the activation tile is fetched again for every one of the 8-16 output-channel tiles -- these layers ran at
-// 0.4-0.65 PFLOP/s and 2-3 TB/s, bound by neither roof (round 5, profiles/r05_per_layer_bench_conv.txt).  Here ("expanding" form, K <= 512):
-//   * a workgroup (8 waves, one per CU) owns a SLAB of 128 (64) output channels -- its [SLAB][K] weights sit in LDS for the whole launch --
-//     and a contiguous range of pixels of one BatchNorm group; the slabs of one pixel range run on the same XCD at the same time, so the
-//     activation rows they all read come out of that XCD's L2;
-//   * every wave streams its own 32-pixel tiles: the activation operand goes global -> registers -> MFMA (B fragment "lane (pixel li,
-//     K chunk lg)" = one 16-byte NHWC load; lazy BatchNorm + activation of the producer applied in registers) and stays there for ALL
-//     K steps and output-channel tiles of the slab; the request for the NEXT tile's K step k is issued the moment step k's fragment has been
-//     consumed (same registers: one tile of look-ahead at no register cost); NO workgroup barrier in the loop;
-//   * the bf16 output tile is staged in a wave-private LDS area (a wave's LDS operations execute in order), the statistics of the stored
-//     values come off the matrix cores from that tile (ones . F and diag(F^T F)), and it leaves as 16-byte stores, 256 bytes per pixel.
-// Same K order and rounding points as conv_gemm_kernel: bit-identical outputs; statistics differ in summation order only.
+// a statistics fold, and the activation tile is fetched again for every one of the 8 output-channel tiles -- these layers ran at
+// 0.4-0.65 PFLOP/s and 2-3 TB/s, bound by neither roof (round 5, profiles/r05_per_layer_bench_conv.txt).  Here:
+//   * a workgroup (8 waves, one per CU, persistent) belongs to one BatchNorm group and walks sets of 8 x 32 pixels; every wave keeps the B
+//     fragments of ITS 32 pixels -- all K steps, the lazy BatchNorm + activation of the producer applied ONCE -- in registers for every
+//     output channel of the layer: activations are read from memory once, transformed once;
+//   * the weights stream past them: slab after slab of 64 output channels goes global -> registers -> LDS (two buffers, XOR-swizzled rows:
+//     conflict-free fragment reads); the request for a slab is issued a whole slab step ahead of its ds_write;
+//   * two wave groups run the same loop { barrier; 64 MFMAs of slab s; barrier; epilogue of slab s } one barrier apart: while one group
+//     multiplies, the other stages its bf16 tile in wave-private LDS, takes the statistics of the stored values off the matrix cores
+//     (ones . F, diag(F^T F)), stores 128 bytes per pixel and moves its share of the next weight slab;
+//   * statistics: per-wave slots per slab step, folded in wave order into the workgroup's [2 N] accumulator one step later (fixed order:
+//     reproducible), ONE exact publication per channel and workgroup.
+// Same K order and rounding points as conv_gemm_kernel: bit-identical outputs; statistics differ in summation order only
+// (tests/test_kernels_gpu.py::test_conv1x1_wide_stream_equals_conv_gemm flips ADAMML_WIDE_STREAM within one process).
+//
+// History of the round (all measured at the layer-3 conv3 shape, 5 x 144 frames x 14^2, 256 -> 1024, lazy input + statistics; conv_gemm_kernel
+// 0.188-0.194 ms; appendix A-15): (1) one 128-channel slab per workgroup, weights LDS-resident, waves streaming pixel tiles with no barrier:
+// 0.154 ms -- fabric reads = the input ONCE (the 8 slabs of a pixel range share it through their XCD's L2, PMC), but the lazy transform, the
+// loads and the address arithmetic are repeated per slab: VALU 45 % / LDS 48 % / MFMA 29 % of the launch, and its waits drained the stores of
+// every tile (a store under a per-lane condition turns every later vmcnt of the loop into the conservative count); (2) all slabs per
+// workgroup, one barrier per slab step: 0.150-0.159 ms -- all 8 waves in the same phase at the same time, the matrix pipe idle through
+// every epilogue; (3) two wave groups in opposite phases: 0.157 ms -- the phase probe (tools/wide_phase_probe.py) showed 1 900-2 200 of a
+// step's 7 000 cycles in "stage + statistics": every 16-channel block was its own chain of LDS read -> MFMA -> exec-masked LDS write; (4)
+// branch-free statistics (all reads, all MFMAs, unconditional slot writes with per-lane sink entries) + swizzled weight rows: 0.142 ms, a
+// slab step 6 200 cycles (MFMA phase 1 800-2 100 for 1 024 of matrix pipe: fragment reads one K step ahead do not cover the LDS latency
+// under the other group's epilogue traffic; epilogue 2 100-2 750).  Forms (1)-(3) are in the history of this file (commit de74dc7 ff.).
 #include <type_traits>
 #include <stdlib.h>
 #include "common.h"
@@ -42,64 +56,50 @@ struct WXP {
     int act, in_gs, K, N;
     long P, Pin;             // output / input pixels per group
     int stride, H, W, OH, OW;   // stride 2: output pixel (n, oh, ow) reads input pixel (n, 2 oh, 2 ow)
-    int nslab, rpg;          // channel slabs, pixel ranges per group
-    int dbg;                 // ADAMML_WIDE_DBG (probe builds): 1 skip the stores, 2 skip the statistics, 4 skip the staging
+    int nslab, rpg;          // channel slabs; BatchNorm groups of the launch
 };
 
 // EPI 0: forward / plain data gradient (store + optional statistics); EPI 2: data gradient accumulating into y
-template <int KS, int SLAB, int NPG, int EPI, bool LAZY, bool S2>
-__global__ __launch_bounds__(512, 1) void wide_expand_kernel(WXP p) {
+template <int KS, int EPI, bool LAZY, bool S2>
+__global__ __launch_bounds__(512, 1) void wide_all_kernel(WXP p) {
     constexpr int KP = KS * 32;
-    constexpr int NCT = SLAB / 16;
-    constexpr int WROW = KP * 2 + 16;                // LDS bytes per weight row (+16: bank skew for the 16-lane row reads)
+    constexpr int SLAB = 64, NCT = 4, NPG = 2, TPX = 32, NW = 8;
+    constexpr int WROW = KP * 2;                     // LDS bytes per weight row; 16-byte chunk c of row r sits at chunk c ^ (r & 15): the 16 lanes
+                                                     // of a ds_read_b128 service group then touch 16 distinct bank quads (pitch + 16 left 43 % of the
+                                                     // LDS cycles of the slab form to bank conflicts, PMC)
     constexpr int SROW = SLAB * 2 + 8;               // staging row bytes
-    constexpr int CPR = SLAB / 8;                    // 16-byte chunks per staged pixel
-    constexpr int TPX = NPG * 16;
-    constexpr int NW = 8;
-    static_assert(NPG == 2, "the statistics fragments read 32 staged pixels");
+    constexpr int CPR = SLAB / 8;
+    constexpr int WLD = SLAB * KP * 2 / (512 * 16);  // 16-byte weight loads per thread and slab
+    static_assert(SLAB * KP * 2 % (512 * 16) == 0, "a slab is a whole number of workgroup-wide 16-byte loads");
+    constexpr int MAXN = 2048;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_w = smem;                                                        // [SLAB][WROW]
-    float* s_vec = reinterpret_cast<float*>(smem + SLAB * WROW);             // [2][KP]: scale, shift of the lazy input
-    float* s_sum = s_vec + 2 * KP;                                           // [NW waves][2 * SLAB]
-    char* s_stage = reinterpret_cast<char*>(s_sum + NW * 2 * SLAB);          // [NW waves][TPX][SROW]
+    char* s_w = smem;                                                        // [2][SLAB][WROW]
+    float* s_vec = reinterpret_cast<float*>(smem + 2 * SLAB * WROW);         // [2][KP]
+    float* s_acc = s_vec + 2 * KP;                                           // [2][MAXN]: sum, sum of squares of every output channel
+    constexpr int SLOTW = 2 * SLAB + 64;                                     // a wave's slot: [sum 64 | sum of squares 64 | 64 sink entries]
+    float* s_slot = s_acc + 2 * MAXN;                                        // [2 buffers][NW][SLOTW]
+    char* s_stage = reinterpret_cast<char*>(s_slot + 2 * NW * SLOTW);        // [NW][TPX][SROW]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
-    // ---- work item of this workgroup: (group, pixel range, slab); the slabs of a range are neighbours on ONE XCD (workgroup id % 8)
-    int slab, rid;
-    {   // the (range, slab) list in range-major order, a contiguous eighth of it per XCD (common.h: xcd_contiguous)
-        const unsigned w = xcd_contiguous(blockIdx.x, gridDim.x);
-        rid = (int)(w / (unsigned)p.nslab);
-        slab = (int)(w - (unsigned)rid * (unsigned)p.nslab);
-    }
-    const int g = rid / p.rpg, r = rid - g * p.rpg;
-    const int n0 = slab * SLAB;
-    p.x += (size_t)g * p.Pin * p.K;
-    p.y += (size_t)g * p.P * p.N;
-    if (p.in_scale) { p.in_scale += (size_t)g * p.in_gs; p.in_shift += (size_t)g * p.in_gs; }
-    for (int i = tid; i < SLAB * (KP / 8); i += 512) {
-        const int row = i / (KP / 8), ch = i - row * (KP / 8);
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (n0 + row < p.N && ch * 8 < p.K) v = *reinterpret_cast<const bf16x8*>(p.w + (size_t)(n0 + row) * p.K + ch * 8);
-        *reinterpret_cast<bf16x8*>(s_w + row * WROW + ch * 16) = v;
-    }
-    for (int i = tid; i < KP; i += 512) {                // (channels >= K: raw 0 -> act(1 * 0 + 0) = 0)
-        s_vec[i] = (p.in_scale && i < p.K) ? p.in_scale[i] : 1.f;
-        s_vec[KP + i] = (p.in_scale && i < p.K) ? p.in_shift[i] : 0.f;
-    }
-    for (int i = tid; i < NW * 2 * SLAB; i += 512) s_sum[i] = 0.f;
-    __syncthreads();
-
-    auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-    const float alo = uniform(p.in_scale ? act_lo(p.act) : -INFINITY), ahi = uniform(p.in_scale ? act_hi(p.act) : INFINITY);
-    float* csw = s_sum + wave * 2 * SLAB;
-    char* stg = s_stage + wave * (TPX * SROW);
-    // (pixel indices of one group fit 32 bits: the launcher checks)
+    const int nslab = p.N / SLAB;
+    // ---- work: a workgroup belongs to ONE BatchNorm group (blockIdx % groups: the groups interleave over the XCDs) and walks that
+    // group's sets of 8 x 32 pixels with the stride of the group's workgroups: one statistics publication per workgroup
     const int P = (int)p.P;
     const int ntile = (P + TPX - 1) / TPX;
-    const int tpr = (ntile + p.rpg - 1) / p.rpg;
-    const int t0 = r * tpr, t1 = t0 + tpr < ntile ? t0 + tpr : ntile;
-    // element offset of the input row of output pixel px (S2: the even rows / columns of the input image)
+    const int nset = (ntile + NW - 1) / NW;                                  // tile sets per group
+    const int groups = p.rpg;                                                // (this form: rpg carries the group count)
+    const int g = blockIdx.x % groups, wi = blockIdx.x / groups, wpg = gridDim.x / groups;
+    for (int i = tid; i < 2 * MAXN; i += 512) s_acc[i] = 0.f;
+    const bf16_t* xg = p.x + (size_t)g * p.Pin * p.K;
+    bf16_t* y0 = p.y + (size_t)g * p.P * p.N;
+    for (int i = tid; i < KP; i += 512) {                // (channels >= K: raw 0 -> act(1 * 0 + 0) = 0)
+        s_vec[i] = (p.in_scale && i < p.K) ? p.in_scale[(size_t)g * p.in_gs + i] : 1.f;
+        s_vec[KP + i] = (p.in_scale && i < p.K) ? p.in_shift[(size_t)g * p.in_gs + i] : 0.f;
+    }
+    auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    const float alo = uniform(p.in_scale ? act_lo(p.act) : -INFINITY), ahi = uniform(p.in_scale ? act_hi(p.act) : INFINITY);
+    char* stg = s_stage + wave * (TPX * SROW);
     auto in_row = [&](int px) -> size_t {
         if (!S2) return (size_t)px * p.K;
         const int q = p.OH * p.OW;
@@ -107,67 +107,92 @@ __global__ __launch_bounds__(512, 1) void wide_expand_kernel(WXP p) {
         const int oh = rem / p.OW, ow = rem - oh * p.OW;
         return ((size_t)(n * p.H + 2 * oh) * p.W + 2 * ow) * p.K;
     };
-    const bf16_t* rowp[NPG];
-    auto set_rows = [&](int tile) {
-#pragma unroll
-        for (int pg = 0; pg < NPG; ++pg) {
-            int px = tile * TPX + pg * 16 + li;
-            px = px < P ? px : P - 1;
-            rowp[pg] = p.x + in_row(px) + lg * 8;
-        }
-    };
-    bf16x8 ring[KS][NPG];
-    auto issue_k = [&](int k) {
-#pragma unroll
-        for (int pg = 0; pg < NPG; ++pg) ring[k][pg] = *reinterpret_cast<const bf16x8*>(rowp[pg] + k * 32);
-    };
     union { s16x4_ h[2]; bf16x8 v; } ones;
     ones.h[0] = s16x4_{0x3F80, 0x3F80, 0x3F80, 0x3F80};
     ones.h[1] = ones.h[0];
     const int trow = 8 * lg + (li >> 2);
-
-    int t = t0 + wave;
-    {   // first tile of this wave (a wave without tiles requests a valid tile and discards it: no load sits under a condition)
-        const int tf = t < ntile ? t : ntile - 1;
-        set_rows(tf);
+    // weight slab loads of this thread: chunk e = tid + 512 j of the slab's SLAB x KP x 2 contiguous bytes
+    bf16x8 wreg[WLD];
+    auto w_issue = [&](int slab) {
+        const bf16_t* src = p.w + (size_t)slab * SLAB * p.K;
 #pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            issue_k(k);
-            __builtin_amdgcn_sched_barrier(0);     // (request order = consumption order: the loop's waits then count the younger requests instead of draining them)
-        }
-    }
-    // weight fragments of HALF a K step (NCT / 2 output-channel tiles of the slab), double-buffered: the reads of the next half step are
-    // issued before the MFMAs of this one, so a read has NCT MFMAs (>= 128 matrix-pipe cycles per wave) to land -- fetched one at a
-    // time in front of its two MFMAs, every fragment exposed its LDS latency (first form of this kernel: 0.155 ms at the layer-3 shape)
-    constexpr int FSPLIT = EPI == 2 ? 4 : 2;                     // part steps per K step (the accumulating form keeps 32 registers of old rows: quarter steps)
-    constexpr int HCT = NCT / FSPLIT;                            // (a whole K step per buffer -- 2 x NCT fragments -- does not fit beside ring + accumulators)
-    bf16x8 fa[2][HCT];
-    auto load_fa = [&](auto buf, int k, int h) {
-#pragma unroll
-        for (int c = 0; c < HCT; ++c)
-            fa[decltype(buf)::value][c] = *reinterpret_cast<const bf16x8*>(s_w + ((h * HCT + c) * 16 + li) * WROW + k * 64 + lg * 16);
+        for (int j = 0; j < WLD; ++j) wreg[j] = *reinterpret_cast<const bf16x8*>(src + (size_t)(tid + 512 * j) * 8);
     };
-    load_fa(std::integral_constant<int, 0>{}, 0, 0);
-    float rs[NCT], rq[NCT];                                      // per-lane partial statistics (EPI 0): see the epilogue
+    auto w_write = [&](int buf) {
 #pragma unroll
-    for (int cb = 0; cb < NCT; ++cb) rs[cb] = rq[cb] = 0.f;
-    constexpr int NOLD = TPX * CPR / 64;
-    bf16x8 old[EPI == 2 ? NOLD : 1];
-    for (; t < t1; t += NW) {
-        {   // rows of this wave's next tile (past the end: this tile again -- the requests stay unconditional)
-            const int tn = t + NW;
-            set_rows(tn < t1 ? tn : t);
+        for (int j = 0; j < WLD; ++j) {
+            const int e = tid + 512 * j, row = e / (KP / 8), ch = e - row * (KP / 8);
+            *reinterpret_cast<bf16x8*>(s_w + buf * (SLAB * WROW) + row * WROW + ((ch ^ (row & 15)) << 4)) = wreg[j];
         }
-        const int npx = P - t * TPX < TPX ? P - t * TPX : TPX;
-        bf16_t* yb = p.y + (size_t)t * TPX * p.N + n0;
-        if (EPI == 2) {                                          // rows of the tensor accumulated into: requested a whole tile of MFMAs ahead of their use
+    };
+    // ---- two wave groups in opposite phases.  With ONE barrier per slab step all 8 waves run the same phase at the same time -- weight
+    // write, MFMAs, epilogue -- and the matrix pipe idles through every epilogue (measured 0.150 ms at the layer-3 shape, no better than the
+    // slab form).  Here group A (waves 0-3) and group B (waves 4-7) run the SAME loop { barrier; MFMAs of slab s; barrier; epilogue of slab s }
+    // with B one barrier behind (it passes one extra barrier first, A one extra at the end): while one group multiplies the other stages,
+    // reduces, stores and moves weights.  Barrier events E0, E1, ..: A multiplies slab s in [E(2s+1), E(2s+2)) and runs its epilogue in
+    // [E(2s+2), E(2s+3)); B multiplies in [E(2s+2), E(2s+3)), epilogue in [E(2s+3), E(2s+4)).  Weight slab j lives in buffer j & 1 from
+    // E(2j+1) to E(2j+3); every wave writes its 4 KB share of slab j inside [E(2j-1), E(2j+1)): A in its epilogue of slab j - 1, B in its
+    // epilogue of slab j - 2 (its idle first phase for j = 1) -- so every wave simply writes slabs 0, 1, 2, .. in order, one per epilogue,
+    // and requests the next one right behind the write (a whole step of look-ahead).  Two buffers suffice.
+    const int grp = wave >> 2;
+    int wslab = 1;                                       // next slab this wave writes (slab j -> weights j % nslab, buffer j & 1)
+    w_issue(0);
+    w_write(0);
+    w_issue(1 % nslab);
+    __syncthreads();                                     // E0: s_vec / s_acc initialised, slab 0 visible
+    bf16x8 bfr[KS][NPG];
+    auto act_issue = [&](int ts) {
+#pragma unroll
+        for (int pg = 0; pg < NPG; ++pg) {
+            int px = (ts * NW + wave) * TPX + pg * 16 + li;
+            px = px < P ? px : P - 1;
+            const bf16_t* row = xg + in_row(px) + lg * 8;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) bfr[k][pg] = *reinterpret_cast<const bf16x8*>(row + k * 32);
+        }
+    };
+    act_issue(wi < nset ? wi : nset - 1);
+    auto w_advance = [&]() {                             // this wave's share of slab `wslab` -> its buffer; request the one after it
+        w_write(wslab & 1);
+        ++wslab;
+        w_issue(wslab % nslab);
+    };
+    if (grp == 1) {
+        __syncthreads();                                 // E1 (A starts slab 0)
+        w_advance();                                     // B's idle first phase: slab 1
+    }
+    int step = 0;                                        // slab-step counter of this wave (buffer parity)
+    int prev_sl = 0;
+    // One slab step.  FULL (compile time): the wave holds a full 32-pixel tile -- its 4 stores are unconditional, so the wait in front of
+    // the next ds_write of the weight registers COUNTS them (vmcnt(7..4)) instead of draining them (stores under a per-lane condition:
+    // vmcnt(3..0) there, i.e. every step waited for the previous step's stores to reach memory).  LAST: the step after which the
+    // activation registers are free -- the next tile set's rows are requested behind its MFMAs.
+#ifdef WIDE_PROBE
+    // phase probe (tools/wide_phase_probe.py builds this file alone with -DWIDE_PROBE): shader-clock ticks this wave spent in each phase of
+    // its slab steps, summed over the launch; workgroup 0 writes them over the head of the statistics buffer at the end
+    unsigned long long pr_t[7] = {0, 0, 0, 0, 0, 0, 0}, pr_last = __builtin_readcyclecounter();
+#define PR_MARK(i) do { const unsigned long long pr_now = __builtin_readcyclecounter(); pr_t[i] += pr_now - pr_last; pr_last = pr_now; } while (0)
+#else
+#define PR_MARK(i) do {} while (0)
+#endif
+    auto slab_step = [&](int ts, int sl, int npx, bf16_t* yb, auto full_c, auto last_c) {
+        constexpr bool FULL = decltype(full_c)::value, LAST = decltype(last_c)::value;
+        const int buf = step & 1;
+        PR_MARK(0);                                      // (everything between two slab steps: tile-set transform, loop control)
+        __syncthreads();                                 // slab `sl` (buffer buf) is complete and visible
+        PR_MARK(1);                                      // wait at the first barrier
+        const char* wb = s_w + buf * (SLAB * WROW);
+        constexpr int NOLD = TPX * CPR / 64;
+        bf16x8 old[EPI == 2 ? NOLD : 1];
+        bf16_t* ys = yb + sl * SLAB;
+        if (EPI == 2) {                                  // rows of the tensor accumulated into: requested a whole MFMA phase ahead of their use
 #pragma unroll
             for (int i = 0; i < NOLD; ++i) {
                 const int e = lane + 64 * i;
                 int px = e / CPR;
                 const int ch = e - px * CPR;
-                px = px < npx ? px : npx - 1;
-                old[i] = *reinterpret_cast<const bf16x8*>(yb + (size_t)px * p.N + ch * 8);
+                if (!FULL) px = px < npx ? px : (npx > 0 ? npx - 1 : 0);
+                old[i] = *reinterpret_cast<const bf16x8*>(((FULL || npx > 0) ? ys : y0) + (size_t)px * p.N + ch * 8);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -176,40 +201,37 @@ __global__ __launch_bounds__(512, 1) void wide_expand_kernel(WXP p) {
         for (int pg = 0; pg < NPG; ++pg)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) acc[pg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 fa[2][NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) fa[0][ct] = *reinterpret_cast<const bf16x8*>(wb + (ct * 16 + li) * WROW + ((lg ^ li) << 4));
         static_for_k<KS>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            bf16x8 fb[NPG];
+            if constexpr (k + 1 < KS) {
 #pragma unroll
-            for (int pg = 0; pg < NPG; ++pg) fb[pg] = ring[k][pg];
-            if constexpr (LAZY) {                                  // act(scale * raw + shift), rounded as the other loaders round it
-                const f32x8 sc = load_f32x8(s_vec + k * 32 + lg * 8), sh = load_f32x8(s_vec + KP + k * 32 + lg * 8);
-#pragma unroll
-                for (int pg = 0; pg < NPG; ++pg) {
-                    f32x8 v = bf8_to_f32(fb[pg]);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = clamp_act(fmaf(v[i], sc[i], sh[i]), alo, ahi);
-                    fb[pg] = f32_to_bf8(v);
-                }
+                for (int ct = 0; ct < NCT; ++ct)
+                    fa[(k + 1) & 1][ct] = *reinterpret_cast<const bf16x8*>(wb + (ct * 16 + li) * WROW + ((((k + 1) * 4 + lg) ^ li) << 4));
             }
-            issue_k(k);                                            // the next tile's K step k, into the registers just consumed
-            static_for_k<FSPLIT>([&](auto hc) {
-                constexpr int h = decltype(hc)::value;
-                // fragments of the NEXT part step (the last one fetches step 0 for the next tile: the weights do not change)
-                if constexpr (h + 1 < FSPLIT) load_fa(std::integral_constant<int, (h + 1) & 1>{}, k, h + 1);
-                else load_fa(std::integral_constant<int, 0>{}, (k + 1) % KS, 0);
-                __builtin_amdgcn_sched_barrier(0);                 // (the scheduler otherwise sinks all requests behind the last MFMA)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int c = 0; c < HCT; ++c)
+            for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                    for (int pg = 0; pg < NPG; ++pg)
-                        acc[pg][h * HCT + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[h & 1][c], fb[pg], acc[pg][h * HCT + c], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            });
+                for (int pg = 0; pg < NPG; ++pg)
+                    acc[pg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[k & 1][ct], bfr[k][pg], acc[pg][ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         });
-        // ---- epilogue: D fragment lane (li, lg) = channels ct * 16 + lg * 4 .. + 3 of pixel pg * 16 + li -> wave-private staging tile
+        if constexpr (LAST) {
+            // the activation registers are free: request the next tile set's rows now, behind this step's epilogue
+            const int nts = ts + wpg;
+            act_issue(nts < nset ? nts : ts);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        PR_MARK(2);                                      // MFMA phase (fragment reads, 64 MFMAs, next-set requests)
+        __syncthreads();                                 // the other group starts its MFMAs of this slab / of the next one
+        PR_MARK(3);                                      // wait at the second barrier
+        // ---- epilogue of the slab step: stage, statistics, store, weights
 #pragma unroll
         for (int pg = 0; pg < NPG; ++pg) {
-            const bool live = pg * 16 + li < npx;
+            const bool live = FULL || pg * 16 + li < npx;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 bf16x4 v = f32_to_bf4(acc[pg][ct]);
@@ -217,86 +239,142 @@ __global__ __launch_bounds__(512, 1) void wide_expand_kernel(WXP p) {
                 *reinterpret_cast<bf16x4*>(stg + (pg * 16 + li) * SROW + (ct * 16 + lg * 4) * 2) = v;
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the wave's own LDS writes have landed; no other wave touches this area)
-        if (EPI == 0 && p.stats && !(p.dbg & 2)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (EPI == 0 && p.stats) {
+            float* slot = s_slot + buf * (NW * SLOTW) + wave * SLOTW;
+            // all fragment reads first, then all MFMAs, then UNCONDITIONAL slot writes (a lane without a valid element writes to its own sink
+            // entry): under exec-masked branches every 16-channel block was its own chain of LDS read -> MFMA -> LDS write latencies
+            // (phase probe: 1 900 - 2 200 of the 7 000 cycles of a slab step went to staging + statistics)
+            union { s16x4_ h[2]; bf16x8 v; } fr[NCT];
 #pragma unroll
             for (int cb = 0; cb < NCT; ++cb) {
-                f32x4 dsum = {0.f, 0.f, 0.f, 0.f}, dsq = {0.f, 0.f, 0.f, 0.f};
+                const char* fp = stg + trow * SROW + (cb * 16 + 4 * (li & 3)) * 2;
+                fr[cb].h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)(fp));
+                fr[cb].h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)(fp + 4 * SROW));
+            }
+            f32x4 dsum[NCT], dsq[NCT];
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int hp = 0; hp < NPG / 2 + (NPG & 1); ++hp) {             // 32 staged pixels per MFMA K (NPG = 1: rows 16 .. 31 read as zero)
-                    const char* fp = stg + (hp * 32 + trow) * SROW + (cb * 16 + 4 * (li & 3)) * 2;
-                    union { s16x4_ h[2]; bf16x8 v; } f;
-                    f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)(fp));
-                    if (NPG >= 2) f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)(fp + 4 * SROW));
-                    else f.h[1] = s16x4_{0, 0, 0, 0};
-                    dsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, f.v, dsum, 0, 0, 0);
-                    dsq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v, f.v, dsq, 0, 0, 0);
-                }
-                // D rows = lg * 4 + r, column = li: row 0 of dsum (lanes lg == 0) holds the column sums, the diagonal of dsq sits in the lanes
-                // with li >> 2 == lg.  Every lane adds ITS element into a register, tile after tile (fixed order); the owner lanes publish
-                // theirs at the end -- a read-modify-write of the wave's LDS row per block and tile was a chain of 16 dependent LDS round trips
-                const int rr = li & 3;
-                rs[cb] += dsum[0];
-                rq[cb] += rr == 0 ? dsq[0] : rr == 1 ? dsq[1] : rr == 2 ? dsq[2] : dsq[3];
+            for (int cb = 0; cb < NCT; ++cb) {
+                dsum[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, fr[cb].v, z4, 0, 0, 0);
+                dsq[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[cb].v, fr[cb].v, z4, 0, 0, 0);
+            }
+            // D rows = lg * 4 + r, column = li: row 0 of dsum (lanes lg == 0) holds the column sums, the diagonal of dsq sits in the lanes
+            // with li >> 2 == lg
+            const int rr = li & 3;
+            float* sink = slot + 2 * SLAB + lane;
+#pragma unroll
+            for (int cb = 0; cb < NCT; ++cb) {
+                float* a1 = lg == 0 ? slot + cb * 16 + li : sink;
+                float* a2 = (li >> 2) == lg ? slot + SLAB + cb * 16 + li : sink;
+                *a1 = dsum[cb][0];
+                *a2 = rr == 0 ? dsq[cb][0] : rr == 1 ? dsq[cb][1] : rr == 2 ? dsq[cb][2] : dsq[cb][3];
+            }
+            // fold the slots of the PREVIOUS step (all 8 waves wrote them before the barrier above; their buffer is rewritten one step
+            // from now): group A, 32 entries per wave, waves in order -> the workgroup's accumulator (one owner thread per entry)
+            if (grp == 0 && step > 0 && lane < 32) {
+                const int ent = wave * 32 + lane;                            // 0 .. 127: [sum 64 | sum of squares 64] of slab prev_sl
+                const float* sp = s_slot + (buf ^ 1) * (NW * SLOTW) + ent;
+                float v = sp[0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) v += sp[w * SLOTW];
+                float* a = s_acc + (ent < SLAB ? 0 : MAXN) + prev_sl * SLAB + (ent < SLAB ? ent : ent - SLAB);
+                *a += v;
             }
         }
-        // ---- the tile leaves as 16-byte stores: CPR lanes cover the SLAB * 2 contiguous bytes of one pixel
-        auto store_tile = [&](auto full) {
-            constexpr bool FULL = decltype(full)::value;
+        PR_MARK(4);                                      // staging + statistics
+        {   // (no run-time switch around these stores: one more history at the join and the waits drain them again)
 #pragma unroll
             for (int i = 0; i < NOLD; ++i) {
                 const int e = lane + 64 * i;
                 const int px = e / CPR, ch = e - px * CPR;
-                if (FULL || px < npx) {                           // (two 8-byte LDS reads: the staging rows are 8-byte aligned only)
+                if (FULL || px < npx) {
                     union { struct { s16x4_ a, b; } s; bf16x8 v; } o;
                     o.s.a = *reinterpret_cast<const s16x4_*>(stg + px * SROW + ch * 16);
                     o.s.b = *reinterpret_cast<const s16x4_*>(stg + px * SROW + ch * 16 + 8);
                     if (EPI == 2) o.v = f32_to_bf8(bf8_to_f32(o.v) + bf8_to_f32(old[i]));
-                    *reinterpret_cast<bf16x8*>(yb + (size_t)px * p.N + ch * 8) = o.v;
+                    *reinterpret_cast<bf16x8*>(ys + (size_t)px * p.N + ch * 8) = o.v;
                 }
             }
-        };
-        // (a full tile stores unconditionally: a store under a per-lane condition makes every later wait of the loop a vmcnt(0))
-        if (p.dbg & 1) {} else
-        if (npx == TPX) store_tile(std::true_type{}); else store_tile(std::false_type{});
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (staging reads done before the next tile overwrites the area)
-    }
-    if (EPI == 0 && p.stats) {
+        }
+        PR_MARK(5);                                      // read-back + stores
+        w_advance();                                     // this wave's share of its next slab (A: slab step + 1, B: step + 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PR_MARK(6);                                      // weight write (waits for the slab requested one step ago) + next request
+        prev_sl = sl;
+        ++step;
+    };
+    auto tile_set = [&](int ts, auto full_c) {
+        const int t = ts * NW + wave;                                        // this wave's 32-pixel tile (partial set: may lie past the group, npx = 0)
+        const int npx = P - t * TPX < TPX ? (P - t * TPX > 0 ? P - t * TPX : 0) : TPX;
+        bf16_t* yb = y0 + (size_t)t * TPX * p.N;
+        if constexpr (LAZY) {                                                // transform the tile ONCE, in place
 #pragma unroll
-        for (int cb = 0; cb < NCT; ++cb) {
-            if (lg == 0) csw[cb * 16 + li] = rs[cb];
-            if ((li >> 2) == lg) csw[SLAB + cb * 16 + li] = rq[cb];
+            for (int k = 0; k < KS; ++k) {
+                const f32x8 sc = load_f32x8(s_vec + k * 32 + lg * 8), sh = load_f32x8(s_vec + KP + k * 32 + lg * 8);
+#pragma unroll
+                for (int pg = 0; pg < NPG; ++pg) {
+                    f32x8 v = bf8_to_f32(bfr[k][pg]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = clamp_act(fmaf(v[i], sc[i], sh[i]), alo, ahi);
+                    bfr[k][pg] = f32_to_bf8(v);
+                }
+            }
+        }
+        for (int sl = 0; sl + 1 < nslab; ++sl) slab_step(ts, sl, npx, yb, full_c, std::false_type{});
+        slab_step(ts, nslab - 1, npx, yb, full_c, std::true_type{});
+    };
+    const int nfull = P / (NW * TPX);                                        // tile sets whose 8 tiles are all full
+    int ts = wi;
+    for (; ts < nfull; ts += wpg) tile_set(ts, std::true_type{});
+    if (ts < nset) tile_set(ts, std::false_type{});                          // (at most one partial set per group, at index nfull)
+    if (grp == 0) __syncthreads();                                           // A's extra barrier: pairs with B's last one
+#ifdef WIDE_PROBE
+    if (blockIdx.x == 0 && lane == 0 && p.stats) {
+        for (int i = 0; i < 7; ++i) p.stats[wave * 8 + i] = (double)pr_t[i];
+        p.stats[wave * 8 + 7] = (double)step;
+        return;
+    }
+    if (blockIdx.x == 0) return;
+#endif
+    if (EPI == 0 && p.stats) {
+        __syncthreads();
+        if (step > 0 && tid < 2 * SLAB) {                                     // the last step's slots
+            const int buf = (step - 1) & 1;
+            const float* sp = s_slot + buf * (NW * SLOTW) + tid;
+            float v = sp[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += sp[w * SLOTW];
+            s_acc[(tid < SLAB ? 0 : MAXN) + prev_sl * SLAB + (tid < SLAB ? tid : tid - SLAB)] += v;
         }
         __syncthreads();
-        for (int i = tid; i < 2 * SLAB; i += 512) {          // wave rows folded in wave order, one exact add per channel and workgroup (common.h)
-            float v = s_sum[i];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) v += s_sum[w * 2 * SLAB + i];
-            const int which = i >= SLAB, c = n0 + (which ? i - SLAB : i);
-            if (c < p.N)
-                stat_publish(p.stats + (size_t)g * ADAMML_STAT_SLOTS * 2 * p.N + (which ? p.N : 0) + c, 2 * p.N, blockIdx.x & (ADAMML_STAT_SLOTS - 1), v);
-        }
+        for (int i = tid; i < 2 * p.N; i += 512)
+            stat_publish(p.stats + (size_t)g * ADAMML_STAT_SLOTS * 2 * p.N + i, 2 * p.N, 0, s_acc[(i < p.N ? 0 : MAXN) + (i < p.N ? i : i - p.N)]);
     }
 }
 
-template <int KS, int SLAB, int NPG, int EPI, bool LAZY, bool S2>
-int wide_expand_launch(WXP& p, int groups, hipStream_t stream) {
-    constexpr int KP = KS * 32;
-    constexpr size_t lds = (size_t)SLAB * (KP * 2 + 16) + 2 * KP * 4 + 8 * 2 * SLAB * 4 + (size_t)8 * NPG * 16 * (SLAB * 2 + 8);
-    static_assert(lds <= 160 * 1024, "wide_expand: LDS budget");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wide_expand_kernel<KS, SLAB, NPG, EPI, LAZY, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv1x1 (wide): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-    p.nslab = (p.N + SLAB - 1) / SLAB;
-    p.dbg = getenv("ADAMML_WIDE_DBG") ? atoi(getenv("ADAMML_WIDE_DBG")) : 0;
-    const long ntile = (p.P + NPG * 16 - 1) / (NPG * 16);
-    long rpg = 256 / ((long)p.nslab * groups);               // one workgroup per CU, all of them resident at once
-    if (rpg < 1) rpg = 1;
-    if (rpg > (ntile + 7) / 8) rpg = (ntile + 7) / 8;        // at least one tile per wave
-    if (rpg < 1) rpg = 1;
-    p.rpg = (int)rpg;
-    hipLaunchKernelGGL((wide_expand_kernel<KS, SLAB, NPG, EPI, LAZY, S2>), dim3((unsigned)(groups * rpg * p.nslab)), dim3(512), lds, stream, p);
-    return adamml_check_launch("conv1x1 (wide stream)");
+template <int KS, int EPI, bool LAZY, bool S2>
+int wide_all_launch(WXP& p, int groups, hipStream_t stream) {
+    constexpr int KP = KS * 32, SLAB = 64;
+    constexpr size_t lds = (size_t)2 * SLAB * (KP * 2) + 2 * KP * 4 + 2 * 2048 * 4 + 2 * 8 * (2 * SLAB + 64) * 4 + (size_t)8 * 32 * (SLAB * 2 + 8);
+    static_assert(lds <= 160 * 1024, "wide_all: LDS budget");
+    static AdamLdsOnce attr_once;                    // (per device: common.h)
+    const int attr_dev = adamml_current_device();
+    if (!attr_once.test(attr_dev)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wide_all_kernel<KS, EPI, LAZY, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv1x1 (wide): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        attr_once.set(attr_dev);
+    }
+    p.nslab = p.N / SLAB;
+    p.rpg = groups;
+    const long ntile = (p.P + 31) / 32, nset = (ntile + 7) / 8;
+    long wpg = 256 / groups;                                 // workgroups per BatchNorm group: one per CU over all groups
+    if (wpg < 1) wpg = 1;
+    if (wpg > nset) wpg = nset;
+    hipLaunchKernelGGL((wide_all_kernel<KS, EPI, LAZY, S2>), dim3((unsigned)(groups * wpg)), dim3(512), lds, stream, p);
+    return adamml_check_launch("conv1x1 (wide, all slabs)");
 }
+
 
 bool wide_on() {           // A/B aid: ADAMML_WIDE_STREAM=0 = conv_gemm_kernel.  Read at every call (no cached state: a test flips it within one process)
     const char* e = getenv("ADAMML_WIDE_STREAM");
@@ -305,15 +383,13 @@ bool wide_on() {           // A/B aid: ADAMML_WIDE_STREAM=0 = conv_gemm_kernel. 
 
 }  // namespace
 
-// Shapes with an instance of the expanding form: 1x1, K = 256 or 512 input channels, at least twice as many output channels (multiple of
-// the slab), stride 1 -- or stride 2 in the forward direction (downsample branch) --, enough pixels to give every wave a tile.
+// Shapes with an instance: 1x1, K = 256 input channels, at least twice as many output channels (multiple of 128, <= 2048), stride 1 -- or
+// stride 2 in the forward direction (downsample branch) --, enough pixels to give the machine whole tile sets.  (K = 512 -- layer 4 -- does
+// not fit: 128 registers of B fragments per wave, and 17 640 pixels are 69 sets of 256 for 256 CUs.)
 bool adamml_conv1x1_wide_expand_supported(const adamml_conv_desc_t* d) {
     if (!wide_on() || d->KH != 1 || d->KW != 1 || d->pad != 0 || d->up > 1) return false;
     if (d->stride != 1 && !(d->stride == 2 && !d->accumulate && d->OH == (d->H - 1) / 2 + 1 && d->OW == (d->W - 1) / 2 + 1)) return false;
-    // (K = 512 -- 32 B fragments per 32-pixel tile -- does not fit the register file beside the accumulators: instances exist, measured slower
-    // than conv_gemm_kernel at the layer-4 shapes, 0.136 vs 0.083 ms; ADAMML_WIDE_K512=1 enables them)
-    static const bool k512 = getenv("ADAMML_WIDE_K512") && getenv("ADAMML_WIDE_K512")[0] == '1';
-    if (!(d->Cin == 256 || (k512 && d->Cin == 512)) || d->Cout < 2 * d->Cin || d->Cout % 128) return false;
+    if (d->Cin != 256 || d->Cout < 2 * d->Cin || d->Cout % 128 || d->Cout > 2048) return false;
     const long P = (long)d->N * d->OH * d->OW;
     return P >= 2048;
 }
@@ -331,14 +407,8 @@ int adamml_conv1x1_wide_expand_launch(const adamml_conv_desc_t* d, const void* x
     const bool lazy = in_scale != nullptr, s2 = d->stride == 2;
     if (d->accumulate && lazy) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv1x1 (wide): an accumulating launch takes a plain operand");
     if (p.P >= (1L << 26) || p.Pin >= (1L << 26)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv1x1 (wide): more than 2^26 pixels per group");
-    if (d->Cin == 256) {
-        if (s2) return lazy ? wide_expand_launch<8, 128, 2, 0, true, true>(p, groups, stream) : wide_expand_launch<8, 128, 2, 0, false, true>(p, groups, stream);
-        if (d->accumulate) return wide_expand_launch<8, 128, 2, 2, false, false>(p, groups, stream);
-        if (lazy) return wide_expand_launch<8, 128, 2, 0, true, false>(p, groups, stream);
-        return wide_expand_launch<8, 128, 2, 0, false, false>(p, groups, stream);
-    }
-    if (s2) return lazy ? wide_expand_launch<16, 64, 2, 0, true, true>(p, groups, stream) : wide_expand_launch<16, 64, 2, 0, false, true>(p, groups, stream);
-    if (d->accumulate) return wide_expand_launch<16, 64, 2, 2, false, false>(p, groups, stream);
-    if (lazy) return wide_expand_launch<16, 64, 2, 0, true, false>(p, groups, stream);
-    return wide_expand_launch<16, 64, 2, 0, false, false>(p, groups, stream);
+    if (s2) return lazy ? wide_all_launch<8, 0, true, true>(p, groups, stream) : wide_all_launch<8, 0, false, true>(p, groups, stream);
+    if (d->accumulate) return wide_all_launch<8, 2, false, false>(p, groups, stream);
+    if (lazy) return wide_all_launch<8, 0, true, false>(p, groups, stream);
+    return wide_all_launch<8, 0, false, false>(p, groups, stream);
 }

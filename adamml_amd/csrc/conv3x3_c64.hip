@@ -689,14 +689,15 @@ int adamml_conv3x3_c64_launch(const adamml_conv_desc_t* d, const void* x, const 
     p.tpb = ceil_div(p.total_tiles, 1024);
     const size_t patch = (size_t)p.PR * p.PW * pitch, stage = (size_t)p.npt * 16 * SROW3;
     const size_t lds = C64 * WROW3 + CS3_BYTES + (patch > stage ? patch : stage);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AdamLdsOnce attr_once;                    // (per device: common.h)
+    const int attr_dev = adamml_current_device();
+    if (!attr_once.test(attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<false, 144>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<true, 144>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<false, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<true, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv3x3_c64: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-        attr_set = true;
+        attr_once.set(attr_dev);
     }
     const dim3 grid(ceil_div(p.total_tiles, p.tpb));
     if (pitch == 160) {
@@ -749,11 +750,12 @@ int adamml_conv3x3_c64_wgrad_launch(const adamml_conv_desc_t* d, const void* dz,
     p.gxy = (size_t)d->N * d->H * d->W * C64;
     const int nblk = adamml_conv3x3_c64_wgrad_blocks(d, &p.tpb);
     const size_t lds = (size_t)p.PR * p.PW * PPIX + (size_t)MAXPX3 * SROW3 + MAXPX3 * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AdamLdsOnce attr_once;                    // (per device: common.h)
+    const int attr_dev = adamml_current_device();
+    if (!attr_once.test(attr_dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv3x3_c64 wgrad: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-        attr_set = true;
+        attr_once.set(attr_dev);
     }
     hipLaunchKernelGGL(conv3x3_c64_wgrad_kernel, dim3(nblk), dim3(NT3), C64_LDS(lds), stream, p);
     return adamml_check_launch("conv3x3_c64 wgrad");

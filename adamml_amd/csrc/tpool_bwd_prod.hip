@@ -232,13 +232,14 @@ __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void tpool_bwd_prod_kerne
 template <int T, int CIN, int NQ>
 int tpp_launch(const TPP& p, int groups, int nblk, hipStream_t stream) {
     constexpr size_t lds = 2 * CIN * 4 + (size_t)NQ * 32 * ((64 * 2 + 8) + (CIN * 2 + 8));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static AdamLdsOnce attr_once;                    // (per device: common.h)
+    const int attr_dev = adamml_current_device();
+    if (!attr_once.test(attr_dev)) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tpool_bwd_prod_kernel<T, CIN, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "temporal_pool_bwd_code_prod: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         }
-        attr_set = true;
+        attr_once.set(attr_dev);
     }
     hipLaunchKernelGGL((tpool_bwd_prod_kernel<T, CIN, NQ>), dim3((unsigned)nblk, groups), dim3(NQ * 64), lds, stream, p);
     return adamml_check_launch("temporal_pool_bwd_code_prod");

@@ -156,6 +156,8 @@ class NetRT:
         self.wgrad_stream = None     # optional side stream for the weight-gradient kernels (_on_wgrad_stream)
         self.wgrad_pending = collections.deque()      # (event, operand tensors) of weight-gradient launches still in flight
         self.capture = None          # test aid: dict id(conv weight Parameter) -> list of raw conv outputs of this forward
+        self.pre_pending = 0         # next-conv results a fused kernel computed ahead (Lazy.next_pre) that no conv_bn has claimed yet
+        self.pre_dropped = 0         # ... and were never claimed by the end of a forward (a silent fallback: tests assert 0)
         self.state_gen = 0           # bumped whenever BatchNorm tensors change behind torch's back (raw-pointer writes)
 
     def begin_forward(self, device, training, need_grad, groups=1):
@@ -165,6 +167,7 @@ class NetRT:
         self.groups = groups
         self.tape = Tape(need_grad)
         self.touched_bns = []
+        self.pre_pending = 0
         if training:
             self.fwd_arena.reset(device)
         return self.tape
@@ -172,6 +175,8 @@ class NetRT:
     def end_forward(self):
         """nn.BatchNorm2d bookkeeping: num_batches_tracked += 1 per group for every BN evaluated in train mode
         (one multi-tensor launch per backbone call instead of one per layer)."""
+        self.pre_dropped += self.pre_pending          # (a precomputed next conv nobody consumed: its launch and its statistics slot were wasted)
+        self.pre_pending = 0
         if self.training and self.touched_bns:
             torch._foreach_add_([b.num_batches_tracked for b in self.touched_bns], self.groups)
             self.state_gen += 1      # adamml_bn_finalize rewrote running_mean / running_var through raw pointers
@@ -367,8 +372,13 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
     if x.shape[0] % G:
         raise RuntimeError("conv_bn: %d images do not split into %d BatchNorm groups" % (x.shape[0], G))
     dev = x.data.device
-    pre = x.next_pre if (x.next_pre is not None and x.next_pre[0] is cs and rt.training) else None     # forward already run by the producer of x
-    x.next_pre = None
+    # forward already run by the producer of x (conv_bn_add next_cs).  Only the conv the result was computed FOR consumes it; another
+    # conv of x issued first (a downsample branch, a reordering) leaves it in place (round-5 advisor finding: it used to be cleared by
+    # whichever conv came first, and the fused result was then silently recomputed) -- NetRT.end_forward counts the ones nobody claimed
+    pre = x.next_pre if (x.next_pre is not None and x.next_pre[0] is cs and rt.training) else None
+    if pre is not None:
+        x.next_pre = None
+        rt.pre_pending -= 1
     y = pre[1] if pre is not None else torch.empty(G * d.N, d.OH, d.OW, d.Cout, dtype=torch.bfloat16, device=dev)
     C = d.Cout
     count = d.N * d.OH * d.OW               # elements per channel per group
@@ -972,6 +982,8 @@ def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False, tpool=0, next_cs=None):
     out = Lazy(out_t)
     if not tpool:
         out.next_pre = nxt
+        if nxt is not None:
+            rt.pre_pending += 1
     if not need_grad:
         return out
     # the raw conv output as a (never materialised) lazy tensor: the generic residual machinery only needs its BatchNorm vectors

@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .backbone import HipBackbone, FlatBuffers, StockDDPAware
+from .backbone import HipBackbone, FlatBuffers, StockDDPAware, NotifyingSequential
 from .common import MeanStdMixin
 from .mobilenet_common import BlockPlan, run_blocks
 from .runtime import Lazy, conv_bn, conv_stem1_bn, stem1_supported, head, clip_to_nhwc, ACT_RELU6
@@ -67,7 +67,8 @@ class MobileNetV2(HipBackbone, MeanStdMixin, StockDDPAware):
         features.append(ConvBNReLU(input_channel, self.last_channel, kernel_size=1))
         self.features = nn.Sequential(*features)
         self.dropout_p = dropout
-        self.classifier = nn.Sequential(nn.Dropout(dropout), nn.Linear(self.last_channel, num_classes))
+        # (a Sequential that reports `net.classifier[1] = nn.Linear(..)` to this backbone: the head is what callers replace)
+        self.classifier = NotifyingSequential(nn.Dropout(dropout), nn.Linear(self.last_channel, num_classes)).bind_owner(self)
         for m in self.modules():                      # models/sound_mobilenet_v2.py:140-150
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out')

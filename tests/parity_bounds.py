@@ -56,23 +56,28 @@ GROWTH_LIMIT = 1.10           # tools/rebase_bounds.py refuses a figure that gre
 # seed: both fixtures are committed).  HIP and the emulation are two bf16-STORAGE pipelines that round at (almost) the same points; in the
 # random-weight stacks each lands a "bf16 distance" away from fp32 in its own direction, so neither e_hf nor e_he can be much smaller than
 # e_ef, and the ratio of two such single-seed maxima scatters: measured e_hf / e_ef over the six full-size steps 0.64 .. 1.75 (round 5
-# build: c2 logits 0.99, c2 policy logits 0.64, c4 logits 1.43, c4 policy logits 1.20, c5 logits 1.22, c5 policy logits 1.75).  The gate is
-# therefore  e_hf <= max(floor, EMU_K x e_ef)  and  e_he <= max(floor, EMU_K x e_ef)  with EMU_K = 2 -- the round-5 review proposed 1.25,
-# which the committed build already misses at c4 logits and c5 policy logits without anything being wrong with it -- and floors at a quarter
-# of the stated tolerance of the category (below that a ratio of two small numbers says nothing).
+# build: c2 logits 0.99, c2 policy logits 0.64, c4 logits 1.43, c4 policy logits 1.20, c5 logits 1.22, c5 policy logits 1.75).
+# What IS tight is the distance between the two bf16 pipelines: measured e_he / e_ef = 0.18 .. 0.76 over every figure above its floor
+# (logits 0.44-0.53, policy logits 0.38-0.76, statistics 0.49-0.56, heads 0.18-0.63; profiles/r06_gpu_tests_parity.txt) -- HIP sits about
+# HALF as far from the emulation as either sits from fp32: the bf16-storage displacement is mostly common to both.  The gate:
+#     e_he <= max(floor, EMU_K_HE x e_ef)   with EMU_K_HE = 1.0   (the tight, stable statement: HIP vs the emulation), and
+#     e_hf <= max(floor, EMU_K x e_ef)      with EMU_K    = 2.0   (implied by the first through the triangle inequality; the round-5 review
+# proposed 1.25, which the committed round-5 build already misses at c4 logits and c5 policy logits with nothing wrong with it),
+# floors at a quarter of the stated tolerance of the category (below that a ratio of two small numbers says nothing).
 EMU_K = 2.0
+EMU_K_HE = 1.0
 EMU_FLOOR = {"logits": 1e-2, "plog": 2e-2, "stats": 7.5e-3, "stats_p90": 2.5e-3, "head": 2.5e-2, "head_policy": 0.1}
 
 
 def emu_gate(key, cat, e_hf, e_he, e_ef, what=""):
     """Hard gate of one forward figure against the emulation (see above); prints the three distances."""
-    lim = max(EMU_FLOOR[cat], EMU_K * e_ef)
-    print("  %-34s |HIP-fp32| %.4e  |HIP-emu| %.4e  |emu-fp32| %.4e  (gate: both <= max(%.1e, %.1f x |emu-fp32|) = %.3e) %s"
-          % (key, e_hf, e_he, e_ef, EMU_FLOOR[cat], EMU_K, lim, what))
+    lim, lim_he = max(EMU_FLOOR[cat], EMU_K * e_ef), max(EMU_FLOOR[cat], EMU_K_HE * e_ef)
+    print("  %-34s |HIP-emu| %.4e <= %.3e   |HIP-fp32| %.4e <= %.3e   (|emu-fp32| %.4e; floors %.1e) %s"
+          % (key, e_he, lim_he, e_hf, lim, e_ef, EMU_FLOOR[cat], what))
     if rebasing():
         return
+    assert e_he <= lim_he, (key, "HIP vs emulation", e_he, lim_he)
     assert e_hf <= lim, (key, "HIP vs fp32", e_hf, lim)
-    assert e_he <= lim, (key, "HIP vs emulation", e_he, lim)
 
 _table = None
 _recorded = {}

@@ -92,19 +92,20 @@ def test_conv_at_benchmark_shape(sig):
         s1 = torch.zeros(Cout, device=DEV, dtype=torch.float64)
         s2 = torch.zeros(Cout, device=DEV, dtype=torch.float64)
         for n0 in range(g * N, (g + 1) * N, CH):
-            xs = x[n0:n0 + CH].float().permute(0, 3, 1, 2).requires_grad_(True)
+            n1 = min(n0 + CH, (g + 1) * N)                       # (N = 72 / 144 frames per group: the last chunk of a group is short)
+            xs = x[n0:n1].float().permute(0, 3, 1, 2).requires_grad_(True)
             wt = wr.clone().requires_grad_(True)
             ref = F.conv2d(xs, wt, stride=s, padding=pad)
-            gys = gy[n0:n0 + CH].float().permute(0, 3, 1, 2)
+            gys = gy[n0:n1].float().permute(0, 3, 1, 2)
             ref.backward(gys)
-            got = y[n0:n0 + CH].float().permute(0, 3, 1, 2)
+            got = y[n0:n1].float().permute(0, 3, 1, 2)
             e_y = max(e_y, (got - ref.detach()).abs().max().item())
             y_scale = max(y_scale, ref.detach().abs().max().item())
-            gdx = dx[n0:n0 + CH].float().permute(0, 3, 1, 2)
+            gdx = dx[n0:n1].float().permute(0, 3, 1, 2)
             e_dx = max(e_dx, (gdx - xs.grad).abs().max().item())
             dx_scale = max(dx_scale, xs.grad.abs().max().item())
             dw_ref += wt.grad.double()
-            yq = y[n0:n0 + CH].double().reshape(-1, Cout)        # statistics are those of the STORED (rounded) output
+            yq = y[n0:n1].double().reshape(-1, Cout)        # statistics are those of the STORED (rounded) output
             s1 += yq.sum(0)
             s2 += (yq * yq).sum(0)
         st_err = max(st_err, ((sums[g, :Cout] - s1).abs().max() / (s1.abs().max() + 1e-30)).item(),

@@ -53,6 +53,10 @@ def test_round5_fused_entry_points_run_in_the_training_step():
     assert names["adamml_dwconv_bwd_fused"] == 17
     assert names["adamml_dwconv_bwd_weight"] == 0 and names["adamml_dwconv_bwd_data_bn"] == 0 and names["adamml_dwconv_bwd_data"] == 0
     assert names["adamml_conv_fwd_bn_add_next"] == 2
+    # ... and the conv1 results those two launches computed ahead were CONSUMED (Lazy.next_pre claimed by the next block's conv_bn: none dropped
+    # and silently recomputed -- round-5 advisor finding)
+    res = model.main_net.nets[0]
+    assert res.rt.pre_dropped == 0 and res.rt.pre_pending == 0
     assert names["adamml_conv_fwd_bn_add_tpool"] >= 2
     assert names["adamml_conv_bwd_data_dual"] >= 17
     # the temporal pool behind stage 1 hands the algebraic backward of conv3 its product (one pass; stage 2 keeps the two launches)

@@ -461,8 +461,8 @@ def test_conv_groups_equal_separate_launches(case):
         close(dw, dw1, rtol=1e-3, atol_frac=1e-4, what="grouped wgrad (ws=%s)" % use_ws)
 
 
-@pytest.mark.parametrize("G,N,H,Cin,Cout,stride", [(3, 3, 28, 256, 1024, 1), (2, 1, 47, 512, 2048, 1), (1, 2, 33, 256, 512, 1), (2, 3, 57, 512, 1024, 2),
-                                                   (5, 4, 28, 256, 1024, 1)])
+@pytest.mark.parametrize("G,N,H,Cin,Cout,stride", [(3, 3, 28, 256, 1024, 1), (2, 1, 47, 256, 2048, 1), (1, 2, 33, 256, 512, 1), (2, 3, 57, 256, 512, 2),
+                                                   (5, 4, 28, 256, 1024, 1), (1, 9, 28, 256, 1024, 1)])
 def test_conv1x1_wide_stream_equals_conv_gemm(G, N, H, Cin, Cout, stride):
     """csrc/conv1x1_wide.hip (activation-stationary streaming form of the wide 1x1 convs of ResNet layers 3-4, models/resnet.py:94-113)
     against conv_gemm_kernel on the same operands (ADAMML_WIDE_STREAM is read at every call): forward with a lazy and with a plain

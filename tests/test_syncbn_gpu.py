@@ -117,10 +117,11 @@ def _worker(rank, world, port, ret, backend, nvid, px=64):
         ddp = HipDDP(model, sync_bn=True)
         interleave.stats["collectives"] = interleave.stats["coalesced_vectors"] = 0
         r = _step(model, ddp, rank, world, nvid, px)
+        exchange = dict(interleave.stats)                            # (the exchange counts of ONE step: the linearity probe below takes another)
         r["lin"] = _exchange_linearity(model, ddp, rank, world, nvid, px, r)
         if rank == 0:
             ret["r"] = plain(r)
-            ret["exchange"] = dict(interleave.stats)
+            ret["exchange"] = exchange
             ret["communicator_ranks"] = int(one.item())
     finally:
         dist.destroy_process_group()
