@@ -449,6 +449,13 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                     and rt.training and hip.load().adamml_conv_bwd_data_dual_supported(byref(d)):
                 _conv1x1_backward_dual(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern_dual)
                 return
+            if DUAL_DGRAD and act != ACT_NONE and out.pre_sums is not None and not cs.depthwise and not stem and out.pool_grad is None \
+                    and x.requires_grad and rt.training and cs.kh * cs.kw == 1 and nar[2]:
+                # expansion conv of an inverted residual (round 6): its gradient arrives ALREADY masked by its ReLU6 (the depthwise conv's fused
+                # backward applied the mask and accumulated the sums), so the BatchNorm-backward apply is the same affine A g' + B z + C as for
+                # a linear BatchNorm and folds into the narrow streaming data gradient's loader the same way
+                _conv1x1_backward_dual(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, macs, in_b, out_b, w_b, kern_dual)
+                return
             if cs.depthwise and DW_FUSED and out.pool_grad is None and out.pre_sums is not None and rt.training and sole_consumer \
                     and cs.weight.requires_grad and x.requires_grad and x.grad is None and x.src is None and x.vec is not None \
                     and x.pre_sums is None and x.scale is not None and x.scale.data_ptr() == x.vec.data_ptr() \

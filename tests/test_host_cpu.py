@@ -614,16 +614,21 @@ def test_parity_bounds_table_respects_the_stated_tolerances():
         # every entry has its OWN ceiling <= the category's (round-5 advisor finding: a category-wide ceiling let a tight entry drift)
         ceil = e["ceil"]
         assert ceil <= pb.CEILINGS[e["cat"]] * (1 + 1e-9), (k, e)
+        if pb.is_soft(e["cat"]):
+            # printed regression figures of the emulation-gated forward quantities (tests/parity_bounds.emu_gate is their hard gate):
+            # 1.3 x the last measurement, the category's STATED tolerance kept beside it for the record
+            assert e.get("soft") and abs(e["bound"] - pb.FACTOR * e["measured"]) <= 2e-3 * e["bound"], (k, e)
+            continue
         assert 0 < e["measured"] <= ceil, (k, e)
         assert e["bound"] <= ceil * (1 + 1e-9), (k, e)
         assert abs(e["bound"] - min(pb.FACTOR * e["measured"], ceil)) <= 2e-3 * e["bound"], (k, e)
     # the re-base refuses a figure above an entry's ceiling and, without --allow-growth, one that grew by more than 10 %
-    old = t["c4.train_main.logits"]
+    old = t["c4.eval.logits"]
     with pytest.raises(SystemExit):
-        pb.rebased_entry("logits", 1.2 * old["measured"], old, False, "c4.train_main.logits")
-    assert pb.rebased_entry("logits", 1.2 * old["measured"], old, True, "x")["ceil"] == old["ceil"]
+        pb.rebased_entry("eval_logits", 1.2 * old["measured"], old, False, "c4.eval.logits")
+    assert pb.rebased_entry("eval_logits", 1.2 * old["measured"], old, True, "x")["ceil"] == old["ceil"]
     with pytest.raises(SystemExit):
-        pb.rebased_entry("logits", 2.5 * old["measured"], old, True, "c4.train_main.logits")        # (above its own ceiling although below the category's 4e-2)
+        pb.rebased_entry("eval_logits", 2.5 * old["measured"], old, True, "c4.eval.logits")        # (above its own ceiling although below the category's 6e-2)
     # the emulation fixtures of the full-size cases exist and the emulation-relative gate has its constants
     for name in ("resnet50_c1", "adamml_c2", "adamml_c4", "adamml_c5"):
         assert os.path.exists(os.path.join(ROOT, "tests", "golden", name + "_bf16emu.npz")), name

@@ -1012,11 +1012,15 @@ def test_maxpool_bwd_bn_fused_equals_unfused_sequence(N, H, W, C, G):
                                                   (2, 16, 144, 24, 1, "bn"), (5, 7, 128, 512, 5, "bn"), (3, 14, 256, 384, 1, "plain"),
                                                   # projection convs of the MobileNetV2s: the narrow streaming kernel (csrc/conv1x1_narrow.hip), ragged pixel counts
                                                   (3, 17, 32, 16, 2, "bn"), (2, 13, 96, 24, 3, "acc"), (2, 11, 192, 32, 1, "plain"), (1, 19, 144, 32, 2, "bn"),
-                                                  (2, 9, 192, 32, 5, "bn"), (1, 21, 96, 24, 1, "bn"), (2, 15, 32, 16, 1, "plain")])
+                                                  (2, 9, 192, 32, 5, "bn"), (1, 21, 96, 24, 1, "bn"), (2, 15, 32, 16, 1, "plain"),
+                                                  # round 6: EXPANSION convs (16 -> 96, 24 -> 144, 32 -> 192) on the same kernel, K = 96 / 144 / 192 gradient channels
+                                                  (3, 17, 16, 96, 2, "bn"), (2, 13, 24, 144, 3, "acc"), (2, 11, 32, 192, 1, "plain"), (1, 21, 32, 192, 2, "bn"),
+                                                  (2, 19, 24, 144, 1, "bn"), (1, 33, 16, 96, 5, "acc")])
 def test_conv_bwd_data_dual_equals_apply_then_dgrad(N, H, Cin, Cout, G, mode):
     """adamml_conv_bwd_data_dual (BatchNorm-backward apply folded into the loader of the 1x1 data gradient, dz as a side
     output) against adamml_bn_bwd_apply + adamml_conv_bwd_data[_bn].  The affine form A g + B z + C rounds differently
     from k0 (g - k1 - zhat k2) in the last fp32 bit: dz within 1 bf16 ulp, dx within 1e-2 of its scale."""
+    import os
     torch.manual_seed(N * 3 + H)
     P = N * H * H
     w = torch.randn(Cout, Cin, 1, 1, device=DEV) * (2.0 / Cout) ** 0.5
@@ -1027,6 +1031,19 @@ def test_conv_bwd_data_dual_equals_apply_then_dgrad(N, H, Cin, Cout, G, mode):
     coef[:, 1:] -= 0.5
     d = ConvDesc(N, H, H, Cin, H, H, Cout, 1, 1, 1, 0, 1, 0, 0, G, 0)
     assert hip.load().adamml_conv_bwd_data_dual_supported(byref(d)) == 1
+    expansion = (Cin, Cout) in ((16, 96), (24, 144), (32, 192))
+    if expansion:        # the narrow streaming instances of the expansion convs are off by default (measured a wash, csrc/conv1x1_narrow.hip): on for this test
+        os.environ["ADAMML_NARROW_DUAL_EXP"] = "1"
+        try:
+            assert hip.load().adamml_conv1x1_narrow_supported(byref(d), 2) == 1
+            _dual_case(N, H, Cin, Cout, G, mode, P, w, g, z, vec, coef, d)
+        finally:
+            os.environ.pop("ADAMML_NARROW_DUAL_EXP", None)
+        return
+    _dual_case(N, H, Cin, Cout, G, mode, P, w, g, z, vec, coef, d)
+
+
+def _dual_case(N, H, Cin, Cout, G, mode, P, w, g, z, vec, coef, d):
     wd = pack(w, Cin, 1)
     zin = torch.randn(G * N, H, H, Cin, device=DEV).to(torch.bfloat16)
     vin = torch.rand(G, 4, Cin, device=DEV) + 0.5
