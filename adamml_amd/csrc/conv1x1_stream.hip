@@ -33,19 +33,9 @@ struct S1P {
     int bn_act;
     double* stats;           // [groups][SLOTS][128]
     long P;                  // pixels per group
-    // POOLED (round 6): g' is the gradient of a block output that fed ONLY a temporal max-pool (models/common.py:4-33 behind the last block of a
-    // ResNet stage): instead of the expanded tensor g (never written) the kernel reads the pooled gradient gy [groups][clips * T/2][HW][256]
-    // and the 2-bit routing codes of adamml_conv_fwd_bn_add_tpool [..][256/8] uint16 and expands them in its B-fragment loader, exactly as
-    // adamml_temporal_pool_bwd_code does: frame 2 to = tap 1 of window to; frame 2 to + 1 = tap 2 of window to + tap 0 of window to + 1
-    // (fp32 add, rounded to bf16) -- bit-identical fragments, half the bytes
-    const bf16_t* gy;
-    const uint16_t* code;
-    int T, HW;
-    unsigned hw_magic;       // ceil(2^32 / HW): px / HW == umulhi(px, hw_magic) for the pixel counts of the hot path (checked by the launcher)
 };
 
-template <bool POOLED>
-__global__ __launch_bounds__(256, POOLED ? 2 : 3) void alg_stream_kernel(S1P p) {
+__global__ __launch_bounds__(256, 3) void alg_stream_kernel(S1P p) {
     __shared__ __attribute__((aligned(16))) bf16_t sw[C2 * KP];
     __shared__ float s_vec[2 * C2];          // lazy transform of a: scale, shift
     __shared__ float s_bn[4 * C2];           // scale, shift, mean, invstd of the epilogue BatchNorm
@@ -53,10 +43,7 @@ __global__ __launch_bounds__(256, POOLED ? 2 : 3) void alg_stream_kernel(S1P p) 
     __shared__ float s_sum[4][2 * C2];       // per-wave rows of the BatchNorm-backward sums (common.h: reproducible reductions)
     const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
-    if (POOLED) {
-        p.gy += (size_t)g * (p.P / 2) * K1;
-        p.code += (size_t)g * (p.P / 2) * (K1 / 8);
-    } else p.g += (size_t)g * p.P * K1;
+    p.g += (size_t)g * p.P * K1;
     p.a += (size_t)g * p.P * C2;
     p.dx += (size_t)g * p.P * C2;
     p.w += (size_t)g * C2 * KT;
@@ -101,38 +88,10 @@ __global__ __launch_bounds__(256, POOLED ? 2 : 3) void alg_stream_kernel(S1P p) 
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) acc[pg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         bf16x8 ring[PD][NPG];
-        bf16x8 ringb[POOLED ? PD : 1][NPG];                           // POOLED: window to + 1 of an odd frame
-        unsigned rcode[POOLED ? PD : 1][NPG];                         // POOLED: code words of both windows (low / high 16 bits)
-        // POOLED: pooled rows of this lane's pixels -- window to of its frame, and window to + 1 (clamped; used by odd frames that have one)
-        unsigned rowa[POOLED ? NPG : 1], rowb[POOLED ? NPG : 1], tapa[POOLED ? NPG : 1];
-        bool useb[POOLED ? NPG : 1];
-        if constexpr (POOLED) {
-            const int To = p.T >> 1;
-#pragma unroll
-            for (int pg = 0; pg < NPG; ++pg) {
-                const unsigned px = (unsigned)prow[pg];
-                const unsigned f = __umulhi(px, p.hw_magic), q = px - f * (unsigned)p.HW;           // frame, pixel of the frame
-                const unsigned t = f & (unsigned)(p.T - 1), clip = f / (unsigned)p.T, to = t >> 1;  // (T is a power of two)
-                const bool odd = (t & 1u) != 0;
-                const unsigned tob = to + 1 < (unsigned)To ? to + 1 : to;
-                rowa[pg] = (clip * To + to) * (unsigned)p.HW + q;
-                rowb[pg] = (clip * To + tob) * (unsigned)p.HW + q;
-                tapa[pg] = odd ? 2u : 1u;
-                useb[pg] = odd && to + 1 < (unsigned)To;
-            }
-        }
         auto issue = [&](int slot, int k) {                         // k: K step (compile-time after unrolling)
 #pragma unroll
             for (int pg = 0; pg < NPG; ++pg) {
-                if (k < K1 / 32) {
-                    if constexpr (POOLED) {
-                        const size_t oa = (size_t)rowa[pg] * K1 + k * 32 + lg * 8, ob = (size_t)rowb[pg] * K1 + k * 32 + lg * 8;
-                        ring[slot][pg] = *reinterpret_cast<const bf16x8*>(p.gy + oa);
-                        ringb[slot][pg] = *reinterpret_cast<const bf16x8*>(p.gy + ob);
-                        rcode[slot][pg] = (unsigned)p.code[oa >> 3] | ((unsigned)p.code[ob >> 3] << 16);
-                    } else
-                    ring[slot][pg] = *reinterpret_cast<const bf16x8*>(p.g + prow[pg] * K1 + k * 32 + lg * 8);      // (not non-temporal: the two 64-byte halves of a line are fetched by consecutive K steps and must meet in L2)
-                }
+                if (k < K1 / 32) ring[slot][pg] = *reinterpret_cast<const bf16x8*>(p.g + prow[pg] * K1 + k * 32 + lg * 8);      // (not non-temporal: the two 64-byte halves of a line are fetched by consecutive K steps and must meet in L2)
                 else ring[slot][pg] = *reinterpret_cast<const bf16x8*>(p.a + prow[pg] * C2 + (k - K1 / 32) * 32 + lg * 8);
             }
         };
@@ -154,22 +113,6 @@ __global__ __launch_bounds__(256, POOLED ? 2 : 3) void alg_stream_kernel(S1P p) 
             bf16x8 fb[NPG];
 #pragma unroll
             for (int pg = 0; pg < NPG; ++pg) fb[pg] = ring[k % PD][pg];
-            if constexpr (POOLED) {
-                if (k < K1 / 32) {                                  // expand the codes (adamml_temporal_pool_bwd_code's arithmetic)
-#pragma unroll
-                    for (int pg = 0; pg < NPG; ++pg) {
-                        const f32x8 ga = bf8_to_f32(ring[k % PD][pg]), gb = bf8_to_f32(ringb[k % PD][pg]);
-                        const unsigned ca = rcode[k % PD][pg] & 0xffffu, cb = rcode[k % PD][pg] >> 16;
-                        f32x8 v;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            v[j] = ((ca >> (2 * j)) & 3u) == tapa[pg] ? ga[j] : 0.f;
-                            v[j] += (useb[pg] && ((cb >> (2 * j)) & 3u) == 0u) ? gb[j] : 0.f;
-                        }
-                        fb[pg] = f32_to_bf8(v);
-                    }
-                }
-            }
             // the ring is refilled two K steps at a time: steps 2s and 2s + 1 are the two 64-byte halves of one 128-byte line of every pixel
             // (g' rows are four lines, a rows one), and requested back to back they cost the vector L1 one miss where requests a K step
             // apart cost two (profiles/r04_pmc_alg_stream.txt: 1.7 L2 requests per line, the L1 stalled 57 % of the time): 1.58 -> 1.55 ms
@@ -260,34 +203,20 @@ __global__ __launch_bounds__(256, POOLED ? 2 : 3) void alg_stream_kernel(S1P p) 
 
 bool adamml_alg_stream_supported(int Cout, int Cin) { return Cout == K1 && Cin == C2; }
 
-// pooled: (g_y, code, T) of a gradient that exists only in pooled form (see S1P::gy); g is then ignored
 int adamml_alg_stream_launch(const adamml_conv_desc_t* d, const void* g, const void* a, const float* a_scale, const float* a_shift,
                              const void* w_alg, const float* epi_add, void* dx, int accumulate, const void* z_in, const float* bn_vec,
-                             int act, double* sums, hipStream_t stream, const void* gy, const uint16_t* code, int T) {
+                             int act, double* sums, hipStream_t stream) {
     S1P p;
     p.g = (const bf16_t*)g; p.a = (const bf16_t*)a; p.a_scale = a_scale; p.a_shift = a_shift; p.a_act = d->act; p.a_gs = d->in_gstride;
     p.w = (const bf16_t*)w_alg; p.cadd = epi_add; p.dx = (bf16_t*)dx; p.accumulate = accumulate;
     p.bn_z = (const bf16_t*)z_in; p.bn_vec = bn_vec; p.bn_act = act; p.stats = sums;
     p.P = (long)d->N * d->H * d->W;
-    p.gy = (const bf16_t*)gy; p.code = code; p.T = T; p.HW = d->H * d->W; p.hw_magic = 0;
     if (p.P <= 0) return ADAMML_OK;
     const int groups = d->groups < 1 ? 1 : d->groups;
     const long ntile = (p.P + TPX - 1) / TPX;
     long nblk = (ntile + 3) / 4;
-    if (gy) {
-        if (!code || T < 2 || (T & (T - 1)) || d->N % T || p.P >= (1L << 26))
-            return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_alg_pooled: T must be a power of two dividing the frames of a group");
-        p.hw_magic = (unsigned)(((1ull << 32) + (unsigned long long)p.HW - 1) / (unsigned long long)p.HW);
-        // umulhi(px, magic) == px / HW needs px * (magic * HW - 2^32) < 2^32: holds for px < 2^32 / HW (checked: P < 2^26, HW <= 2^16 in practice)
-        if ((unsigned long long)p.P * ((unsigned long long)p.hw_magic * p.HW - (1ull << 32)) >= (1ull << 32))
-            return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_alg_pooled: group too large for the reciprocal division");
-        const long cap = 512 / groups > 0 ? 512 / groups : 1;       // 2 persistent workgroups per CU (256 registers)
-        if (nblk > cap) nblk = cap;
-        hipLaunchKernelGGL(alg_stream_kernel<true>, dim3((unsigned)nblk, groups), dim3(256), 0, stream, p);
-        return adamml_check_launch("conv_bwd_data_alg_pooled (stream)");
-    }
     const long cap = 768 / groups > 0 ? 768 / groups : 1;           // ~3 persistent workgroups per CU over all groups
     if (nblk > cap) nblk = cap;
-    hipLaunchKernelGGL(alg_stream_kernel<false>, dim3((unsigned)nblk, groups), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(alg_stream_kernel, dim3((unsigned)nblk, groups), dim3(256), 0, stream, p);
     return adamml_check_launch("conv_bwd_data_alg (stream)");
 }

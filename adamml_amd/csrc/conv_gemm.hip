@@ -171,8 +171,7 @@ constexpr int conv_gemm_wg_per_cu(int BC, int MODE, int PD, bool RES, bool DUAL,
 template <int BC, int MODE, int PD, bool RES = false, bool DUAL = false, bool CAT = false, bool FADD = false, bool GLDS = false, int EID = 0,
           bool LZF = false, int EPI = -1, bool PF = false, int TP = 0>
 __global__ __launch_bounds__(NTHREADS, conv_gemm_wg_per_cu(BC, MODE, PD, RES, DUAL, CAT, FADD, GLDS, EID, EPI)) void conv_gemm_kernel(ConvP p) {
-    static_assert(TP == 0 || (FADD && EID && MODE == 0 && BC == 128 && (TP == 2 || TP == 4 || TP == 8)) || (RES && PF && EID && MODE == 0 && BC == 128 && TP == 8),
-                  "TP: FADD + EID, 128-wide cout tiles; or RES + PF + EID with TP = 8 (identity gradient from the pooled tensor)");
+    static_assert(TP == 0 || (FADD && EID && MODE == 0 && BC == 128 && (TP == 2 || TP == 4 || TP == 8)), "TP: FADD + EID, 128-wide cout tiles");
     constexpr int PPF = TP ? BP / TP : BP;  // TP: pixels of one frame in a tile
     constexpr int WCT = BC / 32;            // 16-wide cout tiles per wave
     constexpr int WROWS = BC / 64;          // weight rows staged per thread
@@ -225,7 +224,6 @@ __global__ __launch_bounds__(NTHREADS, conv_gemm_wg_per_cu(BC, MODE, PD, RES, DU
             p.pf_a += (size_t)g * p.P * PF_C;
             if (p.pf_scale) { p.pf_scale += (size_t)g * p.pf_gs; p.pf_shift += (size_t)g * p.pf_gs; }
         }
-        if (RES && TP) { p.tp_y += (size_t)g * (p.gy >> 1); p.tp_code += ((size_t)g * (p.gy >> 1)) >> 3; }
         if (RES) {
             p.res_out += (size_t)g * p.gy;
             if (p.res_mask) p.res_mask += ((size_t)g * p.gy) >> 3;
@@ -409,11 +407,7 @@ __global__ __launch_bounds__(NTHREADS, conv_gemm_wg_per_cu(BC, MODE, PD, RES, DU
     // EID: identity-side operands of this tile's epilogue (every lane loads -- clamped addresses -- so that the number of
     // outstanding VMEM operations is the same for every wave: the LDS-DMA loop below waits with counted vmcnt)
     constexpr int NRE = BP / RSTEP;
-    constexpr bool RTP = RES && TP != 0;        // RES + PF with the identity gradient in POOLED form (round 6): the tile is (clip, 16 pixels) x 8 frames, a thread's
-                                                // NRE = 8 epilogue rows are the 8 frames of ONE pixel, and it loads the 4 pooled rows + code words of that pixel instead
-    bf16x8 eid[(EID && !RTP) ? NRE : 1];
-    bf16x8 pgy[RTP ? TP / 2 : 1];
-    unsigned pcd[RTP ? TP / 2 : 1];
+    bf16x8 eid[EID ? NRE : 1];
     unsigned embits[EID ? NRE : 1];
     auto issue_eid = [&]() {
         if constexpr (PF) {
@@ -426,12 +420,7 @@ __global__ __launch_bounds__(NTHREADS, conv_gemm_wg_per_cu(BC, MODE, PD, RES, DU
                 const int e = tid + l * NTHREADS;
                 const int row = e >> 3;
                 const int ch = (e & 7) ^ (tr_swz<64>(row & 31) >> 1);
-                const bf16_t* src;
-                if constexpr (TP != 0) {
-                    bool okr;
-                    const int pr_ = tp_row(row, okr);
-                    src = okr ? p.pf_a + (size_t)pr_ * PF_C + ch * 8 : zeros;
-                } else src = (p0 + row < p.P) ? p.pf_a + (size_t)(p0 + row) * PF_C + ch * 8 : zeros;
+                const bf16_t* src = (p0 + row < p.P) ? p.pf_a + (size_t)(p0 + row) * PF_C + ch * 8 : zeros;
                 glds16(src, __builtin_amdgcn_readfirstlane(pbase + l * NTHREADS * 16));
             }
         }
@@ -445,26 +434,14 @@ __global__ __launch_bounds__(NTHREADS, conv_gemm_wg_per_cu(BC, MODE, PD, RES, DU
                     bool ok;
                     pre = (size_t)tp_row(r, ok) * p.Cout + ecoc;
                 }
-                if constexpr (FADD) eid[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.res_out + pre));
-                else if constexpr (RTP) embits[j] = p.res_mask[pre >> 3];
+                if (FADD) eid[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.res_out + pre));
                 else {
                     eid[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.y + pre));
                     embits[j] = p.res_mask[pre >> 3];
                 }
             }
-            if constexpr (RTP) {
-                static_assert(!RTP || (NRE == TP && RSTEP == 16), "RES + TP: a thread's epilogue rows are the frames of one pixel");
-                const int q = tp_q0 + erow0, qc = q < p.tp_Q ? q : 0;
-#pragma unroll
-                for (int to = 0; to < TP / 2; ++to) {
-                    const size_t po = ((size_t)(tp_clip * (TP / 2) + to) * p.tp_Q + qc) * p.Cout + ecoc;
-                    pgy[to] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p.tp_y + po));
-                    pcd[to] = p.tp_code[po >> 3];
-                }
-            }
         }
     };
-    // (RTP: 4 pooled rows + 4 code words + 8 mask bytes = the same 16 loads as 8 identity rows + 8 mask bytes)
     constexpr int NEID = (EID ? (FADD ? NRE : 2 * NRE) : 0) + (PF ? 4 : 0);       // VMEM loads issue_eid() puts in flight per thread
 
     // register prefetch ring of depth PD: global loads run PD K-steps ahead of the MFMAs.  One K step of compute is
@@ -871,28 +848,6 @@ __global__ __launch_bounds__(NTHREADS, conv_gemm_wg_per_cu(BC, MODE, PD, RES, DU
                 const int r = erow0 + (b0 + j) * RSTEP;
                 ok[j] = p0 + r < p.P;
                 pr[j] = (size_t)(ok[j] ? p0 + r : p0) * p.Cout + eco;       // clamped: out-of-range rows re-read row p0, never stored
-                if constexpr (RTP) {
-                    bool okr;
-                    pr[j] = (size_t)tp_row(r, okr) * p.Cout + eco;
-                    ok[j] = okr;
-                    // frame t = b0 + j of this thread's pixel, expanded from the pooled rows exactly as adamml_temporal_pool_bwd_code does:
-                    // frame 2 to = tap 1 of window to; frame 2 to + 1 = tap 2 of window to + tap 0 of window to + 1 (fp32 add, one rounding)
-                    constexpr int To = TP / 2;
-                    const int t = b0 + j, to = t >> 1;
-                    const unsigned ka = (t & 1) ? 2u : 1u;
-                    const f32x8 ga = bf8_to_f32(pgy[to]);
-                    f32x8 v;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = ((pcd[to] >> (2 * i)) & 3u) == ka ? ga[i] : 0.f;
-                    if ((t & 1) && to + 1 < To) {
-                        const f32x8 gb = bf8_to_f32(pgy[to + 1 < To ? to + 1 : to]);
-                        const unsigned cb = pcd[to + 1 < To ? to + 1 : to];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) v[i] += ((cb >> (2 * i)) & 3u) == 0u ? gb[i] : 0.f;
-                    }
-                    dr[j] = f32_to_bf8(v);
-                    mbits[j] = embits[b0 + j];
-                } else
                 if constexpr (EID != 0) {
                     // (the launcher selects EID only for: accumulate, 1-bit mask, no z operands -- the algebraic backward's form)
                     dr[j] = eid[b0 + j];
@@ -1866,8 +1821,7 @@ struct DualIn { const void* z; const float* aff; void* side; };
 struct CatIn { const void* xb; int C2; size_t gw; const float* epi_add; };
 // forward BatchNorm + residual-add epilogue (ConvP::id_scale ..)
 // product with a second tensor accumulated from the gradient tile (ConvP::pf_a ..); ws: partial workspace, nsplit: out
-struct PfIn { const void* a; const float* scale; const float* shift; int act, gs, C; float* out; void* ws; size_t ws_bytes;
-              int tp_frames; const void* gy; const uint16_t* code; };     // tp_frames > 0: the identity gradient comes in pooled form (gy, code)
+struct PfIn { const void* a; const float* scale; const float* shift; int act, gs, C; float* out; void* ws; size_t ws_bytes; };
 struct FaddEpi { const float* vec; const void* idn; const float* id_scale; const float* id_shift; int id_gstride; int act; uint8_t* mask_out;
                  int tp_frames; void* tp_y; uint16_t* tp_code; };      // tp_frames > 0: temporal max-pool in the epilogue (ConvP::tp_y ..)
 
@@ -1938,7 +1892,7 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
     bool narrow = d->Cout <= 64 || (d->Cout % 128 != 0 && d->Cout < 256);
     // small problems: halve the cout tile so that at least ~2 workgroups per CU exist
     if (!narrow && (long)ceil_div(p.P, BP) * ceil_div(d->Cout, 128) * groups < 512) narrow = true;
-    const int tp = fadd ? fadd->tp_frames : (pf ? pf->tp_frames : 0);
+    const int tp = fadd ? fadd->tp_frames : 0;
     if (tp) narrow = false;
     const int BC = narrow ? 64 : 128;
     p.n_ptiles = ceil_div(p.P, BP);
@@ -1947,8 +1901,7 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
         p.tp_Q = d->OH * d->OW;
         p.tp_nblk = ceil_div(p.tp_Q, BP / tp);
         p.n_ptiles = (d->N / tp) * p.tp_nblk;
-        if (fadd) { p.tp_y = (bf16_t*)fadd->tp_y; p.tp_code = fadd->tp_code; }
-        else { p.tp_y = (bf16_t*)const_cast<void*>(pf->gy); p.tp_code = const_cast<uint16_t*>(pf->code); }       // (read-only in the RES + TP instance)
+        p.tp_y = (bf16_t*)fadd->tp_y; p.tp_code = fadd->tp_code;
     }
     p.n_ctiles = ceil_div(d->Cout, BC);
     // consecutive pixel tiles per workgroup (amortises the statistics publication), keeping >= ~2048 workgroups
@@ -2022,10 +1975,6 @@ static int conv_launch(const adamml_conv_desc_t* d, const void* x, const void* w
             if (!pf->ws || pf->ws_bytes < need) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_res_prod: workspace too small (need %zu bytes)", need);
             p.pf_a = (const bf16_t*)pf->a; p.pf_scale = pf->scale; p.pf_shift = pf->scale ? pf->shift : nullptr; p.pf_act = pf->act; p.pf_gs = pf->gs;
             p.pf_ws = (float*)pf->ws;
-            if (tp) {
-                if (tp != 8 || d->N % 8) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res_prod_pooled: T = 8 frames per clip only");
-                hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, true, false, false, false, true, 1, false, -1, true, 8>), grid, block, 0, stream, p);
-            } else
             hipLaunchKernelGGL((conv_gemm_kernel<128, 0, 1, true, false, false, false, true, 1, false, -1, true>), grid, block, 0, stream, p);
             int rc = adamml_check_launch("conv_bwd_data_res_prod");
             if (rc) return rc;
@@ -2311,7 +2260,7 @@ extern "C" int adamml_conv_bwd_data_dual(const adamml_conv_desc_t* d, const void
 bool adamml_alg_stream_supported(int Cout, int Cin);
 int adamml_alg_stream_launch(const adamml_conv_desc_t* d, const void* g, const void* a, const float* a_scale, const float* a_shift,
                              const void* w_alg, const float* epi_add, void* dx, int accumulate, const void* z_in, const float* bn_vec,
-                             int act, double* sums, hipStream_t stream, const void* gy, const uint16_t* code, int T);
+                             int act, double* sums, hipStream_t stream);
 static bool alg_stream_enabled() {           // ADAMML_ALG_STREAM=0: A/B aid (falls back to the CAT instance of conv_gemm_kernel)
     static int on = -1;
     if (on < 0) { const char* e = getenv("ADAMML_ALG_STREAM"); on = (e && e[0] == '0') ? 0 : 1; }
@@ -2446,26 +2395,9 @@ extern "C" int adamml_conv_bwd_data_alg(const adamml_conv_desc_t* d, const void*
     gd.stride = 1; gd.up = 1; gd.pad = 0;
     gd.act = d->act; gd.accumulate = accumulate ? 1 : 0; gd.in_gstride = d->in_gstride;
     if (adamml_alg_stream_supported(d->Cout, d->Cin) && alg_stream_enabled())
-        return adamml_alg_stream_launch(d, g, a, a_scale, a_shift, w_alg, epi_add, dx, accumulate, z_in, bn_vec, act, sums, stream, nullptr, nullptr, 0);
+        return adamml_alg_stream_launch(d, g, a, a_scale, a_shift, w_alg, epi_add, dx, accumulate, z_in, bn_vec, act, sums, stream);
     CatIn c{a, d->Cin, (size_t)d->Cin * (d->Cout + d->Cin), epi_add};
     return conv_launch(&gd, g, w_alg, a_scale, a_shift, dx, sums, z_in, bn_vec, act, stream, nullptr, nullptr, nullptr, &c);
-}
-
-extern "C" int adamml_conv_bwd_data_alg_pooled_supported(const adamml_conv_desc_t* d, int T) {
-    static const bool on = !(getenv("ADAMML_POOLED_GRAD") && getenv("ADAMML_POOLED_GRAD")[0] == '0');            // A/B aid
-    return on && d && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && adamml_alg_stream_supported(d->Cout, d->Cin) && alg_stream_enabled() &&
-           T >= 2 && !(T & (T - 1)) && d->N % T == 0 && (long)d->N * d->H * d->W < (1L << 26) ? 1 : 0;
-}
-
-extern "C" int adamml_conv_bwd_data_alg_pooled(const adamml_conv_desc_t* d, const void* g_y, const uint16_t* code, int T, const void* a, const float* a_scale,
-                                               const float* a_shift, const void* w_alg, const float* epi_add, void* dx, int accumulate, const void* z_in,
-                                               const float* bn_vec, int act, double* sums, hipStream_t stream) {
-    if (!d || !g_y || !code || !a || !w_alg || !epi_add || !dx) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_alg_pooled: null argument");
-    if (!adamml_conv_bwd_data_alg_pooled_supported(d, T)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_alg_pooled: 1x1 / stride-1, 256 <- 64 channels, T a power of two");
-    if ((z_in != nullptr) != (bn_vec != nullptr) || (z_in != nullptr) != (sums != nullptr))
-        return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_alg_pooled: incomplete BatchNorm epilogue operands");
-    if (z_in && accumulate) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_alg_pooled: the BatchNorm epilogue does not accumulate");
-    return adamml_alg_stream_launch(d, nullptr, a, a_scale, a_shift, w_alg, epi_add, dx, accumulate, z_in, bn_vec, act, sums, stream, g_y, code, T);
 }
 
 extern "C" int adamml_conv_bwd_data_res_supported(const adamml_conv_desc_t* d) {
@@ -2514,27 +2446,7 @@ extern "C" int adamml_conv_bwd_data_res_prod(const adamml_conv_desc_t* d, const 
     dd.H = d->OH; dd.W = d->OW; dd.Cin = d->Cout; dd.OH = d->H; dd.OW = d->W; dd.Cout = d->Cin;
     dd.stride = 1; dd.up = 1; dd.pad = 0; dd.act = ACT_NONE; dd.accumulate = 1; dd.in_gstride = 0;
     ResEpi r{dx, res_mask, res_act, nullptr, nullptr, nullptr};       // (res_out is never read in the mask form)
-    PfIn pf{a, a_scale, a_shift, a_act, a_gstride, a_channels, prod, workspace, workspace_bytes, 0, nullptr, nullptr};
-    return conv_launch(&dd, dz, w_dgrad_packed, nullptr, nullptr, dx, sums_a, nullptr, nullptr, 0, stream, nullptr, &r, nullptr, nullptr, nullptr, &pf);
-}
-
-extern "C" int adamml_conv_bwd_data_res_prod_pooled_supported(const adamml_conv_desc_t* d, int a_channels, int T) {
-    static const bool on = !(getenv("ADAMML_POOLED_GRAD") && getenv("ADAMML_POOLED_GRAD")[0] == '0');            // A/B aid
-    return on && adamml_conv_bwd_data_res_prod_supported(d, a_channels) && T == 8 && d->N % 8 == 0 && (d->H * d->W) % 16 == 0 ? 1 : 0;
-}
-
-extern "C" int adamml_conv_bwd_data_res_prod_pooled(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, const void* g_y,
-                                                    const uint16_t* code, int T, void* dx, const uint8_t* res_mask, int res_act, double* sums_a,
-                                                    const void* a, const float* a_scale, const float* a_shift, int a_act, int a_gstride,
-                                                    int a_channels, float* prod, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    if (!adamml_conv_bwd_data_res_prod_pooled_supported(d, a_channels, T))
-        return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res_prod_pooled: unsupported shape");
-    if (!g_y || !code || !res_mask || !sums_a || !a || !prod || !dx) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_res_prod_pooled: null argument");
-    adamml_conv_desc_t dd = *d;                          // data gradient of d: swap the channel roles, as adamml_conv_bwd_data_res does
-    dd.H = d->OH; dd.W = d->OW; dd.Cin = d->Cout; dd.OH = d->H; dd.OW = d->W; dd.Cout = d->Cin;
-    dd.stride = 1; dd.up = 1; dd.pad = 0; dd.act = ACT_NONE; dd.accumulate = 1; dd.in_gstride = 0;
-    ResEpi r{dx, res_mask, res_act, nullptr, nullptr, nullptr};       // (res_out is never read in the mask form)
-    PfIn pf{a, a_scale, a_shift, a_act, a_gstride, a_channels, prod, workspace, workspace_bytes, T, g_y, code};
+    PfIn pf{a, a_scale, a_shift, a_act, a_gstride, a_channels, prod, workspace, workspace_bytes};
     return conv_launch(&dd, dz, w_dgrad_packed, nullptr, nullptr, dx, sums_a, nullptr, nullptr, 0, stream, nullptr, &r, nullptr, nullptr, nullptr, &pf);
 }
 

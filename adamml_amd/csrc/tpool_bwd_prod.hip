@@ -28,9 +28,7 @@ struct TPP {
     int in_gs, act, clips, HW, C;
 };
 
-// STORE = false (round 6): g2 is NOT written -- its two readers expand the codes themselves (alg_stream_kernel<true>, the RES + PF instance of
-// conv_gemm_kernel with TP): the 4.6 GB tensor behind stage 1 is never materialised
-template <int T, int CIN, int NQ, bool STORE>
+template <int T, int CIN, int NQ>
 __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void tpool_bwd_prod_kernel(TPP p) {
     constexpr int To = T / 2, MT = 4, NTL = CIN / 16;
     constexpr int FPX = 16, TPX = 32;                              // pixels of a block per frame; rows of a staged tile = 2 frames x 16 pixels
@@ -145,7 +143,7 @@ __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void tpool_bwd_prod_kerne
                 }
                 bf16x8 gb = f32_to_bf8(v);
                 if (px >= npx) gb = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                else if (STORE) *reinterpret_cast<bf16x8*>(ob + goff[i]) = gb;
+                else *reinterpret_cast<bf16x8*>(ob + goff[i]) = gb;
                 const f32x8 gq = bf8_to_f32(gb);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) sa[j] += gq[j];
@@ -231,19 +229,19 @@ __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void tpool_bwd_prod_kerne
     }
 }
 
-template <int T, int CIN, int NQ, bool STORE>
+template <int T, int CIN, int NQ>
 int tpp_launch(const TPP& p, int groups, int nblk, hipStream_t stream) {
     constexpr size_t lds = 2 * CIN * 4 + (size_t)NQ * 32 * ((64 * 2 + 8) + (CIN * 2 + 8));
     static AdamLdsOnce attr_once;                    // (per device: common.h)
     const int attr_dev = adamml_current_device();
     if (!attr_once.test(attr_dev)) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tpool_bwd_prod_kernel<T, CIN, NQ, STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tpool_bwd_prod_kernel<T, CIN, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "temporal_pool_bwd_code_prod: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         }
         attr_once.set(attr_dev);
     }
-    hipLaunchKernelGGL((tpool_bwd_prod_kernel<T, CIN, NQ, STORE>), dim3((unsigned)nblk, groups), dim3(NQ * 64), lds, stream, p);
+    hipLaunchKernelGGL((tpool_bwd_prod_kernel<T, CIN, NQ>), dim3((unsigned)nblk, groups), dim3(NQ * 64), lds, stream, p);
     return adamml_check_launch("temporal_pool_bwd_code_prod");
 }
 
@@ -275,7 +273,7 @@ extern "C" int adamml_temporal_pool_bwd_code_prod(const void* g_y, const uint16_
                                                   hipStream_t stream) {
     if (!adamml_temporal_pool_bwd_code_prod_supported(T, C, Cin))
         return adamml_set_error(ADAMML_EUNSUPPORTED, "temporal_pool_bwd_code_prod: (T, C, Cin) = (8, 256, 64)");
-    if (!g_y || !code || !sums_a || !a || !prod || !workspace) return adamml_set_error(ADAMML_EINVAL, "temporal_pool_bwd_code_prod: null argument");
+    if (!g_y || !code || !g2 || !sums_a || !a || !prod || !workspace) return adamml_set_error(ADAMML_EINVAL, "temporal_pool_bwd_code_prod: null argument");
     if (NB < 1 || HW < 1) return ADAMML_OK;
     if (groups < 1) groups = 1;
     const int nblk = tpp_blocks(NB, HW, C, groups);
@@ -285,7 +283,7 @@ extern "C" int adamml_temporal_pool_bwd_code_prod(const void* g_y, const uint16_
     p.gy = (const bf16_t*)g_y; p.code = code; p.g2 = (bf16_t*)g2; p.sums = sums_a; p.a = (const bf16_t*)a;
     p.in_scale = in_scale; p.in_shift = in_scale ? in_shift : nullptr; p.ws = (float*)workspace;
     p.in_gs = in_gstride; p.act = in_act; p.clips = NB; p.HW = HW; p.C = C;
-    int rc = g2 ? tpp_launch<8, 64, 4, true>(p, groups, nblk, stream) : tpp_launch<8, 64, 4, false>(p, groups, nblk, stream);
+    int rc = tpp_launch<8, 64, 4>(p, groups, nblk, stream);
     if (rc) return rc;
     return adamml_launch_split_reduce_grouped((const float*)workspace, prod, (size_t)C * Cin, nblk, groups, Cin, stream);
 }

@@ -50,8 +50,6 @@ SIGNATURES = {
     "adamml_alg_pack": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "adamml_alg_wgrad_combine": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "adamml_conv_bwd_data_alg": [_DESC, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
-    "adamml_conv_bwd_data_alg_pooled": [_DESC, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P],
-    "adamml_conv_bwd_data_res_prod_pooled": [_DESC, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _Z, _P],
     "adamml_conv_bwd_data_res": [_DESC, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "adamml_conv_bwd_data_res_prod": [_DESC, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _Z, _P],
     "adamml_bn_act_add_mask": [_P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _Z, _I, _I, _P],
@@ -141,10 +139,6 @@ def load():
     lib.adamml_conv_fused_input_supported.restype = c_int
     lib.adamml_conv1x1_narrow_supported.argtypes = [_DESC, c_int]
     lib.adamml_conv1x1_narrow_supported.restype = c_int
-    lib.adamml_conv_bwd_data_alg_pooled_supported.argtypes = [_DESC, c_int]
-    lib.adamml_conv_bwd_data_alg_pooled_supported.restype = c_int
-    lib.adamml_conv_bwd_data_res_prod_pooled_supported.argtypes = [_DESC, c_int, c_int]
-    lib.adamml_conv_bwd_data_res_prod_pooled_supported.restype = c_int
     lib.adamml_conv1x1_wide_supported.argtypes = [_DESC, c_int]
     lib.adamml_conv1x1_wide_supported.restype = c_int
     lib.adamml_conv_fwd_bn_add_supported.argtypes = [_DESC]

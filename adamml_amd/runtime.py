@@ -65,33 +65,6 @@ class Lazy:
         return self.data
 
 
-class PooledGrad:
-    """Gradient of a full-rate block output that exists only in POOLED form (round 6): the block ended a ResNet stage, its output fed only
-    the temporal max-pool (fused into its conv3 kernel), so the gradient w.r.t. that output is the pooled gradient `gy` routed by the 2-bit
-    codes the forward stored.  Its two readers expand the codes in their loaders (adamml_conv_bwd_data_alg_pooled: the algebraic data
-    gradient of the block's conv3; adamml_conv_bwd_data_res_prod_pooled: the identity path inside the block's conv1 data gradient), so the
-    expanded tensor (4.6 GB behind stage 1) is never written or read.  dense() materialises it for any other reader."""
-    __slots__ = ("gy", "code", "T", "shape", "groups", "_dense")
-
-    def __init__(self, gy, code, T, shape, groups):
-        self.gy, self.code, self.T, self.shape, self.groups = gy, code, T, tuple(shape), groups
-        self._dense = None
-
-    def dense(self):
-        if self._dense is None:
-            n, h, w, C = self.shape
-            G = self.groups
-            gx = torch.empty(self.shape, dtype=torch.bfloat16, device=self.gy.device)
-            sa = torch.zeros(G * 2 * C * STAT_SLOTS, dtype=torch.float64, device=self.gy.device)        # (the kernel's sum(g') output: already accumulated by the pooled producer)
-            call("adamml_temporal_pool_bwd_code", ptr(self.gy), ptr(self.code), ptr(gx), ptr(sa), n // G // self.T, self.T, h * w, C, G)
-            self._dense = gx
-        return self._dense
-
-
-def _dense_grad(g):
-    return g.dense() if isinstance(g, PooledGrad) else g
-
-
 class Tape:
     """Reverse-mode tape for one backbone call; closures run in reverse order."""
 
@@ -518,8 +491,6 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                              ptr(cs.weight.grad), cs.cin_true, ptr(ws), ws.numel() * 4)
             if x.requires_grad:
                 acc = 1
-                if isinstance(x.grad, PooledGrad) and not (last_consumer and not cs.depthwise and _residual_fusable(x, d)):
-                    x.grad = x.grad.dense()              # (only the residual-backward data gradient below reads the pooled form)
                 if x.grad is None:
                     x.grad = torch.empty_like(x.data)
                     acc = 0
@@ -543,22 +514,8 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                                                        + (1 if (fb and not (fb and idn.alg)) else 0)) + out_b + w_b, kern, R_FUSED)
                     fbk = fb and not fb_alg
                     ain = z.alg_in
-                    pgx = x.grad if isinstance(x.grad, PooledGrad) else None
-                    res_prod = (RES_PROD and z.alg and ain is not None and (not fb or fb_alg) and acc == 1 and rmask is not None and ain[0].data is not None
-                                and hip.load().adamml_conv_bwd_data_res_prod_supported(byref(d), ain[1].Cin))
-                    if pgx is not None and not (res_prod and hip.load().adamml_conv_bwd_data_res_prod_pooled_supported(byref(d), ain[1].Cin, pgx.T)):
-                        x.grad, pgx = pgx.dense(), None
-                    if res_prod and pgx is not None:
-                        # identity-path gradient in pooled form (the block ends a stage): expanded inside the epilogue's early identity loads;
-                        # g' goes to a fresh tensor
-                        xa = ain[0]
-                        z.prod = torch.empty(G, d.Cin, ain[1].Cin, dtype=torch.float32, device=dz.device)
-                        wsp = hip.scratch(hip.load().adamml_conv_bwd_data_res_prod_workspace(byref(d)), dz.device)
-                        x.grad = torch.empty(x.shape, dtype=torch.bfloat16, device=dz.device)
-                        hip.next_meta = (2 * macs + 2.0 * G * d.N * d.H * d.W * d.Cin * ain[1].Cin, in_b * (1.0625 + 0.5 + 1.0 / 16) + out_b + w_b + 2.0 * G * d.N * d.H * d.W * ain[1].Cin, kern, R_FUSED)
-                        call("adamml_conv_bwd_data_res_prod_pooled", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(pgx.gy), ptr(pgx.code), pgx.T, ptr(x.grad), ptr(rmask), ract,
-                             ptr(sa), ptr(xa.data), ptr(xa.scale), ptr(xa.shift), xa.act, xa.gs, ain[1].Cin, ptr(z.prod), ptr(wsp), wsp.numel() * 4)
-                    elif res_prod:
+                    if (RES_PROD and z.alg and ain is not None and (not fb or fb_alg) and acc == 1 and rmask is not None and ain[0].data is not None
+                            and hip.load().adamml_conv_bwd_data_res_prod_supported(byref(d), ain[1].Cin)):
                         # the product g'^T a of the algebraic backward of the conv that produced z (its input a = ain[0]) is accumulated
                         # from the gradient tile inside this kernel: no separate pass over g' and a
                         xa = ain[0]
@@ -713,7 +670,6 @@ def _gram_colsum(rt, x, d):
 
 
 TPOOL_PROD = os.environ.get("ADAMML_TPOOL_BWD_PROD", "1") != "0"   # temporal-pool backward + the product g'^T a in one pass (A/B aid)
-POOLED_GRAD = os.environ.get("ADAMML_POOLED_GRAD", "0") == "1"     # round 6: the stage-1 boundary gradient stays in pooled form (PooledGrad; A/B aid)
 RES_PROD = os.environ.get("ADAMML_RES_PROD", "1") != "0"     # g'^T a accumulated inside the residual-backward data gradient (A/B aid)
 POOL_ZSEL = os.environ.get("ADAMML_POOL_ZSEL", "1") != "0"   # stem BatchNorm-backward sums over the pool windows (g_y, z_sel) (A/B aid)
 DW_FUSED = os.environ.get("ADAMML_DW_BWD_FUSED", "1") != "0"    # whole stride-1 depthwise backward in one pass (csrc/dwconv_bwd_fused.hip; A/B aid)
@@ -743,8 +699,6 @@ def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, m
     dev = y.device
     w2 = cs.weight                                              # fp32 master [Cout, Cin, 1, 1], contiguous
     P = out.prod if out.prod is not None else torch.empty(G, Cout, Cin, dtype=torch.float32, device=dev)
-    if out.prod is None:
-        out.grad = _dense_grad(out.grad)                     # (the product kernel reads the expanded gradient)
     g0 = out.grad
 
     def products():
@@ -784,28 +738,16 @@ def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, m
     tgt = x.src if x.src is not None else x
     if (Cout, Cin) == (256, 64):
         kern = "alg_stream_kernel"            # csrc/conv1x1_stream.hip serves this shape (bench.py groups launches by device kernel)
-    pg = g if isinstance(g, PooledGrad) else None
-    if pg is not None and not hip.load().adamml_conv_bwd_data_alg_pooled_supported(byref(d), pg.T):
-        g, pg = pg.dense(), None
-    out_b_g = out_b * (0.5 + 1.0 / 16) if pg is not None else out_b             # pooled rows + code words instead of the expanded gradient
     if sole_consumer and acc == 0 and tgt.vec is not None and tgt.pre_sums is None:
         sums = rt.bwd_arena.take(G * 2 * Cin * STAT_SLOTS)
-        hip.next_meta = (2 * macs, 3 * in_b + out_b_g + w_b, kern, R_FUSED)
-        if pg is not None:
-            call("adamml_conv_bwd_data_alg_pooled", byref(d), ptr(pg.gy), ptr(pg.code), pg.T, ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(w_alg), ptr(cadd),
-                 ptr(x.grad), 0, ptr(tgt.data), ptr(tgt.vec), tgt.act, ptr(sums))
-        else:
-            call("adamml_conv_bwd_data_alg", byref(d), ptr(g), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(w_alg), ptr(cadd), ptr(x.grad), 0,
-                 ptr(tgt.data), ptr(tgt.vec), tgt.act, ptr(sums))
+        hip.next_meta = (2 * macs, 3 * in_b + out_b + w_b, kern, R_FUSED)
+        call("adamml_conv_bwd_data_alg", byref(d), ptr(g), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(w_alg), ptr(cadd), ptr(x.grad), 0,
+             ptr(tgt.data), ptr(tgt.vec), tgt.act, ptr(sums))
         tgt.pre_sums = sums
     else:
-        hip.next_meta = (2 * macs, in_b * (2 + acc) + out_b_g + w_b, kern, R_FUSED)
-        if pg is not None:
-            call("adamml_conv_bwd_data_alg_pooled", byref(d), ptr(pg.gy), ptr(pg.code), pg.T, ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(w_alg), ptr(cadd),
-                 ptr(x.grad), acc, None, None, 0, None)
-        else:
-            call("adamml_conv_bwd_data_alg", byref(d), ptr(g), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(w_alg), ptr(cadd), ptr(x.grad), acc,
-                 None, None, 0, None)
+        hip.next_meta = (2 * macs, in_b * (2 + acc) + out_b + w_b, kern, R_FUSED)
+        call("adamml_conv_bwd_data_alg", byref(d), ptr(g), ptr(x.data), ptr(x.scale), ptr(x.shift), ptr(w_alg), ptr(cadd), ptr(x.grad), acc,
+             None, None, 0, None)
     # ---- weight gradient (weight-gradient stream): products over the pixels, then the per-group combination
     with _on_wgrad_stream(rt, (g, x.data, x.scale, aff, P)):
         if Gm is None:            # (conv_bn_add computed the Gram matrix and the column sums in the forward pass: its statistics)
@@ -872,7 +814,6 @@ def _accum_grad(t, g):
     if t.grad is None:
         t.grad = g
     else:
-        g, t.grad = _dense_grad(g), _dense_grad(t.grad)          # (a second contribution: the pooled form has no accumulating reader)
         n = g.numel() // g.shape[-1]
         call("adamml_bn_act_add", ptr(t.grad), None, None, 0, ACT_NONE, ptr(g), None, None, 0, ptr(t.grad), n, g.shape[-1], 1)
 
@@ -1085,26 +1026,19 @@ def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False, tpool=0, next_cs=None):
             g, out.grad = out.grad, None
             if g is None:
                 return
+            gx = torch.empty(full_shape, dtype=torch.bfloat16, device=dev)
             sa = rt.bwd_arena.take(G * 2 * C * STAT_SLOTS)
             lib = hip.load()
-            pooled_ok = (POOLED_GRAD and TPOOL_PROD and z.alg and idn is not None and x.requires_grad and cs.weight.requires_grad and _alg_supported(cs, d)
-                         and lib.adamml_temporal_pool_bwd_code_prod_supported(tpool, C, d.Cin) and lib.adamml_conv_bwd_data_alg_pooled_supported(byref(d), tpool))
-            gx = None if pooled_ok else torch.empty(full_shape, dtype=torch.bfloat16, device=dev)       # (the pooled form never allocates the 4.6 GB tensor)
             if TPOOL_PROD and z.alg and x.requires_grad and cs.weight.requires_grad and _alg_supported(cs, d) \
                     and lib.adamml_temporal_pool_bwd_code_prod_supported(tpool, C, d.Cin):
                 # the expanded gradient AND the product g'^T a the algebraic backward of conv3 needs first, from one pass (the product
                 # kernel read the 4.6 GB of g' back)
                 P = torch.empty(G, C, d.Cin, dtype=torch.float32, device=dev)
                 ws = hip.scratch(lib.adamml_temporal_pool_bwd_code_prod_workspace(d.N // tpool, tpool, d.OH * d.OW, C, d.Cin, G), dev)
-                # round 6: when both readers of the expanded gradient can expand the codes themselves (the algebraic data gradient of this conv3,
-                # the identity path of the block's conv1 data gradient), it is not written at all: blk.grad becomes a PooledGrad
-                pooled = POOLED_GRAD and idn is not None and bool(lib.adamml_conv_bwd_data_alg_pooled_supported(byref(d), tpool))
-                hip.next_meta = (2 * macs, in_b + (0.5 if pooled else 1.5) * out_b + out_b / 16, "tpool_bwd_prod_kernel", R_WGRAD)
-                call("adamml_temporal_pool_bwd_code_prod", ptr(g), ptr(code_t), None if pooled else ptr(gx), ptr(sa), ptr(x.data), ptr(x.scale), ptr(x.shift),
-                     x.gs, x.act, ptr(P), ptr(ws), ws.numel() * 4, d.N // tpool, tpool, d.OH * d.OW, C, d.Cin, G)
+                hip.next_meta = (2 * macs, in_b + 1.5 * out_b + out_b / 16, "tpool_bwd_prod_kernel", R_WGRAD)
+                call("adamml_temporal_pool_bwd_code_prod", ptr(g), ptr(code_t), ptr(gx), ptr(sa), ptr(x.data), ptr(x.scale), ptr(x.shift), x.gs, x.act,
+                     ptr(P), ptr(ws), ws.numel() * 4, d.N // tpool, tpool, d.OH * d.OW, C, d.Cin, G)
                 z.prod = P
-                if pooled:
-                    gx = PooledGrad(g, code_t, tpool, full_shape, G)
             else:
                 call("adamml_temporal_pool_bwd_code", ptr(g), ptr(code_t), ptr(gx), ptr(sa), d.N // tpool, tpool, d.OH * d.OW, C, G)
             z.pre_sums, z.sums_partial = sa, True

@@ -177,15 +177,6 @@ ADAMML_API int adamml_alg_wgrad_combine(const float* w, const float* aff, const 
 ADAMML_API int adamml_conv_bwd_data_alg(const adamml_conv_desc_t* d, const void* g, const void* a, const float* a_scale, const float* a_shift,
                              const void* w_alg, const float* epi_add, void* dx, int accumulate, const void* z_in, const float* bn_vec,
                              int act, double* sums, hipStream_t stream);
-/* The same data gradient when g' exists only in POOLED form (round 6): the gradient of a block output that fed nothing but a temporal max-pool
- * (models/common.py:4-33 behind the last block of a ResNet stage, models/resnet.py:205-209) is given as the pooled gradient g_y
- * [groups][N / T * (T / 2)][H W][Cout] and the 2-bit routing codes adamml_conv_fwd_bn_add_tpool stored ([..][Cout / 8] uint16); the
- * kernel expands them in its loader exactly as adamml_temporal_pool_bwd_code does (bit-identical fragments), so the expanded tensor is
- * never written or read.  (Cout, Cin) = (256, 64), T a power of two dividing d->N. */
-ADAMML_API int adamml_conv_bwd_data_alg_pooled_supported(const adamml_conv_desc_t* d, int T);
-ADAMML_API int adamml_conv_bwd_data_alg_pooled(const adamml_conv_desc_t* d, const void* g_y, const uint16_t* code, int T, const void* a, const float* a_scale,
-                                    const float* a_shift, const void* w_alg, const float* epi_add, void* dx, int accumulate, const void* z_in,
-                                    const float* bn_vec, int act, double* sums, hipStream_t stream);
 
 /* Data gradient of a 1x1 / stride-1 conv whose INPUT is the output of a residual add  out = act(bn_a(z_a) + idn)
  * (models/resnet.py:110-111; sound_mobilenet_v2.py:67), finishing that add's backward in the epilogue:
@@ -211,16 +202,6 @@ ADAMML_API size_t adamml_conv_bwd_data_res_prod_workspace(const adamml_conv_desc
 ADAMML_API int adamml_conv_bwd_data_res_prod(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx, const uint8_t* res_mask,
                                   int res_act, double* sums_a, const void* a, const float* a_scale, const float* a_shift, int a_act,
                                   int a_gstride, int a_channels, float* prod, void* workspace, size_t workspace_bytes, hipStream_t stream);
-/* adamml_conv_bwd_data_res_prod with the identity-path gradient given in POOLED form (round 6): the block whose conv1 this is ends a ResNet
- * stage, its output fed only the temporal max-pool, so the gradient of that output exists as (g_y, code) of adamml_conv_fwd_bn_add_tpool /
- * adamml_temporal_pool_bwd_code_prod(g2 = NULL).  A tile is (clip, 16 pixels) x T = 8 frames; an epilogue thread loads the 4 pooled rows and
- * code words of its pixel and expands them as adamml_temporal_pool_bwd_code does (bit-identical), adds them to W^T dz, masks with res_mask
- * and writes g' to dx (a fresh tensor, not accumulated into); sums_a / prod as adamml_conv_bwd_data_res_prod.  H W % 16 == 0, N % 8 == 0. */
-ADAMML_API int adamml_conv_bwd_data_res_prod_pooled_supported(const adamml_conv_desc_t* d, int a_channels, int T);
-ADAMML_API int adamml_conv_bwd_data_res_prod_pooled(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, const void* g_y,
-                                         const uint16_t* code, int T, void* dx, const uint8_t* res_mask, int res_act, double* sums_a,
-                                         const void* a, const float* a_scale, const float* a_shift, int a_act, int a_gstride,
-                                         int a_channels, float* prod, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 /* autograd w.r.t. the weight: dw (fp32 OIHW, cin_true input channels) += dz^T * im2col(act(x)).  The pixel axis is
  * split over workgroups; with a workspace of adamml_conv_bwd_weight_workspace() bytes the partial tiles are written
@@ -380,8 +361,7 @@ ADAMML_API int adamml_temporal_pool_bwd_code(const void* g_y, const uint16_t* co
  * BatchNorm in_scale / in_shift / in_act): prod [groups][C][Cin] = g2^T a per group, OVERWRITTEN -- the product
  * adamml_conv_bwd_weight_grouped(dz = g2) computes for the algebraic BatchNorm backward of conv3 (adamml_alg_sumfix needs it before the
  * coefficients exist), without reading g2 back.  g2 bit-identical, sums_a as adamml_temporal_pool_bwd_code.
- * (T, C, Cin) = (8, 256, 64): the end of ResNet-50 stage 1.  g2 may be NULL (round 6): the expanded gradient is then not written at all -- its
- * readers expand (g_y, code) themselves (adamml_conv_bwd_data_alg_pooled, adamml_conv_bwd_data_res_prod_pooled); sums_a and prod as before. */
+ * (T, C, Cin) = (8, 256, 64): the end of ResNet-50 stage 1. */
 ADAMML_API int adamml_temporal_pool_bwd_code_prod_supported(int T, int C, int Cin);
 ADAMML_API size_t adamml_temporal_pool_bwd_code_prod_workspace(int NB, int T, int HW, int C, int Cin, int groups);
 ADAMML_API int adamml_temporal_pool_bwd_code_prod(const void* g_y, const uint16_t* code, void* g2, double* sums_a, const void* a, const float* in_scale,

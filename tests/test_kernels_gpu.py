@@ -1386,84 +1386,6 @@ def test_conv_bwd_data_res_prod_equals_res_then_grouped_product():
     assert e64 <= 2e-4 and ekern <= 2e-5, (e64, ekern)
 
 
-@pytest.mark.parametrize("G,clips,H", [(2, 6, 56), (1, 3, 28), (5, 2, 20)])
-def test_pooled_gradient_readers_equal_expand_then_read(G, clips, H):
-    """Round 6: the gradient behind the stage-1 temporal pool stays in POOLED form (pooled gradient + 2-bit codes); its producer does not
-    write the expanded tensor and its two readers expand the codes in their loaders:
-      * adamml_temporal_pool_bwd_code_prod(g2 = NULL): sum(g2) and P = g2^T a as with g2 written;
-      * adamml_conv_bwd_data_alg_pooled == adamml_conv_bwd_data_alg on the expanded g2 (dx bit-identical; BatchNorm-fused and accumulating forms);
-      * adamml_conv_bwd_data_res_prod_pooled == adamml_conv_bwd_data_res_prod with the expanded g2 as the identity-path gradient (dx
-        bit-identical; sum(g') and P up to summation order: another tile order)."""
-    torch.manual_seed(G * 7 + H)
-    T, To, C, Ca, Cm = 8, 4, 256, 64, 64
-    N, Q = clips * T, H * H
-    assert Q % 16 == 0
-    gy = (torch.randn(G * clips * To, H, H, C, device=DEV)).to(torch.bfloat16)
-    code_i16 = torch.randint(-32768, 32768, (G * clips * To, H, H, C // 8), device=DEV, dtype=torch.int32).to(torch.int16)
-    a = (torch.randn(G * N, H, H, Ca, device=DEV) * 1.5).to(torch.bfloat16)
-    avec = torch.rand(G, 4, Ca, device=DEV) + 0.5
-    avec[:, 1] -= 0.6
-    # ---- the producer with and without the expanded tensor
-    d3 = ConvDesc(N, H, H, Ca, H, H, C, 1, 1, 1, 0, 1, 1, 0, G, 4 * Ca)            # conv3 of the stage's last block: Ca -> C, lazy input a
-    lib = hip.load()
-    assert lib.adamml_temporal_pool_bwd_code_prod_supported(T, C, Ca) == 1
-    ws = torch.empty(lib.adamml_temporal_pool_bwd_code_prod_workspace(clips, T, Q, C, Ca, G) // 4 + 1, device=DEV)
-    g2 = torch.empty(G * N, H, H, C, dtype=torch.bfloat16, device=DEV)
-    s_full, s_none = (torch.zeros(G, STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV) for _ in range(2))
-    P_full, P_none = torch.empty(G, C, Ca, device=DEV), torch.empty(G, C, Ca, device=DEV)
-    call("adamml_temporal_pool_bwd_code_prod", ptr(gy), ptr(code_i16), ptr(g2), ptr(s_full), ptr(a), ptr(avec[0, 0]), ptr(avec[0, 1]), 4 * Ca, 1, ptr(P_full),
-         ptr(ws), ws.numel() * 4, clips, T, Q, C, Ca, G)
-    call("adamml_temporal_pool_bwd_code_prod", ptr(gy), ptr(code_i16), None, ptr(s_none), ptr(a), ptr(avec[0, 0]), ptr(avec[0, 1]), 4 * Ca, 1, ptr(P_none),
-         ptr(ws), ws.numel() * 4, clips, T, Q, C, Ca, G)
-    assert torch.equal(P_full, P_none) and torch.equal(ssum(s_full), ssum(s_none))
-    # ---- reader 1: the algebraic data gradient of conv3 (256 <- 64)
-    assert lib.adamml_conv_bwd_data_alg_pooled_supported(byref(d3), T) == 1
-    w_alg = (torch.randn(G, Ca, C + Ca, device=DEV) * 0.05).to(torch.bfloat16)
-    cadd = torch.randn(G, Ca, device=DEV) * 0.1
-    zin = torch.randn(G * N, H, H, Ca, device=DEV).to(torch.bfloat16)
-    vin = torch.rand(G, 4, Ca, device=DEV) + 0.5
-    vin[:, 1] -= 1.0
-    base = torch.randn(G * N, H, H, Ca, device=DEV).to(torch.bfloat16)
-    for mode in ("bn", "acc", "plain"):
-        dx_ref, dx = base.clone(), base.clone()
-        sr, sp = torch.zeros(G, STAT_SLOTS, 2 * Ca, dtype=torch.float64, device=DEV), torch.zeros(G, STAT_SLOTS, 2 * Ca, dtype=torch.float64, device=DEV)
-        if mode == "bn":
-            call("adamml_conv_bwd_data_alg", byref(d3), ptr(g2), ptr(a), ptr(avec[0, 0]), ptr(avec[0, 1]), ptr(w_alg), ptr(cadd), ptr(dx_ref), 0, ptr(zin), ptr(vin), 1, ptr(sr))
-            call("adamml_conv_bwd_data_alg_pooled", byref(d3), ptr(gy), ptr(code_i16), T, ptr(a), ptr(avec[0, 0]), ptr(avec[0, 1]), ptr(w_alg), ptr(cadd), ptr(dx), 0,
-                 ptr(zin), ptr(vin), 1, ptr(sp))
-            assert torch.allclose(ssum(sp), ssum(sr), rtol=1e-6, atol=1e-6 * ssum(sr).abs().max().item())
-        else:
-            acc = 1 if mode == "acc" else 0
-            call("adamml_conv_bwd_data_alg", byref(d3), ptr(g2), ptr(a), ptr(avec[0, 0]), ptr(avec[0, 1]), ptr(w_alg), ptr(cadd), ptr(dx_ref), acc, None, None, 0, None)
-            call("adamml_conv_bwd_data_alg_pooled", byref(d3), ptr(gy), ptr(code_i16), T, ptr(a), ptr(avec[0, 0]), ptr(avec[0, 1]), ptr(w_alg), ptr(cadd), ptr(dx), acc,
-                 None, None, 0, None)
-        assert torch.equal(dx, dx_ref), "algebraic data gradient from the pooled form (%s)" % mode
-    # ---- reader 2: conv1 of the stage's last block, C -> Cm: its data gradient finishes the PREVIOUS block's residual backward; the identity
-    # path gradient is g2.  a2 = the conv3 input of that previous block (the product operand)
-    d1 = ConvDesc(N, H, H, C, H, H, Cm, 1, 1, 1, 0, 1, 0, 0, G, 0)
-    if not lib.adamml_conv_bwd_data_res_prod_supported(byref(d1), Ca):
-        return                                   # (the product form needs >= 4096 tiles: the 56^2 case only)
-    assert lib.adamml_conv_bwd_data_res_prod_pooled_supported(byref(d1), Ca, T) == 1
-    dz = (torch.randn(G * N, H, H, Cm, device=DEV) * 0.5).to(torch.bfloat16)
-    w1 = torch.randn(Cm, C, 1, 1, device=DEV) * (2.0 / C) ** 0.5
-    wd = pack(w1, C, 1)
-    mask = torch.randint(0, 256, (G * N * Q * C // 8,), dtype=torch.uint8, device=DEV)
-    a2 = (torch.randn(G * N, H, H, Ca, device=DEV) * 1.5).to(torch.bfloat16)
-    wsp = torch.empty(lib.adamml_conv_bwd_data_res_prod_workspace(byref(d1)) // 4 + 1, device=DEV)
-    dx_ref = g2.clone()
-    s_ref, s_p = torch.zeros(G, STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV), torch.zeros(G, STAT_SLOTS, 2 * C, dtype=torch.float64, device=DEV)
-    P_ref, P_p = torch.empty(G, C, Ca, device=DEV), torch.empty(G, C, Ca, device=DEV)
-    call("adamml_conv_bwd_data_res_prod", byref(d1), ptr(dz), ptr(wd), ptr(dx_ref), ptr(mask), 1, ptr(s_ref), ptr(a2), ptr(avec[0, 0]), ptr(avec[0, 1]), 1, 4 * Ca, Ca,
-         ptr(P_ref), ptr(wsp), wsp.numel() * 4)
-    dx = torch.full_like(dx_ref, float("nan"))
-    call("adamml_conv_bwd_data_res_prod_pooled", byref(d1), ptr(dz), ptr(wd), ptr(gy), ptr(code_i16), T, ptr(dx), ptr(mask), 1, ptr(s_p), ptr(a2), ptr(avec[0, 0]),
-         ptr(avec[0, 1]), 1, 4 * Ca, Ca, ptr(P_p), ptr(wsp), wsp.numel() * 4)
-    assert torch.equal(dx, dx_ref), "residual-backward data gradient with the pooled identity path"
-    cr, cp = ssum(s_ref), ssum(s_p)
-    assert torch.allclose(cp, cr, rtol=1e-6, atol=1e-6 * cr.abs().max().item())
-    assert (P_p - P_ref).abs().max().item() <= 2e-5 * P_ref.abs().max().item()
-
-
 @pytest.mark.parametrize("T,clips,H,Cin,Cout,G,lazy", [(8, 3, 56, 64, 256, 2, True), (4, 5, 28, 128, 512, 3, True), (2, 7, 14, 256, 1024, 2, True),
                                                         (8, 2, 13, 64, 128, 1, False), (4, 3, 9, 64, 256, 2, False)])
 def test_conv_fwd_bn_add_tpool_equals_add_then_pool(T, clips, H, Cin, Cout, G, lazy):
