@@ -2421,8 +2421,16 @@ extern "C" int adamml_conv_bwd_data_res(const adamml_conv_desc_t* d, const void*
     return conv_launch(&g, dz, w_dgrad_packed, nullptr, nullptr, dx, sums_a, z_a, vec_a, ACT_NONE, stream, nullptr, &r);
 }
 
+// (csrc/res_prod_stream.hip: the barrier-free streaming form of the layer-1 shape)
+int adamml_res_prod_stream_supported(const adamml_conv_desc_t* d, int a_channels);
+size_t adamml_res_prod_stream_workspace(const adamml_conv_desc_t* d);
+int adamml_res_prod_stream_launch(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx, const uint8_t* res_mask,
+                                  double* sums_a, const void* a, const float* a_scale, const float* a_shift, int a_act, int a_gstride,
+                                  float* prod, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 extern "C" size_t adamml_conv_bwd_data_res_prod_workspace(const adamml_conv_desc_t* d) {
     if (!d) return 0;
+    if (adamml_res_prod_stream_supported(d, 64)) return adamml_res_prod_stream_workspace(d);
     const int groups = d->groups < 1 ? 1 : d->groups;
     const int n_ptiles = ceil_div(d->N * d->OH * d->OW, BP), n_ctiles = ceil_div(d->Cin, 128);      // (dgrad: the output channels are d->Cin)
     long nsp = 1536 / ((long)n_ctiles * groups);
@@ -2432,8 +2440,13 @@ extern "C" size_t adamml_conv_bwd_data_res_prod_workspace(const adamml_conv_desc
 }
 
 extern "C" int adamml_conv_bwd_data_res_prod_supported(const adamml_conv_desc_t* d, int a_channels) {
+    if (d && adamml_conv_bwd_data_res_supported(d) && adamml_res_prod_stream_supported(d, a_channels)) return 1;
     return d && adamml_conv_bwd_data_res_supported(d) && d->Cin % 128 == 0 && a_channels == 64 &&
            (long)ceil_div(d->N * d->OH * d->OW, BP) * (d->Cin / 128) * (d->groups < 1 ? 1 : d->groups) >= 4096 ? 1 : 0;
+}
+
+extern "C" int adamml_conv_bwd_data_res_prod_streams(const adamml_conv_desc_t* d, int a_channels) {
+    return d && adamml_conv_bwd_data_res_supported(d) && adamml_res_prod_stream_supported(d, a_channels) ? 1 : 0;
 }
 
 extern "C" int adamml_conv_bwd_data_res_prod(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
@@ -2442,6 +2455,9 @@ extern "C" int adamml_conv_bwd_data_res_prod(const adamml_conv_desc_t* d, const 
                                              void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!adamml_conv_bwd_data_res_prod_supported(d, a_channels)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res_prod: unsupported shape");
     if (!res_mask || !sums_a || !a || !prod) return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_res_prod: null argument");
+    if (adamml_res_prod_stream_supported(d, a_channels))
+        return adamml_res_prod_stream_launch(d, dz, w_dgrad_packed, dx, res_mask, sums_a, a, a_scale, a_shift, a_act, a_gstride, prod, workspace,
+                                             workspace_bytes, stream);
     adamml_conv_desc_t dd = *d;                          // data gradient of d: swap the channel roles, as adamml_conv_bwd_data_res does
     dd.H = d->OH; dd.W = d->OW; dd.Cin = d->Cout; dd.OH = d->H; dd.OW = d->W; dd.Cout = d->Cin;
     dd.stride = 1; dd.up = 1; dd.pad = 0; dd.act = ACT_NONE; dd.accumulate = 1; dd.in_gstride = 0;

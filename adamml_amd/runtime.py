@@ -405,8 +405,8 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
             # the wide 1x1 layers of ResNet layers 3-4 run on the activation-stationary streaming kernels of csrc/conv1x1_wide.hip
             wide = [bool(lib.adamml_conv1x1_wide_supported(byref(d), k)) for k in (0, 3, 4)]
             if wide[0]:
-                kern_f = "wide_expand_kernel"
-            kern_acc = ("wide_expand_kernel" if wide[2] else kern_acc[0], "wide_expand_kernel" if wide[1] else kern_acc[1])
+                kern_f = "wide_all_kernel"
+            kern_acc = ("wide_all_kernel" if wide[2] else kern_acc[0], "wide_all_kernel" if wide[1] else kern_acc[1])
     role_f = None if cs.depthwise else (R_KXK if cs.kh * cs.kw > 1 else R_1X1)
     role_b = None if cs.depthwise else (R_KXK if (cs.kh * cs.kw > 1 or cs.stride > 1) else R_1X1)
     role_bf = role_b if role_b != R_1X1 else R_FUSED          # data gradient with a fused BatchNorm-backward / residual epilogue
@@ -522,7 +522,9 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                         z.prod = torch.empty(G, d.Cin, ain[1].Cin, dtype=torch.float32, device=dz.device)
                         need = hip.load().adamml_conv_bwd_data_res_prod_workspace(byref(d))
                         wsp = hip.scratch(need, dz.device)
-                        hip.next_meta = (2 * macs + 2.0 * G * d.N * d.H * d.W * d.Cin * ain[1].Cin, in_b * 2.0625 + out_b + w_b + 2.0 * G * d.N * d.H * d.W * ain[1].Cin, kern, R_FUSED)
+                        # (layer 1: the barrier-free streaming kernel of csrc/res_prod_stream.hip; its workspace is sized for it)
+                        kern_rp = "res_prod_stream_kernel" if hip.load().adamml_conv_bwd_data_res_prod_streams(byref(d), ain[1].Cin) else kern
+                        hip.next_meta = (2 * macs + 2.0 * G * d.N * d.H * d.W * d.Cin * ain[1].Cin, in_b * 2.0625 + out_b + w_b + 2.0 * G * d.N * d.H * d.W * ain[1].Cin, kern_rp, R_FUSED)
                         call("adamml_conv_bwd_data_res_prod", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), ptr(rmask), ract, ptr(sa), ptr(xa.data),
                              ptr(xa.scale), ptr(xa.shift), xa.act, xa.gs, ain[1].Cin, ptr(z.prod), ptr(wsp), wsp.numel() * 4)
                     else:

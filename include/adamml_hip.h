@@ -199,6 +199,10 @@ ADAMML_API int adamml_conv_bwd_data_res(const adamml_conv_desc_t* d, const void*
  * workspace of adamml_conv_bwd_data_res_prod_workspace() bytes; prod is overwritten. */
 ADAMML_API int adamml_conv_bwd_data_res_prod_supported(const adamml_conv_desc_t* d, int a_channels);
 ADAMML_API size_t adamml_conv_bwd_data_res_prod_workspace(const adamml_conv_desc_t* d);
+/* 1 when the launch is served by the barrier-free streaming kernel of csrc/res_prod_stream.hip (the layer-1 shape: d->Cin == 256,
+ * d->Cout == 64, a_channels == 64; same results: dx bit-identical) rather than the tile kernel -- a label for profilers, as
+ * adamml_conv1x1_narrow_supported. */
+ADAMML_API int adamml_conv_bwd_data_res_prod_streams(const adamml_conv_desc_t* d, int a_channels);
 ADAMML_API int adamml_conv_bwd_data_res_prod(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx, const uint8_t* res_mask,
                                   int res_act, double* sums_a, const void* a, const float* a_scale, const float* a_shift, int a_act,
                                   int a_gstride, int a_channels, float* prod, void* workspace, size_t workspace_bytes, hipStream_t stream);

@@ -1335,13 +1335,17 @@ def test_gram_colsum_kernel(C, P, G, lazy, act):
         assert torch.allclose(sv, sold, rtol=1e-4, atol=1e-4 * sref.abs().max().item())
 
 
-def test_conv_bwd_data_res_prod_equals_res_then_grouped_product():
+@pytest.mark.parametrize("N,H,stream", [(45, 56, 1), (45, 56, 0), (5, 29, 1), (3, 37, 1)])
+def test_conv_bwd_data_res_prod_equals_res_then_grouped_product(N, H, stream, monkeypatch):
     """adamml_conv_bwd_data_res_prod: the residual-backward data gradient in the algebraic backward's form (accumulate + 1-bit mask +
     sum(g') only) which also accumulates P = g'^T a from the gradient tile it forms -- dx and the sums must equal
     adamml_conv_bwd_data_res bit for bit, and P the product adamml_conv_bwd_weight_grouped computes in its own pass over the g' that
-    kernel wrote (same bf16 operands, fp32 accumulation in another order) and the fp64 product."""
+    kernel wrote (same bf16 operands, fp32 accumulation in another order) and the fp64 product.  Both forms: the barrier-free streaming
+    kernel of csrc/res_prod_stream.hip (the layer-1 shape; also at pixel counts that do not fill its 32-pixel tiles: 4205, 4107) and the
+    tile kernel of csrc/conv_gemm.hip behind it (ADAMML_RES_PROD_STREAM=0, read at every call)."""
+    monkeypatch.setenv("ADAMML_RES_PROD_STREAM", str(stream))
     torch.manual_seed(11)
-    G, N, H, Cb, Cm, Ca = 2, 45, 56, 256, 64, 64
+    G, Cb, Cm, Ca = 2, 256, 64, 64
     P = N * H * H
     d = ConvDesc(N, H, H, Cb, H, H, Cm, 1, 1, 1, 0, 1, 0, 0, G, 0)                  # conv1 of the NEXT block: Cb -> Cm; its data gradient has Cb channels
     assert hip.load().adamml_conv_bwd_data_res_prod_supported(byref(d), Ca)
