@@ -2075,11 +2075,22 @@ extern "C" int adamml_conv_fwd_bn_add_supported(const adamml_conv_desc_t* d) {
     return d && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && (d->up <= 1) && d->Cin % 8 == 0 && d->Cout % 8 == 0 ? 1 : 0;
 }
 
+// (csrc/conv1x1_fadd_stream.hip: the barrier-free streaming form of the layer-2 shape)
+int adamml_conv1x1_fadd_stream_supported(const adamml_conv_desc_t* d);
+int adamml_conv1x1_fadd_stream_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
+                                      const float* bn_vec, const void* idn, const float* id_scale, const float* id_shift, int id_gstride, int act,
+                                      void* out, uint8_t* mask_out, hipStream_t stream);
+extern "C" int adamml_conv_fwd_bn_add_streams(const adamml_conv_desc_t* d) {
+    return d && adamml_conv_fwd_bn_add_supported(d) && adamml_conv1x1_fadd_stream_supported(d) ? 1 : 0;
+}
+
 extern "C" int adamml_conv_fwd_bn_add(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
                                       const float* in_shift, const float* bn_vec, const void* idn, const float* id_scale,
                                       const float* id_shift, int id_gstride, int act, void* out, uint8_t* mask_out, hipStream_t stream) {
     if (!adamml_conv_fwd_bn_add_supported(d)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd_bn_add: 1x1 / stride-1 convs only");
     if (!bn_vec) return adamml_set_error(ADAMML_EINVAL, "conv_fwd_bn_add: null BatchNorm vectors");
+    if (idn && adamml_conv1x1_fadd_stream_supported(d))
+        return adamml_conv1x1_fadd_stream_launch(d, x, w_packed, in_scale, in_shift, bn_vec, idn, id_scale, id_shift, id_gstride, act, out, mask_out, stream);
     FaddEpi f{bn_vec, idn, id_scale, id_shift, id_gstride, act, mask_out, 0, nullptr, nullptr};
     return conv_launch(d, x, w_packed, in_scale, in_shift, out, nullptr, nullptr, nullptr, 0, stream, nullptr, nullptr, nullptr, nullptr, &f);
 }

@@ -984,6 +984,8 @@ def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False, tpool=0, next_cs=None):
                  ptr(next_cs.w_fwd), ptr(y_n), ptr(st_n))
             nxt = (next_cs, y_n, st_n)
         else:
+            if idn is not None and hip.load().adamml_conv_fwd_bn_add_streams(byref(d)):
+                hip.next_meta = hip.next_meta[:2] + ("conv1x1_fadd_stream_kernel", R_FUSED)       # (the layer-2 shape: csrc/conv1x1_fadd_stream.hip)
             call("adamml_conv_fwd_bn_add", byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(vec),
                  ptr(idn.data) if idn is not None else None, ptr(idn.scale) if idn is not None else None,
                  ptr(idn.shift) if idn is not None else None, idn.gs if idn is not None else 0, act, ptr(out_t), ptr(mask_t))

@@ -94,6 +94,10 @@ ADAMML_API int adamml_conv1x1_wide_supported(const adamml_conv_desc_t* d, int ki
  * id_gstride floats) when given; out = act(scale*z + shift + idn'), mask_out (optional) = 1 bit per element, act'(out) != 0.
  * The raw conv output z is never written. */
 ADAMML_API int adamml_conv_fwd_bn_add_supported(const adamml_conv_desc_t* d);
+/* 1 when an adamml_conv_fwd_bn_add launch WITH an identity operand is served by the barrier-free streaming kernel of
+ * csrc/conv1x1_fadd_stream.hip (the ResNet-50 layer-2 shape: 128 -> 512 channels, >= 4096 pixels per group; out and mask_out
+ * bit-identical) rather than the tile kernel -- a label for profilers.  ADAMML_FADD_STREAM=0 disables it (read at every call). */
+ADAMML_API int adamml_conv_fwd_bn_add_streams(const adamml_conv_desc_t* d);
 ADAMML_API int adamml_conv_fwd_bn_add(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
                            const float* bn_vec, const void* idn, const float* id_scale, const float* id_shift, int id_gstride, int act,
                            void* out, uint8_t* mask_out, hipStream_t stream);

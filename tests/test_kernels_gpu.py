@@ -1,6 +1,7 @@
 """Per-kernel parity: every C-ABI entry point of libadamml_hip against the torch fp32 operator it replaces
 (computed on the same bf16-rounded operands).  Tolerances: bf16 output rounding (2^-8 relative) on top of
 fp32 accumulation -> rtol 1e-2 / atol scaled to the output magnitude."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -1182,7 +1183,10 @@ def test_algebraic_bn_backward_equals_explicit_dz(N, H, Cin, Cout, G, mode):
 
 
 @pytest.mark.parametrize("G,N,H,Cin,Cout,lazy_idn,act", [(3, 2, 28, 64, 256, False, 1), (2, 3, 14, 128, 512, True, 1), (1, 2, 10, 96, 24, False, 0),
-                                                         (5, 1, 7, 256, 512, False, 1)])
+                                                         (5, 1, 7, 256, 512, False, 1),
+                                                         # the layer-2 shape at pixel counts the streaming kernel of csrc/conv1x1_fadd_stream.hip
+                                                         # serves (4704 = 147 full tiles; 4205 and 8410: a partial last tile)
+                                                         (2, 6, 28, 128, 512, True, 1), (1, 5, 29, 128, 512, False, 1), (3, 10, 29, 128, 512, True, 1)])
 def test_conv_fwd_bn_add_and_gram_statistics(G, N, H, Cin, Cout, lazy_idn, act):
     """conv3 + BatchNorm + residual add + activation in ONE kernel (adamml_conv_fwd_bn_add) == conv (adamml_conv_fwd) followed
     by adamml_bn_act_add_mask, i.e. models/resnet.py:104-112 on a lazily normalised input; the train-mode statistics it needs
@@ -1235,6 +1239,23 @@ def test_conv_fwd_bn_add_and_gram_statistics(G, N, H, Cin, Cout, lazy_idn, act):
          ptr(ivec[0, 0]) if lazy_idn else None, ptr(ivec[0, 1]) if lazy_idn else None, 4 * Cout if lazy_idn else 0, act, ptr(got), ptr(got_mask))
     assert torch.equal(got, want)                        # same staged bf16 conv tile, same fp32 epilogue arithmetic
     assert torch.equal(got_mask, want_mask)
+    streams = hip.load().adamml_conv_fwd_bn_add_streams(byref(d))
+    assert streams == (1 if (Cin, Cout) == (128, 512) and P >= 4096 else 0)
+    if streams:
+        # the tile kernel behind it (ADAMML_FADD_STREAM is read at every call), and the streaming kernel without a mask
+        os.environ["ADAMML_FADD_STREAM"] = "0"
+        try:
+            assert hip.load().adamml_conv_fwd_bn_add_streams(byref(d)) == 0
+            got2, got_mask2 = torch.empty_like(z), torch.zeros_like(want_mask)
+            call("adamml_conv_fwd_bn_add", byref(d), ptr(x), ptr(wp), ptr(xvec[0, 0]), ptr(xvec[0, 1]), ptr(vec), ptr(idn),
+                 ptr(ivec[0, 0]) if lazy_idn else None, ptr(ivec[0, 1]) if lazy_idn else None, 4 * Cout if lazy_idn else 0, act, ptr(got2), ptr(got_mask2))
+        finally:
+            del os.environ["ADAMML_FADD_STREAM"]
+        assert torch.equal(got2, got) and torch.equal(got_mask2, got_mask)
+        got2.zero_()
+        call("adamml_conv_fwd_bn_add", byref(d), ptr(x), ptr(wp), ptr(xvec[0, 0]), ptr(xvec[0, 1]), ptr(vec), ptr(idn),
+             ptr(ivec[0, 0]) if lazy_idn else None, ptr(ivec[0, 1]) if lazy_idn else None, 4 * Cout if lazy_idn else 0, act, ptr(got2), None)
+        assert torch.equal(got2, got)
     # without an identity operand and without a mask
     call("adamml_bn_act_add_mask", ptr(z), ptr(vec[0, 0]), ptr(vec[0, 1]), 4 * Cout, act, None, None, None, 0, ptr(want), None, P, Cout, G)
     call("adamml_conv_fwd_bn_add", byref(d), ptr(x), ptr(wp), ptr(xvec[0, 0]), ptr(xvec[0, 1]), ptr(vec), None, None, None, 0, act, ptr(got), None)
