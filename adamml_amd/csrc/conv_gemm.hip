@@ -2415,6 +2415,14 @@ extern "C" int adamml_conv_bwd_data_res_supported(const adamml_conv_desc_t* d) {
     return d && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cin % 8 == 0 && d->Cout % 8 == 0 ? 1 : 0;
 }
 
+// (csrc/res_prod_stream.hip: the barrier-free streaming forms)
+int adamml_res_stream_supported(const adamml_conv_desc_t* d);
+int adamml_res_stream_launch(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx, const uint8_t* res_mask, double* sums_a,
+                             hipStream_t stream);
+extern "C" int adamml_conv_bwd_data_res_streams(const adamml_conv_desc_t* d) {
+    return d && adamml_conv_bwd_data_res_supported(d) && adamml_res_stream_supported(d) ? 1 : 0;
+}
+
 extern "C" int adamml_conv_bwd_data_res(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
                                         int accumulate, const void* res_out, const uint8_t* res_mask, int res_act, const void* z_a, const float* vec_a,
                                         double* sums_a, const void* z_b, const float* vec_b, double* sums_b,
@@ -2423,6 +2431,8 @@ extern "C" int adamml_conv_bwd_data_res(const adamml_conv_desc_t* d, const void*
     if ((z_b != nullptr) != (vec_b != nullptr) || (z_b != nullptr) != (sums_b != nullptr))
         return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_res: incomplete second BatchNorm operand");
     if (!adamml_conv_bwd_data_res_supported(d)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res: only 1x1 / stride-1 convs");
+    if (accumulate && res_mask && !z_a && !z_b && adamml_res_stream_supported(d))       // (the algebraic backward's form at the layer-2 shape)
+        return adamml_res_stream_launch(d, dz, w_dgrad_packed, dx, res_mask, sums_a, stream);
     adamml_conv_desc_t g = *d;
     g.N = d->N; g.H = d->OH; g.W = d->OW; g.Cin = d->Cout;
     g.OH = d->H; g.OW = d->W; g.Cout = d->Cin;

@@ -33,10 +33,13 @@ struct RPS {
     int in_gs, act, P;
 };
 
-constexpr int C = 256, K = 64, CIN = 64, TPX = 32;
+constexpr int CIN = 64, TPX = 32;
 constexpr int ZROW = 64 * 2 + 8, XROW = CIN * 2 + 8;
 
-__global__ __launch_bounds__(256, 2) void res_prod_stream_kernel(RPS p) {
+// NQ waves = NQ x 64 gradient channels; K = channels of dz; PF: with the product (layer 1: <4, 64, true>; layer 2 without it: <8, 128, false>)
+template <int NQ, int K, bool PF>
+__global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void res_prod_stream_kernel(RPS p) {
+    constexpr int C = NQ * 64, KS = K / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_vec = reinterpret_cast<float*>(smem);                  // [2][CIN]
     char* s_stage = smem + 2 * CIN * 4;                             // [4 waves][32][ZROW + XROW]
@@ -48,30 +51,32 @@ __global__ __launch_bounds__(256, 2) void res_prod_stream_kernel(RPS p) {
         p.dz += pp * K;
         p.dx += pp * C + q * 64;
         p.mask += pp * (C / 8) + q * 8;
-        p.a += pp * CIN;
+        if (PF) p.a += pp * CIN;
         p.sums += (size_t)g * ADAMML_STAT_SLOTS * 2 * C;
     }
-    for (int i = tid; i < CIN; i += 256) {
-        s_vec[i] = p.in_scale ? p.in_scale[(size_t)g * p.in_gs + i] : 1.f;
-        s_vec[CIN + i] = p.in_scale ? p.in_shift[(size_t)g * p.in_gs + i] : 0.f;
-    }
-    char* zs = s_stage + q * (TPX * (ZROW + XROW));
+    if (PF)
+        for (int i = tid; i < CIN; i += NQ * 64) {
+            s_vec[i] = p.in_scale ? p.in_scale[(size_t)g * p.in_gs + i] : 1.f;
+            s_vec[CIN + i] = p.in_scale ? p.in_shift[(size_t)g * p.in_gs + i] : 0.f;
+        }
+    constexpr int WAREA = TPX * (ZROW + (PF ? XROW : 0));
+    char* zs = s_stage + q * WAREA;
     char* xs = zs + TPX * ZROW;
-    for (int i = lane; i < TPX * (ZROW + XROW) / 8; i += 64) reinterpret_cast<unsigned long long*>(zs)[i] = 0ull;
+    for (int i = lane; i < WAREA / 8; i += 64) reinterpret_cast<unsigned long long*>(zs)[i] = 0ull;
     __syncthreads();
     auto uniform = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
     const float alo = uniform(p.in_scale ? act_lo(p.act) : -INFINITY), ahi = uniform(p.in_scale ? act_hi(p.act) : INFINITY);
-    const bool lazy = p.in_scale != nullptr;
+    const bool lazy = PF && p.in_scale != nullptr;
     // ---- this wave's weight slice: A fragments (row = gradient channel 64 q + 16 ct + li, k = 32 ks + 8 lg ..)
-    bf16x8 wr[4][2];
+    bf16x8 wr[4][KS];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
             wr[ct][ks] = *reinterpret_cast<const bf16x8*>(p.w + (size_t)(q * 64 + ct * 16 + li) * K + ks * 32 + lg * 8);
-    f32x4 acc[4][4];
+    f32x4 acc[PF ? 4 : 1][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < (PF ? 4 : 1); ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     float sa[8];
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void res_prod_stream_kernel(RPS p) {
     // this lane's four (pixel, 8-channel chunk) slots of a tile: chunk lane % 8 of pixels lane / 8 + 8 i
     const int zch = lane & 7, zpx = lane >> 3;
 
-    bf16x8 dzf[2][2], old[4], ra[4];
+    bf16x8 dzf[2][KS], old[4], ra[PF ? 4 : 1];
     unsigned mb[4];
     // (uniform 64-bit bases -- the tile is the same for the whole wave -- plus 32-bit lane offsets)
     auto issue = [&](int tile) {
@@ -89,20 +94,20 @@ __global__ __launch_bounds__(256, 2) void res_prod_stream_kernel(RPS p) {
         const int npx = p.P - p0 < TPX ? p.P - p0 : TPX;
         const char* zb = reinterpret_cast<const char*>(p.dz + (size_t)p0 * K);
         const char* ob = reinterpret_cast<const char*>(p.dx + (size_t)p0 * C);
-        const char* ab = reinterpret_cast<const char*>(p.a + (size_t)p0 * CIN);
+        const char* ab = PF ? reinterpret_cast<const char*>(p.a + (size_t)p0 * CIN) : nullptr;
         const uint8_t* mk = p.mask + (size_t)p0 * (C / 8);
 #pragma unroll
         for (int pg = 0; pg < 2; ++pg) {
             const int px = pg * 16 + li, pc = px < npx ? px : npx - 1;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) dzf[pg][ks] = *reinterpret_cast<const bf16x8*>(zb + (unsigned)((pc * K + ks * 32 + lg * 8) * 2));
+            for (int ks = 0; ks < KS; ++ks) dzf[pg][ks] = *reinterpret_cast<const bf16x8*>(zb + (unsigned)((pc * K + ks * 32 + lg * 8) * 2));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int px = zpx + 8 * i, pc = px < npx ? px : npx - 1;
             old[i] = *reinterpret_cast<const bf16x8*>(ob + (unsigned)((pc * C + zch * 8) * 2));
             mb[i] = mk[(unsigned)(pc * (C / 8) + zch)];
-            ra[i] = *reinterpret_cast<const bf16x8*>(ab + (unsigned)((pc * CIN + zch * 8) * 2));
+            if constexpr (PF) ra[i] = *reinterpret_cast<const bf16x8*>(ab + (unsigned)((pc * CIN + zch * 8) * 2));
         }
     };
     const int trow = 8 * lg + (li >> 2);
@@ -127,7 +132,8 @@ __global__ __launch_bounds__(256, 2) void res_prod_stream_kernel(RPS p) {
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 c[pg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[ct][0], dzf[pg][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                c[pg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[ct][1], dzf[pg][1], c[pg][ct], 0, 0, 0);
+#pragma unroll
+                for (int ks = 1; ks < KS; ++ks) c[pg][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[ct][ks], dzf[pg][ks], c[pg][ct], 0, 0, 0);
             }
         // raw tile as bf16 (the tile kernel's rounding point): lane (li, lg) holds channels 16 ct + 4 lg .. + 3 of pixel 16 pg + li
 #pragma unroll
@@ -158,10 +164,13 @@ __global__ __launch_bounds__(256, 2) void res_prod_stream_kernel(RPS p) {
             const f32x8 gq = bf8_to_f32(v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) sa[j] += gq[j];
-            u.v = v;
-            *reinterpret_cast<s16x4_*>(zp) = u.s.a;
-            *reinterpret_cast<s16x4_*>(zp + 8) = u.s.b;
+            if constexpr (PF) {
+                u.v = v;
+                *reinterpret_cast<s16x4_*>(zp) = u.s.a;
+                *reinterpret_cast<s16x4_*>(zp + 8) = u.s.b;
+            }
         }
+        if constexpr (PF) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int px = zpx + 8 * i;
@@ -178,11 +187,12 @@ __global__ __launch_bounds__(256, 2) void res_prod_stream_kernel(RPS p) {
             *reinterpret_cast<s16x4_*>(xs + px * XROW + zch * 16) = u.s.a;
             *reinterpret_cast<s16x4_*>(xs + px * XROW + zch * 16 + 8) = u.s.b;
         }
+        }
         // (unconditional request of the workgroup's next tile; past the end: this tile again, unused)
         issue(tile + (int)gridDim.x < ntile ? tile + (int)gridDim.x : tile);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // ---- product: P[slice][:] += g'^T a over the tile's 32 pixels
-        {
+        if constexpr (PF) {
             bf16x8 fb[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) fb[nt] = frag(xs, XROW, nt);
@@ -203,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void res_prod_stream_kernel(RPS p) {
         if (tile < ntile) body(tile, std::false_type{});
     }
     // ---- this wave's slice of the workgroup's partial product (disjoint slices: no fold)
+    if constexpr (PF) {
     float* out = p.ws + ((size_t)g * gridDim.x + blockIdx.x) * (C * CIN) + (size_t)q * 64 * CIN;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -210,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void res_prod_stream_kernel(RPS p) {
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) out[(size_t)(mt * 16 + lg * 4 + r) * CIN + nt * 16 + li] = acc[mt][nt][r];
+    }
     // ---- sum(g'): the eight lanes that share a chunk (lane % 8) fold their pixels, one exact publication per channel and wave
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -221,36 +233,39 @@ __global__ __launch_bounds__(256, 2) void res_prod_stream_kernel(RPS p) {
     }
 }
 
-int rps_blocks(long P, int groups) {
+int rps_blocks(long P, int groups, int per_cu) {
     const long ntile = (P + TPX - 1) / TPX;
-    static const long cap0 = getenv("ADAMML_RPS_CAP") ? atol(getenv("ADAMML_RPS_CAP")) : 512;                    // A/B aid
-    long cap = cap0 / (groups < 1 ? 1 : groups);
+    static const long cap0 = getenv("ADAMML_RPS_CAP") ? atol(getenv("ADAMML_RPS_CAP")) : 256;                    // A/B aid: CUs
+    long cap = cap0 * per_cu / (groups < 1 ? 1 : groups);
     if (cap < 1) cap = 1;
     return (int)(ntile < cap ? ntile : cap);
 }
 
 bool rps_on() { const char* e = getenv("ADAMML_RES_PROD_STREAM"); return !(e && atoi(e) == 0); }                 // A/B aid, read at every call
 
+bool rps_1x1(const adamml_conv_desc_t* d) {
+    return d && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->up <= 1 && (long)d->N * d->OH * d->OW >= 4096;
+}
+
 }  // namespace
 
-// (declared in conv_gemm.hip, which owns the C entry point and falls back to its tile kernel)
+// (declared in conv_gemm.hip, which owns the C entry points and falls back to its tile kernel)
 int adamml_res_prod_stream_supported(const adamml_conv_desc_t* d, int a_channels) {
-    if (!rps_on() || !d) return 0;
-    return d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->up <= 1 && d->Cin == C && d->Cout == K && a_channels == CIN &&
-           (long)d->N * d->OH * d->OW >= 4096 ? 1 : 0;
+    return rps_on() && rps_1x1(d) && d->Cin == 256 && d->Cout == 64 && a_channels == CIN ? 1 : 0;
 }
 
 size_t adamml_res_prod_stream_workspace(const adamml_conv_desc_t* d) {
     const int groups = d->groups < 1 ? 1 : d->groups;
-    return (size_t)groups * rps_blocks((long)d->N * d->OH * d->OW, groups) * C * CIN * sizeof(float);
+    return (size_t)groups * rps_blocks((long)d->N * d->OH * d->OW, groups, 2) * 256 * CIN * sizeof(float);
 }
 
 int adamml_res_prod_stream_launch(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx, const uint8_t* res_mask,
                                   double* sums_a, const void* a, const float* a_scale, const float* a_shift, int a_act, int a_gstride,
                                   float* prod, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    constexpr int C = 256;
     const int groups = d->groups < 1 ? 1 : d->groups;
     const long P = (long)d->N * d->OH * d->OW;
-    const int nblk = rps_blocks(P, groups);
+    const int nblk = rps_blocks(P, groups, 2);
     if (!workspace || workspace_bytes < (size_t)groups * nblk * C * CIN * sizeof(float))
         return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_res_prod: workspace too small (adamml_conv_bwd_data_res_prod_workspace)");
     RPS p;
@@ -258,8 +273,26 @@ int adamml_res_prod_stream_launch(const adamml_conv_desc_t* d, const void* dz, c
     p.a = (const bf16_t*)a; p.in_scale = a_scale; p.in_shift = a_scale ? a_shift : nullptr; p.ws = (float*)workspace;
     p.in_gs = a_gstride; p.act = a_act; p.P = (int)P;
     constexpr size_t lds = 2 * CIN * 4 + (size_t)4 * TPX * (ZROW + XROW);
-    hipLaunchKernelGGL(res_prod_stream_kernel, dim3((unsigned)nblk, groups), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((res_prod_stream_kernel<4, 64, true>), dim3((unsigned)nblk, groups), dim3(256), lds, stream, p);
     int rc = adamml_check_launch("conv_bwd_data_res_prod(stream)");
     if (rc) return rc;
     return adamml_launch_split_reduce_grouped((const float*)workspace, prod, (size_t)C * CIN, nblk, groups, CIN, stream);
+}
+
+// adamml_conv_bwd_data_res in the algebraic backward's form (accumulate onto the identity-path gradient in dx, 1-bit mask, sum(g') only, no
+// BatchNorm operands) at the layer-2 shape: the data gradient of a bottleneck's conv1, 128 -> 512 channels
+int adamml_res_stream_supported(const adamml_conv_desc_t* d) {
+    return rps_on() && rps_1x1(d) && d->Cin == 512 && d->Cout == 128 ? 1 : 0;
+}
+
+int adamml_res_stream_launch(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx, const uint8_t* res_mask, double* sums_a,
+                             hipStream_t stream) {
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    const long P = (long)d->N * d->OH * d->OW;
+    RPS p;
+    p.dz = (const bf16_t*)dz; p.w = (const bf16_t*)w_dgrad_packed; p.dx = (bf16_t*)dx; p.mask = res_mask; p.sums = sums_a;
+    p.a = nullptr; p.in_scale = nullptr; p.in_shift = nullptr; p.ws = nullptr; p.in_gs = 0; p.act = 0; p.P = (int)P;
+    constexpr size_t lds = 2 * CIN * 4 + (size_t)8 * TPX * ZROW;
+    hipLaunchKernelGGL((res_prod_stream_kernel<8, 128, false>), dim3((unsigned)rps_blocks(P, groups, 1), groups), dim3(512), lds, stream, p);
+    return adamml_check_launch("conv_bwd_data_res(stream)");
 }

@@ -528,6 +528,8 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                         call("adamml_conv_bwd_data_res_prod", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), ptr(rmask), ract, ptr(sa), ptr(xa.data),
                              ptr(xa.scale), ptr(xa.shift), xa.act, xa.gs, ain[1].Cin, ptr(z.prod), ptr(wsp), wsp.numel() * 4)
                     else:
+                        if acc == 1 and rmask is not None and z.alg and not fbk and hip.load().adamml_conv_bwd_data_res_streams(byref(d)):
+                            hip.next_meta = hip.next_meta[:2] + ("res_prod_stream_kernel", R_FUSED)       # (layer 2: csrc/res_prod_stream.hip)
                         call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc, ptr(x.data), ptr(rmask), ract,
                              None if z.alg else ptr(z.data), ptr(z.vec), ptr(sa), ptr(idn.data) if fbk else None, ptr(idn.vec) if fbk else None,
                              ptr(sb) if fbk else None)

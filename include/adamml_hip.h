@@ -191,6 +191,10 @@ ADAMML_API int adamml_conv_bwd_data_alg(const adamml_conv_desc_t* d, const void*
  * instead of res_out (1/16 of the bytes).
  * Replaces adamml_conv_bwd_data(accumulate) + adamml_residual_bwd: the block-output gradient is written once. */
 ADAMML_API int adamml_conv_bwd_data_res_supported(const adamml_conv_desc_t* d);
+/* 1 when an adamml_conv_bwd_data_res launch in the algebraic backward's form (accumulate, res_mask, z_a == z_b == NULL) is served by
+ * the barrier-free streaming kernel of csrc/res_prod_stream.hip (the ResNet-50 layer-2 shape: d->Cin == 512, d->Cout == 128, >= 4096
+ * pixels per group; dx bit-identical) rather than the tile kernel -- a label for profilers.  ADAMML_RES_PROD_STREAM=0 disables it. */
+ADAMML_API int adamml_conv_bwd_data_res_streams(const adamml_conv_desc_t* d);
 ADAMML_API int adamml_conv_bwd_data_res(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx,
                              int accumulate, const void* res_out, const uint8_t* res_mask, int res_act, const void* z_a, const float* vec_a,
                              double* sums_a, const void* z_b, const float* vec_b, double* sums_b, hipStream_t stream);

@@ -904,6 +904,42 @@ def test_conv_bwd_data_res_equals_dgrad_then_residual_bwd(N, H, Cin, Cout, G, se
     assert torch.equal(dx_m, dx)
 
 
+@pytest.mark.parametrize("G,N,H", [(2, 6, 28), (1, 5, 29), (3, 10, 29)])
+def test_conv_bwd_data_res_stream_equals_tile_kernel(G, N, H, monkeypatch):
+    """adamml_conv_bwd_data_res in the algebraic backward's form (accumulate, 1-bit mask, sum(g') only) at the layer-2 shape (the data
+    gradient of a bottleneck's conv1, 128 -> 512 channels): the barrier-free streaming kernel of csrc/res_prod_stream.hip against the tile
+    kernel of csrc/conv_gemm.hip behind it (ADAMML_RES_PROD_STREAM=0, read at every call) -- dx bit-identical, sums equal up to the
+    summation order -- at full and partial last tiles (4704, 4205, 8410 pixels per group), and against fp32 torch arithmetic."""
+    torch.manual_seed(G * 100 + H)
+    Cb, Cm = 512, 128
+    P = N * H * H
+    d = ConvDesc(N, H, H, Cb, H, H, Cm, 1, 1, 1, 0, 1, 0, 0, G, 0)
+    assert hip.load().adamml_conv_bwd_data_res_streams(byref(d)) == 1
+    dz = (torch.randn(G * N, H, H, Cm, device=DEV) * 0.5).to(torch.bfloat16)
+    w = torch.randn(Cm, Cb, 1, 1, device=DEV) * (2.0 / Cb) ** 0.5
+    wd = pack(w, Cb, 1)
+    gid = torch.randn(G * N, H, H, Cb, device=DEV).to(torch.bfloat16)
+    mask = torch.randint(0, 256, (G * P * Cb // 8,), dtype=torch.uint8, device=DEV)
+    vec = torch.rand(G, 4, Cb, device=DEV) + 0.5
+    res = {}
+    for stream in (1, 0):
+        monkeypatch.setenv("ADAMML_RES_PROD_STREAM", str(stream))
+        assert hip.load().adamml_conv_bwd_data_res_streams(byref(d)) == stream
+        dx = gid.clone()
+        s = torch.zeros(G, STAT_SLOTS, 2 * Cb, dtype=torch.float64, device=DEV)
+        call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(wd), ptr(dx), 1, ptr(dx), ptr(mask), 1, None, ptr(vec), ptr(s), None, None, None)
+        cs = torch.empty(G, 2 * Cb, dtype=torch.float64, device=DEV)
+        call("adamml_stats_collapse", ptr(s), ptr(cs), Cb, G)
+        res[stream] = (dx, cs)
+    assert torch.equal(res[1][0], res[0][0])
+    assert torch.allclose(res[1][1], res[0][1], rtol=1e-6, atol=1e-6 * res[0][1].abs().max().item())
+    bits = ((mask.view(-1, 1).to(torch.int32) >> torch.arange(8, device=DEV, dtype=torch.int32)) & 1).view(G * N, H, H, Cb).float()
+    full = (torch.einsum("nhwo,oc->nhwc", dz.float(), rb(w).view(Cm, Cb)) + gid.float()) * bits
+    assert (res[1][0].float() - full).abs().max().item() <= 1e-2 * full.abs().max().item()
+    exp = res[1][0].float().view(G, P, Cb).double().sum(1)                                           # from the values the kernel stored
+    assert (res[1][1][:, :Cb] - exp).abs().max().item() <= 1e-6 * exp.abs().max().item() + 1e-6
+
+
 def test_bn_act_add_mask_bits():
     torch.manual_seed(5)
     P, C, G = 333, 64, 2
