@@ -2121,6 +2121,10 @@ int adamml_conv1x1_fadd_tpool_launch(const adamml_conv_desc_t* d, const void* x,
                                      const float* bn_vec, const void* idn, const float* id_scale, const float* id_shift, int id_gstride, int act,
                                      int frames, void* pooled, uint16_t* code, hipStream_t stream);
 
+int adamml_conv1x1_fadd_tpool_stream_supported(const adamml_conv_desc_t* d, int frames);
+int adamml_conv1x1_fadd_tpool_stream_launch(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
+                                            const float* bn_vec, const void* idn, const float* id_scale, const float* id_shift, int id_gstride, int act,
+                                            int frames, void* pooled, uint16_t* code, hipStream_t stream);
 extern "C" int adamml_conv_fwd_bn_add_tpool_supported(const adamml_conv_desc_t* d, int frames, int act, int lazy_input) {
     if (!adamml_conv_fwd_bn_add_supported(d)) return 0;
     if (!(frames == 2 || frames == 4 || frames == 8) || d->N % frames || d->Cout % 128 || act != ADAMML_ACT_RELU) return 0;
@@ -2137,6 +2141,9 @@ extern "C" int adamml_conv_fwd_bn_add_tpool(const adamml_conv_desc_t* d, const v
     if (!adamml_conv_fwd_bn_add_tpool_supported(d, frames, act, in_scale != nullptr))
         return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_fwd_bn_add_tpool: 1x1 / stride-1 conv, Cout %% 128 == 0, ReLU, 2 / 4 / 8 frames per clip");
     if (!bn_vec || !idn || !pooled) return adamml_set_error(ADAMML_EINVAL, "conv_fwd_bn_add_tpool: null argument");
+    if (adamml_conv1x1_fadd_tpool_stream_supported(d, frames))        // (csrc/conv1x1_fadd_stream.hip: the wave-slice streaming structure)
+        return adamml_conv1x1_fadd_tpool_stream_launch(d, x, w_packed, in_scale, in_shift, bn_vec, idn, id_scale, id_shift, id_gstride, act, frames, pooled,
+                                                       code, stream);
     if (adamml_conv1x1_fadd_tpool_supported(d, frames))
         return adamml_conv1x1_fadd_tpool_launch(d, x, w_packed, in_scale, in_shift, bn_vec, idn, id_scale, id_shift, id_gstride, act, frames, pooled, code,
                                                 stream);
