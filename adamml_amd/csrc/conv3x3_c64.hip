@@ -454,6 +454,7 @@ struct C3WP {
     const float* in_shift;
     float* ws;
     int act, N, H, W, R, tiles_per_img, tiles_per_group, total_tiles, tpb, PW, PR, in_gstride;
+    int cp;                  // channels of x and dz (pixel pitch in elements): 64, or 128 = four 64 x 64 quadrants (blockIdx.y)
     size_t gxy;
 };
 
@@ -469,6 +470,10 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_wgrad_kernel(C3WP p) {
     const int li = lane & 15, lg = lane >> 4;
     const int ech = tid & 7;
     const int nslots = p.PR * p.PW * 8;
+    // 128 channels (conv2 of the layer-2 bottlenecks): workgroup (x, y) computes quadrant y = (dz half qo, x half qi) of dW for the strips of
+    // workgroup x -- the same kernel on 64-channel slices of 256-byte pixels; the four partials of a block land in one [128][9 x 128] block
+    const int nq = p.cp >> 6, qo = blockIdx.y / nq, qi = blockIdx.y - qo * nq;
+    const int cpb = p.cp * 2;                                        // pixel pitch in bytes
     C64_STAGGER_START;
     for (int q = tid; q < MAXPX3; q += NT3) {
         const int qq = q < p.R * p.W ? q : 0;
@@ -490,11 +495,11 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_wgrad_kernel(C3WP p) {
         const int g = tile / p.tiles_per_group, tg = tile - g * p.tiles_per_group;
         const int n = tg / p.tiles_per_img, tr = tg - n * p.tiles_per_img;
         nih0 = tr * p.R - 1;
-        const size_t ibase = (size_t)g * p.gxy + (size_t)n * p.H * p.W * C64;
-        nimg = reinterpret_cast<const char*>(p.x + ibase);
+        const size_t ibase = (size_t)g * p.gxy + (size_t)n * p.H * p.W * p.cp;
+        nimg = reinterpret_cast<const char*>(p.x + ibase + qi * C64);
         const int oh0 = tr * p.R;
         nnpx8 = min(p.R, p.H - oh0) * p.W * 8;
-        nzb = reinterpret_cast<const char*>(p.dz + ibase + (size_t)oh0 * p.W * C64);
+        nzb = reinterpret_cast<const char*>(p.dz + ibase + (size_t)oh0 * p.W * p.cp + qo * C64);
         rok = 0;
         cpr = pr0; cpc = pc0;
         asm volatile("" : "+v"(cpr), "+v"(cpc));      // (opaque: the whole carry chain is tile-invariant and would be hoisted out of the tile loop as a 20-register table)
@@ -504,7 +509,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_wgrad_kernel(C3WP p) {
         const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W && tid + l * NT3 < nslots;
         rok |= (ok ? 1u : 0u) << l;
         const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
-        const unsigned off = (unsigned)(ihc * p.W + iwc) * (C64 * 2) + ech * 16;       // (uniform 64-bit base + 32-bit lane offset)
+        const unsigned off = (unsigned)(ihc * p.W + iwc) * (unsigned)cpb + ech * 16;   // (uniform 64-bit base + 32-bit lane offset)
         rp[l] = *reinterpret_cast<const bf16x8*>(nimg + off);
         cpc += pstep_c;
         const bool wrap = cpc >= p.PW;
@@ -513,7 +518,8 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_wgrad_kernel(C3WP p) {
     };
     auto load_z = [&](int l) {
         const int e = tid + l * NT3;
-        rz[l] = *reinterpret_cast<const bf16x8*>(nzb + (unsigned)(e < nnpx8 ? e : 0) * 16u);
+        const unsigned ec = (unsigned)(e < nnpx8 ? e : 0);
+        rz[l] = *reinterpret_cast<const bf16x8*>(nzb + (ec >> 3) * (unsigned)cpb + (ec & 7u) * 16u);
         rok |= (e < nnpx8 ? 1u : 0u) << (16 + l);
     };
     auto load_tile = [&](int tile) {
@@ -551,8 +557,8 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_wgrad_kernel(C3WP p) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) { sc[i] = 1.f; sh[i] = 0.f; }
             if (p.in_scale) {
-                sc = load_f32x8(p.in_scale + (size_t)g * p.in_gstride + ech * 8);
-                sh = load_f32x8(p.in_shift + (size_t)g * p.in_gstride + ech * 8);
+                sc = load_f32x8(p.in_scale + (size_t)g * p.in_gstride + qi * C64 + ech * 8);
+                sh = load_f32x8(p.in_shift + (size_t)g * p.in_gstride + qi * C64 + ech * 8);
             }
             const bool relu_bn = p.in_scale && p.act == ACT_RELU;
 #pragma unroll
@@ -619,7 +625,9 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_wgrad_kernel(C3WP p) {
         C64_TS(5);
         C64_TS_FLUSH;
     }
-    float* out = p.ws + (size_t)blockIdx.x * C64 * KT3;
+    // partial [cp][9][cp] of this block (tap-major columns); quadrant (qo, qi) of it
+    const int ktot = 9 * p.cp;
+    float* out = p.ws + (size_t)blockIdx.x * p.cp * ktot + (size_t)qo * C64 * ktot + qi * C64;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(NT3, 1) void conv3x3_c64_wgrad_kernel(C3WP p) {
             const int nt = wave + 8 * j;
             if (nt < 36) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) out[(size_t)(mt * 16 + lg * 4 + r) * KT3 + nt * 16 + li] = acc[mt][j][r];
+                for (int r = 0; r < 4; ++r) out[(size_t)(mt * 16 + lg * 4 + r) * ktot + (nt >> 2) * p.cp + (nt & 3) * 16 + li] = acc[mt][j][r];
             }
         }
 }
@@ -719,8 +727,17 @@ static int c3_geometry(const adamml_conv_desc_t* d, int* R_out) {
     return ceil_div(d->H, R);
 }
 
+// (128 channels: the four-quadrant form; ADAMML_C64_WGRAD_Q=0 disables it, read at every call: A/B aid)
+static bool c3_wgrad_quad(const adamml_conv_desc_t* d, int cin_true) {
+    const char* e = getenv("ADAMML_C64_WGRAD_Q");
+    if (e && atoi(e) == 0) return false;
+    if (cin_true != 128 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->Cin != 128 || d->Cout != 128 || d->up > 1) return false;
+    if (d->OH != d->H || d->OW != d->W || d->W < 8 || d->W > MAXPX3 / 2) return false;
+    return (long)d->N * d->H * d->W >= 65536;                // (a partial [128][9][128] per workgroup: only where the tensors dwarf 256 of them)
+}
+
 bool adamml_conv3x3_c64_wgrad_supported(const adamml_conv_desc_t* d, int cin_true) {
-    if (cin_true != C64 || !adamml_conv3x3_c64_supported(d)) return false;
+    if (!c3_wgrad_quad(d, cin_true) && (cin_true != C64 || !adamml_conv3x3_c64_supported(d))) return false;
     int R;
     c3_geometry(d, &R);
     const size_t lds = (size_t)(R + 2) * (d->W + 2) * PPIX + (size_t)MAXPX3 * SROW3 + MAXPX3 * sizeof(int);
@@ -730,7 +747,8 @@ bool adamml_conv3x3_c64_wgrad_supported(const adamml_conv_desc_t* d, int cin_tru
 int adamml_conv3x3_c64_wgrad_blocks(const adamml_conv_desc_t* d, int* tpb_out) {
     int R;
     const long total = (long)(d->groups < 1 ? 1 : d->groups) * d->N * c3_geometry(d, &R);
-    int tpb = (int)((total + 255) / 256);                  // one workgroup per CU
+    const int nwg = d->Cin == 128 ? 64 : 256;              // one workgroup per CU (128 channels: x four quadrants)
+    int tpb = (int)((total + nwg - 1) / nwg);
     if (tpb < 1) tpb = 1;
     if (tpb_out) *tpb_out = tpb;
     return (int)((total + tpb - 1) / tpb);
@@ -747,7 +765,8 @@ int adamml_conv3x3_c64_wgrad_launch(const adamml_conv_desc_t* d, const void* dz,
     p.tiles_per_group = d->N * p.tiles_per_img;
     p.total_tiles = groups * p.tiles_per_group;
     p.in_gstride = d->in_gstride;
-    p.gxy = (size_t)d->N * d->H * d->W * C64;
+    p.cp = d->Cin;
+    p.gxy = (size_t)d->N * d->H * d->W * p.cp;
     const int nblk = adamml_conv3x3_c64_wgrad_blocks(d, &p.tpb);
     const size_t lds = (size_t)p.PR * p.PW * PPIX + (size_t)MAXPX3 * SROW3 + MAXPX3 * sizeof(int);
     static AdamLdsOnce attr_once;                    // (per device: common.h)
@@ -757,7 +776,7 @@ int adamml_conv3x3_c64_wgrad_launch(const adamml_conv_desc_t* d, const void* dz,
         if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv3x3_c64 wgrad: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         attr_once.set(attr_dev);
     }
-    hipLaunchKernelGGL(conv3x3_c64_wgrad_kernel, dim3(nblk), dim3(NT3), C64_LDS(lds), stream, p);
+    hipLaunchKernelGGL(conv3x3_c64_wgrad_kernel, dim3(nblk, (p.cp >> 6) * (p.cp >> 6)), dim3(NT3), C64_LDS(lds), stream, p);
     return adamml_check_launch("conv3x3_c64 wgrad");
 }
 

@@ -2576,7 +2576,7 @@ extern "C" size_t adamml_conv_bwd_weight_workspace(const adamml_conv_desc_t* d, 
     const int groups = d->groups < 1 ? 1 : d->groups;
     size_t need = (size_t)groups * pl.nsplit * d->Cout * cin_true * d->KH * d->KW * sizeof(float);
     if (adamml_conv3x3_c64_wgrad_supported(d, cin_true)) {
-        const size_t n3 = (size_t)adamml_conv3x3_c64_wgrad_blocks(d, nullptr) * 64 * 576 * sizeof(float);
+        const size_t n3 = (size_t)adamml_conv3x3_c64_wgrad_blocks(d, nullptr) * d->Cout * cin_true * 9 * sizeof(float);
         if (n3 > need) need = n3;
     }
     return need;

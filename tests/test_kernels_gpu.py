@@ -158,6 +158,38 @@ def test_conv_fwd_bwd(case, lazy):
     close(dw2 - 1, wr.grad, what="conv wgrad (workspace path)")
 
 
+@pytest.mark.parametrize("G,N,H,lazy", [(2, 42, 28, True), (1, 90, 27, False)])
+def test_conv3x3_128_wgrad_quadrants_equal_tile_kernel(G, N, H, lazy, monkeypatch):
+    """Weight gradient of a 3x3 / stride-1 / 128 -> 128 conv (conv2 of the ResNet-50 layer-2 bottlenecks, models/resnet.py:84-86 under
+    backward) on the LDS-patch kernel of csrc/conv3x3_c64.hip run over the four 64 x 64 quadrants of dW (blockIdx.y; 64-channel slices of
+    256-byte pixels) against the generic kernel behind it (ADAMML_C64_WGRAD_Q=0, read at every call) and against torch's fp32 conv backward on
+    the same bf16 operands -- fp32 accumulation in another order: 1e-4 of the largest entry between the kernels."""
+    torch.manual_seed(G * 31 + H)
+    C = 128
+    x = torch.randn(G * N, H, H, C, device=DEV).to(torch.bfloat16)
+    dz = (torch.randn(G * N, H, H, C, device=DEV) * 0.25).to(torch.bfloat16)
+    vec = torch.rand(G, 4, C, device=DEV) + 0.5
+    vec[:, 1] -= 0.8
+    d = ConvDesc(N, H, H, C, H, H, C, 3, 3, 1, 1, 1, 1 if lazy else 0, 0, G, 4 * C if lazy else 0)
+    sc, sh = (ptr(vec[0, 0]), ptr(vec[0, 1])) if lazy else (None, None)
+    res = {}
+    for quad in ("1", "0"):
+        monkeypatch.setenv("ADAMML_C64_WGRAD_Q", quad)
+        ws = hip.wgrad_workspace(d, C, DEV)
+        dw = torch.zeros(C, C, 3, 3, device=DEV)
+        call("adamml_conv_bwd_weight", byref(d), ptr(dz), ptr(x), sc, sh, ptr(dw), C, ptr(ws), ws.numel() * 4)
+        res[quad] = dw
+    a = x.float().view(G, N, H, H, C)
+    if lazy:
+        a = torch.relu(a * vec[:, 0].view(G, 1, 1, 1, C) + vec[:, 1].view(G, 1, 1, 1, C)).to(torch.bfloat16).float()
+    a = a.view(G * N, H, H, C).permute(0, 3, 1, 2).contiguous()
+    w0 = torch.zeros(C, C, 3, 3, device=DEV, requires_grad=True)
+    F.conv2d(a, w0, padding=1).backward(dz.float().permute(0, 3, 1, 2).contiguous())
+    scale = w0.grad.abs().max().item()
+    assert (res["1"] - res["0"]).abs().max().item() <= 1e-4 * scale
+    assert (res["1"] - w0.grad).abs().max().item() <= 2e-3 * scale
+
+
 @pytest.mark.parametrize("case", [(2, 40, 40, 32, 1), (2, 41, 41, 96, 2), (1, 20, 20, 144, 2), (2, 10, 10, 960, 1), (1, 16, 16, 576, 2),
                                   (3, 13, 18, 24, 2), (2, 1, 7, 16, 2), (1, 50, 22, 384, 1), (1, 53, 9, 192, 2)])
 def test_dwconv(case):
