@@ -132,9 +132,21 @@ def test_fadd_next_at_benchmark_shape():
 
 @pytest.mark.parametrize("T,H,Cin,Cout", [(8, 56, 64, 256), (4, 28, 128, 512)])
 def test_fadd_tpool_at_benchmark_shape(T, H, Cin, Cout):
-    """adamml_conv_fwd_bn_add_tpool (the streaming form at layer 1, conv_gemm_kernel's TP instance at layer 2): 72 clips x T frames x 5 groups."""
-    from tests.test_kernels_gpu import test_conv_fwd_bn_add_tpool_equals_add_then_pool as eq
+    """adamml_conv_fwd_bn_add_tpool (the round-5 streaming form at layer 1, the wave-slice streaming form of csrc/conv1x1_fadd_stream.hip at
+    layer 2): 72 clips x T frames x 5 groups."""
+    from tests.test_kernels_gpu import fadd_tpool_case as eq
     eq(T, B, H, Cin, Cout, G, True)
+
+
+def test_round6_stream_kernels_at_benchmark_shape(monkeypatch):
+    """The wave-slice streaming kernels of round 6 at the frame counts the benchmark launches them with: conv3 + bn3 + add + ReLU of the
+    layer-2 bottlenecks (csrc/conv1x1_fadd_stream.hip: 5 groups x 288 frames of 28^2), the residual data gradient of their conv1
+    (csrc/res_prod_stream.hip <8, 128, false>) and the layer-1 residual data gradient + product (<4, 64, true>: 576 frames of 56^2 per group)."""
+    from tests.test_kernels_gpu import (test_conv_fwd_bn_add_and_gram_statistics as fadd, test_conv_bwd_data_res_stream_equals_tile_kernel as res,
+                                        test_conv_bwd_data_res_prod_equals_res_then_grouped_product as res_prod)
+    fadd(G, B * 4, 28, 128, 512, True, 1)
+    res(G, B * 4, 28, monkeypatch)
+    res_prod(B * 8, 56, 1, monkeypatch)
 
 
 def test_tpool_bwd_prod_at_benchmark_shape():

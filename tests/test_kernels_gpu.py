@@ -1484,14 +1484,18 @@ def test_conv_bwd_data_res_prod_equals_res_then_grouped_product(N, H, stream, mo
 @pytest.mark.parametrize("slice_mode", ["1", "2", "0"])
 def test_conv_fwd_bn_add_tpool_equals_add_then_pool(T, clips, H, Cin, Cout, G, lazy, slice_mode, monkeypatch):
     """(slice_mode = ADAMML_FADD_TPOOL_SLICE, read at every call: 1 = the wave-slice streaming kernel of csrc/conv1x1_fadd_stream.hip for the
-    layer-2 shape (default), 2 = for the layer-1 shape too, 0 = neither: the round-5 streaming kernel / the tile kernel)
-    adamml_conv_fwd_bn_add_tpool (conv3 + bn3 + identity + ReLU + TemporalPooling(max) in ONE kernel: models/resnet.py:104-112 then
+    layer-2 shape (default), 2 = for the layer-1 shape too, 0 = neither: the round-5 streaming kernel / the tile kernel)"""
+    monkeypatch.setenv("ADAMML_FADD_TPOOL_SLICE", slice_mode)
+    fadd_tpool_case(T, clips, H, Cin, Cout, G, lazy)
+
+
+def fadd_tpool_case(T, clips, H, Cin, Cout, G, lazy):
+    """adamml_conv_fwd_bn_add_tpool (conv3 + bn3 + identity + ReLU + TemporalPooling(max) in ONE kernel: models/resnet.py:104-112 then
     :205-209 -> models/common.py:4-33) == adamml_conv_fwd_bn_add followed by adamml_temporal_pool_fwd, BIT FOR BIT, at the three
     stage boundaries' shapes (56^2 x 8 frames, 28^2 x 4: 784 pixels do not fill 32-pixel blocks, 14^2 x 2: 196 pixels / 64) and two odd
     ones; and adamml_temporal_pool_bwd_code on the 2-bit codes it stores == adamml_temporal_pool_bwd_res(z = NULL) on the block
     output it no longer stores: routed + masked gradient bit-identical, sum(g') equal."""
     from adamml_amd.runtime import ACT_RELU
-    monkeypatch.setenv("ADAMML_FADD_TPOOL_SLICE", slice_mode)
     torch.manual_seed(T * 100 + H)
     N = clips * T
     Q = H * H
