@@ -331,7 +331,7 @@ __global__ __launch_bounds__(NT) void residual_bwd_kernel(const bf16_t* g_out, c
 }
 
 __global__ void bn_bwd_finalize_kernel(const double* sums, int nslots, int groups, double count, const float* gamma, const float* vec,
-                                       float* dgamma, float* dbeta, float* coef, int C, float grad_scale) {
+                                       float* dgamma, float* dbeta, float* coef, float* aff, int C, float grad_scale) {
     const int c = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), k = threadIdx.x & 31;
     const bool lead = c < C && k == 0;
     float dg = 0.f, db = 0.f;
@@ -341,9 +341,18 @@ __global__ void bn_bwd_finalize_kernel(const double* sums, int nslots, int group
         const int g = g0 + k;
         if (c < C && g < groups) {
             float* cf = coef + (size_t)g * 3 * C;
-            cf[c] = gamma[c] * vec[(size_t)g * 4 * C + 3 * C + c];
-            cf[C + c] = (float)(sg / count);
-            cf[2 * C + c] = (float)(sgz / count);
+            const float* v = vec + (size_t)g * 4 * C;
+            const float k0 = gamma[c] * v[3 * C + c], k1 = (float)(sg / count), k2 = (float)(sgz / count);
+            cf[c] = k0;
+            cf[C + c] = k1;
+            cf[2 * C + c] = k2;
+            if (aff) {               // dz = A g' + B z + C of bn_bwd_affine_kernel in the same launch (same expressions on the same fp32 values)
+                const float mu = v[2 * C + c], is = v[3 * C + c];
+                float* a = aff + (size_t)g * 3 * C;
+                a[c] = k0;
+                a[C + c] = -k0 * k2 * is;
+                a[2 * C + c] = k0 * (k2 * mu * is - k1);
+            }
         }
         const float sgf = (float)sg, sgzf = (float)sgz;
         const int ng = groups - g0 < 32 ? groups - g0 : 32, base = threadIdx.x & 32;
@@ -1617,8 +1626,17 @@ extern "C" int adamml_bn_bwd_finalize(const double* sums, int nslots, int groups
                                       float* dgamma, float* dbeta, float* coef, int C, float grad_scale, hipStream_t stream) {
     if (nslots < 1 || nslots > ADAMML_STAT_SLOTS || groups < 1) return adamml_set_error(ADAMML_EINVAL, "bn_bwd_finalize: nslots=%d groups=%d", nslots, groups);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, stream, sums, nslots, groups, count, gamma, vec, dgamma,
-                       dbeta, coef, C, grad_scale);
+                       dbeta, coef, (float*)nullptr, C, grad_scale);
     return adamml_check_launch("bn_bwd_finalize");
+}
+
+extern "C" int adamml_bn_bwd_finalize_affine(const double* sums, int nslots, int groups, double count, const float* gamma, const float* vec,
+                                             float* dgamma, float* dbeta, float* coef, float* aff, int C, float grad_scale, hipStream_t stream) {
+    if (nslots < 1 || nslots > ADAMML_STAT_SLOTS || groups < 1) return adamml_set_error(ADAMML_EINVAL, "bn_bwd_finalize_affine: nslots=%d groups=%d", nslots, groups);
+    if (!coef || !aff) return adamml_set_error(ADAMML_EINVAL, "bn_bwd_finalize_affine: null argument");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 8)), dim3(256), 0, stream, sums, nslots, groups, count, gamma, vec, dgamma,
+                       dbeta, coef, aff, C, grad_scale);
+    return adamml_check_launch("bn_bwd_finalize_affine");
 }
 
 extern "C" int adamml_lazy_colsum(const void* x, const float* scale, const float* shift, int gstride, int act, float* s, size_t P, int C,

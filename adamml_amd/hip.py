@@ -74,6 +74,7 @@ SIGNATURES = {
     "adamml_act_bwd_from_output": [_P, _P, _I, _P, _Z, _P],
     "adamml_bn_bwd_reduce": [_P, _P, _P, _I, _P, _Z, _I, _I, _P],
     "adamml_bn_bwd_finalize": [_P, _I, _I, _D, _P, _P, _P, _P, _P, _I, _F, _P],
+    "adamml_bn_bwd_finalize_affine": [_P, _I, _I, _D, _P, _P, _P, _P, _P, _P, _I, _F, _P],
     "adamml_bn_bwd_apply": [_P, _P, _P, _I, _P, _P, _Z, _I, _I, _P],
     "adamml_maxpool2d_fwd": [_P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "adamml_maxpool2d_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -292,7 +292,7 @@ def _bn_eval_vectors(rt, bn, C, device):
 
 def _bn_backward(rt, out, y, vec, bn, act, count, defer_apply=False):
     """Turns out.grad (w.r.t. the activated value) into dz (w.r.t. the raw conv output); accumulates dgamma/dbeta.
-    defer_apply=True stops after the finalize step and returns (g, coef): the caller's data-gradient kernel applies
+    defer_apply=True stops after the finalize step and returns (g, coef, aff): the caller's data-gradient kernel applies
     dz = k0 (g - k1 - zhat k2) in its loader (adamml_conv_bwd_data_dual) instead of a separate pass over g and z."""
     g = out.grad
     out.grad = None
@@ -325,10 +325,14 @@ def _bn_backward(rt, out, y, vec, bn, act, count, defer_apply=False):
     sums, nslots = rt.sync.reduce(sums, C, G)
     coef = torch.empty(G, 3, C, dtype=torch.float32, device=y.device)
     train_bn = bn.weight.requires_grad
+    if defer_apply:
+        # the caller's data-gradient loader wants dz = A g + B z + C: finalize and the affine form in one launch
+        aff = torch.empty(G, 3, C, dtype=torch.float32, device=y.device)
+        call("adamml_bn_bwd_finalize_affine", ptr(sums), nslots, G, float(count * rt.sync.world), ptr(bn.weight), ptr(vec),
+             ptr(bn.weight.grad) if train_bn else None, ptr(bn.bias.grad) if train_bn else None, ptr(coef), ptr(aff), C, 1.0 / rt.sync.world)
+        return g, coef, aff
     call("adamml_bn_bwd_finalize", ptr(sums), nslots, G, float(count * rt.sync.world), ptr(bn.weight), ptr(vec),
          ptr(bn.weight.grad) if train_bn else None, ptr(bn.bias.grad) if train_bn else None, ptr(coef), C, 1.0 / rt.sync.world)
-    if defer_apply:
-        return g, coef
     dz = torch.empty_like(y)
     call("adamml_bn_bwd_apply", ptr(g), ptr(y), ptr(vec), act, ptr(coef), ptr(dz), P, C, G)
     return dz
@@ -462,9 +466,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                     and hip.load().adamml_dwconv_bwd_fused_supported(byref(d)):
                 # g is already masked by this conv's activation (out.pre_sums: the projection's data gradient did that), so
                 # dz = A g + B z + C in the loader; apply + weight gradient + data gradient (mask / sums of the expansion) in one pass
-                g, coef = _bn_backward(rt, out, y, vec, bn, act, count, defer_apply=True)
-                aff = torch.empty(G, 3, C, dtype=torch.float32, device=dev)
-                call("adamml_bn_bwd_affine", ptr(coef), ptr(vec), ptr(aff), C, G)
+                g, coef, aff = _bn_backward(rt, out, y, vec, bn, act, count, defer_apply=True)
                 x.grad = torch.empty_like(x.data)
                 sums = rt.bwd_arena.take(G * 2 * d.Cin * STAT_SLOTS)
                 ws = hip.scratch(hip.load().adamml_dwconv_bwd_fused_workspace(byref(d)), dev)
@@ -722,9 +724,7 @@ def _conv1x1_backward_alg(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, m
     else:
         with _on_wgrad_stream(rt, (g0, x.data, x.scale)):
             products()
-    g, coef = _bn_backward(rt, out, y, vec, bn, ACT_NONE, count, defer_apply=True)
-    aff = torch.empty(G, 3, Cout, dtype=torch.float32, device=dev)
-    call("adamml_bn_bwd_affine", ptr(coef), ptr(vec), ptr(aff), Cout, G)
+    g, coef, aff = _bn_backward(rt, out, y, vec, bn, ACT_NONE, count, defer_apply=True)
     # ---- data gradient (main stream)
     w_alg = torch.empty(G, Cin, Cout + Cin, dtype=torch.bfloat16, device=dev)
     cadd = torch.empty(G, Cin, dtype=torch.float32, device=dev)
@@ -773,9 +773,7 @@ def _conv1x1_backward_dual(rt, out, x, y, vec, bn, cs, d, count, sole_consumer, 
     once, as a side output, for the weight-gradient kernel.  Saves one full pass over the layer's largest tensor."""
     G = rt.groups
     C = d.Cout
-    g, coef = _bn_backward(rt, out, y, vec, bn, ACT_NONE, count, defer_apply=True)
-    aff = torch.empty(G, 3, C, dtype=torch.float32, device=y.device)
-    call("adamml_bn_bwd_affine", ptr(coef), ptr(vec), ptr(aff), C, G)
+    g, coef, aff = _bn_backward(rt, out, y, vec, bn, ACT_NONE, count, defer_apply=True)
     need_w = cs.weight.requires_grad
     dz = torch.empty_like(y) if need_w else None
     acc = 1

@@ -327,6 +327,11 @@ ADAMML_API int adamml_bn_bwd_reduce(const void* g, const void* z, const float* b
  * grad_weight / grad_bias local, train_adamml.py:126-129). */
 ADAMML_API int adamml_bn_bwd_finalize(const double* sums, int nslots, int groups, double count, const float* gamma, const float* bn_vec,
                            float* dgamma, float* dbeta, float* coef, int C, float grad_scale, hipStream_t stream);
+/* adamml_bn_bwd_finalize and adamml_bn_bwd_affine (aff [groups][3][C]: dz = A g' + B z + C) in one launch -- the pair runs back to back in
+ * front of every data gradient with a BatchNorm-backward loader (adamml_conv_bwd_data_dual, adamml_conv_bwd_data_alg,
+ * adamml_dwconv_bwd_fused); same values, one launch less on the critical path. */
+ADAMML_API int adamml_bn_bwd_finalize_affine(const double* sums, int nslots, int groups, double count, const float* gamma, const float* bn_vec,
+                                  float* dgamma, float* dbeta, float* coef, float* aff, int C, float grad_scale, hipStream_t stream);
 /* dz = coef0 * (g' - coef1 - zhat*coef2) */
 ADAMML_API int adamml_bn_bwd_apply(const void* g, const void* z, const float* bn_vec, int act, const float* coef, void* dz, size_t P, int C,
                         int groups, hipStream_t stream);
