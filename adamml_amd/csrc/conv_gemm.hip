@@ -2134,6 +2134,14 @@ extern "C" int adamml_conv_fwd_bn_add_tpool_supported(const adamml_conv_desc_t* 
     return on ? 1 : 0;
 }
 
+// which kernel serves adamml_conv_fwd_bn_add_tpool (a label for profilers): 0 = the tile kernel's TP instance, 1 = the round-5 streaming kernel
+// (csrc/conv1x1_fadd_next.hip: a wave owns all 256 channels of 16 pixels), 2 = the wave-slice streaming kernel (csrc/conv1x1_fadd_stream.hip)
+extern "C" int adamml_conv_fwd_bn_add_tpool_streams(const adamml_conv_desc_t* d, int frames) {
+    if (!d) return 0;
+    if (adamml_conv1x1_fadd_tpool_stream_supported(d, frames)) return 2;
+    return adamml_conv1x1_fadd_tpool_supported(d, frames) ? 1 : 0;
+}
+
 extern "C" int adamml_conv_fwd_bn_add_tpool(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale,
                                             const float* in_shift, const float* bn_vec, const void* idn, const float* id_scale,
                                             const float* id_shift, int id_gstride, int act, int frames, void* pooled, uint16_t* code,
@@ -2425,7 +2433,7 @@ extern "C" int adamml_conv_bwd_data_res_supported(const adamml_conv_desc_t* d) {
 // (csrc/res_prod_stream.hip: the barrier-free streaming forms)
 int adamml_res_stream_supported(const adamml_conv_desc_t* d);
 int adamml_res_stream_launch(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx, const uint8_t* res_mask, double* sums_a,
-                             hipStream_t stream);
+                             const void* z_b, const float* vec_b, double* sums_b, hipStream_t stream);
 extern "C" int adamml_conv_bwd_data_res_streams(const adamml_conv_desc_t* d) {
     return d && adamml_conv_bwd_data_res_supported(d) && adamml_res_stream_supported(d) ? 1 : 0;
 }
@@ -2438,8 +2446,8 @@ extern "C" int adamml_conv_bwd_data_res(const adamml_conv_desc_t* d, const void*
     if ((z_b != nullptr) != (vec_b != nullptr) || (z_b != nullptr) != (sums_b != nullptr))
         return adamml_set_error(ADAMML_EINVAL, "conv_bwd_data_res: incomplete second BatchNorm operand");
     if (!adamml_conv_bwd_data_res_supported(d)) return adamml_set_error(ADAMML_EUNSUPPORTED, "conv_bwd_data_res: only 1x1 / stride-1 convs");
-    if (accumulate && res_mask && !z_a && !z_b && adamml_res_stream_supported(d))       // (the algebraic backward's form at the layer-2 shape)
-        return adamml_res_stream_launch(d, dz, w_dgrad_packed, dx, res_mask, sums_a, stream);
+    if (accumulate && res_mask && !z_a && adamml_res_stream_supported(d))       // (the algebraic backward's form at the layer-2 shape)
+        return adamml_res_stream_launch(d, dz, w_dgrad_packed, dx, res_mask, sums_a, z_b, vec_b, sums_b, stream);
     adamml_conv_desc_t g = *d;
     g.N = d->N; g.H = d->OH; g.W = d->OW; g.Cin = d->Cout;
     g.OH = d->H; g.OW = d->W; g.Cout = d->Cin;

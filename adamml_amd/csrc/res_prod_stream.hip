@@ -30,6 +30,9 @@ struct RPS {
     const float* in_scale;   // its lazy BatchNorm (group stride in_gs) or null
     const float* in_shift;
     float* ws;               // [groups][gridDim.x][256][64] partial products
+    const bf16_t* zb;        // SECOND: raw output of the second BatchNorm'd operand of the add (the downsample branch) [groups][P][C]
+    const float* vecb;       //         its vectors [groups][4][C] (mean, invstd in rows 2, 3)
+    double* sums_b;          //         [groups][SLOTS][2C]: sum(g') and sum(g' zhat_b)
     int in_gs, act, P;
 };
 
@@ -37,7 +40,7 @@ constexpr int CIN = 64, TPX = 32;
 constexpr int ZROW = 64 * 2 + 8, XROW = CIN * 2 + 8;
 
 // NQ waves = NQ x 64 gradient channels; K = channels of dz; PF: with the product (layer 1: <4, 64, true>; layer 2 without it: <8, 128, false>)
-template <int NQ, int K, bool PF>
+template <int NQ, int K, bool PF, bool SECOND = false>
 __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void res_prod_stream_kernel(RPS p) {
     constexpr int C = NQ * 64, KS = K / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -52,6 +55,7 @@ __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void res_prod_stream_kern
         p.dx += pp * C + q * 64;
         p.mask += pp * (C / 8) + q * 8;
         if (PF) p.a += pp * CIN;
+        if (SECOND) { p.zb += pp * C + q * 64; p.vecb += (size_t)g * 4 * C; p.sums_b += (size_t)g * ADAMML_STAT_SLOTS * 2 * C; }
         p.sums += (size_t)g * ADAMML_STAT_SLOTS * 2 * C;
     }
     if (PF)
@@ -79,14 +83,18 @@ __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void res_prod_stream_kern
     for (int a = 0; a < (PF ? 4 : 1); ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float sa[8];
+    float sa[8], sb[SECOND ? 8 : 1];
 #pragma unroll
     for (int i = 0; i < 8; ++i) sa[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (SECOND ? 8 : 1); ++i) sb[i] = 0.f;
     const int ntile = (p.P + TPX - 1) / TPX;
     // this lane's four (pixel, 8-channel chunk) slots of a tile: chunk lane % 8 of pixels lane / 8 + 8 i
     const int zch = lane & 7, zpx = lane >> 3;
 
-    bf16x8 dzf[2][KS], old[4], ra[PF ? 4 : 1];
+    bf16x8 dzf[2][KS], old[4], ra[PF ? 4 : 1], rzb[SECOND ? 4 : 1];
+    f32x8 mu2, is2;                                                         // SECOND: mean / invstd of this lane's 8 channels
+    if constexpr (SECOND) { mu2 = load_f32x8(p.vecb + 2 * C + q * 64 + (lane & 7) * 8); is2 = load_f32x8(p.vecb + 3 * C + q * 64 + (lane & 7) * 8); }
     unsigned mb[4];
     // (uniform 64-bit bases -- the tile is the same for the whole wave -- plus 32-bit lane offsets)
     auto issue = [&](int tile) {
@@ -108,6 +116,8 @@ __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void res_prod_stream_kern
             old[i] = *reinterpret_cast<const bf16x8*>(ob + (unsigned)((pc * C + zch * 8) * 2));
             mb[i] = mk[(unsigned)(pc * (C / 8) + zch)];
             if constexpr (PF) ra[i] = *reinterpret_cast<const bf16x8*>(ab + (unsigned)((pc * CIN + zch * 8) * 2));
+            if constexpr (SECOND)
+                rzb[i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(p.zb + (size_t)p0 * C) + (unsigned)((pc * C + zch * 8) * 2));
         }
     };
     const int trow = 8 * lg + (li >> 2);
@@ -164,6 +174,11 @@ __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void res_prod_stream_kern
             const f32x8 gq = bf8_to_f32(v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) sa[j] += gq[j];
+            if constexpr (SECOND) {
+                const f32x8 z2 = bf8_to_f32(rzb[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sb[j] += gq[j] * (z2[j] - mu2[j]) * is2[j];
+            }
             if constexpr (PF) {
                 u.v = v;
                 *reinterpret_cast<s16x4_*>(zp) = u.s.a;
@@ -230,6 +245,14 @@ __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void res_prod_stream_kern
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
         if (lane < 8 && v != 0.f) stat_publish(p.sums + q * 64 + lane * 8 + j, 2 * C, blockIdx.x & (ADAMML_STAT_SLOTS - 1), v);
+        if constexpr (SECOND) {
+            if (lane < 8 && v != 0.f) stat_publish(p.sums_b + q * 64 + lane * 8 + j, 2 * C, blockIdx.x & (ADAMML_STAT_SLOTS - 1), v);
+            float v2 = sb[j];
+            v2 += __shfl_xor(v2, 8, 64);
+            v2 += __shfl_xor(v2, 16, 64);
+            v2 += __shfl_xor(v2, 32, 64);
+            if (lane < 8 && v2 != 0.f) stat_publish(p.sums_b + C + q * 64 + lane * 8 + j, 2 * C, blockIdx.x & (ADAMML_STAT_SLOTS - 1), v2);
+        }
     }
 }
 
@@ -272,6 +295,7 @@ int adamml_res_prod_stream_launch(const adamml_conv_desc_t* d, const void* dz, c
     p.dz = (const bf16_t*)dz; p.w = (const bf16_t*)w_dgrad_packed; p.dx = (bf16_t*)dx; p.mask = res_mask; p.sums = sums_a;
     p.a = (const bf16_t*)a; p.in_scale = a_scale; p.in_shift = a_scale ? a_shift : nullptr; p.ws = (float*)workspace;
     p.in_gs = a_gstride; p.act = a_act; p.P = (int)P;
+    p.zb = nullptr; p.vecb = nullptr; p.sums_b = nullptr;
     constexpr size_t lds = 2 * CIN * 4 + (size_t)4 * TPX * (ZROW + XROW);
     hipLaunchKernelGGL((res_prod_stream_kernel<4, 64, true>), dim3((unsigned)nblk, groups), dim3(256), lds, stream, p);
     int rc = adamml_check_launch("conv_bwd_data_res_prod(stream)");
@@ -279,20 +303,24 @@ int adamml_res_prod_stream_launch(const adamml_conv_desc_t* d, const void* dz, c
     return adamml_launch_split_reduce_grouped((const float*)workspace, prod, (size_t)C * CIN, nblk, groups, CIN, stream);
 }
 
-// adamml_conv_bwd_data_res in the algebraic backward's form (accumulate onto the identity-path gradient in dx, 1-bit mask, sum(g') only, no
-// BatchNorm operands) at the layer-2 shape: the data gradient of a bottleneck's conv1, 128 -> 512 channels
+// adamml_conv_bwd_data_res in the algebraic backward's form (accumulate onto the identity-path gradient in dx, 1-bit mask, sum(g') only for
+// the main branch; optionally the second BatchNorm'd operand of the add -- the downsample branch of the stage's first block -- with
+// sum(g') / sum(g' zhat_b) into sums_b) at the layer-2 shape: the data gradient of a bottleneck's conv1, 128 -> 512 channels
 int adamml_res_stream_supported(const adamml_conv_desc_t* d) {
     return rps_on() && rps_1x1(d) && d->Cin == 512 && d->Cout == 128 ? 1 : 0;
 }
 
 int adamml_res_stream_launch(const adamml_conv_desc_t* d, const void* dz, const void* w_dgrad_packed, void* dx, const uint8_t* res_mask, double* sums_a,
-                             hipStream_t stream) {
+                             const void* z_b, const float* vec_b, double* sums_b, hipStream_t stream) {
     const int groups = d->groups < 1 ? 1 : d->groups;
     const long P = (long)d->N * d->OH * d->OW;
     RPS p;
     p.dz = (const bf16_t*)dz; p.w = (const bf16_t*)w_dgrad_packed; p.dx = (bf16_t*)dx; p.mask = res_mask; p.sums = sums_a;
     p.a = nullptr; p.in_scale = nullptr; p.in_shift = nullptr; p.ws = nullptr; p.in_gs = 0; p.act = 0; p.P = (int)P;
+    p.zb = (const bf16_t*)z_b; p.vecb = vec_b; p.sums_b = sums_b;
     constexpr size_t lds = 2 * CIN * 4 + (size_t)8 * TPX * ZROW;
-    hipLaunchKernelGGL((res_prod_stream_kernel<8, 128, false>), dim3((unsigned)rps_blocks(P, groups, 1), groups), dim3(512), lds, stream, p);
+    const dim3 grid((unsigned)rps_blocks(P, groups, 1), groups);
+    if (z_b) hipLaunchKernelGGL((res_prod_stream_kernel<8, 128, false, true>), grid, dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL((res_prod_stream_kernel<8, 128, false, false>), grid, dim3(512), lds, stream, p);
     return adamml_check_launch("conv_bwd_data_res(stream)");
 }

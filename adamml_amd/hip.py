@@ -142,6 +142,8 @@ def load():
     lib.adamml_conv_fwd_bn_add_streams.restype = c_int
     lib.adamml_conv_bwd_data_res_streams.argtypes = [_DESC]
     lib.adamml_conv_bwd_data_res_streams.restype = c_int
+    lib.adamml_conv_fwd_bn_add_tpool_streams.argtypes = [_DESC, _I]
+    lib.adamml_conv_fwd_bn_add_tpool_streams.restype = c_int
     lib.adamml_conv_fused_input_supported.argtypes = [_DESC]
     lib.adamml_conv_fused_input_supported.restype = c_int
     lib.adamml_conv1x1_narrow_supported.argtypes = [_DESC, c_int]

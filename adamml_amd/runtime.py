@@ -530,7 +530,7 @@ def conv_bn(rt, x, cs, bn, act, sole_consumer=False, last_consumer=False):
                         call("adamml_conv_bwd_data_res_prod", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), ptr(rmask), ract, ptr(sa), ptr(xa.data),
                              ptr(xa.scale), ptr(xa.shift), xa.act, xa.gs, ain[1].Cin, ptr(z.prod), ptr(wsp), wsp.numel() * 4)
                     else:
-                        if acc == 1 and rmask is not None and z.alg and not fbk and hip.load().adamml_conv_bwd_data_res_streams(byref(d)):
+                        if acc == 1 and rmask is not None and z.alg and hip.load().adamml_conv_bwd_data_res_streams(byref(d)):
                             hip.next_meta = hip.next_meta[:2] + ("res_prod_stream_kernel", R_FUSED)       # (layer 2: csrc/res_prod_stream.hip)
                         call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(cs.w_dgrad), ptr(x.grad), acc, ptr(x.data), ptr(rmask), ract,
                              None if z.alg else ptr(z.data), ptr(z.vec), ptr(sa), ptr(idn.data) if fbk else None, ptr(idn.vec) if fbk else None,
@@ -960,7 +960,8 @@ def conv_bn_add(rt, x, cs, bn, idn, act, idn_sole=False, tpool=0, next_cs=None):
         out_t = torch.empty(G * d.N // tpool * to, d.OH, d.OW, C, dtype=torch.bfloat16, device=dev)        # POOLED block output
         code_t = torch.empty(G * d.N // tpool * to, d.OH, d.OW, C // 8, dtype=torch.int16, device=dev) if need_grad else None
         mask_t = None
-        hip.next_meta = (2 * macs, in_b + 1.5 * out_b + w_b + (out_b / 16 if code_t is not None else 0), kern, R_FUSED)
+        kern_tp = (kern, "conv1x1_fadd_tpool_kernel", "conv1x1_fadd_tpool_stream_kernel")[hip.load().adamml_conv_fwd_bn_add_tpool_streams(byref(d), tpool)]
+        hip.next_meta = (2 * macs, in_b + 1.5 * out_b + w_b + (out_b / 16 if code_t is not None else 0), kern_tp, R_FUSED)
         call("adamml_conv_fwd_bn_add_tpool", byref(d), ptr(x.data), ptr(cs.w_fwd), ptr(x.scale), ptr(x.shift), ptr(vec), ptr(idn.data), None, None, 0,
              act, tpool, ptr(out_t), ptr(code_t))
         full_shape = (G * d.N, d.OH, d.OW, C)

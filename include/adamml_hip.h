@@ -118,6 +118,9 @@ ADAMML_API int adamml_conv_fwd_bn_add_next(const adamml_conv_desc_t* d, const vo
  * is <= 0, i.e. the ReLU passes no gradient) for adamml_temporal_pool_bwd_code.  The full-rate block output, its activation mask and the
  * pool's own pass (adamml_temporal_pool_fwd) never touch HBM.  frames in {2, 4, 8}, Cout % 128 == 0, act = ReLU, idn required. */
 ADAMML_API int adamml_conv_fwd_bn_add_tpool_supported(const adamml_conv_desc_t* d, int frames, int act, int lazy_input);
+/* which device kernel serves the launch (a label for profilers): 0 = the tile kernel, 1 = the streaming kernel of csrc/conv1x1_fadd_next.hip
+ * (64 -> 256 channels), 2 = the wave-slice streaming kernel of csrc/conv1x1_fadd_stream.hip (128 -> 512); same pooled tensor and codes. */
+ADAMML_API int adamml_conv_fwd_bn_add_tpool_streams(const adamml_conv_desc_t* d, int frames);
 ADAMML_API int adamml_conv_fwd_bn_add_tpool(const adamml_conv_desc_t* d, const void* x, const void* w_packed, const float* in_scale, const float* in_shift,
                                  const float* bn_vec, const void* idn, const float* id_scale, const float* id_shift, int id_gstride, int act,
                                  int frames, void* pooled, uint16_t* code, hipStream_t stream);

@@ -145,7 +145,8 @@ def test_round6_stream_kernels_at_benchmark_shape(monkeypatch):
     from tests.test_kernels_gpu import (test_conv_fwd_bn_add_and_gram_statistics as fadd, test_conv_bwd_data_res_stream_equals_tile_kernel as res,
                                         test_conv_bwd_data_res_prod_equals_res_then_grouped_product as res_prod)
     fadd(G, B * 4, 28, 128, 512, True, 1)
-    res(G, B * 4, 28, monkeypatch)
+    res(G, B * 4, 28, False, monkeypatch)
+    res(G, B * 4, 28, True, monkeypatch)
     res_prod(B * 8, 56, 1, monkeypatch)
 
 

@@ -936,12 +936,14 @@ def test_conv_bwd_data_res_equals_dgrad_then_residual_bwd(N, H, Cin, Cout, G, se
     assert torch.equal(dx_m, dx)
 
 
-@pytest.mark.parametrize("G,N,H", [(2, 6, 28), (1, 5, 29), (3, 10, 29)])
-def test_conv_bwd_data_res_stream_equals_tile_kernel(G, N, H, monkeypatch):
+@pytest.mark.parametrize("G,N,H,second", [(2, 6, 28, False), (1, 5, 29, False), (3, 10, 29, False), (2, 6, 28, True), (3, 10, 29, True)])
+def test_conv_bwd_data_res_stream_equals_tile_kernel(G, N, H, second, monkeypatch):
     """adamml_conv_bwd_data_res in the algebraic backward's form (accumulate, 1-bit mask, sum(g') only) at the layer-2 shape (the data
     gradient of a bottleneck's conv1, 128 -> 512 channels): the barrier-free streaming kernel of csrc/res_prod_stream.hip against the tile
     kernel of csrc/conv_gemm.hip behind it (ADAMML_RES_PROD_STREAM=0, read at every call) -- dx bit-identical, sums equal up to the
-    summation order -- at full and partial last tiles (4704, 4205, 8410 pixels per group), and against fp32 torch arithmetic."""
+    summation order -- at full and partial last tiles (4704, 4205, 8410 pixels per group), and against fp32 torch arithmetic.  second: with the
+    second BatchNorm'd operand of the add (the downsample branch of a stage's first block: z_b, its vectors, sums_b = sum(g') | sum(g' zhat_b))."""
+    monkeypatch.delenv("ADAMML_RES_PROD_STREAM", raising=False)
     torch.manual_seed(G * 100 + H)
     Cb, Cm = 512, 128
     P = N * H * H
@@ -953,18 +955,31 @@ def test_conv_bwd_data_res_stream_equals_tile_kernel(G, N, H, monkeypatch):
     gid = torch.randn(G * N, H, H, Cb, device=DEV).to(torch.bfloat16)
     mask = torch.randint(0, 256, (G * P * Cb // 8,), dtype=torch.uint8, device=DEV)
     vec = torch.rand(G, 4, Cb, device=DEV) + 0.5
+    zb = torch.randn(G * N, H, H, Cb, device=DEV).to(torch.bfloat16)
+    vecb = torch.rand(G, 4, Cb, device=DEV) + 0.5
     res = {}
     for stream in (1, 0):
         monkeypatch.setenv("ADAMML_RES_PROD_STREAM", str(stream))
         assert hip.load().adamml_conv_bwd_data_res_streams(byref(d)) == stream
         dx = gid.clone()
         s = torch.zeros(G, STAT_SLOTS, 2 * Cb, dtype=torch.float64, device=DEV)
-        call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(wd), ptr(dx), 1, ptr(dx), ptr(mask), 1, None, ptr(vec), ptr(s), None, None, None)
-        cs = torch.empty(G, 2 * Cb, dtype=torch.float64, device=DEV)
+        s2 = torch.zeros_like(s)
+        call("adamml_conv_bwd_data_res", byref(d), ptr(dz), ptr(wd), ptr(dx), 1, ptr(dx), ptr(mask), 1, None, ptr(vec), ptr(s),
+             ptr(zb) if second else None, ptr(vecb) if second else None, ptr(s2) if second else None)
+        cs, cs2 = torch.empty(G, 2 * Cb, dtype=torch.float64, device=DEV), torch.empty(G, 2 * Cb, dtype=torch.float64, device=DEV)
         call("adamml_stats_collapse", ptr(s), ptr(cs), Cb, G)
-        res[stream] = (dx, cs)
+        call("adamml_stats_collapse", ptr(s2), ptr(cs2), Cb, G)
+        res[stream] = (dx, cs, cs2)
     assert torch.equal(res[1][0], res[0][0])
     assert torch.allclose(res[1][1], res[0][1], rtol=1e-6, atol=1e-6 * res[0][1].abs().max().item())
+    if second:
+        gq = res[1][0].float().view(G, P, Cb).double()
+        zh = (zb.float().view(G, P, Cb) - vecb[:, 2].view(G, 1, Cb)) * vecb[:, 3].view(G, 1, Cb)
+        exp2 = torch.cat([gq.sum(1), (gq * zh.double()).sum(1)], dim=1)                                 # from the values the kernel stored
+        tol = 1e-4 * exp2.abs().max().item()
+        assert (res[1][2] - exp2).abs().max().item() <= tol and (res[0][2] - exp2).abs().max().item() <= tol
+    else:
+        assert res[1][2].abs().max().item() == 0.0
     bits = ((mask.view(-1, 1).to(torch.int32) >> torch.arange(8, device=DEV, dtype=torch.int32)) & 1).view(G * N, H, H, Cb).float()
     full = (torch.einsum("nhwo,oc->nhwc", dz.float(), rb(w).view(Cm, Cb)) + gid.float()) * bits
     assert (res[1][0].float() - full).abs().max().item() <= 1e-2 * full.abs().max().item()
