@@ -48,8 +48,11 @@ def role(name):
         return "weight_gradient"
     if b in ("conv3x3_c64_kernel", "conv_stem_kernel"):
         return "convKxK_mfma"
-    if b in ("alg_stream_kernel", "conv1x1_fadd_next_kernel"):
+    if b in ("alg_stream_kernel", "conv1x1_fadd_next_kernel", "conv1x1_fadd_tpool_kernel", "res_prod_stream_kernel", "conv1x1_fadd_stream_kernel",
+             "conv1x1_fadd_tpool_stream_kernel"):
         return "conv1x1_fused_streaming"
+    if b == "wide_all_kernel":                              # (csrc/conv1x1_wide.hip: plain forward / data gradient of the wide expanding 1x1 convs)
+        return "conv1x1_streaming"
     if b in ("conv_wgrad_kernel", "conv_wgrad_glds_kernel", "conv3x3_wgrad_kernel", "conv3x3_c64_wgrad_kernel", "conv_stem_wgrad_kernel",
              "wgrad_reduce_kernel", "stem_wgrad_reduce_kernel", "gram_colsum_kernel", "gram_reduce_kernel", "tpool_bwd_prod_kernel"):
         return "weight_gradient"
