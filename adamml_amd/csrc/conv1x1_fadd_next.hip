@@ -14,6 +14,7 @@
 // Same K order, rounding points and epilogue expression as conv_gemm_kernel's FADD instance and forward instance: X', the mask and z1 are
 // bit-identical to the two-launch form (tests/test_kernels_gpu.py); the statistics of z1 differ in summation order only.
 // One 8-wave workgroup per CU (W3 36 KB + W1 33 KB + 8 x 8.25 KB tiles + vectors = 144 KB of LDS), no barrier in the tile loop.
+#include <type_traits>
 #include "common.h"
 #include "../../include/adamml_hip.h"
 
@@ -48,7 +49,9 @@ struct FNP {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_;
 
-template <bool NEXT>
+// ALLFULL: P % 16 == 0 (the launcher's choice) and MASK: mask_out given -- compile-time, so that the tile loop holds no store under a per-lane
+// or run-time condition (behind one, every wait is a conservative one: tpool_bwd_prod.hip went 1.83 -> 1.68 ms on that alone)
+template <bool NEXT, bool ALLFULL, bool MASK>
 __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_next_kernel(FNP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_w3 = smem;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_next_kernel(FNP p) {
     p.x += (size_t)g * p.P * C3IN;
     p.out += (size_t)g * p.P * CB;
     if (p.idn) p.idn += (size_t)g * p.P * CB;
-    if (p.mask_out) p.mask_out += (size_t)g * p.P * (CB / 8);
+    if (MASK) p.mask_out += (size_t)g * p.P * (CB / 8);
     if (NEXT) p.y1 += (size_t)g * p.P * C1OUT;
     for (int i = tid; i < CB * (C3IN / 8); i += NW * 64) {
         const int row = i / (C3IN / 8), ch = i - row * (C3IN / 8);
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_next_kernel(FNP p) {
     issue_aux(wid < ntile ? wid : ntile - 1);
 
     for (long t = wid; t < ntile; t += nw) {
-        const int npx = (int)(p.P - t * TPX < TPX ? p.P - t * TPX : TPX);
+        const int npx = ALLFULL ? TPX : (int)(p.P - t * TPX < TPX ? p.P - t * TPX : TPX);
         bf16x8 fb[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -172,12 +175,12 @@ __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_next_kernel(FNP p) {
                     for (int j = 0; j < 8; ++j) f[j] = clamp_act(fmaf(f[j], sc[j], sh[j]), rlo, rhi);
                 }
                 bf16x8 v = f32_to_bf8(f);
-                if (px >= npx) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};       // (rows past the end: zero operand of the next conv, never stored)
+                if (!ALLFULL && px >= npx) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};       // (rows past the end: zero operand of the next conv, never stored)
                 if (NEXT) *reinterpret_cast<bf16x8*>(sp) = v;            // the block output tile stays in LDS: B operand of the next conv
-                if (px < npx) {
+                if (ALLFULL || px < npx) {
                     const size_t e = ((size_t)t * TPX + px) * CB + c0;
                     *reinterpret_cast<bf16x8*>(p.out + e) = v;
-                    if (p.mask_out) {
+                    if (MASK) {
                         const f32x8 q = bf8_to_f32(v);
                         unsigned bits = 0;
 #pragma unroll
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_next_kernel(FNP p) {
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (every fragment read of the tile is done: the area becomes the z1 tile)
-            const bool live = li < npx;
+            const bool live = ALLFULL || li < npx;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 const bf16x4 v = f32_to_bf4(a1[ct]);
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_next_kernel(FNP p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int e = lane + 64 * i, px = e >> 3, ch = e & 7;
-                if (px < npx) {
+                if (ALLFULL || px < npx) {
                     union { struct { s16x4_ a, b; } s; bf16x8 v; } u;
                     u.s.a = *reinterpret_cast<const s16x4_*>(stg + px * ZROW + ch * 16);
                     u.s.b = *reinterpret_cast<const s16x4_*>(stg + px * ZROW + ch * 16 + 8);
@@ -275,6 +278,9 @@ struct FTP {
     int in_act, in_gs, id_gs, act, T, HW, clips;
 };
 
+// ALLFULL (HW % 16 == 0) and CODE (codes wanted) are compile-time and the frame loop is unrolled by frame parity, so that the stores of a
+// closing window are unconditional code (see conv1x1_fadd_next_kernel)
+template <bool ALLFULL, bool CODE>
 __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_tpool_kernel(FTP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_w3 = smem;
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_tpool_kernel(FTP p) {
         p.x += (size_t)g * P * C3IN;
         p.idn += (size_t)g * P * CB;
         p.pooled += (size_t)g * Pp * CB;
-        if (p.code) p.code += (size_t)g * Pp * (CB / 8);
+        if (CODE) p.code += (size_t)g * Pp * (CB / 8);
     }
     for (int i = tid; i < CB * (C3IN / 8); i += NW * 64) {
         const int row = i / (C3IN / 8), ch = i - row * (C3IN / 8);
@@ -349,10 +355,12 @@ __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_tpool_kernel(FTP p) {
     }
     for (long task = wid; task < ntask; task += nw) {
         const int clip = (int)(task / tpf), blk = (int)(task - (long)clip * tpf);
-        const int npx = p.HW - blk * TPX < TPX ? p.HW - blk * TPX : TPX;
+        const int npx = ALLFULL ? TPX : (p.HW - blk * TPX < TPX ? p.HW - blk * TPX : TPX);
         f32x8 best[2][4];
         unsigned code[2][4];
-        for (int t = 0; t < p.T; ++t) {
+        auto frame = [&](int t, auto odd_c) {
+            constexpr bool ODD = decltype(odd_c)::value;
+            __builtin_amdgcn_sched_barrier(0);
             // the (task, frame) after this one, clamped to the last: its rows are requested while this frame is computed
             long ntask_ = task;
             int nt = t + 1;
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_tpool_kernel(FTP p) {
                 }
             }
             issue(ntask_, nt);
-            const unsigned tapbits = (t & 1) ? 0xAAAAu : 0x5555u;            // this frame's tap in the open window: 2 (odd frame) or 1
+            constexpr unsigned tapbits = ODD ? 0xAAAAu : 0x5555u;            // this frame's tap in the open window: 2 (odd frame) or 1
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 f32x4 acc[8];
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_tpool_kernel(FTP p) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) f[j] = clamp_act(fmaf(f[j], sc[j], sh[j]) + fmaf(w[j], isc[j], ish[j]), rlo, rhi);
                     const f32x8 v = bf8_to_f32(f32_to_bf8(f));              // the value the unfused path stores and the pool re-reads
-                    if (t == 0) {                                           // window 0 has no tap 0: the scan starts at tap 1
+                    if (!ODD && t == 0) {                                   // window 0 has no tap 0: the scan starts at tap 1
                         best[b][i] = v;
                         code[b][i] = 0x5555u;
                     } else {
@@ -407,16 +415,16 @@ __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_tpool_kernel(FTP p) {
                             if (v[j] > best[b][i][j]) { best[b][i][j] = v[j]; cd = (cd & ~(3u << (2 * j))) | (tapbits & (3u << (2 * j))); }   // first maximum in scan order
                         code[b][i] = cd;
                     }
-                    if (t & 1) {
+                    if constexpr (ODD) {
                         // window t >> 1 is complete
-                        if (px < npx) {
+                        if (ALLFULL || px < npx) {
                             unsigned cd = code[b][i];
 #pragma unroll
                             for (int j = 0; j < 8; ++j)
                                 if (!(best[b][i][j] > rlo && best[b][i][j] < rhi)) cd |= 3u << (2 * j);       // act'(maximum) == 0: no gradient through this window
                             const size_t po = (((size_t)clip * To + (t >> 1)) * p.HW + (size_t)blk * TPX + px) * CB + c0;
                             *reinterpret_cast<bf16x8*>(p.pooled + po) = f32_to_bf8(best[b][i]);
-                            if (p.code) p.code[po >> 3] = (uint16_t)cd;
+                            if (CODE) p.code[po >> 3] = (uint16_t)cd;
                         }
                         best[b][i] = v;                                     // tap 0 of the next window
                         code[b][i] = 0u;
@@ -425,6 +433,11 @@ __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_tpool_kernel(FTP p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the staged block is consumed before the next one overwrites it)
             }
             issue_aux(ntask_, nt);
+        };
+#pragma unroll 1
+        for (int t = 0; t < p.T; t += 2) {
+            frame(t, std::false_type{});
+            frame(t + 1, std::true_type{});
         }
     }
 }
@@ -449,21 +462,32 @@ int adamml_conv1x1_fadd_next_launch(const adamml_conv_desc_t* d, const void* x, 
     p.P = (long)d->N * d->H * d->W;
     if (p.P <= 0) return ADAMML_OK;
     const int groups = d->groups < 1 ? 1 : d->groups;
-    static AdamLdsOnce attr_once;                    // (per device: common.h)
-    const int attr_dev = adamml_current_device();
-    if (!attr_once.test(attr_dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fadd_next_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fadd_next_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv_fwd_bn_add_next: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-        attr_once.set(attr_dev);
-    }
     const long ntile = (p.P + TPX - 1) / TPX;
     long nblk = (ntile + NW - 1) / NW;
     long cap = 256 / groups;                                             // one workgroup per CU over all groups
     if (cap < 1) cap = 1;
     if (nblk > cap) nblk = cap;
-    if (w1_packed) hipLaunchKernelGGL(conv1x1_fadd_next_kernel<true>, dim3((unsigned)nblk, groups), dim3(NW * 64), LDS_BYTES, stream, p);
-    else hipLaunchKernelGGL(conv1x1_fadd_next_kernel<false>, dim3((unsigned)nblk, groups), dim3(NW * 64), LDS_BYTES, stream, p);
+    const dim3 grid((unsigned)nblk, groups);
+    const int attr_dev = adamml_current_device();
+    auto launch = [&](auto next_c, auto full_c, auto mask_c) -> int {
+        constexpr bool NEXT = decltype(next_c)::value, FULL = decltype(full_c)::value, MASK = decltype(mask_c)::value;
+        static AdamLdsOnce attr_once;                // (per device and instance: common.h)
+        if (!attr_once.test(attr_dev)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fadd_next_kernel<NEXT, FULL, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv_fwd_bn_add_next: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+            attr_once.set(attr_dev);
+        }
+        hipLaunchKernelGGL((conv1x1_fadd_next_kernel<NEXT, FULL, MASK>), grid, dim3(NW * 64), LDS_BYTES, stream, p);
+        return 0;
+    };
+    auto pick_mask = [&](auto next_c, auto full_c) -> int {
+        return mask_out ? launch(next_c, full_c, std::true_type{}) : launch(next_c, full_c, std::false_type{});
+    };
+    auto pick_full = [&](auto next_c) -> int {
+        return p.P % TPX == 0 ? pick_mask(next_c, std::true_type{}) : pick_mask(next_c, std::false_type{});
+    };
+    const int lrc = w1_packed ? pick_full(std::true_type{}) : pick_full(std::false_type{});
+    if (lrc) return lrc;
     return adamml_check_launch("conv_fwd_bn_add_next");
 }
 
@@ -486,18 +510,26 @@ int adamml_conv1x1_fadd_tpool_launch(const adamml_conv_desc_t* d, const void* x,
     if (p.clips <= 0 || p.HW <= 0) return ADAMML_OK;
     const int groups = d->groups < 1 ? 1 : d->groups;
     constexpr int LDS_TP = CB * W3ROW + 2 * C3IN * 4 + 4 * CB * 4 + NW * TPX * SROW;
-    static AdamLdsOnce attr_once;                    // (per device: common.h)
-    const int attr_dev = adamml_current_device();
-    if (!attr_once.test(attr_dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fadd_tpool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TP);
-        if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv_fwd_bn_add_tpool: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-        attr_once.set(attr_dev);
-    }
     const long ntask = (long)p.clips * ((p.HW + TPX - 1) / TPX);
     long nblk = (ntask + NW - 1) / NW;
     long cap = 256 / groups;                                             // one workgroup per CU over all groups
     if (cap < 1) cap = 1;
     if (nblk > cap) nblk = cap;
-    hipLaunchKernelGGL(conv1x1_fadd_tpool_kernel, dim3((unsigned)nblk, groups), dim3(NW * 64), LDS_TP, stream, p);
+    const dim3 grid((unsigned)nblk, groups);
+    const int attr_dev = adamml_current_device();
+    auto launch = [&](auto full_c, auto code_c) -> int {
+        constexpr bool FULL = decltype(full_c)::value, CODE = decltype(code_c)::value;
+        static AdamLdsOnce attr_once;                // (per device and instance: common.h)
+        if (!attr_once.test(attr_dev)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fadd_tpool_kernel<FULL, CODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TP);
+            if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv_fwd_bn_add_tpool: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+            attr_once.set(attr_dev);
+        }
+        hipLaunchKernelGGL((conv1x1_fadd_tpool_kernel<FULL, CODE>), grid, dim3(NW * 64), LDS_TP, stream, p);
+        return 0;
+    };
+    auto pick = [&](auto full_c) -> int { return code ? launch(full_c, std::true_type{}) : launch(full_c, std::false_type{}); };
+    const int lrc = p.HW % TPX == 0 ? pick(std::true_type{}) : pick(std::false_type{});
+    if (lrc) return lrc;
     return adamml_check_launch("conv_fwd_bn_add_tpool");
 }

@@ -9,6 +9,7 @@
 // P[64 q .. 64 q + 63][:] in registers (4 x Cin/16 MFMA tiles) for the whole kernel; per window (two frames x 16 pixels = one K step of 32) it stages its g2 slice and the a rows
 // (every wave loads the a tile itself: L1 / L2 hits) in its private LDS area and reads both MFMA operands back as hardware transpose reads
 // (pixels = the reduction dimension).  g2 and sum(g2) as adamml_temporal_pool_bwd_code (g2 bit-identical); one partial P per workgroup.
+#include <type_traits>
 #include "common.h"
 #include "../../include/adamml_hip.h"
 
@@ -28,7 +29,7 @@ struct TPP {
     int in_gs, act, clips, HW, C;
 };
 
-template <int T, int CIN, int NQ>
+template <int T, int CIN, int NQ, bool ALLFULL>
 __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void tpool_bwd_prod_kernel(TPP p) {
     constexpr int To = T / 2, MT = 4, NTL = CIN / 16;
     constexpr int FPX = 16, TPX = 32;                              // pixels of a block per frame; rows of a staged tile = 2 frames x 16 pixels
@@ -101,9 +102,12 @@ __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void tpool_bwd_prod_kerne
         const long t0 = blockIdx.x < ntask ? blockIdx.x : ntask - 1;
         issue_a(t0, 0);
     }
-    for (long task = blockIdx.x; task < ntask; task += gridDim.x) {
+    // one task; FULL (a compile-time flag: all 16 pixels of the block live) keeps the stores unconditional -- behind a store under a per-lane
+    // condition every wait is a conservative one (the loop waited vmcnt(0) between the two frames' stores)
+    auto task_body = [&](long task, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
         const int clip = (int)(task / nblk_px), blk = (int)(task - (long)clip * nblk_px);
-        const int npx = p.HW - blk * FPX < FPX ? p.HW - blk * FPX : FPX;
+        const int npx = FULL ? FPX : p.HW - blk * FPX;
         // ---- window `to` (cur) and window `to + 1` (nxt) of this lane's two slots: frame 2 to is tap 1 of cur; frame 2 to + 1 is tap 2 of
         // cur plus tap 0 of nxt.  One step of the (runtime) window loop expands both frames into the 32-row staged tile -- rows 0..15 the
         // even frame's pixels, 16..31 the odd frame's -- and multiplies it with the matching rows of a: K = 2 frames x 16 pixels.
@@ -142,7 +146,8 @@ __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void tpool_bwd_prod_kerne
                     for (int j = 0; j < 8; ++j) v[j] += ((nxt.c[i] >> (2 * j)) & 3u) == 0u ? g1[j] : 0.f;
                 }
                 bf16x8 gb = f32_to_bf8(v);
-                if (px >= npx) gb = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (FULL) *reinterpret_cast<bf16x8*>(ob + goff[i]) = gb;
+                else if (px >= npx) gb = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 else *reinterpret_cast<bf16x8*>(ob + goff[i]) = gb;
                 const f32x8 gq = bf8_to_f32(gb);
 #pragma unroll
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void tpool_bwd_prod_kerne
                     v = f32_to_bf8(f);
                 }
                 union { struct { s16x4_ a, b; } s; bf16x8 v; } u;
-                u.v = px < npx ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                u.v = FULL || px < npx ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
                 *reinterpret_cast<s16x4_*>(xs + (r0 + px) * XROW + ch * 16) = u.s.a;
                 *reinterpret_cast<s16x4_*>(xs + (r0 + px) * XROW + ch * 16 + 8) = u.s.b;
             }
@@ -209,7 +214,10 @@ __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void tpool_bwd_prod_kerne
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the transpose reads are done before the next window overwrites the area)
         }
-    }
+    };
+    // (ALLFULL: HW % 16 == 0, the launcher's choice -- one path per kernel instance: with both in one kernel the allocator spilled 44 registers)
+#pragma unroll 1
+    for (long task = blockIdx.x; task < ntask; task += gridDim.x) task_body(task, std::integral_constant<bool, ALLFULL>{});
     // ---- this wave's slice of the workgroup's partial product (disjoint slices: no fold)
     float* out = p.ws + ((size_t)g * gridDim.x + blockIdx.x) * (C * CIN) + (size_t)q * 64 * CIN;
 #pragma unroll
@@ -229,19 +237,19 @@ __global__ __launch_bounds__(NQ * 64, NQ == 4 ? 2 : 1) void tpool_bwd_prod_kerne
     }
 }
 
-template <int T, int CIN, int NQ>
+template <int T, int CIN, int NQ, bool ALLFULL>
 int tpp_launch(const TPP& p, int groups, int nblk, hipStream_t stream) {
     constexpr size_t lds = 2 * CIN * 4 + (size_t)NQ * 32 * ((64 * 2 + 8) + (CIN * 2 + 8));
     static AdamLdsOnce attr_once;                    // (per device: common.h)
     const int attr_dev = adamml_current_device();
     if (!attr_once.test(attr_dev)) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tpool_bwd_prod_kernel<T, CIN, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tpool_bwd_prod_kernel<T, CIN, NQ, ALLFULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "temporal_pool_bwd_code_prod: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         }
         attr_once.set(attr_dev);
     }
-    hipLaunchKernelGGL((tpool_bwd_prod_kernel<T, CIN, NQ>), dim3((unsigned)nblk, groups), dim3(NQ * 64), lds, stream, p);
+    hipLaunchKernelGGL((tpool_bwd_prod_kernel<T, CIN, NQ, ALLFULL>), dim3((unsigned)nblk, groups), dim3(NQ * 64), lds, stream, p);
     return adamml_check_launch("temporal_pool_bwd_code_prod");
 }
 
@@ -283,7 +291,7 @@ extern "C" int adamml_temporal_pool_bwd_code_prod(const void* g_y, const uint16_
     p.gy = (const bf16_t*)g_y; p.code = code; p.g2 = (bf16_t*)g2; p.sums = sums_a; p.a = (const bf16_t*)a;
     p.in_scale = in_scale; p.in_shift = in_scale ? in_shift : nullptr; p.ws = (float*)workspace;
     p.in_gs = in_gstride; p.act = in_act; p.clips = NB; p.HW = HW; p.C = C;
-    int rc = tpp_launch<8, 64, 4>(p, groups, nblk, stream);
+    int rc = HW % 16 == 0 ? tpp_launch<8, 64, 4, true>(p, groups, nblk, stream) : tpp_launch<8, 64, 4, false>(p, groups, nblk, stream);
     if (rc) return rc;
     return adamml_launch_split_reduce_grouped((const float*)workspace, prod, (size_t)C * Cin, nblk, groups, Cin, stream);
 }
