@@ -57,7 +57,10 @@ struct DwP {
 // normalised tensor z -- the mask act'(bn(z)) is applied before the store and the statistics become sum(g'), sum(g' zhat), so the
 // BatchNorm-backward reduction pass over (g, z) disappears (one read of z here instead of a read of g and of z there).  The z rows
 // are requested three output rows ahead (three rotating register rows, like the input window).
-template <int S, bool BNZ = false, bool X1 = false>
+// WF: OW % SEGW == 0 (the launcher's choice) -- every output column of a thread's segment exists, so the stores of the row walk are
+// unconditional code; the next input rows are requested unconditionally either way (load_row clamps): no load or store of the walk sits
+// under a per-thread condition (behind one, every wait is a conservative one).
+template <int S, bool BNZ = false, bool X1 = false, bool WF = false>
 __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
     constexpr int SEGW = S == 1 ? 4 : 2;                // output columns per thread
     constexpr int NCOL = (SEGW - 1) * S + 3;            // input columns feeding them
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
             bf16_t* yrow = yimg + (size_t)oh * p.OW * p.C;
 #pragma unroll
             for (int o = 0; o < SEGW; ++o) {
-                if (ow_b + o < p.OW) {
+                if (WF || ow_b + o < p.OW) {
                     f32x4 acc = r0[o * S] * wt[0];
                     acc += r0[o * S + 1] * wt[1];
                     acc += r0[o * S + 2] * wt[2];
@@ -193,17 +196,17 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
             if (BNZ) { load_z(oh_b, zr[0]); load_z(oh_b + 1, zr[BNZ ? 1 : 0]); load_z(oh_b + 2, zr[BNZ ? 2 : 0]); }
             for (int oh = oh_b; oh < oh_e; oh += 3) {
                 xform(nxt[0], win[2]);
-                if (oh + 1 < oh_e) load_row(oh + 1 - p.pad + 2, nxt[0]);
+                load_row(oh + 1 - p.pad + 2, nxt[0]);
                 emit(oh, win[0], win[1], win[2], zr[0]);
                 if (BNZ && oh + 3 < oh_e) load_z(oh + 3, zr[0]);
                 if (oh + 1 >= oh_e) break;
                 xform(nxt[0], win[0]);
-                if (oh + 2 < oh_e) load_row(oh + 2 - p.pad + 2, nxt[0]);
+                load_row(oh + 2 - p.pad + 2, nxt[0]);
                 emit(oh + 1, win[1], win[2], win[0], zr[BNZ ? 1 : 0]);
                 if (BNZ && oh + 4 < oh_e) load_z(oh + 4, zr[BNZ ? 1 : 0]);
                 if (oh + 2 >= oh_e) break;
                 xform(nxt[0], win[1]);
-                if (oh + 3 < oh_e) load_row(oh + 3 - p.pad + 2, nxt[0]);
+                load_row(oh + 3 - p.pad + 2, nxt[0]);
                 emit(oh + 2, win[2], win[0], win[1], zr[BNZ ? 2 : 0]);
                 if (BNZ && oh + 5 < oh_e) load_z(oh + 5, zr[BNZ ? 2 : 0]);
             }
@@ -214,15 +217,15 @@ __global__ __launch_bounds__(NT, 2) void dwconv_fwd_kernel(DwP p) {
             load_row(oh_b * 2 - p.pad + 2, nxt[1]);
             for (int oh = oh_b; oh < oh_e; oh += 3) {
                 xform(nxt[0], win[1]); xform(nxt[1], win[2]);
-                if (oh + 1 < oh_e) { load_row((oh + 1) * 2 - p.pad + 1, nxt[0]); load_row((oh + 1) * 2 - p.pad + 2, nxt[1]); }
+                { load_row((oh + 1) * 2 - p.pad + 1, nxt[0]); load_row((oh + 1) * 2 - p.pad + 2, nxt[1]); }
                 emit(oh, win[0], win[1], win[2], zr[0]);
                 if (oh + 1 >= oh_e) break;
                 xform(nxt[0], win[0]); xform(nxt[1], win[1]);
-                if (oh + 2 < oh_e) { load_row((oh + 2) * 2 - p.pad + 1, nxt[0]); load_row((oh + 2) * 2 - p.pad + 2, nxt[1]); }
+                { load_row((oh + 2) * 2 - p.pad + 1, nxt[0]); load_row((oh + 2) * 2 - p.pad + 2, nxt[1]); }
                 emit(oh + 1, win[2], win[0], win[1], zr[0]);
                 if (oh + 2 >= oh_e) break;
                 xform(nxt[0], win[2]); xform(nxt[1], win[0]);
-                if (oh + 3 < oh_e) { load_row((oh + 3) * 2 - p.pad + 1, nxt[0]); load_row((oh + 3) * 2 - p.pad + 2, nxt[1]); }
+                { load_row((oh + 3) * 2 - p.pad + 1, nxt[0]); load_row((oh + 3) * 2 - p.pad + 2, nxt[1]); }
                 emit(oh + 2, win[1], win[2], win[0], zr[0]);
             }
         }
@@ -817,8 +820,13 @@ extern "C" int adamml_dwconv_fwd(const adamml_conv_desc_t* d, const void* x, con
     p.ppb = 0;
     p.flip = 0;
     const unsigned nblk = dw_walk_grid(p, d->stride == 1 ? 4 : 2, groups);          // segw == SEGW of dwconv_fwd_kernel<S>
-    if (d->stride == 1) hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3(nblk, groups), dim3(NT), 0, stream, p);
-    else hipLaunchKernelGGL(dwconv_fwd_kernel<2>, dim3(nblk, groups), dim3(NT), 0, stream, p);
+    if (d->stride == 1) {
+        if (d->OW % 4 == 0) hipLaunchKernelGGL((dwconv_fwd_kernel<1, false, false, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
+        else hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3(nblk, groups), dim3(NT), 0, stream, p);
+    } else {
+        if (d->OW % 2 == 0) hipLaunchKernelGGL((dwconv_fwd_kernel<2, false, false, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
+        else hipLaunchKernelGGL(dwconv_fwd_kernel<2>, dim3(nblk, groups), dim3(NT), 0, stream, p);
+    }
     return adamml_check_launch("dwconv_fwd");
 }
 
@@ -840,8 +848,14 @@ static int dw_bwd_data_launch(const adamml_conv_desc_t* d, const void* dz, const
         // stride 1: the data gradient IS the forward walk over dz with the taps reversed (no transform, no statistics)
         p.H = d->OH; p.W = d->OW; p.OH = d->H; p.OW = d->W; p.flip = 1;
         const unsigned nblk = dw_walk_grid(p, 4, groups);
-        if (bn_z) hipLaunchKernelGGL((dwconv_fwd_kernel<1, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
-        else hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3(nblk, groups), dim3(NT), 0, stream, p);
+        const bool wf = p.OW % 4 == 0;                  // (p.OW: the width of dx here)
+        if (bn_z) {
+            if (wf) hipLaunchKernelGGL((dwconv_fwd_kernel<1, true, false, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
+            else hipLaunchKernelGGL((dwconv_fwd_kernel<1, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
+        } else {
+            if (wf) hipLaunchKernelGGL((dwconv_fwd_kernel<1, false, false, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
+            else hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3(nblk, groups), dim3(NT), 0, stream, p);
+        }
         return adamml_check_launch("dwconv_bwd_data");
     }
     static const bool quads = !(getenv("ADAMML_DW_S2_QUADS") && atoi(getenv("ADAMML_DW_S2_QUADS")) == 0);       // A/B aid
@@ -967,7 +981,8 @@ extern "C" int adamml_conv_stem1_fwd(const adamml_conv_desc_t* d, const float* x
     p.ppb = 0;
     p.flip = 0;
     const unsigned nblk = dw_walk_grid(p, 2, groups);
-    hipLaunchKernelGGL((dwconv_fwd_kernel<2, false, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
+    if (p.OW % 2 == 0) hipLaunchKernelGGL((dwconv_fwd_kernel<2, false, true, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
+    else hipLaunchKernelGGL((dwconv_fwd_kernel<2, false, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
     return adamml_check_launch("conv_stem1_fwd");
 }
 
