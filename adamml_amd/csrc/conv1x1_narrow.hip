@@ -32,7 +32,9 @@ struct N1P {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_;
 
-template <int KS, int COUT>
+// ALLFULL: P % 32 == 0 (the launcher's choice): the tile's run leaves through unconditional stores (behind a store under a per-lane condition
+// every wait of the loop is a conservative one: csrc/conv1x1_fadd_next.hip went 2.40 -> 2.24 ms on that alone)
+template <int KS, int COUT, bool ALLFULL>
 __global__ __launch_bounds__(256, 2) void conv1x1_narrow_fwd_kernel(N1P p) {
     constexpr int KP = KS * 32;                      // padded K
     constexpr int NCT = (COUT + 15) / 16;            // 16-wide cout tiles
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_narrow_fwd_kernel(N1P p) {
 #pragma unroll
         for (int pg = 0; pg < 2; ++pg) {
             long px = p0 + pg * 16 + li;
-            px = px < p.P ? px : p.P - 1;
+            if (!ALLFULL) px = px < p.P ? px : p.P - 1;
             const bf16_t* row = p.x + px * p.Cin;
 #pragma unroll
             for (int k = 0; k < KS; ++k) {
@@ -141,10 +143,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_narrow_fwd_kernel(N1P p) {
                 issue(u, tn < ntile ? tn : ntile - 1);
             }
             // ---- epilogue: D fragment lane (li, lg) = channels ct * 16 + lg * 4 .. + 3 of pixel pg * 16 + li -> wave-private staging tile
-            const int npx = (int)(p.P - t * TPX < TPX ? p.P - t * TPX : TPX);
+            const int npx = ALLFULL ? TPX : (int)(p.P - t * TPX < TPX ? p.P - t * TPX : TPX);
 #pragma unroll
             for (int pg = 0; pg < 2; ++pg) {
-                const bool live = pg * 16 + li < npx;
+                const bool live = ALLFULL || pg * 16 + li < npx;
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
                     bf16x4 v = f32_to_bf4(acc[pg][ct]);
@@ -174,9 +176,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_narrow_fwd_kernel(N1P p) {
             bf16_t* yb = p.y + (size_t)t * TPX * COUT;
 #pragma unroll
             for (int i = 0; i < (TPX * CPR + 63) / 64; ++i) {
-                const int e = lane + 64 * i;
+                int e = lane + 64 * i;
+                // (ALLFULL: a run of 32 CPR chunks that does not fill its last 64-lane pass -- 24 channels: 96 chunks -- lets the idle lanes
+                // repeat the chunks 32 below theirs: the same bytes to the same address, no predicate)
+                if (ALLFULL && (TPX * CPR) % 64 != 0 && e >= TPX * CPR) e -= 32;
                 const int px = e / CPR, ch = e - px * CPR;
-                if (e < npx * CPR) {                                 // (two 8-byte LDS reads: the staging rows are 8-byte aligned only)
+                if (ALLFULL || e < npx * CPR) {                      // (two 8-byte LDS reads: the staging rows are 8-byte aligned only)
                     union { struct { s16x4_ a, b; } s; bf16x8 v; } o;
                     o.s.a = *reinterpret_cast<const s16x4_*>(stg + px * SROW + ch * 16);
                     o.s.b = *reinterpret_cast<const s16x4_*>(stg + px * SROW + ch * 16 + 8);
@@ -196,15 +201,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_narrow_fwd_kernel(N1P p) {
     }
 }
 
-template <int KS, int COUT>
-int narrow_launch(const N1P& p, int groups, hipStream_t stream) {
+template <int KS, int COUT, bool ALLFULL>
+int narrow_launch_(const N1P& p, int groups, hipStream_t stream) {
     constexpr int KP = KS * 32, NCT = (COUT + 15) / 16, CW = NCT * 16;
     constexpr size_t lds = (size_t)CW * (KP * 2 + 16) + 2 * KP * 4 + 4 * 2 * CW * 4 + 4 * 32 * (CW * 2 + 8);
     static AdamLdsOnce attr_once;                    // (per device: common.h)
     const int attr_dev = adamml_current_device();
     if (!attr_once.test(attr_dev)) {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_narrow_fwd_kernel<KS, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_narrow_fwd_kernel<KS, COUT, ALLFULL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return adamml_set_error(ADAMML_ELAUNCH, "conv1x1 (narrow): cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         }
         attr_once.set(attr_dev);
@@ -215,8 +220,13 @@ int narrow_launch(const N1P& p, int groups, hipStream_t stream) {
     long cap = 256 * (per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu)) / groups;         // persistent workgroups over all groups
     if (cap < 1) cap = 1;
     if (nblk > cap) nblk = cap;
-    hipLaunchKernelGGL((conv1x1_narrow_fwd_kernel<KS, COUT>), dim3((unsigned)nblk, groups), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv1x1_narrow_fwd_kernel<KS, COUT, ALLFULL>), dim3((unsigned)nblk, groups), dim3(256), lds, stream, p);
     return adamml_check_launch("conv_fwd (narrow 1x1 stream)");
+}
+
+template <int KS, int COUT>
+int narrow_launch(const N1P& p, int groups, hipStream_t stream) {
+    return p.P % 32 == 0 ? narrow_launch_<KS, COUT, true>(p, groups, stream) : narrow_launch_<KS, COUT, false>(p, groups, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
