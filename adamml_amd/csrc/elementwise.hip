@@ -603,7 +603,8 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_walk_kernel(const bf16_t* x, c
     xform(top, oh_b * 2 - 1, ttop);
     for (int oh = oh_b; oh < oh_e; ++oh) {
         mid = nmid; bot = nbot;
-        if (oh + 1 < oh_e) { load_row(oh * 2 + 2, nmid); load_row(oh * 2 + 3, nbot); }
+        load_row(oh * 2 + 2, nmid);                          // (unconditional: load_row clamps; under `oh + 1 < oh_e` every wait of the walk
+        load_row(oh * 2 + 3, nbot);                          //  behind the request was a conservative one -- appendix A-18)
         xform(mid, oh * 2, tmid);
         xform(bot, oh * 2 + 1, tbot);
         f32x8 best;
