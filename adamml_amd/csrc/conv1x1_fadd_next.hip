@@ -50,7 +50,7 @@ struct FNP {
 typedef __attribute__((ext_vector_type(4))) short s16x4_;
 
 // ALLFULL: P % 16 == 0 (the launcher's choice) and MASK: mask_out given -- compile-time, so that the tile loop holds no store under a per-lane
-// or run-time condition (behind one, every wait is a conservative one: tpool_bwd_prod.hip went 1.83 -> 1.68 ms on that alone)
+// or run-time condition (behind one, every wait is a conservative one: tpool_bwd_prod.hip went 1.74 -> 1.60 ms on that alone; THIS kernel measured the same either way, 2.32 ms)
 template <bool NEXT, bool ALLFULL, bool MASK>
 __global__ __launch_bounds__(NW * 64, 1) void conv1x1_fadd_next_kernel(FNP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -33,7 +33,7 @@ struct N1P {
 typedef __attribute__((ext_vector_type(4))) short s16x4_;
 
 // ALLFULL: P % 32 == 0 (the launcher's choice): the tile's run leaves through unconditional stores (behind a store under a per-lane condition
-// every wait of the loop is a conservative one: csrc/conv1x1_fadd_next.hip went 2.40 -> 2.24 ms on that alone)
+// every wait of the loop is a conservative one: csrc/tpool_bwd_prod.hip went 1.74 -> 1.60 ms on that alone)
 template <int KS, int COUT, bool ALLFULL>
 __global__ __launch_bounds__(256, 2) void conv1x1_narrow_fwd_kernel(N1P p) {
     constexpr int KP = KS * 32;                      // padded K
