@@ -850,8 +850,8 @@ static int dw_bwd_data_launch(const adamml_conv_desc_t* d, const void* dz, const
         const unsigned nblk = dw_walk_grid(p, 4, groups);
         const bool wf = p.OW % 4 == 0;                  // (p.OW: the width of dx here)
         if (bn_z) {
-            if (wf) hipLaunchKernelGGL((dwconv_fwd_kernel<1, true, false, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
-            else hipLaunchKernelGGL((dwconv_fwd_kernel<1, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
+            // (no WF instance of the BatchNorm-fused form: at 256 registers it spilled 4 and measured the same)
+            hipLaunchKernelGGL((dwconv_fwd_kernel<1, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
         } else {
             if (wf) hipLaunchKernelGGL((dwconv_fwd_kernel<1, false, false, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
             else hipLaunchKernelGGL(dwconv_fwd_kernel<1>, dim3(nblk, groups), dim3(NT), 0, stream, p);
@@ -981,8 +981,7 @@ extern "C" int adamml_conv_stem1_fwd(const adamml_conv_desc_t* d, const float* x
     p.ppb = 0;
     p.flip = 0;
     const unsigned nblk = dw_walk_grid(p, 2, groups);
-    if (p.OW % 2 == 0) hipLaunchKernelGGL((dwconv_fwd_kernel<2, false, true, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
-    else hipLaunchKernelGGL((dwconv_fwd_kernel<2, false, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);
+    hipLaunchKernelGGL((dwconv_fwd_kernel<2, false, true>), dim3(nblk, groups), dim3(NT), 0, stream, p);      // (no WF instance: 136 instead of 126 registers = one wave per SIMD less)
     return adamml_check_launch("conv_stem1_fwd");
 }
 
