@@ -683,7 +683,8 @@ __global__ void maxpool_bwd_kernel(const bf16_t* gy, const uint8_t* idx, bf16_t*
 // A thread owns one 8-channel chunk of a 2x2 input quad (rows 2k, 2k+1; columns 2j, 2j+1): the quad is covered by exactly
 // the four windows (k+a, j+b), a, b in {0, 1}, and pixel (dy, dx) belongs to window (a, b) iff a <= dy and b <= dx, at tap
 // (dy - 2a + 1) * 3 + (dx - 2b + 1) -- four (index, gradient) loads per four pixels instead of 2.25 per pixel.
-template <bool APPLY>
+// EVEN: H and W even (the launcher's choice) -- every pixel of a quad exists, the four stores of a quad are unconditional code (appendix A-18)
+template <bool APPLY, bool EVEN = false>
 __global__ __launch_bounds__(NT) void maxpool_bwd_bn_kernel(const bf16_t* gy, const uint8_t* idx, const bf16_t* z, const float* vec, int act,
                                                             double* sums, const float* coef, bf16_t* dz, int N, int H, int W, int C,
                                                             int OH, int OW, size_t qpb) {
@@ -765,7 +766,7 @@ __global__ __launch_bounds__(NT) void maxpool_bwd_bn_kernel(const bf16_t* gy, co
                             const float zh = (zv[i] - mu[i]) * is[i];
                             o[i] = k0[i] * (gp - k1[i] - zh * k2[i]);
                         }
-                        if (ok) {
+                        if (EVEN || ok) {
                             const size_t pp = ((size_t)n * H + 2 * k + dy) * W + 2 * j + dx;
                             __builtin_nontemporal_store(f32_to_bf8(o), reinterpret_cast<bf16x8*>(dz + pp * C + c));
                         }
@@ -1745,8 +1746,12 @@ extern "C" int adamml_maxpool2d_bwd_bn_apply(const void* g_y, const uint8_t* idx
     if (groups < 1) groups = 1;
     size_t ppb, nblk;
     rowwalk_grid(P, C, groups, 8192, &ppb, &nblk);
-    hipLaunchKernelGGL(maxpool_bwd_bn_kernel<true>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g_y, idx,
-                       (const bf16_t*)z, vec, act, (double*)nullptr, coef, (bf16_t*)dz, N, H, W, C, OH, OW, ppb);
+    if (H % 2 == 0 && W % 2 == 0)
+        hipLaunchKernelGGL((maxpool_bwd_bn_kernel<true, true>), dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g_y, idx,
+                           (const bf16_t*)z, vec, act, (double*)nullptr, coef, (bf16_t*)dz, N, H, W, C, OH, OW, ppb);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_bn_kernel<true>, dim3((unsigned)nblk, groups), dim3(NT), 0, stream, (const bf16_t*)g_y, idx,
+                           (const bf16_t*)z, vec, act, (double*)nullptr, coef, (bf16_t*)dz, N, H, W, C, OH, OW, ppb);
     return adamml_check_launch("maxpool2d_bwd_bn_apply");
 }
 
